@@ -1,0 +1,166 @@
+"""Generates the golden fixtures under tests/golden/ (run in the build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Part A imports the reference's own Python functions from /root/reference (read-only;
+nothing of it is copied -- only inputs and outputs are stored):
+  * utils/sh_utils.py:57-112 eval_sh            -> ref_sh.npz
+  * utils/graphics_utils.py:204-248 quaternion_to_matrix, :266-277 getWorld2View2,
+    :305-337 getProjectionMatrixwithPrincipalPointOffset, :342-343 focal2fov -> ref_camera.npz
+  * loss/normal_guidance.py:3-22 loss_normal_guidance (value + gradients w.r.t.
+    cov_quat / cov_scale)                        -> ref_normal_guidance.npz
+Part B runs the independent float64 autograd restatement oracle/torch_ref.py on tiny
+seeded scenes (vegs_amd/scenes.py) and stores inputs, forward images and input gradients
+-> raster_case*.npz.  These pin vr_oracle.c and, on the GPU box, the HIP kernels.
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def part_a():
+    sys.path.insert(0, REF)
+    import utils.graphics_utils as gu
+    import utils.sh_utils as shu
+    spec = importlib.util.spec_from_file_location("ref_normal_guidance", os.path.join(REF, "loss/normal_guidance.py"))
+    ng = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ng)
+
+    rng = np.random.default_rng(100)
+    n = 64
+    sh = rng.normal(0, 0.5, (n, 3, 16)).astype(np.float32)          # [n, C, K] as eval_sh wants
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    out = {"sh": sh, "dirs": d}
+    for deg in range(4):
+        out[f"rgb_deg{deg}"] = shu.eval_sh(deg, torch.tensor(sh), torch.tensor(d)).numpy()
+    np.savez_compressed(os.path.join(HERE, "ref_sh.npz"), **out)
+
+    # camera matrices at KITTI-360-like intrinsics, built as scene/cameras.py:70-88 does
+    from vegs_amd import scenes
+    cams = {}
+    for tag, (W, H) in {"1408": (1408, 376), "1376": (1376, 376)}.items():
+        s = W / 1408
+        fx, fy, cx, cy = scenes.KITTI360_FX, scenes.KITTI360_FY, scenes.KITTI360_CX * s, scenes.KITTI360_CY
+        R = scenes.R_KITTI
+        eye = np.array([3.0, -0.3, 0.1])
+        T = -R.T @ eye
+        fovx, fovy = gu.focal2fov(fx, W), gu.focal2fov(fy, H)
+        wv = torch.tensor(gu.getWorld2View2(R, T)).transpose(0, 1)
+        pm = gu.getProjectionMatrixwithPrincipalPointOffset(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy, fx=fx, fy=fy,
+                                                            cx=cx, cy=cy, w=W, h=H).transpose(0, 1)
+        full = (wv.unsqueeze(0).bmm(pm.unsqueeze(0))).squeeze(0)
+        center = wv.inverse()[3, :3]
+        cams.update({f"R_{tag}": R, f"T_{tag}": T, f"K_{tag}": np.array([fx, fy, cx, cy, W, H]),
+                     f"fov_{tag}": np.array([fovx, fovy]), f"view_{tag}": wv.numpy(), f"full_{tag}": full.numpy(),
+                     f"center_{tag}": center.numpy()})
+    q = rng.normal(size=(32, 4)).astype(np.float32)
+    cams["quat"] = q
+    cams["quat_matrix"] = gu.quaternion_to_matrix(torch.tensor(q)).numpy()
+    np.savez_compressed(os.path.join(HERE, "ref_camera.npz"), **cams)
+
+    # normal-guidance loss (the consumer of cov_quat / cov_scale): value and gradients
+    H, W = 12, 20
+
+    class Cam:
+        pass
+    cam = Cam()
+    cam.original_normal = torch.tensor(rng.normal(size=(3, H, W)).astype(np.float32))
+    cam.R = scenes.R_KITTI.copy()
+    cq = torch.tensor(rng.normal(size=(4, H, W)).astype(np.float32), requires_grad=True)
+    cs = torch.tensor(rng.uniform(0.01, 0.2, (3, H, W)).astype(np.float32), requires_grad=True)
+    loss = ng.loss_normal_guidance(cam, cq, cs)
+    loss.backward()
+    np.savez_compressed(os.path.join(HERE, "ref_normal_guidance.npz"), normal=cam.original_normal.numpy(), R=cam.R,
+                        cov_quat=cq.detach().numpy(), cov_scale=cs.detach().numpy(), loss=loss.item(),
+                        grad_cov_quat=cq.grad.numpy(), grad_cov_scale=cs.grad.numpy())
+
+
+CASES = {
+    # name: (scene kwargs, camera (W,H), sh_degree, bg, mode)
+    "case_sh3": dict(P=300, seed=11, scale=0.05, W=64, H=48, deg=3, bg=(0.1, 0.2, 0.3), mode="sh_sr", mod=1.0),
+    "case_precomp": dict(P=250, seed=12, scale=0.04, W=48, H=48, deg=0, bg=(0.0, 0.0, 0.0), mode="precomp", mod=1.0),
+    "case_cull_deg1": dict(P=400, seed=13, scale=0.08, W=80, H=40, deg=1, bg=(1.0, 1.0, 1.0), mode="sh_sr", mod=1.3,
+                           extent=2.5, opaque=True),
+}
+
+
+def build_case(c):
+    from vegs_amd import scenes
+    sc, deg = scenes.scene_random(P=c["P"], sh_degree=c["deg"], seed=c["seed"], scale=c["scale"],
+                                  extent=c.get("extent", 0.5))
+    if c.get("opaque"):
+        rng = np.random.default_rng(c["seed"] + 1000)
+        sc["opacities"] = rng.uniform(0.5, 1.0, sc["opacities"].shape).astype(np.float32)
+        sc["rotations"] = (sc["rotations"] * rng.uniform(0.8, 1.2, (c["P"], 1))).astype(np.float32)  # un-normalised q
+    cam = scenes.camera_c1(c["W"], c["H"])
+    return sc, deg, cam
+
+
+def part_b():
+    from oracle import torch_ref
+    for name, c in CASES.items():
+        sc, deg, cam = build_case(c)
+        P = c["P"]
+        T = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in sc.items()}
+        m2d = torch.zeros(P, 3, dtype=torch.float64, requires_grad=True)
+        kw = dict(H=cam.image_height, W=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+                  bg=torch.tensor(c["bg"], dtype=torch.float64), scale_modifier=c["mod"],
+                  viewmatrix=torch.tensor(cam.world_view_transform), projmatrix=torch.tensor(cam.full_proj_transform),
+                  campos=torch.tensor(cam.camera_center), sh_degree=deg)
+        extra = {}
+        if c["mode"] == "precomp":
+            with torch.no_grad():
+                cov = torch_ref.build_cov3d(T["scales"], c["mod"], T["rotations"])
+                cov6 = torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1)
+                col = torch.rand(P, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(c["seed"]))
+            # round through float32 so stored inputs are exactly what was rendered
+            cov6 = cov6.float().double().requires_grad_(True)
+            col = col.float().double().requires_grad_(True)
+            res = torch_ref.rasterize(T["means3D"], None, col, T["opacities"], None, None, cov6, means2D=m2d, **kw)
+            extra = {"in_colors_precomp": col, "in_cov3D_precomp": cov6}
+        else:
+            res = torch_ref.rasterize(T["means3D"], T["shs"], None, T["opacities"], T["scales"], T["rotations"], None,
+                                      means2D=m2d, **kw)
+        rng = np.random.default_rng(c["seed"] + 7)
+        names = ["color", "depth", "cov_quat", "cov_scale", "alpha"]
+        gouts = [rng.normal(size=tuple(r.shape)).astype(np.float32) for r in res[:5]]
+        loss = sum((r * torch.tensor(g, dtype=torch.float64)).sum() for r, g in zip(res[:5], gouts))
+        loss.backward()
+        blob = {"meta": np.array([P, cam.image_width, cam.image_height, deg], np.int64),
+                "bg": np.array(c["bg"], np.float32), "scale_modifier": np.float32(c["mod"]),
+                "tanfov": np.array([cam.tanfovx, cam.tanfovy], np.float64),
+                "viewmatrix": cam.world_view_transform, "projmatrix": cam.full_proj_transform,
+                "campos": cam.camera_center, "radii": res[5].numpy()}
+        for k, v in sc.items():
+            blob["in_" + k] = v
+        for k, v in extra.items():
+            blob[k] = v.detach().numpy().astype(np.float32)
+        for n, r, g in zip(names, res[:5], gouts):
+            blob["out_" + n] = r.detach().numpy().astype(np.float32)
+            blob["gout_" + n] = g
+        blob["grad_means2D"] = m2d.grad.numpy().astype(np.float32)
+        blob["grad_means3D"] = T["means3D"].grad.numpy().astype(np.float32)
+        blob["grad_opacities"] = T["opacities"].grad.numpy().astype(np.float32)
+        if c["mode"] == "precomp":
+            blob["grad_colors_precomp"] = extra["in_colors_precomp"].grad.numpy().astype(np.float32)
+            blob["grad_cov3D_precomp"] = extra["in_cov3D_precomp"].grad.numpy().astype(np.float32)
+        else:
+            blob["grad_shs"] = T["shs"].grad.numpy().astype(np.float32)
+            blob["grad_scales"] = T["scales"].grad.numpy().astype(np.float32)
+            blob["grad_rotations"] = T["rotations"].grad.numpy().astype(np.float32)
+        np.savez_compressed(os.path.join(HERE, f"raster_{name}.npz"), **blob)
+        print(name, "visible", int((res[5] > 0).sum()), "of", P)
+
+
+if __name__ == "__main__":
+    part_a()
+    part_b()

@@ -1,0 +1,119 @@
+"""CPU: pin the oracle (oracle/vr_oracle.c) against the golden fixtures.
+
+ref_*.npz come from importing the reference's own functions; raster_*.npz from the
+independent float64 autograd restatement (tests/golden/make_golden.py).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, OUT_NAMES, case_inputs, load_case, normal_guidance_loss, oracle_cam_from_case, rel_err
+from oracle import oracle as orc
+from vegs_amd import scenes
+
+CASES = ["case_sh3", "case_precomp", "case_cull_deg1"]
+
+
+def test_sh_colour_matches_reference_eval_sh():
+    """utils/sh_utils.py:57-112 through the oracle's preprocess (colour = clamp(eval_sh + 0.5))."""
+    z = np.load(os.path.join(GOLDEN, "ref_sh.npz"))
+    sh, dirs = z["sh"], z["dirs"]                       # [n,3,16], [n,3]
+    n = sh.shape[0]
+    cam = scenes.camera_c1(64, 64)
+    # put Gaussian i at campos + 2*dir_i... visible or not, colour is only computed for visible ones,
+    # so instead place all points in front of the camera and move campos per direction via means.
+    centre = np.array([0.0, 0.0, 0.0], np.float32)
+    for deg in range(4):
+        # means = centre + small offsets; campos = means - dirs*len  -> one render per Gaussian is
+        # wasteful; use the trick that colour depends only on (mean - campos)/|.|: choose campos = 0
+        # offset so that mean_i - campos = dirs_i * r.
+        got = np.zeros((n, 3), np.float32)
+        for i in range(n):
+            mean = centre[None].copy()
+            campos = mean[0] - dirs[i] * 1.7
+            oc = orc.make_cam(64, 64, cam.tanfovx, cam.tanfovy, [0, 0, 0], 1.0, cam.world_view_transform,
+                              cam.full_proj_transform, campos, deg, 16)
+            shs = np.ascontiguousarray(sh[i].T[None])   # [1,16,3]
+            _, st = orc.forward(oc, mean, shs, None, np.ones((1, 1), np.float32), np.full((1, 3), 0.05, np.float32),
+                                np.array([[1, 0, 0, 0]], np.float32), None)
+            assert st["radii"][0] > 0
+            got[i] = st["rgb"][0]
+        want = np.maximum(z[f"rgb_deg{deg}"] + 0.5, 0.0)
+        assert np.abs(got - want).max() < 2e-6, deg
+
+
+def test_camera_matrices_match_reference():
+    """scene/cameras.py:76-88 via vegs_amd.scenes.make_camera."""
+    z = np.load(os.path.join(GOLDEN, "ref_camera.npz"))
+    for tag in ("1408", "1376"):
+        fx, fy, cx, cy, W, H = z[f"K_{tag}"]
+        cam = scenes.make_camera(z[f"R_{tag}"], z[f"T_{tag}"], int(W), int(H), fx, fy, cx, cy)
+        assert np.allclose([cam.FoVx, cam.FoVy], z[f"fov_{tag}"], rtol=0, atol=1e-12)
+        assert np.abs(cam.world_view_transform - z[f"view_{tag}"]).max() < 1e-6
+        assert np.abs(cam.full_proj_transform - z[f"full_{tag}"]).max() < 2e-6
+        assert np.abs(cam.camera_center - z[f"center_{tag}"]).max() < 1e-5
+
+
+def test_normal_guidance_restatement_matches_reference():
+    """loss/normal_guidance.py:3-22: value and gradients w.r.t. the op's extra outputs."""
+    z = np.load(os.path.join(GOLDEN, "ref_normal_guidance.npz"))
+    cq = torch.tensor(z["cov_quat"], requires_grad=True)
+    cs = torch.tensor(z["cov_scale"], requires_grad=True)
+    loss = normal_guidance_loss(cq, cs, torch.tensor(z["normal"]), z["R"])
+    loss.backward()
+    assert abs(loss.item() - float(z["loss"])) < 1e-6
+    assert np.abs(cq.grad.numpy() - z["grad_cov_quat"]).max() < 1e-7
+    assert np.abs(cs.grad.numpy() - z["grad_cov_scale"]).max() < 1e-7
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_forward_matches_golden(name):
+    c = load_case(name)
+    oc = oracle_cam_from_case(c)
+    out, st = orc.forward(oc, **case_inputs(c))
+    assert np.array_equal(out["radii"], c["radii"])
+    for n in OUT_NAMES:
+        scale = max(1.0, np.abs(c["out_" + n]).max())
+        assert np.abs(out[n] - c["out_" + n]).max() < 1e-5 * scale, n   # fp32 oracle vs fp64 golden
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_backward_matches_golden(name):
+    c = load_case(name)
+    oc = oracle_cam_from_case(c)
+    out, st = orc.forward(oc, **case_inputs(c))
+    g = orc.backward(oc, st, c["gout_color"], c["gout_depth"], c["gout_cov_quat"], c["gout_cov_scale"], c["gout_alpha"])
+    keys = [k[5:] for k in c if k.startswith("grad_")]
+    assert len(keys) >= 5
+    for k in keys:
+        assert g[k] is not None, k
+        assert g[k].shape == c["grad_" + k].shape, k
+        assert rel_err(g[k], c["grad_" + k]) < 2e-4, (k, rel_err(g[k], c["grad_" + k]))
+    assert np.all(g["means2D"][:, 2] == 0)
+
+
+def test_oracle_sort_order_is_tile_depth_id():
+    c = load_case("case_sh3")
+    oc = oracle_cam_from_case(c)
+    out, st = orc.forward(oc, **case_inputs(c))
+    keys, pl = st["keys"], st["point_list"]
+    assert np.all(np.diff(keys.astype(np.uint64)) >= 0) or np.all(keys[1:] >= keys[:-1])
+    same = keys[1:] == keys[:-1]
+    assert np.all(pl[1:][same] > pl[:-1][same])
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    for t, (s, e) in enumerate(st["ranges"]):
+        assert np.all(tiles[s:e] == t)
+    assert sum(e - s for s, e in st["ranges"]) == st["R"]
+
+
+def test_oracle_mark_visible():
+    c = load_case("case_cull_deg1")
+    oc = oracle_cam_from_case(c)
+    vis = orc.mark_visible(oc, c["in_means3D"])
+    V = c["viewmatrix"]
+    z = c["in_means3D"] @ V[:3, 2] + V[3, 2]
+    far = np.abs(z - 0.2) > 1e-5
+    assert np.array_equal(vis[far], (z > 0.2)[far])
+    assert 0 < vis.sum() < len(vis)

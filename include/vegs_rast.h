@@ -1,0 +1,164 @@
+/*
+ * vegs_rast.h -- C ABI of libvegsrast.so: MI355X (gfx950) differentiable Gaussian-splatting
+ * rasterizer, the drop-in for the native half of VEGS' `diff_gaussian_rasterization`
+ * extension (un-vendored submodule, reference .gitmodules:7-9).
+ *
+ * What each entry point replaces (the reference binds these through the extension's
+ * pybind module `_C`; its callers are cited):
+ *   vr_forward       <- _C.rasterize_gaussians          called by GaussianRasterizer.forward,
+ *                       reference gaussian_renderer/__init__.py:86-94, :230, :303
+ *   vr_backward      <- _C.rasterize_gaussians_backward triggered by loss.backward(),
+ *                       reference train.py:196
+ *   vr_mark_visible  <- _C.mark_visible                 called by GaussianRasterizer.markVisible,
+ *                       reference utils/norminit_utils.py:55, :179
+ * Settings mirror the 12 fields of GaussianRasterizationSettings as filled at reference
+ * gaussian_renderer/__init__.py:38-51.
+ *
+ * Conventions: plain C structs of DEVICE pointers (fp32, contiguous) plus scalars; no
+ * exceptions cross the ABI; every function returns 0 on success or a negative VrStatus and
+ * vr_last_error() describes the failure.  All work is enqueued on `stream` (a hipStream_t
+ * passed as void*) of the CURRENT device.  vr_forward blocks the host once (to learn the
+ * number of tile-list entries) exactly as the reference op does.  Memory is owned by the
+ * caller: the library asks for buffers through VrAllocFn and never frees them.
+ */
+#ifndef VEGS_RAST_H
+#define VEGS_RAST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VR_ABI_VERSION 1
+
+typedef enum VrStatus {
+    VR_OK = 0,
+    VR_ERR_INVALID_ARGUMENT = -1, /* shape / NULL / either-or violations (same rules as the reference shim) */
+    VR_ERR_ALLOC = -2,            /* allocator callback returned NULL */
+    VR_ERR_HIP = -3,              /* a HIP runtime call or kernel failed */
+    VR_ERR_NO_DEVICE = -4
+} VrStatus;
+
+/* which buffer the library is asking for */
+typedef enum VrBufferKind {
+    VR_BUF_GEOM = 0,    /* per-Gaussian state, kept for backward  (O(P)) */
+    VR_BUF_BINNING = 1, /* sorted tile lists, kept for backward   (O(R)) */
+    VR_BUF_IMAGE = 2,   /* per-pixel state, kept for backward     (O(H*W)) */
+    VR_BUF_SCRATCH = 3  /* transient; may be released when the call returns (several requests per call) */
+} VrBufferKind;
+
+/* Must return a device pointer to at least `bytes` bytes, 256-byte aligned, valid on `stream`
+ * (NULL = failure).  GEOM/BINNING/IMAGE must stay alive until the matching vr_backward. */
+typedef void* (*VrAllocFn)(void* user, int kind, size_t bytes);
+
+typedef struct VrSettings {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    int32_t sh_degree;   /* active degree 0..3 */
+    int32_t prefiltered; /* accepted for API parity; unused (as upstream) */
+    int32_t debug;       /* !=0: synchronise and check after every kernel */
+    const float* bg;         /* device [3] */
+    const float* viewmatrix; /* device [16], row-major 4x4, row-vector convention (scene/cameras.py:76) */
+    const float* projmatrix; /* device [16], full_proj_transform (scene/cameras.py:87) */
+    const float* campos;     /* device [3] */
+} VrSettings;
+
+/* The op's tensor arguments (reference gaussian_renderer/__init__.py:86-94). Exactly one of
+ * shs / colors_precomp and exactly one of (scales, rotations) / cov3D_precomp is non-NULL. */
+typedef struct VrInputs {
+    int32_t P;                   /* number of Gaussians */
+    int32_t M;                   /* SH coefficients stored per Gaussian (shs.shape[1]); 0 if shs == NULL */
+    const float* means3D;        /* [P,3] */
+    const float* shs;            /* [P,M,3] or NULL */
+    const float* colors_precomp; /* [P,3] or NULL */
+    const float* opacities;      /* [P,1] */
+    const float* scales;         /* [P,3] or NULL */
+    const float* rotations;      /* [P,4] (w,x,y,z) or NULL */
+    const float* cov3D_precomp;  /* [P,6] or NULL */
+} VrInputs;
+
+typedef struct VrOutputs {
+    float* color;     /* [3,H,W] */
+    float* depth;     /* [1,H,W] */
+    float* cov_quat;  /* [4,H,W] */
+    float* cov_scale; /* [3,H,W] */
+    float* alpha;     /* [1,H,W] */
+    int32_t* radii;   /* [P] */
+} VrOutputs;
+
+/* Filled by vr_forward; pass it unchanged to vr_backward. */
+typedef struct VrSaved {
+    void* geom;
+    void* binning;
+    void* image;
+    int64_t num_rendered; /* R: tile-list entries */
+    int64_t num_visible;  /* V: Gaussians with radii > 0 */
+} VrSaved;
+
+/* Incoming gradients, one per differentiable output (NULL = zero). */
+typedef struct VrOutGrads {
+    const float* dL_dcolor;     /* [3,H,W] */
+    const float* dL_ddepth;     /* [1,H,W] */
+    const float* dL_dcov_quat;  /* [4,H,W] */
+    const float* dL_dcov_scale; /* [3,H,W] */
+    const float* dL_dalpha;     /* [1,H,W] */
+} VrOutGrads;
+
+/* Dense gradients w.r.t. the inputs; the library fully overwrites every non-NULL array
+ * (zeros for culled Gaussians).  dL_dmeans2D is [P,3] with z == 0 and x,y = d loss / d NDC
+ * (the quantity scene/gaussian_model.py:411-413 norms).  Arrays whose input was NULL are NULL. */
+typedef struct VrInGrads {
+    float* dL_dmeans3D;        /* [P,3] */
+    float* dL_dmeans2D;        /* [P,3] */
+    float* dL_dshs;            /* [P,M,3] or NULL */
+    float* dL_dcolors_precomp; /* [P,3] or NULL */
+    float* dL_dopacities;      /* [P,1] */
+    float* dL_dscales;         /* [P,3] or NULL */
+    float* dL_drotations;      /* [P,4] or NULL */
+    float* dL_dcov3D_precomp;  /* [P,6] or NULL */
+} VrInGrads;
+
+/* Work counters of the most recent vr_forward on this thread (roofline accounting). */
+typedef struct VrCounters {
+    int64_t P;           /* Gaussians */
+    int64_t num_visible; /* V */
+    int64_t num_rendered;/* R */
+    int64_t num_tiles;   /* T */
+    int64_t num_pixels;  /* N */
+} VrCounters;
+
+int vr_abi_version(void);
+const char* vr_last_error(void);
+
+int vr_forward(const VrSettings* settings, const VrInputs* in, const VrOutputs* out,
+               VrAllocFn alloc, void* alloc_user, void* stream, VrSaved* saved);
+
+int vr_backward(const VrSettings* settings, const VrInputs* in, const int32_t* radii,
+                const VrSaved* saved, const VrOutGrads* gout, const VrInGrads* gin,
+                VrAllocFn alloc, void* alloc_user, void* stream);
+
+/* present[i] = view-space z of xyz[i] > 0.2 (no screen-bounds test). */
+int vr_mark_visible(const float* xyz, int32_t P, const float* viewmatrix, const float* projmatrix,
+                    uint8_t* present, void* stream);
+
+void vr_get_counters(VrCounters* out);
+
+/* F = sum over pixels of n_contrib (fragments traversed by the forward blend loop) of the
+ * forward whose state is `saved`; blocks the host. */
+int vr_count_fragments(const VrSaved* saved, int32_t image_height, int32_t image_width, void* stream,
+                       int64_t* fragments);
+
+/* Introspection for tests: copies of the sorted tile lists kept in `saved` (device -> device).
+ * point_list [R] uint32, ranges [T][2] int32 (start,end).  Either pointer may be NULL. */
+int vr_debug_export_binning(const VrSaved* saved, int32_t image_height, int32_t image_width,
+                            uint32_t* point_list, int32_t* ranges, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VEGS_RAST_H */

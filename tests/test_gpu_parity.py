@@ -1,0 +1,263 @@
+"""GPU (-m gpu): parity of the HIP path (through the C ABI of libvegsrast.so, via the
+diff_gaussian_rasterization surface) against the CPU oracle and the committed golden fixtures.
+
+Bars: integer/index results (radii, point lists, tile ranges) bit-exact; forward images bit-exact
+against the fp32 oracle (same operation order) and within 1e-5 of the float64 golden images;
+gradients within a tensor-level relative tolerance (fp32 atomics are order-dependent).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import OUT_NAMES, case_inputs, load_case, normal_guidance_loss, oracle_cam, oracle_cam_from_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+GRAD_RTOL = 2e-4   # tensor-level relative error, gradients (HIP fp32 atomics vs oracle double sums)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from vegs_amd import _capi
+    _capi.load()   # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def _settings(c_or_cam, bg, deg, mod, dev, debug=False):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    if isinstance(c_or_cam, dict):
+        c = c_or_cam
+        P, W, H, deg = (int(v) for v in c["meta"])
+        return GaussianRasterizationSettings(H, W, float(c["tanfov"][0]), float(c["tanfov"][1]),
+                                             torch.tensor(c["bg"], device=dev), float(c["scale_modifier"]),
+                                             torch.tensor(c["viewmatrix"], device=dev),
+                                             torch.tensor(c["projmatrix"], device=dev), deg,
+                                             torch.tensor(c["campos"], device=dev), False, debug)
+    cam = c_or_cam
+    return GaussianRasterizationSettings(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy,
+                                         torch.tensor(np.asarray(bg, np.float32), device=dev), mod,
+                                         torch.tensor(cam.world_view_transform, device=dev),
+                                         torch.tensor(cam.full_proj_transform, device=dev), deg,
+                                         torch.tensor(cam.camera_center, device=dev), False, debug)
+
+
+def _run_hip(settings, inputs, dev, gouts=None):
+    """inputs: dict of numpy (op kwargs).  Returns (outputs dict np, grads dict np or None, ctx info)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    T = {k: (None if v is None else torch.tensor(v, device=dev, requires_grad=True)) for k, v in inputs.items()}
+    P = inputs["means3D"].shape[0]
+    m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
+    rast = GaussianRasterizer(raster_settings=settings)
+    res = rast(means3D=T["means3D"], means2D=m2d, shs=T["shs"], colors_precomp=T["colors_precomp"],
+               opacities=T["opacities"], scales=T["scales"], rotations=T["rotations"],
+               cov3D_precomp=T["cov3D_precomp"])
+    out = {n: r.detach().cpu().numpy() for n, r in zip(OUT_NAMES, res[:5])}
+    out["radii"] = res[5].cpu().numpy()
+    grads = None
+    if gouts is not None:
+        loss = sum((r * torch.tensor(g, device=dev)).sum() for r, g in zip(res[:5], gouts) if g is not None)
+        loss.backward()
+        grads = {k: (None if t is None else t.grad.cpu().numpy()) for k, t in T.items()}
+        grads["means2D"] = m2d.grad.cpu().numpy()
+    return out, grads, res
+
+
+def _export_binning(res, H, W, dev):
+    """(point_list, ranges) of the forward that produced `res`, through vr_debug_export_binning."""
+    from vegs_amd import _capi
+    fn = res[0].grad_fn
+    geom, binning, image = fn.buffers
+    R = fn.num_rendered
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    pl = torch.zeros(max(R, 1), dtype=torch.int32, device=dev)
+    rg = torch.zeros((T, 2), dtype=torch.int32, device=dev)
+    saved = _capi.VrSaved(geom.data_ptr(), binning.data_ptr(), image.data_ptr(), R, fn.num_visible)
+    rc = _capi.load().vr_debug_export_binning(C.byref(saved), H, W, pl.data_ptr(), rg.data_ptr(),
+                                              torch.cuda.current_stream(dev).cuda_stream)
+    _capi.check(rc)
+    torch.cuda.synchronize()
+    return pl[:R].cpu().numpy().astype(np.uint32), rg.cpu().numpy()
+
+
+def _check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=0, grad_rtol=GRAD_RTOL, gmask=(1, 1, 1, 1, 1)):
+    from oracle import oracle as orc
+    oc = oracle_cam(cam, bg, deg, mod)
+    o_out, st = orc.forward(oc, **inputs)
+    rng = np.random.default_rng(seed)
+    H, W = cam.image_height, cam.image_width
+    shapes = [(3, H, W), (1, H, W), (4, H, W), (3, H, W), (1, H, W)]
+    gouts = [rng.normal(size=s).astype(np.float32) if m else None for s, m in zip(shapes, gmask)]
+    h_out, h_grads, res = _run_hip(_settings(cam, bg, deg, mod, dev), inputs, dev, gouts)
+    # integers: bit exact
+    assert np.array_equal(h_out["radii"], o_out["radii"])
+    pl, rg = _export_binning(res, H, W, dev)
+    assert res[0].grad_fn.num_rendered == st["R"]
+    assert np.array_equal(rg, st["ranges"])
+    assert np.array_equal(pl, st["point_list"])
+    # forward images: same fp32 operation order -> bit exact
+    for n in OUT_NAMES:
+        assert np.array_equal(h_out[n], o_out[n]), (n, np.abs(h_out[n] - o_out[n]).max())
+    o_grads = orc.backward(oc, st, *gouts)
+    for k, g in h_grads.items():
+        if g is None:
+            assert o_grads[k] is None, k
+            continue
+        assert g.shape == o_grads[k].shape, k
+        assert rel_err(g, o_grads[k]) < grad_rtol, (k, rel_err(g, o_grads[k]))
+    return h_out, h_grads, o_out, st
+
+
+@pytest.mark.parametrize("name", ["case_sh3", "case_precomp", "case_cull_deg1"])
+def test_golden_fixture(name, dev):
+    """HIP vs the committed float64 golden vectors (tests/golden/raster_*.npz)."""
+    c = load_case(name)
+    gouts = [c["gout_" + n] for n in OUT_NAMES]
+    out, grads, _ = _run_hip(_settings(c, None, None, None, dev), case_inputs(c), dev, gouts)
+    assert np.array_equal(out["radii"], c["radii"])
+    for n in OUT_NAMES:
+        scale = max(1.0, np.abs(c["out_" + n]).max())
+        assert np.abs(out[n] - c["out_" + n]).max() < 1e-5 * scale, n
+    for k in [k[5:] for k in c if k.startswith("grad_")]:
+        assert rel_err(grads[k], c["grad_" + k]) < 3e-4, (k, rel_err(grads[k], c["grad_" + k]))
+    assert np.all(grads["means2D"][:, 2] == 0)
+
+
+@pytest.mark.parametrize("name", ["case_sh3", "case_precomp", "case_cull_deg1"])
+def test_golden_inputs_vs_oracle_bit_exact(name, dev):
+    from vegs_amd import scenes
+    c = load_case(name)
+    P, W, H, deg = (int(v) for v in c["meta"])
+    cam = scenes.camera_c1(W, H)
+    _check_against_oracle(case_inputs(c), cam, c["bg"], deg, float(c["scale_modifier"]), dev)
+
+
+def test_c1_random_10k(dev):
+    """BASELINE config 1: 10k random Gaussians, 256x256, SH degree 0."""
+    from vegs_amd import scenes
+    sc, deg = scenes.scene_random(P=10000, sh_degree=0, seed=0)
+    inputs = dict(means3D=sc["means3D"], shs=sc["shs"], colors_precomp=None, opacities=sc["opacities"],
+                  scales=sc["scales"], rotations=sc["rotations"], cov3D_precomp=None)
+    _check_against_oracle(inputs, scenes.camera_c1(256, 256), [0, 0, 0], deg, 1.0, dev)
+
+
+@pytest.mark.parametrize("W,H", [(1376, 376), (200, 120)])
+def test_street_small_ragged_image(W, H, dev):
+    """KITTI-360-shaped street (VEGS discs), SH degree 3; 376 and 120/200 are not multiples of 16."""
+    from vegs_amd import scenes
+    sc, deg = scenes.scene_street(P=20000, length=60.0, sh_degree=3, seed=1)
+    inputs = dict(means3D=sc["means3D"], shs=sc["shs"], colors_precomp=None, opacities=sc["opacities"],
+                  scales=sc["scales"], rotations=sc["rotations"], cov3D_precomp=None)
+    cam = scenes.kitti_camera(0.0, 0.0, W, H)
+    h_out, *_ = _check_against_oracle(inputs, cam, [0.0, 0.0, 0.0], deg, 1.0, dev, grad_rtol=5e-4)
+    assert (h_out["radii"] > 0).sum() > 1000
+
+
+def test_training_shaped_gradients_normal_guidance(dev):
+    """The losses VEGS trains with (train.py:162-168): L1 on colour + normal guidance on
+    cov_quat / cov_scale; only those three outputs carry gradient (depth/alpha grads are None)."""
+    from oracle import oracle as orc
+    from vegs_amd import harness, scenes
+    sc, deg = scenes.scene_street(P=6000, length=40.0, sh_degree=2, seed=5)
+    cam = scenes.kitti_camera(0.0, 0.0, 352, 96)
+    H, W = cam.image_height, cam.image_width
+    rng = np.random.default_rng(3)
+    target = torch.tensor(rng.uniform(0, 1, (3, H, W)).astype(np.float32), device=dev)
+    normal = torch.tensor(rng.normal(size=(3, H, W)).astype(np.float32), device=dev)
+    T = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in sc.items()}
+    bg = torch.zeros(3, device=dev)
+    pkg = harness.render(cam, T, deg, bg)
+    q = pkg["render_cov_quat"]
+    covered = (q * q).sum(0, keepdim=True) > 0           # A-5: empty pixels are exact zeros -> mask them
+    qs = torch.where(covered, q, torch.ones_like(q))
+    loss = (pkg["render"] - target).abs().mean() + 1e-3 * normal_guidance_loss(qs, pkg["render_cov_scale"], normal, cam.R)
+    gq, gs, gc = torch.autograd.grad(loss, [pkg["render_cov_quat"], pkg["render_cov_scale"], pkg["render"]],
+                                     retain_graph=True)
+    loss.backward()
+    vsp = pkg["viewspace_points"]
+    assert vsp.grad is not None and vsp.grad.shape == (6000, 3) and torch.all(vsp.grad[:, 2] == 0)
+    oc = oracle_cam(cam, [0, 0, 0], deg)
+    o_out, st = orc.forward(oc, sc["means3D"], sc["shs"], None, sc["opacities"], sc["scales"], sc["rotations"], None)
+    og = orc.backward(oc, st, gc.cpu().numpy(), None, gq.cpu().numpy(), gs.cpu().numpy(), None)
+    for k in ("means3D", "shs", "opacities", "scales", "rotations"):
+        assert rel_err(T[k].grad.cpu().numpy(), og[k]) < 5e-4, (k, rel_err(T[k].grad.cpu().numpy(), og[k]))
+    assert rel_err(vsp.grad.cpu().numpy(), og["means2D"]) < 5e-4
+    vis = pkg["visibility_filter"].cpu().numpy()
+    assert np.array_equal(vis, o_out["radii"] > 0)
+
+
+def test_edge_cases(dev):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from vegs_amd import scenes
+    cam = scenes.camera_c1(50, 35)
+    bgv = [0.2, 0.5, 0.7]
+    st = _settings(cam, bgv, 1, 1.0, dev)
+    rast = GaussianRasterizer(raster_settings=st)
+    # empty input -> background everywhere
+    z = lambda *s: torch.zeros(*s, device=dev)
+    color, depth, q, s, alpha, radii = rast(means3D=z(0, 3), means2D=z(0, 3), shs=z(0, 16, 3), opacities=z(0, 1),
+                                            scales=z(0, 3), rotations=z(0, 4))
+    assert radii.numel() == 0 and torch.all(alpha == 0) and torch.all(depth == 0)
+    assert torch.allclose(color, torch.tensor(bgv, device=dev)[:, None, None].expand(3, 35, 50))
+    # everything behind the camera -> culled, background
+    sc, deg = scenes.scene_random(P=100, sh_degree=1, seed=2)
+    sc["means3D"][:, 1] -= 10.0
+    inputs = dict(means3D=sc["means3D"], shs=sc["shs"], colors_precomp=None, opacities=sc["opacities"],
+                  scales=sc["scales"], rotations=sc["rotations"], cov3D_precomp=None)
+    out, grads, o_out, _ = _check_against_oracle(inputs, cam, bgv, 1, 1.0, dev)
+    assert np.all(out["radii"] == 0) and np.all(out["alpha"] == 0)
+    assert all(np.all(g == 0) for g in grads.values() if g is not None)
+    # one huge opaque Gaussian covering the screen + opacity 1 (alpha clamps at 0.99) + unnormalised quaternion
+    inputs = dict(means3D=np.array([[0, 0, 0], [0.1, 0.3, 0.0]], np.float32), shs=np.zeros((2, 16, 3), np.float32),
+                  colors_precomp=None, opacities=np.array([[1.0], [1.0]], np.float32),
+                  scales=np.array([[5.0, 5.0, 5.0], [0.05, 0.2, 0.1]], np.float32),
+                  rotations=np.array([[2.0, 0, 0, 0], [0.3, 0.9, -0.4, 0.2]], np.float32), cov3D_precomp=None)
+    inputs["shs"][:, 0] = 1.0
+    out, *_ = _check_against_oracle(inputs, cam, bgv, 1, 1.0, dev)
+    assert out["alpha"].min() > 0.9
+
+
+def test_mark_visible(dev):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from oracle import oracle as orc
+    from vegs_amd import scenes
+    sc, _ = scenes.scene_random(P=5000, sh_degree=0, seed=4, extent=3.0)
+    cam = scenes.camera_c1(64, 64)
+    rast = GaussianRasterizer(raster_settings=_settings(cam, [0, 0, 0], 0, 1.0, dev))
+    got = rast.markVisible(torch.tensor(sc["means3D"], device=dev))
+    want = orc.mark_visible(oracle_cam(cam, [0, 0, 0], 0), sc["means3D"])
+    assert got.dtype == torch.bool and np.array_equal(got.cpu().numpy(), want)
+    assert 0 < want.sum() < 5000
+
+
+def test_argument_errors(dev):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from vegs_amd import scenes
+    cam = scenes.camera_c1(32, 32)
+    rast = GaussianRasterizer(raster_settings=_settings(cam, [0, 0, 0], 3, 1.0, dev))
+    z = lambda *s: torch.zeros(*s, device=dev)
+    with pytest.raises(Exception):
+        rast(means3D=z(4, 3), means2D=z(4, 3), opacities=z(4, 1), scales=z(4, 3), rotations=z(4, 4))
+    with pytest.raises(Exception):
+        rast(means3D=z(4, 3), means2D=z(4, 3), opacities=z(4, 1), shs=z(4, 16, 3), colors_precomp=z(4, 3),
+             scales=z(4, 3), rotations=z(4, 4))
+    with pytest.raises(Exception):
+        rast(means3D=z(4, 3), means2D=z(4, 3), opacities=z(4, 1), shs=z(4, 16, 3), scales=z(4, 3))
+    with pytest.raises(Exception):   # degree 3 needs 16 coefficients
+        rast(means3D=z(4, 3), means2D=z(4, 3), opacities=z(4, 1), shs=z(4, 4, 3), scales=z(4, 3), rotations=z(4, 4))
+    with pytest.raises(Exception):
+        rast(means3D=z(4, 2), means2D=z(4, 3), opacities=z(4, 1), shs=z(4, 16, 3), scales=z(4, 3), rotations=z(4, 4))
+    with pytest.raises(Exception):   # CPU tensors: no CPU path, fail loudly
+        rast(means3D=torch.zeros(4, 3), means2D=torch.zeros(4, 3), opacities=torch.zeros(4, 1),
+             shs=torch.zeros(4, 16, 3), scales=torch.zeros(4, 3), rotations=torch.zeros(4, 4))
+
+
+def test_debug_mode_runs(dev):
+    from vegs_amd import harness, scenes
+    sc, deg = scenes.scene_random(P=500, sh_degree=1, seed=8)
+    T = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in sc.items()}
+    pkg = harness.render(scenes.camera_c1(64, 64), T, deg, torch.zeros(3, device=dev), debug=True)
+    pkg["render"].sum().backward()
+    assert torch.isfinite(T["means3D"].grad).all()

@@ -1,0 +1,146 @@
+"""ctypes binding of libvegsrast.so (C ABI declared in include/vegs_rast.h).
+
+There is no fallback: if the HIP library is missing or does not export the ABI, importing the
+product path raises.  PyTorch is plumbing here (device memory, current stream); the signatures
+crossing the boundary are plain pointers and sizes.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libvegsrast.so")
+ABI_VERSION = 1
+
+VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH = 0, 1, 2, 3
+
+# every symbol include/vegs_rast.h declares
+EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_mark_visible", "vr_get_counters",
+           "vr_count_fragments", "vr_debug_export_binning"]
+
+
+class VrSettings(C.Structure):
+    _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float),
+                ("tanfovy", C.c_float), ("scale_modifier", C.c_float), ("sh_degree", C.c_int32),
+                ("prefiltered", C.c_int32), ("debug", C.c_int32), ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
+                ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
+
+
+class VrInputs(C.Structure):
+    _fields_ = [("P", C.c_int32), ("M", C.c_int32), ("means3D", C.c_void_p), ("shs", C.c_void_p),
+                ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
+                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p)]
+
+
+class VrOutputs(C.Structure):
+    _fields_ = [("color", C.c_void_p), ("depth", C.c_void_p), ("cov_quat", C.c_void_p), ("cov_scale", C.c_void_p),
+                ("alpha", C.c_void_p), ("radii", C.c_void_p)]
+
+
+class VrSaved(C.Structure):
+    _fields_ = [("geom", C.c_void_p), ("binning", C.c_void_p), ("image", C.c_void_p), ("num_rendered", C.c_int64),
+                ("num_visible", C.c_int64)]
+
+
+class VrOutGrads(C.Structure):
+    _fields_ = [("dL_dcolor", C.c_void_p), ("dL_ddepth", C.c_void_p), ("dL_dcov_quat", C.c_void_p),
+                ("dL_dcov_scale", C.c_void_p), ("dL_dalpha", C.c_void_p)]
+
+
+class VrInGrads(C.Structure):
+    _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
+                ("dL_dcolors_precomp", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
+                ("dL_drotations", C.c_void_p), ("dL_dcov3D_precomp", C.c_void_p)]
+
+
+class VrCounters(C.Structure):
+    _fields_ = [("P", C.c_int64), ("num_visible", C.c_int64), ("num_rendered", C.c_int64), ("num_tiles", C.c_int64),
+                ("num_pixels", C.c_int64)]
+
+
+VrAllocFn = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
+
+_lib = None
+
+
+def load():
+    """Load libvegsrast.so; raise (never fall back) if it is absent or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `python -m vegs_amd.build` "
+                          "(there is no CPU or PyTorch fallback for the rasterizer)")
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise ImportError(f"{LIB_PATH} does not export {name}")
+    lib.vr_abi_version.restype = C.c_int
+    lib.vr_last_error.restype = C.c_char_p
+    lib.vr_forward.restype = C.c_int
+    lib.vr_forward.argtypes = [C.POINTER(VrSettings), C.POINTER(VrInputs), C.POINTER(VrOutputs), VrAllocFn,
+                               C.c_void_p, C.c_void_p, C.POINTER(VrSaved)]
+    lib.vr_backward.restype = C.c_int
+    lib.vr_backward.argtypes = [C.POINTER(VrSettings), C.POINTER(VrInputs), C.c_void_p, C.POINTER(VrSaved),
+                                C.POINTER(VrOutGrads), C.POINTER(VrInGrads), VrAllocFn, C.c_void_p, C.c_void_p]
+    lib.vr_mark_visible.restype = C.c_int
+    lib.vr_mark_visible.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.vr_get_counters.restype = None
+    lib.vr_get_counters.argtypes = [C.POINTER(VrCounters)]
+    lib.vr_count_fragments.restype = C.c_int
+    lib.vr_count_fragments.argtypes = [C.POINTER(VrSaved), C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]
+    lib.vr_debug_export_binning.restype = C.c_int
+    lib.vr_debug_export_binning.argtypes = [C.POINTER(VrSaved), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]
+    if lib.vr_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.vr_abi_version()} != {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+class VegsRastError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise VegsRastError(f"libvegsrast error {rc}: {load().vr_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor, or NULL for None / empty tensors."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+class Arena:
+    """Allocator handed to the library: byte tensors from torch's caching allocator.
+
+    GEOM / BINNING / IMAGE tensors are kept (they are saved for backward); SCRATCH tensors
+    are dropped when the arena is released, i.e. returned to the caching allocator, which is
+    safe because all work was enqueued on the same stream.
+    """
+
+    def __init__(self, device):
+        self.device = device
+        self.kept = {}
+        self.scratch = []
+        self.error = None
+        self.callback = VrAllocFn(self._alloc)
+
+    def _alloc(self, _user, kind, nbytes):
+        try:
+            t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)
+            if kind == VR_BUF_SCRATCH:
+                self.scratch.append(t)
+            else:
+                self.kept[kind] = t
+            return t.data_ptr()
+        except BaseException as e:  # never let an exception cross the C boundary
+            self.error = e
+            return 0
+
+    def release_scratch(self):
+        self.scratch.clear()

@@ -1,0 +1,68 @@
+"""Builds vegs_amd/_lib/libvegsrast.so (C ABI: include/vegs_rast.h) with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU.  Flags that are part of the numerics contract:
+  -ffp-contract=off      every fused multiply-add in the kernels is an explicit fmaf()
+  -munsafe-fp-atomics    fp32 atomicAdd lowers to the hardware global/LDS atomic, not a CAS loop
+Run:  python -m vegs_amd.build [--force]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "_lib")
+OBJ_DIR = os.path.join(OUT_DIR, "obj")
+LIB = os.path.join(OUT_DIR, "libvegsrast.so")
+SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "render_fwd.hip", "render_bwd.hip", "preprocess_bwd.hip"]
+HEADERS = ["vr_device.h", "vr_host.h", os.path.join("..", "..", "include", "vegs_rast.h")]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        if force or _newer(obj, [sp] + hdrs):
+            jobs.append([_hipcc(), *FLAGS, "-c", sp, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        return r.stderr
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            for warn in ex.map(run, jobs):
+                if verbose and warn.strip():
+                    print(warn)
+    objs = [os.path.join(OBJ_DIR, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _newer(LIB, objs):
+        run([_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

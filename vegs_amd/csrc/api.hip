@@ -1,0 +1,289 @@
+// api.hip -- the C ABI of libvegsrast.so (include/vegs_rast.h): argument validation, buffer
+// layout, and the kernel sequence of forward / backward / mark_visible.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/vegs_rast.h"
+#include "vr_host.h"
+
+namespace vr {
+
+static thread_local char g_err[512] = "";
+static thread_local VrCounters g_counters = {0, 0, 0, 0, 0};
+static thread_local uint32_t* g_pinned = nullptr;  // 2 x uint32 host-pinned mailbox for (V, R)
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int make_camera(const VrSettings* st, int M, Camera* cam)
+{
+    if (!st) return fail(VR_ERR_INVALID_ARGUMENT, "settings is NULL");
+    if (st->image_height <= 0 || st->image_width <= 0)
+        return fail(VR_ERR_INVALID_ARGUMENT, "image size must be positive (got %d x %d)", st->image_height,
+                    st->image_width);
+    if (!st->bg || !st->viewmatrix || !st->projmatrix || !st->campos)
+        return fail(VR_ERR_INVALID_ARGUMENT, "bg, viewmatrix, projmatrix and campos must be device pointers");
+    if (st->sh_degree < 0 || st->sh_degree > 3)
+        return fail(VR_ERR_INVALID_ARGUMENT, "sh_degree must be in 0..3 (got %d)", st->sh_degree);
+    cam->H = st->image_height;
+    cam->W = st->image_width;
+    cam->gx = (cam->W + TILE - 1) / TILE;
+    cam->gy = (cam->H + TILE - 1) / TILE;
+    cam->tanfovx = st->tanfovx;
+    cam->tanfovy = st->tanfovy;
+    cam->fx = (float)cam->W / (2.0f * st->tanfovx);
+    cam->fy = (float)cam->H / (2.0f * st->tanfovy);
+    cam->mod = st->scale_modifier;
+    cam->deg = st->sh_degree;
+    cam->M = M;
+    cam->view = st->viewmatrix;
+    cam->proj = st->projmatrix;
+    cam->campos = st->campos;
+    cam->bg = st->bg;
+    return 0;
+}
+
+static int check_inputs(const VrSettings* st, const VrInputs* in)
+{
+    if (!in) return fail(VR_ERR_INVALID_ARGUMENT, "inputs is NULL");
+    if (in->P < 0) return fail(VR_ERR_INVALID_ARGUMENT, "means3D must have dimensions (num_points, 3)");
+    if (in->P > 0 && (!in->means3D || !in->opacities))
+        return fail(VR_ERR_INVALID_ARGUMENT, "means3D and opacities are required");
+    if ((in->shs == nullptr) == (in->colors_precomp == nullptr) && in->P > 0)
+        return fail(VR_ERR_INVALID_ARGUMENT, "exactly one of shs and colors_precomp must be given");
+    bool sr = in->scales != nullptr || in->rotations != nullptr;
+    if (in->P > 0) {
+        if (sr == (in->cov3D_precomp != nullptr) || (sr && (!in->scales || !in->rotations)))
+            return fail(VR_ERR_INVALID_ARGUMENT,
+                        "exactly one of (scales, rotations) and cov3D_precomp must be given");
+        if (in->shs) {
+            int K = (st->sh_degree + 1) * (st->sh_degree + 1);
+            if (in->M < K)
+                return fail(VR_ERR_INVALID_ARGUMENT, "shs holds %d coefficients but sh_degree %d needs %d", in->M,
+                            st->sh_degree, K);
+        }
+    }
+    return 0;
+}
+
+struct ImageLayout { size_t counters, final_T, n_contrib, total; };
+static ImageLayout image_layout(size_t N)
+{
+    ImageLayout L;
+    L.counters = 0;
+    L.final_T = 256;
+    L.n_contrib = L.final_T + align_up(N * 4, 256);
+    L.total = L.n_contrib + align_up(N * 4, 256);
+    return L;
+}
+struct BinLayout { size_t ranges, point_list, total; };
+static BinLayout bin_layout(size_t T, size_t R)
+{
+    BinLayout L;
+    L.ranges = 0;
+    L.point_list = align_up(T * 8, 256);
+    L.total = L.point_list + align_up((R > 0 ? R : 1) * 4, 256);
+    return L;
+}
+
+}  // namespace vr
+
+using namespace vr;
+
+extern "C" {
+
+int vr_abi_version(void) { return VR_ABI_VERSION; }
+
+const char* vr_last_error(void) { return g_err; }
+
+void vr_get_counters(VrCounters* out)
+{
+    if (out) *out = g_counters;
+}
+
+int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, VrAllocFn alloc, void* user,
+               void* stream, VrSaved* saved)
+{
+    g_err[0] = 0;
+    if (!out || !saved || !alloc) return fail(VR_ERR_INVALID_ARGUMENT, "outputs, saved and alloc are required");
+    int rc = check_inputs(st, in);
+    if (rc) return rc;
+    Camera cam;
+    rc = make_camera(st, in->M, &cam);
+    if (rc) return rc;
+    if (!out->color || !out->depth || !out->cov_quat || !out->cov_scale || !out->alpha || (in->P > 0 && !out->radii))
+        return fail(VR_ERR_INVALID_ARGUMENT, "all six output arrays are required");
+    hipStream_t s = (hipStream_t)stream;
+    const bool debug = st->debug != 0;
+    const int P = in->P;
+    const size_t N = (size_t)cam.H * cam.W, T = (size_t)cam.gx * cam.gy;
+
+    if (!g_pinned) VR_HIP(hipHostMalloc((void**)&g_pinned, 256, hipHostMallocDefault));
+
+    // ---- buffers that survive until backward
+    const size_t p1 = (size_t)(P > 0 ? P : 1);
+    void* geom = alloc(user, VR_BUF_GEOM, align_up(p1 * sizeof(Splat), 256));
+    const ImageLayout IL = image_layout(N);
+    void* image = alloc(user, VR_BUF_IMAGE, IL.total);
+    // ---- transient, P-sized
+    const size_t s1 = binning_stage1_scratch_bytes(P);
+    const size_t arr = align_up(p1 * 4, 256);
+    void* scr = alloc(user, VR_BUF_SCRATCH, 4 * arr + s1 + 256);
+    if (!geom || !image || !scr) return fail(VR_ERR_ALLOC, "allocator returned NULL");
+    Splat* rec = (Splat*)geom;
+    float* final_T = (float*)((char*)image + IL.final_T);
+    uint32_t* n_contrib = (uint32_t*)((char*)image + IL.n_contrib);
+    uint32_t* tiles_touched = (uint32_t*)scr;
+    uint32_t* depth_key = (uint32_t*)((char*)scr + arr);
+    uint32_t* vis_key = (uint32_t*)((char*)scr + 2 * arr);
+    uint32_t* vis_id = (uint32_t*)((char*)scr + 3 * arr);
+    void* scan_scr = (char*)scr + 4 * arr;
+    uint32_t* totals_dev = (uint32_t*)((char*)scr + 4 * arr + s1);
+
+    uint32_t V = 0, R = 0;
+    if (P > 0) {
+        rc = launch_preprocess(cam, P, in->means3D, in->shs, in->colors_precomp, in->opacities, in->scales,
+                               in->rotations, in->cov3D_precomp, rec, out->radii, tiles_touched, depth_key, s, debug);
+        if (rc) return rc;
+        rc = launch_compact_visible(P, tiles_touched, depth_key, scan_scr, vis_key, vis_id, totals_dev, s, debug);
+        if (rc) return rc;
+        // the one host<->device round trip of the forward pass: sizes of the data-dependent lists
+        VR_HIP(hipMemcpyAsync(g_pinned, totals_dev, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        VR_HIP(hipStreamSynchronize(s));
+        V = g_pinned[0];
+        R = g_pinned[1];
+    }
+    const BinLayout BL = bin_layout(T, R);
+    void* binning = alloc(user, VR_BUF_BINNING, BL.total);
+    void* scr2 = alloc(user, VR_BUF_SCRATCH, binning_stage2_scratch_bytes((int)V, (long)R, (int)T));
+    if (!binning || !scr2) return fail(VR_ERR_ALLOC, "allocator returned NULL");
+    int2* ranges = (int2*)((char*)binning + BL.ranges);
+    uint32_t* point_list = (uint32_t*)((char*)binning + BL.point_list);
+    rc = launch_binning(cam, (int)V, (long)R, vis_key, vis_id, rec, out->radii, tiles_touched, scr2, point_list,
+                        ranges, s, debug);
+    if (rc) return rc;
+    rc = launch_render_fwd(cam, ranges, point_list, rec, out->color, out->depth, out->cov_quat, out->cov_scale,
+                           out->alpha, final_T, n_contrib, s, debug);
+    if (rc) return rc;
+
+    saved->geom = geom;
+    saved->binning = binning;
+    saved->image = image;
+    saved->num_rendered = (int64_t)R;
+    saved->num_visible = (int64_t)V;
+    g_counters.P = P;
+    g_counters.num_visible = V;
+    g_counters.num_rendered = R;
+    g_counters.num_tiles = (int64_t)T;
+    g_counters.num_pixels = (int64_t)N;
+    return VR_OK;
+}
+
+int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, const VrSaved* saved,
+                const VrOutGrads* gout, const VrInGrads* gin, VrAllocFn alloc, void* user, void* stream)
+{
+    g_err[0] = 0;
+    if (!saved || !gout || !gin || !alloc) return fail(VR_ERR_INVALID_ARGUMENT, "saved, grads and alloc are required");
+    int rc = check_inputs(st, in);
+    if (rc) return rc;
+    Camera cam;
+    rc = make_camera(st, in->M, &cam);
+    if (rc) return rc;
+    const int P = in->P;
+    if (P == 0) return VR_OK;
+    if (!radii || !saved->geom || !saved->binning || !saved->image)
+        return fail(VR_ERR_INVALID_ARGUMENT, "radii and the saved forward buffers are required");
+    if (!gin->dL_dmeans3D || !gin->dL_dmeans2D || !gin->dL_dopacities)
+        return fail(VR_ERR_INVALID_ARGUMENT, "dL_dmeans3D, dL_dmeans2D and dL_dopacities are required");
+    if ((in->shs && !gin->dL_dshs) || (in->colors_precomp && !gin->dL_dcolors_precomp) ||
+        (in->scales && (!gin->dL_dscales || !gin->dL_drotations)) || (in->cov3D_precomp && !gin->dL_dcov3D_precomp))
+        return fail(VR_ERR_INVALID_ARGUMENT, "a gradient array is missing for a provided input");
+    hipStream_t s = (hipStream_t)stream;
+    const bool debug = st->debug != 0;
+    const size_t N = (size_t)cam.H * cam.W, T = (size_t)cam.gx * cam.gy;
+    const ImageLayout IL = image_layout(N);
+    const BinLayout BL = bin_layout(T, (size_t)saved->num_rendered);
+    const Splat* rec = (const Splat*)saved->geom;
+    const float* final_T = (const float*)((const char*)saved->image + IL.final_T);
+    const uint32_t* n_contrib = (const uint32_t*)((const char*)saved->image + IL.n_contrib);
+    const int2* ranges = (const int2*)((const char*)saved->binning + BL.ranges);
+    const uint32_t* point_list = (const uint32_t*)((const char*)saved->binning + BL.point_list);
+
+    float* gacc = (float*)alloc(user, VR_BUF_SCRATCH, (size_t)P * 16 * sizeof(float));
+    if (!gacc) return fail(VR_ERR_ALLOC, "allocator returned NULL");
+    VR_HIP(hipMemsetAsync(gacc, 0, (size_t)P * 16 * sizeof(float), s));
+    VR_HIP(hipMemsetAsync(gin->dL_dmeans2D, 0, (size_t)P * 3 * sizeof(float), s));
+    if (gin->dL_dshs) VR_HIP(hipMemsetAsync(gin->dL_dshs, 0, (size_t)P * in->M * 3 * sizeof(float), s));
+    if (saved->num_rendered > 0) {
+        rc = launch_render_bwd(cam, ranges, point_list, rec, final_T, n_contrib, gout->dL_dcolor, gout->dL_ddepth,
+                               gout->dL_dcov_quat, gout->dL_dcov_scale, gout->dL_dalpha, gacc, gin->dL_dmeans2D, s,
+                               debug);
+        if (rc) return rc;
+    }
+    rc = launch_preprocess_bwd(cam, P, in->means3D, in->shs, in->colors_precomp, in->scales, in->rotations,
+                               in->cov3D_precomp, radii, rec, gacc, gin->dL_dmeans2D, gin->dL_dmeans3D, gin->dL_dshs,
+                               gin->dL_dcolors_precomp, gin->dL_dopacities, gin->dL_dscales, gin->dL_drotations,
+                               gin->dL_dcov3D_precomp, s, debug);
+    return rc;
+}
+
+int vr_mark_visible(const float* xyz, int32_t P, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                    void* stream)
+{
+    g_err[0] = 0;
+    (void)projmatrix;  // accepted for API parity; the test is on view-space depth only
+    if (P < 0 || (P > 0 && (!xyz || !viewmatrix || !present)))
+        return fail(VR_ERR_INVALID_ARGUMENT, "mark_visible: bad arguments");
+    return launch_mark_visible(xyz, P, viewmatrix, present, (hipStream_t)stream);
+}
+
+int vr_count_fragments(const VrSaved* saved, int32_t H, int32_t W, void* stream, int64_t* fragments)
+{
+    g_err[0] = 0;
+    if (!saved || !saved->image || !fragments || H <= 0 || W <= 0)
+        return fail(VR_ERR_INVALID_ARGUMENT, "count_fragments: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t N = (size_t)H * W;
+    const ImageLayout IL = image_layout(N);
+    unsigned long long* ctr = (unsigned long long*)((char*)saved->image + IL.counters);
+    int rc = launch_count_fragments((const uint32_t*)((const char*)saved->image + IL.n_contrib), (long)N, ctr, s);
+    if (rc) return rc;
+    unsigned long long host = 0;
+    VR_HIP(hipMemcpyAsync(&host, ctr, sizeof host, hipMemcpyDeviceToHost, s));
+    VR_HIP(hipStreamSynchronize(s));
+    *fragments = (int64_t)host;
+    return VR_OK;
+}
+
+int vr_debug_export_binning(const VrSaved* saved, int32_t H, int32_t W, uint32_t* point_list, int32_t* ranges,
+                            void* stream)
+{
+    g_err[0] = 0;
+    if (!saved || !saved->binning || H <= 0 || W <= 0)
+        return fail(VR_ERR_INVALID_ARGUMENT, "debug_export_binning: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    const BinLayout BL = bin_layout(T, (size_t)saved->num_rendered);
+    if (ranges)
+        VR_HIP(hipMemcpyAsync(ranges, (const char*)saved->binning + BL.ranges, T * 8, hipMemcpyDeviceToDevice, s));
+    if (point_list && saved->num_rendered > 0)
+        VR_HIP(hipMemcpyAsync(point_list, (const char*)saved->binning + BL.point_list,
+                              (size_t)saved->num_rendered * 4, hipMemcpyDeviceToDevice, s));
+    return VR_OK;
+}
+
+}  // extern "C"

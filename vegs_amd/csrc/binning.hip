@@ -1,0 +1,442 @@
+// binning.hip -- builds the per-tile, depth-ordered splat lists.
+//
+// Contract (what the reference's native binning stage produces): the list of
+// (tile, Gaussian) pairs ordered by (tile id, fp32 depth bits, Gaussian id) plus [start,end) per tile.
+//
+// MI355X design (not the upstream 64-bit global radix sort): the order is produced by two short,
+// stable, LSD radix sorts on 32-bit keys:
+//   1. compact the V visible Gaussians in id order (wave scan + block scan),
+//   2. stable-sort them by depth bits              (4 passes x 8 bit over V  <<  R elements),
+//   3. exclusive-scan tiles_touched in that order and emit (tile, id) pairs: emission order is
+//      already (depth, id)-sorted within every tile,
+//   4. stable-sort the R pairs by tile id only     (ceil(log2(T)/8) = 2 passes for 2064 tiles),
+//   5. tile ranges from key boundaries.
+// R-sized traffic is 2 passes of 8-byte pairs instead of upstream's 6 passes of 12-byte pairs.
+// Ranking inside a pass uses wave64 ballots (match-by-digit), no per-element atomics.
+#include "vr_host.h"
+
+namespace vr {
+
+constexpr int SCAN_ITEMS = 8;                   // per thread
+constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;    // elements per block
+constexpr int RADIX_ITEMS = 16;                 // per thread
+constexpr int RADIX_BLOCK = 256 * RADIX_ITEMS;  // elements per block
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX_SIZE = 1 << RADIX_BITS;
+
+// ---------------------------------------------------------------- wave / block primitives
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t n = __shfl_up(v, d, 64);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread across a 256-thread block; returns block total via `total`
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total, uint32_t* lds4)
+{
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t incl = wave_incl_scan(v, lane);
+    if (lane == 63) lds4[w] = incl;
+    __syncthreads();
+    uint32_t s0 = lds4[0], s1 = lds4[1], s2 = lds4[2], s3 = lds4[3];
+    uint32_t woff = (w > 0 ? s0 : 0) + (w > 1 ? s1 : 0) + (w > 2 ? s2 : 0);
+    total = s0 + s1 + s2 + s3;
+    __syncthreads();
+    return woff + incl - v;
+}
+
+// ---------------------------------------------------------------- generic 3-kernel scan
+
+struct SrcFlagTiles {  // 1 for visible Gaussians; secondary value = tiles_touched (summed only)
+    const uint32_t* tiles;
+    __device__ uint32_t operator()(long i) const { return tiles[i] ? 1u : 0u; }
+    __device__ uint32_t second(long i) const { return tiles[i]; }
+};
+struct SrcGather {  // tiles_touched in depth-sorted order
+    const uint32_t* tiles;
+    const uint32_t* ids;
+    __device__ uint32_t operator()(long i) const { return tiles[ids[i]]; }
+    __device__ uint32_t second(long) const { return 0; }
+};
+struct SrcPlain {
+    const uint32_t* v;
+    __device__ uint32_t operator()(long i) const { return v[i]; }
+    __device__ uint32_t second(long) const { return 0; }
+};
+
+struct SinkCompact {
+    const uint32_t* tiles;
+    const uint32_t* depth_key;
+    uint32_t* vis_key;
+    uint32_t* vis_id;
+    __device__ void operator()(long i, uint32_t v, uint32_t excl) const
+    {
+        if (v) { vis_key[excl] = depth_key[i]; vis_id[excl] = (uint32_t)i; }
+    }
+};
+struct SinkStore {
+    uint32_t* out;
+    __device__ void operator()(long i, uint32_t, uint32_t excl) const { out[i] = excl; }
+};
+
+template <class Src>
+__global__ void __launch_bounds__(256) k_scan_reduce(Src src, long n, uint32_t* bsum, uint32_t* bsum2)
+{
+    __shared__ uint32_t lds[8];
+    long base = (long)blockIdx.x * SCAN_BLOCK + (long)threadIdx.x * SCAN_ITEMS;
+    uint32_t a = 0, b = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) { a += src(base + k); b += src.second(base + k); }
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { a += __shfl_down(a, d, 64); b += __shfl_down(b, d, 64); }
+    if (lane == 0) { lds[w] = a; lds[4 + w] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bsum[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+        if (bsum2) bsum2[blockIdx.x] = lds[4] + lds[5] + lds[6] + lds[7];
+    }
+}
+
+// single block: in-place exclusive scan of bsum[0..nb), total -> totals[0]; sum of bsum2 -> totals[1]
+__global__ void __launch_bounds__(256) k_scan_sums(uint32_t* bsum, const uint32_t* bsum2, int nb, uint32_t* totals)
+{
+    __shared__ uint32_t lds4[4];
+    uint32_t carry = 0, acc2 = 0;
+    for (int base = 0; base < nb; base += 256) {
+        int i = base + threadIdx.x;
+        uint32_t v = i < nb ? bsum[i] : 0;
+        if (bsum2 && i < nb) acc2 += bsum2[i];
+        uint32_t total;
+        uint32_t ex = block_excl_scan(v, total, lds4);
+        if (i < nb) bsum[i] = carry + ex;
+        carry += total;
+    }
+    if (totals) {
+        if (threadIdx.x == 0) totals[0] = carry;
+        if (bsum2) {
+            uint32_t t2;
+            (void)block_excl_scan(acc2, t2, lds4);
+            if (threadIdx.x == 0) totals[1] = t2;
+        }
+    }
+}
+
+template <class Src, class Sink>
+__global__ void __launch_bounds__(256) k_scan_apply(Src src, Sink sink, long n, const uint32_t* bsum_excl)
+{
+    __shared__ uint32_t lds4[4];
+    long base = (long)blockIdx.x * SCAN_BLOCK + (long)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? src(base + k) : 0;
+        tsum += v[k];
+    }
+    uint32_t total;
+    uint32_t ex = block_excl_scan(tsum, total, lds4) + bsum_excl[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) sink(base + k, v[k], ex);
+        ex += v[k];
+    }
+}
+
+template <class Src, class Sink>
+static int run_scan(Src src, Sink sink, long n, uint32_t* bsum, uint32_t* bsum2, uint32_t* totals, hipStream_t s,
+                    bool debug, const char* what)
+{
+    if (n <= 0) return 0;
+    int nb = cdiv(n, SCAN_BLOCK);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_reduce<Src>), dim3(nb), dim3(256), 0, s, src, n, bsum, bsum2);
+    VR_KERNEL_CHECK(what, s, debug);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, s, bsum, (const uint32_t*)bsum2, nb, totals);
+    VR_KERNEL_CHECK(what, s, debug);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<Src, Sink>), dim3(nb), dim3(256), 0, s, src, sink, n,
+                       (const uint32_t*)bsum);
+    VR_KERNEL_CHECK(what, s, debug);
+    return 0;
+}
+
+// ---------------------------------------------------------------- stage 1: compaction
+
+size_t binning_stage1_scratch_bytes(int P)
+{
+    size_t nb = (size_t)cdiv(P > 0 ? P : 1, SCAN_BLOCK);
+    return align_up(2 * nb * sizeof(uint32_t), 256);
+}
+
+int launch_compact_visible(int P, const uint32_t* tiles_touched, const uint32_t* depth_key, void* scratch,
+                           uint32_t* vis_key, uint32_t* vis_id, uint32_t* totals_dev, hipStream_t s, bool debug)
+{
+    int nb = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
+    uint32_t* bsum = (uint32_t*)scratch;
+    uint32_t* bsum2 = bsum + nb;
+    SrcFlagTiles src{tiles_touched};
+    SinkCompact sink{tiles_touched, depth_key, vis_key, vis_id};
+    return run_scan(src, sink, P, bsum, bsum2, totals_dev, s, debug, "compact_visible");
+}
+
+// ---------------------------------------------------------------- radix sort pass (stable LSD)
+
+// lanes of the wave (restricted to `valid`) holding the same 8-bit digit as this lane
+__device__ __forceinline__ unsigned long long match_digit(uint32_t d, unsigned long long valid)
+{
+    unsigned long long m = valid;
+#pragma unroll
+    for (int b = 0; b < RADIX_BITS; ++b) {
+        unsigned long long bal = __ballot((d >> b) & 1u);
+        m &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    return m;
+}
+
+__device__ __forceinline__ unsigned long long lanemask_lt()
+{
+    return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+// hist layout: digit-major [RADIX_SIZE][nblk]
+__global__ void __launch_bounds__(256)
+k_radix_hist(const uint32_t* __restrict__ keys, long n, int shift, uint32_t* __restrict__ hist, int nblk)
+{
+    __shared__ uint32_t h[RADIX_SIZE];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    long wbase = (long)blockIdx.x * RADIX_BLOCK + (long)w * (64 * RADIX_ITEMS);
+#pragma unroll 4
+    for (int i = 0; i < RADIX_ITEMS; ++i) {
+        long idx = wbase + i * 64 + lane;
+        bool ok = idx < n;
+        uint32_t d = ok ? ((keys[idx] >> shift) & (RADIX_SIZE - 1)) : 0;
+        unsigned long long valid = __ballot(ok);
+        unsigned long long m = match_digit(d, valid);
+        if (ok && (m & lanemask_lt()) == 0) atomicAdd(&h[d], (uint32_t)__popcll(m));
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+// IDENT: values are the element indices (first pass over freshly generated keys)
+template <bool IDENT>
+__global__ void __launch_bounds__(256)
+k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, long n, int shift,
+                const uint32_t* __restrict__ hist_scanned, int nblk)
+{
+    __shared__ uint32_t cnt[4][RADIX_SIZE];
+    __shared__ uint32_t off[4][RADIX_SIZE];
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cnt[k][threadIdx.x] = 0;
+    __syncthreads();
+    long wbase = (long)blockIdx.x * RADIX_BLOCK + (long)w * (64 * RADIX_ITEMS);
+    uint32_t key[RADIX_ITEMS], rank[RADIX_ITEMS];
+    unsigned long long lt = lanemask_lt();
+#pragma unroll
+    for (int i = 0; i < RADIX_ITEMS; ++i) {
+        long idx = wbase + i * 64 + lane;
+        bool ok = idx < n;
+        key[i] = ok ? keys_in[idx] : 0xFFFFFFFFu;
+        uint32_t d = (key[i] >> shift) & (RADIX_SIZE - 1);
+        unsigned long long valid = __ballot(ok);
+        unsigned long long m = match_digit(d, valid);
+        uint32_t prior = ok ? cnt[w][d] : 0;
+        rank[i] = prior + (uint32_t)__popcll(m & lt);
+        if (ok && (m & lt) == 0) cnt[w][d] = prior + (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {
+        int d = threadIdx.x;
+        uint32_t g = hist_scanned[(size_t)d * nblk + blockIdx.x];
+        uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d];
+        off[0][d] = g;
+        off[1][d] = g + c0;
+        off[2][d] = g + c0 + c1;
+        off[3][d] = g + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RADIX_ITEMS; ++i) {
+        long idx = wbase + i * 64 + lane;
+        if (idx < n) {
+            uint32_t d = (key[i] >> shift) & (RADIX_SIZE - 1);
+            uint32_t dst = off[w][d] + rank[i];
+            keys_out[dst] = key[i];
+            vals_out[dst] = IDENT ? (uint32_t)idx : vals_in[idx];
+        }
+    }
+}
+
+static int radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, long n, int shift,
+                      uint32_t* hist, uint32_t* bsum, hipStream_t s, bool debug)
+{
+    int nblk = cdiv(n, RADIX_BLOCK);
+    hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(256), 0, s, kin, n, shift, hist, nblk);
+    VR_KERNEL_CHECK("radix_hist", s, debug);
+    long hn = (long)RADIX_SIZE * nblk;
+    int rc = run_scan(SrcPlain{hist}, SinkStore{hist}, hn, bsum, (uint32_t*)nullptr, (uint32_t*)nullptr, s, debug,
+                      "radix_scan");
+    if (rc) return rc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<false>), dim3(nblk), dim3(256), 0, s, kin, vin, kout, vout,
+                       n, shift, (const uint32_t*)hist, nblk);
+    VR_KERNEL_CHECK("radix_scatter", s, debug);
+    return 0;
+}
+
+// ---------------------------------------------------------------- emission + ranges
+
+// One block per 256 depth-sorted Gaussians; lanes are spread over OUTPUT entries (binary search in
+// the block's LDS prefix), so long rectangles do not serialise a lane and writes are coalesced.
+__global__ void __launch_bounds__(256)
+k_emit(int V, int gx, int gy, const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ offs,
+       const uint32_t* __restrict__ tiles_touched, const Splat* __restrict__ rec, const int* __restrict__ radii,
+       uint32_t* __restrict__ tkeys, uint32_t* __restrict__ tvals)
+{
+    __shared__ uint32_t l_off[257];
+    __shared__ uint32_t l_id[256];
+    __shared__ int l_x0[256], l_y0[256], l_w[256];
+    int r = blockIdx.x * 256 + threadIdx.x;
+    uint32_t myoff = 0, cnt = 0;
+    if (r < V) {
+        uint32_t id = sorted_id[r];
+        myoff = offs[r];
+        cnt = tiles_touched[id];
+        int x0, y0, x1, y1;
+        tile_rect(rec[id].x, rec[id].y, radii[id], gx, gy, x0, y0, x1, y1);
+        l_id[threadIdx.x] = id;
+        l_x0[threadIdx.x] = x0;
+        l_y0[threadIdx.x] = y0;
+        l_w[threadIdx.x] = x1 - x0;
+    }
+    int last = min(V - blockIdx.x * 256, 256) - 1;  // last valid thread of this block
+    l_off[threadIdx.x] = myoff;
+    if (threadIdx.x == last) l_off[256] = myoff + cnt;
+    __syncthreads();
+    uint32_t base = l_off[0];
+    uint32_t total = l_off[256] - base;
+    for (uint32_t e = threadIdx.x; e < total; e += 256) {
+        uint32_t target = base + e;
+        int lo = 0, hi = last;  // largest j with l_off[j] <= target
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (l_off[mid] <= target) lo = mid; else hi = mid - 1;
+        }
+        uint32_t k = target - l_off[lo];
+        int w = l_w[lo];
+        int ry = (int)(k / (uint32_t)w), rx = (int)(k - (uint32_t)ry * (uint32_t)w);
+        tkeys[target] = (uint32_t)((l_y0[lo] + ry) * gx + l_x0[lo] + rx);
+        tvals[target] = l_id[lo];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_tile_ranges(const uint32_t* __restrict__ tkeys, long R, int2* __restrict__ ranges)
+{
+    long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= R) return;
+    uint32_t k = tkeys[j];
+    if (j == 0) ranges[k].x = 0;
+    else {
+        uint32_t kp = tkeys[j - 1];
+        if (kp != k) { ranges[kp].y = (int)j; ranges[k].x = (int)j; }
+    }
+    if (j == R - 1) ranges[k].y = (int)R;
+}
+
+// ---------------------------------------------------------------- stage 2 driver
+
+struct Stage2Layout {
+    size_t tmp_key, tmp_id, offs, tkeysA, tkeysB, tvalsB, hist, bsum, total;
+};
+
+static Stage2Layout stage2_layout(int V, long R)
+{
+    Stage2Layout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
+    size_t v = (size_t)(V > 0 ? V : 1), r = (size_t)(R > 0 ? R : 1);
+    L.tmp_key = take(v * 4);
+    L.tmp_id = take(v * 4);
+    L.offs = take(v * 4);
+    L.tkeysA = take(r * 4);
+    L.tkeysB = take(r * 4);
+    L.tvalsB = take(r * 4);
+    size_t nmax = r > v ? r : v;
+    size_t nblk = (size_t)cdiv((long)nmax, RADIX_BLOCK);
+    L.hist = take(nblk * RADIX_SIZE * 4);
+    size_t scan_n = nblk * RADIX_SIZE > nmax ? nblk * RADIX_SIZE : nmax;
+    L.bsum = take((size_t)cdiv((long)scan_n, SCAN_BLOCK) * 4 + 256);
+    L.total = o;
+    return L;
+}
+
+size_t binning_stage2_scratch_bytes(int V, long R, int) { return stage2_layout(V, R).total; }
+
+int launch_binning(const Camera& cam, int V, long R, uint32_t* vis_key, uint32_t* vis_id, const Splat* rec,
+                   const int* radii, const uint32_t* tiles_touched, void* scratch, uint32_t* point_list,
+                   int2* ranges, hipStream_t s, bool debug)
+{
+    int ntiles = cam.gx * cam.gy;
+    VR_HIP(hipMemsetAsync(ranges, 0, sizeof(int2) * (size_t)ntiles, s));
+    if (V == 0 || R == 0) return 0;
+    Stage2Layout L = stage2_layout(V, R);
+    char* base = (char*)scratch;
+    uint32_t* tmp_key = (uint32_t*)(base + L.tmp_key);
+    uint32_t* tmp_id = (uint32_t*)(base + L.tmp_id);
+    uint32_t* offs = (uint32_t*)(base + L.offs);
+    uint32_t* tkeysA = (uint32_t*)(base + L.tkeysA);
+    uint32_t* tkeysB = (uint32_t*)(base + L.tkeysB);
+    uint32_t* tvalsB = (uint32_t*)(base + L.tvalsB);
+    uint32_t* hist = (uint32_t*)(base + L.hist);
+    uint32_t* bsum = (uint32_t*)(base + L.bsum);
+
+    // 2. depth sort of the visible Gaussians (ping-pong; 4 passes end in vis_key/vis_id)
+    {
+        uint32_t *ka = vis_key, *va = vis_id, *kb = tmp_key, *vb = tmp_id;
+        for (int pass = 0; pass < 4; ++pass) {
+            int rc = radix_pass(ka, va, kb, vb, V, pass * RADIX_BITS, hist, bsum, s, debug);
+            if (rc) return rc;
+            uint32_t* t = ka; ka = kb; kb = t;
+            t = va; va = vb; vb = t;
+        }
+    }
+    // 3. offsets in depth order, then emission
+    {
+        int rc = run_scan(SrcGather{tiles_touched, vis_id}, SinkStore{offs}, V, bsum, (uint32_t*)nullptr,
+                          (uint32_t*)nullptr, s, debug, "offset_scan");
+        if (rc) return rc;
+    }
+    int bits = 0;
+    while ((1 << bits) < ntiles) ++bits;
+    int passes = bits == 0 ? 0 : cdiv(bits, RADIX_BITS);
+    // choose the starting value buffer so that the last pass lands in point_list
+    uint32_t* va = (passes % 2 == 0) ? point_list : tvalsB;
+    uint32_t* vb = (passes % 2 == 0) ? tvalsB : point_list;
+    uint32_t *ka = tkeysA, *kb = tkeysB;
+    hipLaunchKernelGGL(k_emit, dim3(cdiv(V, 256)), dim3(256), 0, s, V, cam.gx, cam.gy, (const uint32_t*)vis_id,
+                       (const uint32_t*)offs, tiles_touched, rec, radii, ka, va);
+    VR_KERNEL_CHECK("emit", s, debug);
+    // 4. stable sort by tile id
+    for (int pass = 0; pass < passes; ++pass) {
+        int rc = radix_pass(ka, va, kb, vb, R, pass * RADIX_BITS, hist, bsum, s, debug);
+        if (rc) return rc;
+        uint32_t* t = ka; ka = kb; kb = t;
+        t = va; va = vb; vb = t;
+    }
+    // 5. ranges
+    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(R, 256)), dim3(256), 0, s, (const uint32_t*)ka, R, ranges);
+    VR_KERNEL_CHECK("tile_ranges", s, debug);
+    return 0;
+}
+
+}  // namespace vr

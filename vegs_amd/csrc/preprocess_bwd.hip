@@ -1,0 +1,234 @@
+// preprocess_bwd.hip -- per-Gaussian backward: conic -> cov2D -> (cov3D, view-space point) ->
+// (scale, rotation, mean); NDC gradient -> mean through the perspective divide; SH colour backward;
+// plus the direct gradients of the fork's blended channels (depth -> mean, rotation row, scale row).
+//
+// Replaces the native preprocess-backward stage reached from loss.backward() (reference
+// train.py:196); semantics SURVEY.md A.6.  Gradients must be right for means3D, scales AND
+// rotations because render_all feeds box-transformed tensors (reference
+// gaussian_renderer/__init__.py:123-153) whose gradients flow on into model/boxmodel.py:30-42.
+// One lane per Gaussian; every row of the small outputs is written (zeros when culled), dL_dshs is
+// pre-zeroed by the caller and only visible rows are written.
+#include "vr_host.h"
+
+namespace vr {
+
+__device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float* bx, float* by, float* bz)
+{
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { bx[k] = 0.f; by[k] = 0.f; bz[k] = 0.f; }
+    if (deg < 1) return;
+    by[1] = -SH_C1; bz[2] = SH_C1; bx[3] = -SH_C1;
+    if (deg < 2) return;
+    float xx = x * x, yy = y * y, zz = z * z;
+    bx[4] = SH_C2[0] * y; by[4] = SH_C2[0] * x;
+    by[5] = SH_C2[1] * z; bz[5] = SH_C2[1] * y;
+    bx[6] = SH_C2[2] * -2.0f * x; by[6] = SH_C2[2] * -2.0f * y; bz[6] = SH_C2[2] * 4.0f * z;
+    bx[7] = SH_C2[3] * z; bz[7] = SH_C2[3] * x;
+    bx[8] = SH_C2[4] * 2.0f * x; by[8] = SH_C2[4] * -2.0f * y;
+    if (deg < 3) return;
+    bx[9] = SH_C3[0] * 6.0f * x * y; by[9] = SH_C3[0] * (3.0f * xx - 3.0f * yy);
+    bx[10] = SH_C3[1] * y * z; by[10] = SH_C3[1] * x * z; bz[10] = SH_C3[1] * x * y;
+    bx[11] = SH_C3[2] * -2.0f * x * y; by[11] = SH_C3[2] * (4.0f * zz - xx - 3.0f * yy); bz[11] = SH_C3[2] * 8.0f * y * z;
+    bx[12] = SH_C3[3] * -6.0f * x * z; by[12] = SH_C3[3] * -6.0f * y * z; bz[12] = SH_C3[3] * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+    bx[13] = SH_C3[4] * (4.0f * zz - 3.0f * xx - yy); by[13] = SH_C3[4] * -2.0f * x * y; bz[13] = SH_C3[4] * 8.0f * x * z;
+    bx[14] = SH_C3[5] * 2.0f * x * z; by[14] = SH_C3[5] * -2.0f * y * z; bz[14] = SH_C3[5] * (xx - yy);
+    bx[15] = SH_C3[6] * (3.0f * xx - 3.0f * yy); by[15] = SH_C3[6] * -6.0f * x * y;
+}
+
+__global__ void __launch_bounds__(256)
+k_preprocess_bwd(Camera cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
+                 const float* __restrict__ colors_precomp, const float* __restrict__ scales,
+                 const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+                 const int* __restrict__ radii, const Splat* __restrict__ rec, const float* __restrict__ gacc,
+                 const float* __restrict__ gmean2D, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dshs,
+                 float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
+                 float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float dsc[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f}, dcol[3] = {0.f, 0.f, 0.f};
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dop = 0.f;
+    if (radii[i] > 0) {
+        const float* V = cam.view;
+        const float* Pm = cam.proj;
+        const float4* ga4 = reinterpret_cast<const float4*>(gacc + (size_t)i * 16);
+        const float4 a0 = ga4[0], a1 = ga4[1], a2 = ga4[2], a3 = ga4[3];
+        const float gA = a0.x, gB = a0.y, gC = a0.z;
+        dop = a0.w;
+        const float ga[NCH] = {a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z};
+        const float px3 = means3D[3 * (size_t)i], py3 = means3D[3 * (size_t)i + 1], pz3 = means3D[3 * (size_t)i + 2];
+
+        // ---- recompute the forward intermediates (identical expressions as preprocess)
+        float t0, t1, t2;
+        xform43(V, px3, py3, pz3, t0, t1, t2);
+        float c6[6], q[4] = {0.f, 0.f, 0.f, 0.f}, sc[3] = {0.f, 0.f, 0.f};
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * (size_t)i + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sc[k] = scales[3 * (size_t)i + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = rotations[4 * (size_t)i + k];
+            cov3d_from_scale_rot(sc, cam.mod, q, c6);
+        }
+        Cov2D cv;
+        cov2d(cam, V, t0, t1, t2, c6, cv);
+        const float a = cv.a, b = cv.b, c = cv.c;
+        const float det = a * c - b * b;
+        float da = 0.f, db = 0.f, dc = 0.f;
+        if (det != 0.0f) {
+            const float d2 = 1.0f / (det * det);
+            da = d2 * (-c * c * gA + b * c * gB - b * b * gC);
+            db = d2 * (2.0f * b * c * gA - (a * c + b * b) * gB + 2.0f * a * b * gC);
+            dc = d2 * (-b * b * gA + a * b * gB - a * a * gC);
+        }
+        const float* m0 = cv.m0; const float* m1 = cv.m1;
+        float gS[6];
+        gS[0] = da * m0[0] * m0[0] + db * m0[0] * m1[0] + dc * m1[0] * m1[0];
+        gS[3] = da * m0[1] * m0[1] + db * m0[1] * m1[1] + dc * m1[1] * m1[1];
+        gS[5] = da * m0[2] * m0[2] + db * m0[2] * m1[2] + dc * m1[2] * m1[2];
+        gS[1] = 2.f * da * m0[0] * m0[1] + db * (m0[0] * m1[1] + m0[1] * m1[0]) + 2.f * dc * m1[0] * m1[1];
+        gS[2] = 2.f * da * m0[0] * m0[2] + db * (m0[0] * m1[2] + m0[2] * m1[0]) + 2.f * dc * m1[0] * m1[2];
+        gS[4] = 2.f * da * m0[1] * m0[2] + db * (m0[1] * m1[2] + m0[2] * m1[1]) + 2.f * dc * m1[1] * m1[2];
+        const float u[3] = {c6[0] * m0[0] + c6[1] * m0[1] + c6[2] * m0[2], c6[1] * m0[0] + c6[3] * m0[1] + c6[4] * m0[2],
+                            c6[2] * m0[0] + c6[4] * m0[1] + c6[5] * m0[2]};
+        const float wv[3] = {c6[0] * m1[0] + c6[1] * m1[1] + c6[2] * m1[2], c6[1] * m1[0] + c6[3] * m1[1] + c6[4] * m1[2],
+                             c6[2] * m1[0] + c6[4] * m1[1] + c6[5] * m1[2]};
+        float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float dm0 = 2.f * da * u[k] + db * wv[k];
+            const float dm1 = db * u[k] + 2.f * dc * wv[k];
+            dJ00 += dm0 * V[4 * k + 0];
+            dJ02 += dm0 * V[4 * k + 2];
+            dJ11 += dm1 * V[4 * k + 1];
+            dJ12 += dm1 * V[4 * k + 2];
+        }
+        const float tzi = 1.0f / cv.tz, tzi2 = tzi * tzi, tzi3 = tzi2 * tzi;
+        float dt[3];
+        dt[0] = cv.clampx ? 0.f : -cam.fx * tzi2 * dJ02;
+        dt[1] = cv.clampy ? 0.f : -cam.fy * tzi2 * dJ12;
+        dt[2] = -cam.fx * tzi2 * dJ00 - cam.fy * tzi2 * dJ11 + 2.f * cam.fx * cv.tx * tzi3 * dJ02 +
+                2.f * cam.fy * cv.ty * tzi3 * dJ12;
+        dt[2] += ga[3];  // blended depth channel: depth_i = t.z
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dmean[k] += V[4 * k + 0] * dt[0] + V[4 * k + 1] * dt[1] + V[4 * k + 2] * dt[2];
+
+        // ---- NDC gradient -> mean
+        float h0, h1, h2;
+        xform43(Pm, px3, py3, pz3, h0, h1, h2);
+        const float hw = xform_w(Pm, px3, py3, pz3);
+        const float mw = 1.0f / (hw + 0.0000001f);
+        const float gx2 = gmean2D[3 * (size_t)i], gy2 = gmean2D[3 * (size_t)i + 1];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float mul1 = Pm[4 * k + 0] * mw - Pm[4 * k + 3] * h0 * mw * mw;
+            const float mul2 = Pm[4 * k + 1] * mw - Pm[4 * k + 3] * h1 * mw * mw;
+            dmean[k] += mul1 * gx2 + mul2 * gy2;
+        }
+
+        // ---- colour
+        if (colors_precomp) {
+            dcol[0] = ga[0]; dcol[1] = ga[1]; dcol[2] = ga[2];
+        } else {
+            const float d0 = px3 - cam.campos[0], d1 = py3 - cam.campos[1], d2v = pz3 - cam.campos[2];
+            const float len = sqrtf(d0 * d0 + d1 * d1 + d2v * d2v);
+            const float il = 1.0f / len;
+            const float dir[3] = {d0 * il, d1 * il, d2v * il};
+            float bas[16], bx[16], by[16], bz[16];
+            sh_basis(cam.deg, dir[0], dir[1], dir[2], bas);
+            sh_basis_grad(cam.deg, dir[0], dir[1], dir[2], bx, by, bz);
+            const int K = (cam.deg + 1) * (cam.deg + 1);
+            const float* sh = shs + (size_t)i * cam.M * 3;
+            float* gsh = dL_dshs + (size_t)i * cam.M * 3;
+            const uint32_t clampbits = rec[i].clamped;
+            const float gc0 = (clampbits & 1u) ? 0.f : ga[0];
+            const float gc1 = (clampbits & 2u) ? 0.f : ga[1];
+            const float gc2 = (clampbits & 4u) ? 0.f : ga[2];
+            float ddir[3] = {0.f, 0.f, 0.f};
+            for (int k = 0; k < K; ++k) {
+                gsh[3 * k + 0] = bas[k] * gc0;
+                gsh[3 * k + 1] = bas[k] * gc1;
+                gsh[3 * k + 2] = bas[k] * gc2;
+                const float sg = sh[3 * k] * gc0 + sh[3 * k + 1] * gc1 + sh[3 * k + 2] * gc2;
+                ddir[0] += bx[k] * sg;
+                ddir[1] += by[k] * sg;
+                ddir[2] += bz[k] * sg;
+            }
+            const float dot = dir[0] * ddir[0] + dir[1] * ddir[1] + dir[2] * ddir[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dmean[k] += (ddir[k] - dir[k] * dot) * il;
+        }
+
+        // ---- cov3D -> scale / rotation, plus the directly blended rows
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dcov[k] = gS[k];
+        } else {
+            float R[9];
+            quat_to_R(q[0], q[1], q[2], q[3], R);
+            const float Gf[9] = {gS[0], 0.5f * gS[1], 0.5f * gS[2], 0.5f * gS[1], gS[3], 0.5f * gS[4],
+                                 0.5f * gS[2], 0.5f * gS[4], gS[5]};
+            const float sp[3] = {cam.mod * sc[0], cam.mod * sc[1], cam.mod * sc[2]};
+            float D[9];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float accs = 0.f;
+#pragma unroll
+                for (int ii = 0; ii < 3; ++ii) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc += Gf[3 * ii + j] * (R[3 * j + k] * sp[k]);
+                    const float dLm = 2.f * acc;
+                    accs += dLm * R[3 * ii + k];
+                    D[3 * ii + k] = dLm * sp[k];
+                }
+                dsc[k] = cam.mod * accs + ga[8 + k];
+            }
+            const float r = q[0], x = q[1], y = q[2], z = q[3];
+            drot[0] = 2.f * (z * (D[3] - D[1]) + y * (D[2] - D[6]) + x * (D[7] - D[5])) + ga[4];
+            drot[1] = 2.f * (y * (D[1] + D[3]) + z * (D[2] + D[6]) + r * (D[7] - D[5])) - 4.f * x * (D[4] + D[8]) + ga[5];
+            drot[2] = 2.f * (x * (D[1] + D[3]) + r * (D[2] - D[6]) + z * (D[5] + D[7])) - 4.f * y * (D[0] + D[8]) + ga[6];
+            drot[3] = 2.f * (r * (D[3] - D[1]) + x * (D[2] + D[6]) + y * (D[5] + D[7])) - 4.f * z * (D[0] + D[4]) + ga[7];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * (size_t)i + k] = dmean[k];
+    dL_dopacities[i] = dop;
+    if (dL_dcolors) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dL_dcolors[3 * (size_t)i + k] = dcol[k];
+    }
+    if (dL_dscales) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dL_dscales[3 * (size_t)i + k] = dsc[k];
+    }
+    if (dL_drots) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dL_drots[4 * (size_t)i + k] = drot[k];
+    }
+    if (dL_dcov3D) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = dcov[k];
+    }
+}
+
+int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const float* shs,
+                          const float* colors_precomp, const float* scales, const float* rotations,
+                          const float* cov3D_precomp, const int* radii, const Splat* rec, const float* gacc,
+                          const float* gmean2D, float* dL_dmeans3D, float* dL_dshs, float* dL_dcolors,
+                          float* dL_dopacities, float* dL_dscales, float* dL_drots, float* dL_dcov3D,
+                          hipStream_t s, bool debug)
+{
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, means3D, shs, colors_precomp,
+                       scales, rotations, cov3D_precomp, radii, rec, gacc, gmean2D, dL_dmeans3D, dL_dshs, dL_dcolors,
+                       dL_dopacities, dL_dscales, dL_drots, dL_dcov3D);
+    VR_KERNEL_CHECK("preprocess_bwd", s, debug);
+    return 0;
+}
+
+}  // namespace vr

@@ -1,0 +1,206 @@
+// vr_device.h -- shared device-side definitions for the gfx950 rasterizer kernels.
+//
+// The fp32 operation order of every function here is part of the behavioural spec (see
+// DESIGN.md "numerics"): translation units are compiled with -ffp-contract=off and every
+// fused multiply-add is an explicit fmaf(), so that radii, tile rectangles, sort keys and
+// forward images are bit-reproducible against the CPU oracle used by the tests.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vr {
+
+constexpr int TILE = 16;          // pixels per tile edge (16x16 = 256 threads = 4 waves of 64)
+constexpr int NCH = 11;           // blended channels: rgb(3) depth(1) quat(4) scale(3)
+constexpr float NEAR_Z = 0.2f;
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float ALPHA_MAX = 0.99f;
+constexpr float T_EPS = 0.0001f;
+
+// Per-Gaussian record written by preprocess for visible Gaussians and gathered by the render
+// kernels: 5 x 16 B so a record is fetched with five dwordx4 loads.
+struct __attribute__((aligned(16))) Splat {
+    float x, y, conA, conB;          // pixel centre, conic A,B
+    float conC, opacity, depth, r;   // conic C, opacity, view depth, red
+    float g, b, qw, qx;              // green, blue, quaternion w,x  (input rotation row, A-2)
+    float qy, qz, s0, s1;            // quaternion y,z, scale 0,1    (input scale row, A-3)
+    float s2;                        // scale 2
+    uint32_t clamped;                // bit c set: colour channel c was clamped at 0
+    uint32_t pad0, pad1;
+};
+static_assert(sizeof(Splat) == 80, "Splat must be 80 bytes");
+
+struct Camera {
+    int H, W, gx, gy;
+    float tanfovx, tanfovy, fx, fy;
+    float mod;
+    int deg, M;
+    const float* view;
+    const float* proj;
+    const float* campos;
+    const float* bg;
+};
+
+// exp(x), x <= 0, from IEEE basic operations only: bit-identical on host and device.
+__device__ __forceinline__ float vr_exp(float x)
+{
+    float t = x * 1.44269504088896341f;
+    float n = rintf(t);
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.0f / 720.0f;
+    p = fmaf(p, r, 1.0f / 120.0f);
+    p = fmaf(p, r, 1.0f / 24.0f);
+    p = fmaf(p, r, 1.0f / 6.0f);
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    float v = ldexpf(p, (int)n);
+    return x < -87.0f ? 0.0f : v;
+}
+
+__device__ __forceinline__ void xform43(const float* __restrict__ m, float px, float py, float pz, float& ox,
+                                        float& oy, float& oz)
+{
+    ox = fmaf(m[8], pz, fmaf(m[4], py, fmaf(m[0], px, m[12])));
+    oy = fmaf(m[9], pz, fmaf(m[5], py, fmaf(m[1], px, m[13])));
+    oz = fmaf(m[10], pz, fmaf(m[6], py, fmaf(m[2], px, m[14])));
+}
+__device__ __forceinline__ float xform_w(const float* __restrict__ m, float px, float py, float pz)
+{
+    return fmaf(m[11], pz, fmaf(m[7], py, fmaf(m[3], px, m[15])));
+}
+
+__device__ __forceinline__ float ndc2pix(float v, int S) { return ((v + 1.0f) * (float)S - 1.0f) * 0.5f; }
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// tile rectangle [x0,x1) x [y0,y1) touched by a splat of integer radius rad centred at (px,py)
+__device__ __forceinline__ void tile_rect(float px, float py, int rad, int gx, int gy, int& x0, int& y0, int& x1,
+                                          int& y1)
+{
+    x0 = clampi((int)((px - (float)rad) / (float)TILE), 0, gx);
+    y0 = clampi((int)((py - (float)rad) / (float)TILE), 0, gy);
+    x1 = clampi((int)((px + (float)rad + (float)(TILE - 1)) / (float)TILE), 0, gx);
+    y1 = clampi((int)((py + (float)rad + (float)(TILE - 1)) / (float)TILE), 0, gy);
+}
+
+// Gaussian exponent at a pixel; identical expression in forward and backward.
+__device__ __forceinline__ float splat_power(float sx, float sy, float A, float B, float C, float pxf, float pyf,
+                                             float& dx, float& dy)
+{
+    dx = sx - pxf;
+    dy = sy - pyf;
+    float q = fmaf(C * dy, dy, (A * dx) * dx);
+    return fmaf(-0.5f, q, -((B * dx) * dy));
+}
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+// Real SH basis up to degree 3 at unit direction (x,y,z) (polynomials: reference utils/sh_utils.py:74-100).
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float* b)
+{
+    b[0] = SH_C0;
+    if (deg < 1) return;
+    b[1] = -SH_C1 * y;
+    b[2] = SH_C1 * z;
+    b[3] = -SH_C1 * x;
+    if (deg < 2) return;
+    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    b[4] = SH_C2[0] * xy;
+    b[5] = SH_C2[1] * yz;
+    b[6] = SH_C2[2] * (2.0f * zz - xx - yy);
+    b[7] = SH_C2[3] * xz;
+    b[8] = SH_C2[4] * (xx - yy);
+    if (deg < 3) return;
+    b[9] = SH_C3[0] * y * (3.0f * xx - yy);
+    b[10] = SH_C3[1] * xy * z;
+    b[11] = SH_C3[2] * y * (4.0f * zz - xx - yy);
+    b[12] = SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+    b[13] = SH_C3[4] * x * (4.0f * zz - xx - yy);
+    b[14] = SH_C3[5] * z * (xx - yy);
+    b[15] = SH_C3[6] * x * (xx - 3.0f * yy);
+}
+
+// Rotation matrix of a (not re-normalised) quaternion (w,x,y,z), row-major.
+__device__ __forceinline__ void quat_to_R(float r, float x, float y, float z, float* R)
+{
+    R[0] = 1.0f - 2.0f * (y * y + z * z); R[1] = 2.0f * (x * y - r * z); R[2] = 2.0f * (x * z + r * y);
+    R[3] = 2.0f * (x * y + r * z); R[4] = 1.0f - 2.0f * (x * x + z * z); R[5] = 2.0f * (y * z - r * x);
+    R[6] = 2.0f * (x * z - r * y); R[7] = 2.0f * (y * z + r * x); R[8] = 1.0f - 2.0f * (x * x + y * y);
+}
+
+// Sigma = R diag(mod*s)^2 R^T as 6 upper-triangular floats (xx xy xz yy yz zz).
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* s, float mod, const float* q, float* c6)
+{
+    float R[9], L[9];
+    quat_to_R(q[0], q[1], q[2], q[3], R);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) L[3 * i + k] = R[3 * i + k] * (mod * s[k]);
+    c6[0] = fmaf(L[2], L[2], fmaf(L[1], L[1], L[0] * L[0]));
+    c6[1] = fmaf(L[2], L[5], fmaf(L[1], L[4], L[0] * L[3]));
+    c6[2] = fmaf(L[2], L[8], fmaf(L[1], L[7], L[0] * L[6]));
+    c6[3] = fmaf(L[5], L[5], fmaf(L[4], L[4], L[3] * L[3]));
+    c6[4] = fmaf(L[5], L[8], fmaf(L[4], L[7], L[3] * L[6]));
+    c6[5] = fmaf(L[8], L[8], fmaf(L[7], L[7], L[6] * L[6]));
+}
+
+// EWA splat projection: rows m0,m1 of J*W (2x3), clamped view-space point and the 2D covariance.
+struct Cov2D {
+    float m0[3], m1[3];
+    float tx, ty, tz;
+    bool clampx, clampy;
+    float a, b, c;
+};
+
+__device__ __forceinline__ void cov2d(const Camera& cam, const float* __restrict__ v, float t0, float t1, float t2,
+                                      const float* c6, Cov2D& o)
+{
+    float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
+    float tz = t2;
+    float txtz = t0 / tz, tytz = t1 / tz;
+    o.clampx = (txtz < -limx) || (txtz > limx);
+    o.clampy = (tytz < -limy) || (tytz > limy);
+    float tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+    float ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+    o.tx = tx; o.ty = ty; o.tz = tz;
+    float j00 = cam.fx / tz, j02 = -(cam.fx * tx) / (tz * tz);
+    float j11 = cam.fy / tz, j12 = -(cam.fy * ty) / (tz * tz);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        o.m0[i] = fmaf(j02, v[4 * i + 2], j00 * v[4 * i + 0]);
+        o.m1[i] = fmaf(j12, v[4 * i + 2], j11 * v[4 * i + 1]);
+    }
+    const float* m0 = o.m0; const float* m1 = o.m1;
+    float u0 = fmaf(c6[2], m0[2], fmaf(c6[1], m0[1], c6[0] * m0[0]));
+    float u1 = fmaf(c6[4], m0[2], fmaf(c6[3], m0[1], c6[1] * m0[0]));
+    float u2 = fmaf(c6[5], m0[2], fmaf(c6[4], m0[1], c6[2] * m0[0]));
+    float w0 = fmaf(c6[2], m1[2], fmaf(c6[1], m1[1], c6[0] * m1[0]));
+    float w1 = fmaf(c6[4], m1[2], fmaf(c6[3], m1[1], c6[1] * m1[0]));
+    float w2 = fmaf(c6[5], m1[2], fmaf(c6[4], m1[1], c6[2] * m1[0]));
+    o.a = fmaf(m0[2], u2, fmaf(m0[1], u1, m0[0] * u0)) + 0.3f;
+    o.b = fmaf(m1[2], u2, fmaf(m1[1], u1, m1[0] * u0));
+    o.c = fmaf(m1[2], w2, fmaf(m1[1], w1, m1[0] * w0)) + 0.3f;
+}
+
+// XCD-aware block -> tile map: the dispatcher places block b on XCD b % 8 (speed only, never
+// correctness); give each XCD a contiguous run of tiles so neighbouring tiles, which share
+// splats, hit the same L2.  Bijective for any tile count.
+__device__ __forceinline__ int xcd_tile(int b, int ntiles)
+{
+    constexpr int NX = 8;
+    int q = ntiles / NX, r = ntiles % NX;
+    int xcd = b % NX, k = b / NX;
+    int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + k;
+}
+
+}  // namespace vr

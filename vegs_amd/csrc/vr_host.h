@@ -1,0 +1,79 @@
+// vr_host.h -- host-side declarations shared by the translation units of libvegsrast.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vr_device.h"
+
+namespace vr {
+
+// thread-local error string behind vr_last_error()
+void set_error(const char* fmt, ...);
+
+#define VR_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            vr::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return -3;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+// after a kernel launch: always check the launch; in debug mode also synchronise
+#define VR_KERNEL_CHECK(name, stream, debug)                                                  \
+    do {                                                                                      \
+        hipError_t _e = hipGetLastError();                                                    \
+        if (_e == hipSuccess && (debug)) _e = hipStreamSynchronize(stream);                   \
+        if (_e != hipSuccess) {                                                               \
+            vr::set_error("kernel %s failed: %s", name, hipGetErrorString(_e));               \
+            return -3;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- preprocess.hip
+int launch_preprocess(const Camera& cam, int P, const float* means3D, const float* shs, const float* colors_precomp,
+                      const float* opacities, const float* scales, const float* rotations,
+                      const float* cov3D_precomp, Splat* rec, int* radii, uint32_t* tiles_touched,
+                      uint32_t* depth_key, hipStream_t s, bool debug);
+int launch_mark_visible(const float* xyz, int P, const float* view, uint8_t* present, hipStream_t s);
+
+// ---- binning.hip
+struct BinningPlan {
+    // sizes of the transient arrays needed once V and R are known
+    size_t scratch_bytes;
+};
+// stage 1 (P-sized): compaction of visible Gaussians in id order + totals.  totals_dev[0]=V, [1]=R.
+size_t binning_stage1_scratch_bytes(int P);
+int launch_compact_visible(int P, const uint32_t* tiles_touched, const uint32_t* depth_key, void* scratch,
+                           uint32_t* vis_key, uint32_t* vis_id, uint32_t* totals_dev, hipStream_t s, bool debug);
+// stage 2 (V- and R-sized): depth sort, emission, tile sort, ranges.
+size_t binning_stage2_scratch_bytes(int V, long R, int ntiles);
+int launch_binning(const Camera& cam, int V, long R, uint32_t* vis_key, uint32_t* vis_id, const Splat* rec,
+                   const int* radii, const uint32_t* tiles_touched, void* scratch, uint32_t* point_list,
+                   int2* ranges, hipStream_t s, bool debug);
+
+// ---- render_fwd.hip
+int launch_render_fwd(const Camera& cam, const int2* ranges, const uint32_t* point_list, const Splat* rec,
+                      float* out_color, float* out_depth, float* out_quat, float* out_scale, float* out_alpha,
+                      float* final_T, uint32_t* n_contrib, hipStream_t s, bool debug);
+int launch_count_fragments(const uint32_t* n_contrib, long N, unsigned long long* out_dev, hipStream_t s);
+
+// ---- render_bwd.hip
+// gacc: [P][16] floats = conic dA,dB,dC | opacity | attr[11] | pad ; gmean2D: [P][3] (x,y used)
+int launch_render_bwd(const Camera& cam, const int2* ranges, const uint32_t* point_list, const Splat* rec,
+                      const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
+                      const float* dL_ddepth, const float* dL_dquat, const float* dL_dscale,
+                      const float* dL_dalpha, float* gacc, float* gmean2D, hipStream_t s, bool debug);
+
+// ---- preprocess_bwd.hip
+int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const float* shs,
+                          const float* colors_precomp, const float* scales, const float* rotations,
+                          const float* cov3D_precomp, const int* radii, const Splat* rec, const float* gacc,
+                          const float* gmean2D, float* dL_dmeans3D, float* dL_dshs, float* dL_dcolors,
+                          float* dL_dopacities, float* dL_dscales, float* dL_drots, float* dL_dcov3D,
+                          hipStream_t s, bool debug);
+
+}  // namespace vr

@@ -1,0 +1,237 @@
+"""Python operator surface of the rasterizer -- the drop-in for the reference's
+`diff_gaussian_rasterization` package (un-vendored submodule, reference .gitmodules:7-9).
+
+Same names, arguments and return values as the reference's call sites use:
+  * GaussianRasterizationSettings(...)  12 keyword fields   gaussian_renderer/__init__.py:38-51
+  * GaussianRasterizer(raster_settings=...)(means3D=, means2D=, shs=, colors_precomp=, opacities=,
+    scales=, rotations=, cov3D_precomp=) -> (color[3,H,W], depth[1,H,W], cov_quat[4,H,W],
+    cov_scale[3,H,W], alpha[1,H,W], radii[P] int32)          gaussian_renderer/__init__.py:86-94
+  * GaussianRasterizer.markVisible(positions) -> bool[P]     utils/norminit_utils.py:55,179
+  * means2D receives the screen-space gradient ([P,3], z = 0) that
+    scene/gaussian_model.py:411-413 accumulates for densification.
+All computation happens in libvegsrast.so (hand-written HIP, gfx950) through the C ABI of
+include/vegs_rast.h; there is no PyTorch/CPU fallback.
+"""
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _capi
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _dev_f32(t, device):
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def _prep(t, name, device, cols=None):
+    """None/empty -> None; otherwise a contiguous fp32 tensor on `device` (validated)."""
+    if t is None or t.numel() == 0:
+        return None
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a GPU tensor (the rasterizer has no CPU path)")
+    if t.device != device:
+        raise ValueError(f"{name} is on {t.device}, expected {device}")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name} must be float32 (got {t.dtype})")
+    return t.contiguous()
+
+
+def _settings_struct(rs, device, keep):
+    bg = _dev_f32(rs.bg, device)
+    view = _dev_f32(rs.viewmatrix, device)
+    proj = _dev_f32(rs.projmatrix, device)
+    campos = _dev_f32(rs.campos, device)
+    if bg.numel() != 3 or view.numel() != 16 or proj.numel() != 16 or campos.numel() != 3:
+        raise ValueError("bg/campos must hold 3 values and viewmatrix/projmatrix 16")
+    keep.extend([bg, view, proj, campos])
+    return _capi.VrSettings(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
+                            float(rs.scale_modifier), int(rs.sh_degree), int(bool(rs.prefiltered)),
+                            int(bool(rs.debug)), bg.data_ptr(), view.data_ptr(), proj.data_ptr(), campos.data_ptr())
+
+
+def _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp):
+    P = means3D.shape[0]
+    M = sh.shape[1] if sh is not None else 0
+    return _capi.VrInputs(P, M, _capi.ptr(means3D), _capi.ptr(sh), _capi.ptr(colors_precomp), _capi.ptr(opacities),
+                          _capi.ptr(scales), _capi.ptr(rotations), _capi.ptr(cov3Ds_precomp))
+
+
+def _cpu_args_copy(args):
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        lib = _capi.load()
+        rs = raster_settings
+        if means3D.dim() != 2 or means3D.shape[1] != 3:
+            raise ValueError("means3D must have dimensions (num_points, 3)")
+        if not means3D.is_cuda:
+            raise ValueError("means3D must be a GPU tensor (the rasterizer has no CPU path)")
+        device = means3D.device
+        P = means3D.shape[0]
+        means3D = _prep(means3D, "means3D", device) if P > 0 else means3D.contiguous()
+        sh = _prep(sh, "shs", device)
+        colors_precomp = _prep(colors_precomp, "colors_precomp", device)
+        opacities = _prep(opacities, "opacities", device)
+        scales = _prep(scales, "scales", device)
+        rotations = _prep(rotations, "rotations", device)
+        cov3Ds_precomp = _prep(cov3Ds_precomp, "cov3D_precomp", device)
+        for t, name, shape in ((sh, "shs", (P, None, 3)), (colors_precomp, "colors_precomp", (P, 3)),
+                               (opacities, "opacities", None), (scales, "scales", (P, 3)),
+                               (rotations, "rotations", (P, 4)), (cov3Ds_precomp, "cov3D_precomp", (P, 6))):
+            if t is None:
+                continue
+            if shape is None:
+                if t.numel() != P:
+                    raise ValueError(f"{name} must hold one value per Gaussian")
+            elif t.dim() != len(shape) or any(s is not None and s != d for s, d in zip(shape, t.shape)):
+                raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {shape}")
+        H, W = int(rs.image_height), int(rs.image_width)
+        keep = []
+        with torch.cuda.device(device):
+            st = _settings_struct(rs, device, keep)
+            inp = _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+            # one [12,H,W] block: colour(3) depth(1) quat(4) scale(3) alpha(1) -- sliced into the 5 outputs
+            img = torch.empty((12, H, W), dtype=torch.float32, device=device)
+            color, depth, cov_quat, cov_scale, alpha = img[0:3], img[3:4], img[4:8], img[8:11], img[11:12]
+            radii = torch.empty((P,), dtype=torch.int32, device=device)
+            out = _capi.VrOutputs(color.data_ptr(), depth.data_ptr(), cov_quat.data_ptr(), cov_scale.data_ptr(),
+                                  alpha.data_ptr(), _capi.ptr(radii))
+            arena = _capi.Arena(device)
+            saved = _capi.VrSaved()
+            stream = torch.cuda.current_stream(device).cuda_stream
+            cpu_args = _cpu_args_copy((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)) \
+                if rs.debug else None
+            rc = lib.vr_forward(C.byref(st), C.byref(inp), C.byref(out), arena.callback, None, stream, C.byref(saved))
+            arena.release_scratch()
+            if rc != 0:
+                if rs.debug:
+                    torch.save((cpu_args, tuple(rs)), "snapshot_fw.dump")
+                    print("rasterizer forward failed; inputs written to snapshot_fw.dump")
+                if arena.error is not None:
+                    raise arena.error
+                _capi.check(rc)
+        ctx.raster_settings = rs
+        ctx.num_rendered = int(saved.num_rendered)
+        ctx.num_visible = int(saved.num_visible)
+        ctx.buffers = (arena.kept[_capi.VR_BUF_GEOM], arena.kept[_capi.VR_BUF_BINNING], arena.kept[_capi.VR_BUF_IMAGE])
+        ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
+        ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii)
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None -> NULL, no zero tensors
+        return color, depth, cov_quat, cov_scale, alpha, radii
+
+    @staticmethod
+    def backward(ctx, g_color, g_depth, g_quat, g_scale, g_alpha, _g_radii):
+        lib = _capi.load()
+        rs = ctx.raster_settings
+        means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii = ctx.saved_tensors
+        geom, binning, image = ctx.buffers
+        device = means3D.device
+        P = means3D.shape[0]
+        keep = []
+
+        def g(t):
+            return None if t is None else _dev_f32(t, device)
+        g_color, g_depth, g_quat, g_scale, g_alpha = g(g_color), g(g_depth), g(g_quat), g(g_scale), g(g_alpha)
+        with torch.cuda.device(device):
+            st = _settings_struct(rs, device, keep)
+            inp = _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+            d_means3D = torch.empty_like(means3D)
+            d_means2D = torch.empty((P, 3), dtype=torch.float32, device=device)
+            d_opac = torch.empty_like(opacities) if opacities is not None else None
+            d_sh = torch.empty_like(sh) if sh is not None else None
+            d_col = torch.empty_like(colors_precomp) if colors_precomp is not None else None
+            d_scales = torch.empty_like(scales) if scales is not None else None
+            d_rot = torch.empty_like(rotations) if rotations is not None else None
+            d_cov = torch.empty_like(cov3Ds_precomp) if cov3Ds_precomp is not None else None
+            gout = _capi.VrOutGrads(_capi.ptr(g_color), _capi.ptr(g_depth), _capi.ptr(g_quat), _capi.ptr(g_scale),
+                                    _capi.ptr(g_alpha))
+            gin = _capi.VrInGrads(_capi.ptr(d_means3D), _capi.ptr(d_means2D), _capi.ptr(d_sh), _capi.ptr(d_col),
+                                  _capi.ptr(d_opac), _capi.ptr(d_scales), _capi.ptr(d_rot), _capi.ptr(d_cov))
+            saved = _capi.VrSaved(geom.data_ptr(), binning.data_ptr(), image.data_ptr(), ctx.num_rendered,
+                                  ctx.num_visible)
+            arena = _capi.Arena(device)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            cpu_args = _cpu_args_copy((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                       radii, g_color, g_depth, g_quat, g_scale, g_alpha)) if rs.debug else None
+            rc = lib.vr_backward(C.byref(st), C.byref(inp), _capi.ptr(radii), C.byref(saved), C.byref(gout),
+                                 C.byref(gin), arena.callback, None, stream)
+            arena.release_scratch()
+            if rc != 0:
+                if rs.debug:
+                    torch.save((cpu_args, tuple(rs)), "snapshot_bw.dump")
+                    print("rasterizer backward failed; inputs written to snapshot_bw.dump")
+                if arena.error is not None:
+                    raise arena.error
+                _capi.check(rc)
+        # input order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings
+        return d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """bool[P]: view-space depth > 0.2 (reference utils/norminit_utils.py:179 uses it as a mask)."""
+        lib = _capi.load()
+        rs = self.raster_settings
+        with torch.no_grad():
+            if not positions.is_cuda:
+                raise ValueError("positions must be a GPU tensor (the rasterizer has no CPU path)")
+            device = positions.device
+            pos = positions.detach().to(torch.float32).contiguous()
+            P = pos.shape[0]
+            view = _dev_f32(rs.viewmatrix, device)
+            proj = _dev_f32(rs.projmatrix, device)
+            present = torch.empty((P,), dtype=torch.uint8, device=device)
+            with torch.cuda.device(device):
+                rc = lib.vr_mark_visible(_capi.ptr(pos), P, view.data_ptr(), proj.data_ptr(), _capi.ptr(present),
+                                         torch.cuda.current_stream(device).cuda_stream)
+            _capi.check(rc)
+            return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("exactly one of shs and colors_precomp must be given")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("exactly one of (scales, rotations) and cov3D_precomp must be given")
+        empty = torch.Tensor([])
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, rs)

@@ -153,6 +153,26 @@ void vr_get_counters(VrCounters* out);
 int vr_count_fragments(const VrSaved* saved, int32_t image_height, int32_t image_width, void* stream,
                        int64_t* fragments);
 
+/* ---- stage timing (HIP events recorded on `stream` around the kernels of each stage).
+ * level 0 = off (default), 1 = only the two render kernels, 2 = every stage.
+ * vr_profile_collect synchronises the recorded events, ADDS the elapsed milliseconds and launch
+ * counts of each stage to ms[VR_STAGE_COUNT] / count[VR_STAGE_COUNT], and clears the record. */
+typedef enum VrStage {
+    VR_STAGE_PREPROCESS = 0,
+    VR_STAGE_COMPACT = 1,
+    VR_STAGE_DEPTH_SORT = 2,
+    VR_STAGE_EMIT = 3,
+    VR_STAGE_TILE_SORT = 4,
+    VR_STAGE_RANGES = 5,
+    VR_STAGE_RENDER_FWD = 6,
+    VR_STAGE_BWD_ZERO = 7,
+    VR_STAGE_RENDER_BWD = 8,
+    VR_STAGE_PREPROCESS_BWD = 9,
+    VR_STAGE_COUNT = 10
+} VrStage;
+int vr_profile_level(int level);
+int vr_profile_collect(double* ms, int64_t* count);
+
 /* Introspection for tests: copies of the sorted tile lists kept in `saved` (device -> device).
  * point_list [R] uint32, ranges [T][2] int32 (start,end).  Either pointer may be NULL. */
 int vr_debug_export_binning(const VrSaved* saved, int32_t image_height, int32_t image_width,

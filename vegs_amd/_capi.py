@@ -17,7 +17,9 @@ VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH = 0, 1, 2, 3
 
 # every symbol include/vegs_rast.h declares
 EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_mark_visible", "vr_get_counters",
-           "vr_count_fragments", "vr_debug_export_binning"]
+           "vr_count_fragments", "vr_debug_export_binning", "vr_profile_level", "vr_profile_collect"]
+STAGES = ["preprocess", "compact", "depth_sort", "emit", "tile_sort", "ranges", "render_fwd", "bwd_zero",
+          "render_bwd", "preprocess_bwd"]
 
 
 class VrSettings(C.Structure):
@@ -93,6 +95,10 @@ def load():
     lib.vr_debug_export_binning.restype = C.c_int
     lib.vr_debug_export_binning.argtypes = [C.POINTER(VrSaved), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_void_p]
+    lib.vr_profile_level.restype = C.c_int
+    lib.vr_profile_level.argtypes = [C.c_int]
+    lib.vr_profile_collect.restype = C.c_int
+    lib.vr_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     if lib.vr_abi_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.vr_abi_version()} != {ABI_VERSION}")
     _lib = lib
@@ -144,3 +150,33 @@ class Arena:
 
     def release_scratch(self):
         self.scratch.clear()
+
+
+def profile_level(level):
+    return load().vr_profile_level(int(level))
+
+
+def profile_collect():
+    """dict stage -> (total ms, launches) accumulated since the last collect."""
+    n = len(STAGES)
+    ms = (C.c_double * n)()
+    cnt = (C.c_int64 * n)()
+    check(load().vr_profile_collect(ms, cnt))
+    return {STAGES[i]: (ms[i], cnt[i]) for i in range(n)}
+
+
+def counters():
+    c = VrCounters()
+    load().vr_get_counters(C.byref(c))
+    return dict(P=c.P, V=c.num_visible, R=c.num_rendered, T=c.num_tiles, N=c.num_pixels)
+
+
+def count_fragments(grad_fn, H, W, device):
+    """F = sum of n_contrib of the forward behind `grad_fn` (the op's autograd node)."""
+    geom, binning, image = grad_fn.buffers
+    saved = VrSaved(geom.data_ptr(), binning.data_ptr(), image.data_ptr(), grad_fn.num_rendered, grad_fn.num_visible)
+    out = C.c_int64(0)
+    with torch.cuda.device(device):
+        check(load().vr_count_fragments(C.byref(saved), H, W, torch.cuda.current_stream(device).cuda_stream,
+                                        C.byref(out)))
+    return out.value

@@ -3,6 +3,10 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <atomic>
+#include <mutex>
+#include <vector>
+
 #include "../../include/vegs_rast.h"
 #include "vr_host.h"
 
@@ -18,6 +22,50 @@ void set_error(const char* fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
+}
+
+// ---- stage profiler: pairs of events on the caller's stream, resolved in vr_profile_collect
+// (process-wide, not thread-local: PyTorch runs the op's backward on its autograd thread)
+struct ProfRec { int stage; hipEvent_t a, b; };
+static std::atomic<int> g_prof_level{0};
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+static thread_local hipEvent_t g_prof_open[VR_STAGE_COUNT];
+
+static bool prof_on(int stage)
+{
+    int lvl = g_prof_level.load(std::memory_order_relaxed);
+    if (lvl >= 2) return true;
+    return lvl == 1 && (stage == VR_STAGE_RENDER_FWD || stage == VR_STAGE_RENDER_BWD);
+}
+static hipEvent_t prof_event()
+{
+    hipEvent_t e = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_prof_pool.empty()) { e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    }
+    if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+    return e;
+}
+void prof_begin(int stage, hipStream_t s)
+{
+    if (!prof_on(stage)) return;
+    hipEvent_t e = prof_event();
+    if (e) (void)hipEventRecord(e, s);
+    g_prof_open[stage] = e;
+}
+void prof_end(int stage, hipStream_t s)
+{
+    if (!prof_on(stage) || !g_prof_open[stage]) return;
+    hipEvent_t e = prof_event();
+    if (e) {
+        (void)hipEventRecord(e, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof_recs.push_back({stage, g_prof_open[stage], e});
+    }
+    g_prof_open[stage] = nullptr;
 }
 
 static int fail(int code, const char* fmt, ...)
@@ -156,10 +204,14 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
 
     uint32_t V = 0, R = 0;
     if (P > 0) {
+        prof_begin(VR_STAGE_PREPROCESS, s);
         rc = launch_preprocess(cam, P, in->means3D, in->shs, in->colors_precomp, in->opacities, in->scales,
                                in->rotations, in->cov3D_precomp, rec, out->radii, tiles_touched, depth_key, s, debug);
+        prof_end(VR_STAGE_PREPROCESS, s);
         if (rc) return rc;
+        prof_begin(VR_STAGE_COMPACT, s);
         rc = launch_compact_visible(P, tiles_touched, depth_key, scan_scr, vis_key, vis_id, totals_dev, s, debug);
+        prof_end(VR_STAGE_COMPACT, s);
         if (rc) return rc;
         // the one host<->device round trip of the forward pass: sizes of the data-dependent lists
         VR_HIP(hipMemcpyAsync(g_pinned, totals_dev, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -176,8 +228,10 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     rc = launch_binning(cam, (int)V, (long)R, vis_key, vis_id, rec, out->radii, tiles_touched, scr2, point_list,
                         ranges, s, debug);
     if (rc) return rc;
+    prof_begin(VR_STAGE_RENDER_FWD, s);
     rc = launch_render_fwd(cam, ranges, point_list, rec, out->color, out->depth, out->cov_quat, out->cov_scale,
                            out->alpha, final_T, n_contrib, s, debug);
+    prof_end(VR_STAGE_RENDER_FWD, s);
     if (rc) return rc;
 
     saved->geom = geom;
@@ -225,20 +279,46 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
 
     float* gacc = (float*)alloc(user, VR_BUF_SCRATCH, (size_t)P * 16 * sizeof(float));
     if (!gacc) return fail(VR_ERR_ALLOC, "allocator returned NULL");
+    prof_begin(VR_STAGE_BWD_ZERO, s);
     VR_HIP(hipMemsetAsync(gacc, 0, (size_t)P * 16 * sizeof(float), s));
     VR_HIP(hipMemsetAsync(gin->dL_dmeans2D, 0, (size_t)P * 3 * sizeof(float), s));
     if (gin->dL_dshs) VR_HIP(hipMemsetAsync(gin->dL_dshs, 0, (size_t)P * in->M * 3 * sizeof(float), s));
+    prof_end(VR_STAGE_BWD_ZERO, s);
     if (saved->num_rendered > 0) {
+        ProfScope ps(VR_STAGE_RENDER_BWD, s);
         rc = launch_render_bwd(cam, ranges, point_list, rec, final_T, n_contrib, gout->dL_dcolor, gout->dL_ddepth,
                                gout->dL_dcov_quat, gout->dL_dcov_scale, gout->dL_dalpha, gacc, gin->dL_dmeans2D, s,
                                debug);
         if (rc) return rc;
     }
+    ProfScope ps2(VR_STAGE_PREPROCESS_BWD, s);
     rc = launch_preprocess_bwd(cam, P, in->means3D, in->shs, in->colors_precomp, in->scales, in->rotations,
                                in->cov3D_precomp, radii, rec, gacc, gin->dL_dmeans2D, gin->dL_dmeans3D, gin->dL_dshs,
                                gin->dL_dcolors_precomp, gin->dL_dopacities, gin->dL_dscales, gin->dL_drotations,
                                gin->dL_dcov3D_precomp, s, debug);
     return rc;
+}
+
+int vr_profile_level(int level)
+{
+    return g_prof_level.exchange(level < 0 ? 0 : (level > 2 ? 2 : level));
+}
+
+int vr_profile_collect(double* ms, int64_t* count)
+{
+    g_err[0] = 0;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof_recs) {
+        float t = 0.f;
+        VR_HIP(hipEventSynchronize(r.b));
+        VR_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        if (ms) ms[r.stage] += (double)t;
+        if (count) count[r.stage] += 1;
+        g_prof_pool.push_back(r.a);
+        g_prof_pool.push_back(r.b);
+    }
+    g_prof_recs.clear();
+    return VR_OK;
 }
 
 int vr_mark_visible(const float* xyz, int32_t P, const float* viewmatrix, const float* projmatrix, uint8_t* present,

@@ -13,6 +13,7 @@
 //   5. tile ranges from key boundaries.
 // R-sized traffic is 2 passes of 8-byte pairs instead of upstream's 6 passes of 12-byte pairs.
 // Ranking inside a pass uses wave64 ballots (match-by-digit), no per-element atomics.
+#include "../../include/vegs_rast.h"
 #include "vr_host.h"
 
 namespace vr {
@@ -402,6 +403,7 @@ int launch_binning(const Camera& cam, int V, long R, uint32_t* vis_key, uint32_t
 
     // 2. depth sort of the visible Gaussians (ping-pong; 4 passes end in vis_key/vis_id)
     {
+        ProfScope ps(VR_STAGE_DEPTH_SORT, s);
         uint32_t *ka = vis_key, *va = vis_id, *kb = tmp_key, *vb = tmp_id;
         for (int pass = 0; pass < 4; ++pass) {
             int rc = radix_pass(ka, va, kb, vb, V, pass * RADIX_BITS, hist, bsum, s, debug);
@@ -411,6 +413,7 @@ int launch_binning(const Camera& cam, int V, long R, uint32_t* vis_key, uint32_t
         }
     }
     // 3. offsets in depth order, then emission
+    prof_begin(VR_STAGE_EMIT, s);
     {
         int rc = run_scan(SrcGather{tiles_touched, vis_id}, SinkStore{offs}, V, bsum, (uint32_t*)nullptr,
                           (uint32_t*)nullptr, s, debug, "offset_scan");
@@ -426,16 +429,21 @@ int launch_binning(const Camera& cam, int V, long R, uint32_t* vis_key, uint32_t
     hipLaunchKernelGGL(k_emit, dim3(cdiv(V, 256)), dim3(256), 0, s, V, cam.gx, cam.gy, (const uint32_t*)vis_id,
                        (const uint32_t*)offs, tiles_touched, rec, radii, ka, va);
     VR_KERNEL_CHECK("emit", s, debug);
+    prof_end(VR_STAGE_EMIT, s);
     // 4. stable sort by tile id
+    prof_begin(VR_STAGE_TILE_SORT, s);
     for (int pass = 0; pass < passes; ++pass) {
         int rc = radix_pass(ka, va, kb, vb, R, pass * RADIX_BITS, hist, bsum, s, debug);
         if (rc) return rc;
         uint32_t* t = ka; ka = kb; kb = t;
         t = va; va = vb; vb = t;
     }
+    prof_end(VR_STAGE_TILE_SORT, s);
     // 5. ranges
+    prof_begin(VR_STAGE_RANGES, s);
     hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(R, 256)), dim3(256), 0, s, (const uint32_t*)ka, R, ranges);
     VR_KERNEL_CHECK("tile_ranges", s, debug);
+    prof_end(VR_STAGE_RANGES, s);
     return 0;
 }
 

@@ -30,6 +30,15 @@ void set_error(const char* fmt, ...);
         }                                                                                     \
     } while (0)
 
+// stage timing (api.hip); no-ops unless vr_profile_level() enabled them
+void prof_begin(int stage, hipStream_t s);
+void prof_end(int stage, hipStream_t s);
+struct ProfScope {
+    int stage; hipStream_t s;
+    ProfScope(int st, hipStream_t str) : stage(st), s(str) { prof_begin(stage, s); }
+    ~ProfScope() { prof_end(stage, s); }
+};
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -352,7 +352,17 @@ static inline void splat_attrs(int id, const float* rgb, const float* depth, con
     else { for (int k = 0; k < 3; ++k) a[8 + k] = 0.f; }
 }
 
-/* A.4 + A-1..A-5.  out_* planar [C,H,W]. */
+#define SEG 256 /* entries per compositing segment */
+
+/* A.4 + A-1..A-5.  out_* planar [C,H,W].
+ *
+ * Arithmetic of the blend (part of the spec, chosen so that a massively parallel implementation
+ * can reproduce it bit for bit): the tile list is cut into segments of SEG entries.  Inside a
+ * segment the pixel keeps a LOCAL transmittance product p (from 1) and LOCAL channel sums Cs (from
+ * 0); the transmittance in front of an entry is Tb*p with Tb the transmittance at the segment
+ * start; at the segment end  C += Cs  and  Tb *= p.  Mathematically this is the usual
+ * front-to-back compositing  C = sum a_i alpha_i T_i,  T_{i+1} = T_i (1 - alpha_i),  stop when
+ * T_i (1 - alpha_i) < 1e-4 (that entry is not applied). */
 void or_render_fwd(const OrCam* cam, const int* ranges, const uint32_t* point_list,
                    const float* xy, const float* conic_op, const float* rgb, const float* depth,
                    const float* rotations, const float* scales,
@@ -370,25 +380,33 @@ void or_render_fwd(const OrCam* cam, const int* ranges, const uint32_t* point_li
                 int px = tx * TILE + lx, py = ty * TILE + ly;
                 if (px >= W || py >= H) continue;
                 float pxf = (float)px, pyf = (float)py;
-                float T = 1.0f, C[NCH];
+                float Tb = 1.0f, C[NCH];
                 for (int k = 0; k < NCH; ++k) C[k] = 0.f;
-                uint32_t contributor = 0, last = 0;
-                for (int j = s; j < e; ++j) {
-                    ++contributor;
-                    int id = (int)point_list[j];
-                    float dx, dy;
-                    float power = splat_power(xy + 2 * id, conic_op + 4 * id, pxf, pyf, &dx, &dy);
-                    if (power > 0.0f) continue;
-                    float alpha = fminf(ALPHA_MAX, conic_op[4 * id + 3] * vr_exp(power));
-                    if (alpha < ALPHA_MIN) continue;
-                    float test_T = T * (1.0f - alpha);
-                    if (test_T < T_EPS) break;
-                    float w = alpha * T, a[NCH];
-                    splat_attrs(id, rgb, depth, rotations, scales, a);
-                    for (int k = 0; k < NCH; ++k) C[k] = fmaf(a[k], w, C[k]);
-                    T = test_T;
-                    last = contributor;
+                uint32_t last = 0;
+                int done = 0;
+                for (int sb = s; sb < e && !done; sb += SEG) {
+                    int se = sb + SEG < e ? sb + SEG : e;
+                    float p = 1.0f, Cs[NCH];
+                    for (int k = 0; k < NCH; ++k) Cs[k] = 0.f;
+                    for (int j = sb; j < se; ++j) {
+                        int id = (int)point_list[j];
+                        float dx, dy;
+                        float power = splat_power(xy + 2 * id, conic_op + 4 * id, pxf, pyf, &dx, &dy);
+                        if (power > 0.0f) continue;
+                        float alpha = fminf(ALPHA_MAX, conic_op[4 * id + 3] * vr_exp(power));
+                        if (alpha < ALPHA_MIN) continue;
+                        float pn = p * (1.0f - alpha);
+                        if (Tb * pn < T_EPS) { done = 1; break; }
+                        float w = alpha * (Tb * p), a[NCH];
+                        splat_attrs(id, rgb, depth, rotations, scales, a);
+                        for (int k = 0; k < NCH; ++k) Cs[k] = fmaf(a[k], w, Cs[k]);
+                        p = pn;
+                        last = (uint32_t)(j - s + 1);
+                    }
+                    for (int k = 0; k < NCH; ++k) C[k] += Cs[k];
+                    Tb = Tb * p;
                 }
+                float T = Tb;
                 size_t pix = (size_t)py * W + px, N = (size_t)H * W;
                 final_T[pix] = T;
                 n_contrib[pix] = last;

@@ -138,13 +138,17 @@ static ImageLayout image_layout(size_t N)
     L.total = L.n_contrib + align_up(N * 4, 256);
     return L;
 }
-struct BinLayout { size_t ranges, point_list, total; };
+// binning buffer: tile ranges | segment table | point list | boundary transmittances per (segment, pixel)
+struct BinLayout { size_t ranges, seg_off, seg_needed, point_list, tbuf, total; };
 static BinLayout bin_layout(size_t T, size_t R)
 {
     BinLayout L;
     L.ranges = 0;
-    L.point_list = align_up(T * 8, 256);
-    L.total = L.point_list + align_up((R > 0 ? R : 1) * 4, 256);
+    L.seg_off = align_up(T * 8, 256);
+    L.seg_needed = L.seg_off + align_up((T + 1) * 4, 256);
+    L.point_list = L.seg_needed + align_up(T * 4, 256);
+    L.tbuf = L.point_list + align_up((R > 0 ? R : 1) * 4, 256);
+    L.total = L.tbuf + align_up(seg_capacity((long)R, (int)T) * 256 * sizeof(float), 256);
     return L;
 }
 
@@ -228,9 +232,13 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     rc = launch_binning(cam, (int)V, (long)R, vis_key, vis_id, rec, out->radii, tiles_touched, scr2, point_list,
                         ranges, s, debug);
     if (rc) return rc;
+    void* scr3 = alloc(user, VR_BUF_SCRATCH, render_fwd_scratch_bytes((long)R, (int)T) + 256);
+    if (!scr3) return fail(VR_ERR_ALLOC, "allocator returned NULL");
     prof_begin(VR_STAGE_RENDER_FWD, s);
-    rc = launch_render_fwd(cam, ranges, point_list, rec, out->color, out->depth, out->cov_quat, out->cov_scale,
-                           out->alpha, final_T, n_contrib, s, debug);
+    rc = launch_render_fwd(cam, (long)R, ranges, point_list, rec, (uint32_t*)((char*)binning + BL.seg_off),
+                           (uint32_t*)((char*)binning + BL.seg_needed), (float*)((char*)binning + BL.tbuf), scr3,
+                           out->color, out->depth, out->cov_quat, out->cov_scale, out->alpha, final_T, n_contrib, s,
+                           debug);
     prof_end(VR_STAGE_RENDER_FWD, s);
     if (rc) return rc;
 
@@ -285,10 +293,15 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
     if (gin->dL_dshs) VR_HIP(hipMemsetAsync(gin->dL_dshs, 0, (size_t)P * in->M * 3 * sizeof(float), s));
     prof_end(VR_STAGE_BWD_ZERO, s);
     if (saved->num_rendered > 0) {
+        void* scr = alloc(user, VR_BUF_SCRATCH, render_bwd_scratch_bytes((long)saved->num_rendered, (int)T) + 256);
+        if (!scr) return fail(VR_ERR_ALLOC, "allocator returned NULL");
         ProfScope ps(VR_STAGE_RENDER_BWD, s);
-        rc = launch_render_bwd(cam, ranges, point_list, rec, final_T, n_contrib, gout->dL_dcolor, gout->dL_ddepth,
-                               gout->dL_dcov_quat, gout->dL_dcov_scale, gout->dL_dalpha, gacc, gin->dL_dmeans2D, s,
-                               debug);
+        rc = launch_render_bwd(cam, (long)saved->num_rendered, ranges, point_list, rec,
+                               (const uint32_t*)((const char*)saved->binning + BL.seg_off),
+                               (const uint32_t*)((const char*)saved->binning + BL.seg_needed),
+                               (const float*)((const char*)saved->binning + BL.tbuf), scr, final_T, n_contrib,
+                               gout->dL_dcolor, gout->dL_ddepth, gout->dL_dcov_quat, gout->dL_dcov_scale,
+                               gout->dL_dalpha, gacc, gin->dL_dmeans2D, s, debug);
         if (rc) return rc;
     }
     ProfScope ps2(VR_STAGE_PREPROCESS_BWD, s);

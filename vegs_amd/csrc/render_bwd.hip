@@ -8,21 +8,27 @@
 //                   behind = sum_{j behind s} w_j u_j
 // and dL/dalpha fans out to opacity, conic and the 2D mean.
 //
-// MI355X design -- SPLAT-parallel with wave64 scans (not the pixel-parallel + per-fragment-atomic
-// scheme of CUDA rasterizers).  The reduction target of the backward pass is the splat, so the splat
-// owns the lane: a wave loads 64 consecutive list entries (one per lane, kept in registers together
-// with their 17 gradient accumulators) and walks its 64 pixels; the per-pixel quantities are
-// wave-uniform (v_readlane -> SGPR).  The two compositing recurrences become wave scans:
-//   T before splat s   = T_after_chunk / prod_{j>=s}(1-alpha_j)    (inclusive scan-product)
-//   behind(s)          = carry + sum_{j>s} w_j u_j                 (inclusive scan-sum)
-// Lanes hold the chunk back-to-front (lane l <-> entry 63-l) so both are PREFIX scans over lanes.
-// Per-splat gradients never leave registers until the chunk is finished; the four waves of a tile
-// are then reduced through LDS and one coalesced set of global atomics per (tile, splat) is issued
-// -- 256x fewer atomics than one per fragment.
+// MI355X design.  (1) SEGMENTED like the forward: the unit of work is (tile, 256-entry segment), so
+// the 10^5-entry vanishing-point tiles spread over the whole chip.  The two compositing carries are
+// made available per segment: the transmittance at the segment end comes from the forward's boundary
+// buffer (Tbuf, kept in the binning buffer), and the "behind" sum comes from a cheap pixel-parallel
+// pass (k_seg_wu: U = sum of w*u per segment) followed by a per-tile suffix sum (k_seg_suffix).
+// (2) SPLAT-parallel inside a segment with wave64 DPP scans (not the pixel-parallel +
+// per-fragment-atomic scheme of CUDA rasterizers): the reduction target of the backward pass is the
+// splat, so the splat owns the lane.  A wave holds 64 consecutive list entries in registers (record +
+// 17 gradient accumulators) and walks its 64 pixels, whose quantities are wave-uniform
+// (v_readlane -> SGPR).  The two recurrences become wave scans in DPP (row_shr / row_bcast):
+//   T in front of splat s = T_after_chunk / prod_{j>=s}(1-alpha_j)   (inclusive scan-product)
+//   behind(s)             = carry + sum_{j>s} w_j u_j                (inclusive scan-sum)
+// Lanes hold a chunk back-to-front (lane l <-> entry 63-l) so both are PREFIX scans over lanes.
+// Per-splat gradients stay in registers until the chunk is finished; the four waves (pixel strips)
+// of the tile are reduced through LDS and one coalesced set of global atomics per (tile, splat) is
+// issued -- 256x fewer atomics than one per fragment.
 #include "vr_host.h"
 
 namespace vr {
 
+constexpr int SEG = 256;
 constexpr int NACC = 17;  // conic(3) opacity(1) attr(11) mean2D(2)
 
 __device__ __forceinline__ float readlane_f(float v, int l)
@@ -30,42 +36,178 @@ __device__ __forceinline__ float readlane_f(float v, int l)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-__device__ __forceinline__ float wave_prefix_mul(float v, int lane)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float identity, float v)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float n = __shfl_up(v, d, 64);
-        if (lane >= d) v *= n;
-    }
+    // lanes whose DPP source is out of range (or whose row is masked off) read `identity`
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// wave64 inclusive prefix scans: row_shr 1,2,4,8 inside each 16-lane row, then row_bcast 15 / 31
+__device__ __forceinline__ float wave_prefix_mul(float v)
+{
+    v *= dpp_f<0x111, 0xf>(1.0f, v);
+    v *= dpp_f<0x112, 0xf>(1.0f, v);
+    v *= dpp_f<0x114, 0xf>(1.0f, v);
+    v *= dpp_f<0x118, 0xf>(1.0f, v);
+    v *= dpp_f<0x142, 0xa>(1.0f, v);
+    v *= dpp_f<0x143, 0xc>(1.0f, v);
     return v;
 }
-__device__ __forceinline__ float wave_prefix_add(float v, int lane)
+__device__ __forceinline__ float wave_prefix_add(float v)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float n = __shfl_up(v, d, 64);
-        if (lane >= d) v += n;
-    }
+    v += dpp_f<0x111, 0xf>(0.0f, v);
+    v += dpp_f<0x112, 0xf>(0.0f, v);
+    v += dpp_f<0x114, 0xf>(0.0f, v);
+    v += dpp_f<0x118, 0xf>(0.0f, v);
+    v += dpp_f<0x142, 0xa>(0.0f, v);
+    v += dpp_f<0x143, 0xc>(0.0f, v);
     return v;
 }
 
+__device__ __forceinline__ int seg_find_tile_b(const uint32_t* __restrict__ seg_off, int ntiles, uint32_t b)
+{
+    int lo = 0, hi = ntiles;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (seg_off[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// per-pixel upstream gradients of the 11 blended channels
+struct PixGrad {
+    float g[NCH];
+    float galpha;
+};
+__device__ __forceinline__ void load_pixgrad(bool inside, size_t pix, size_t N, const float* dL_dcolor,
+                                             const float* dL_ddepth, const float* dL_dquat, const float* dL_dscale,
+                                             const float* dL_dalpha, PixGrad& o)
+{
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) o.g[k] = 0.0f;
+    o.galpha = 0.0f;
+    if (!inside) return;
+    if (dL_dcolor) { o.g[0] = dL_dcolor[pix]; o.g[1] = dL_dcolor[N + pix]; o.g[2] = dL_dcolor[2 * N + pix]; }
+    if (dL_ddepth) o.g[3] = dL_ddepth[pix];
+    if (dL_dquat) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o.g[4 + k] = dL_dquat[k * N + pix];
+    }
+    if (dL_dscale) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o.g[8 + k] = dL_dscale[k * N + pix];
+    }
+    if (dL_dalpha) o.galpha = dL_dalpha[pix];
+}
+
+// ---- A': U[seg][pix] = sum over the segment's applied entries of w*u (pixel-parallel, lane = pixel)
 __global__ void __launch_bounds__(256)
-k_render_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-             const Splat* __restrict__ rec, const float* __restrict__ final_T,
-             const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
-             const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dquat,
-             const float* __restrict__ dL_dscale, const float* __restrict__ dL_dalpha, float* __restrict__ gacc,
-             float* __restrict__ gmean2D)
+k_seg_wu(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
+         const uint32_t* __restrict__ seg_needed, const uint32_t* __restrict__ point_list,
+         const Splat* __restrict__ rec, const float* __restrict__ Tbuf, const uint32_t* __restrict__ n_contrib,
+         const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dquat,
+         const float* __restrict__ dL_dscale, float* __restrict__ Ubuf)
+{
+    __shared__ float4 lds[5][SEG];
+    const int ntiles = cam.gx * cam.gy;
+    const uint32_t b = blockIdx.x;
+    if (b >= seg_off[ntiles]) return;
+    const int tile = seg_find_tile_b(seg_off, ntiles, b);
+    const int sl = (int)(b - seg_off[tile]);
+    if ((uint32_t)sl >= seg_needed[tile]) return;
+    const int2 r = ranges[tile];
+    const int first = r.x + sl * SEG;
+    const int count = min(SEG, r.y - first);
+    const int tx = tile % cam.gx, ty = tile / cam.gx;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int px = tx * TILE + (lane & 15), py = ty * TILE + w * 4 + (lane >> 4);
+    const bool inside = px < cam.W && py < cam.H;
+    const size_t N = (size_t)cam.H * cam.W, pix = (size_t)py * cam.W + px;
+    if ((int)threadIdx.x < count) {
+        const float4* src = reinterpret_cast<const float4*>(rec + point_list[first + threadIdx.x]);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) lds[k][threadIdx.x] = src[k];
+    }
+    __syncthreads();
+    PixGrad pg;
+    load_pixgrad(inside, pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, nullptr, pg);
+    const int nc = inside ? (int)n_contrib[pix] : 0;
+    const int lim = min(count, nc - sl * SEG);  // entries of this segment in front of the pixel's last contributor
+    float U = 0.0f;
+    if (__ballot(lim > 0) != 0ull) {
+        const float Tb = Tbuf[(size_t)b * SEG + threadIdx.x];
+        float p = 1.0f;
+        for (int k = 0; k < count; ++k) {
+            if (k >= lim) continue;
+            const float4 a = lds[0][k];
+            const float4 bq = lds[1][k];
+            float dx, dy;
+            const float power = splat_power(a.x, a.y, a.z, a.w, bq.x, (float)px, (float)py, dx, dy);
+            if (power > 0.0f) continue;
+            const float alpha = fminf(ALPHA_MAX, bq.y * vr_exp(power));
+            if (alpha < ALPHA_MIN) continue;
+            const float wgt = alpha * (Tb * p);
+            const float4 cc = lds[2][k];
+            const float4 d = lds[3][k];
+            const float s2 = lds[4][k].x;
+            float u = bq.w * pg.g[0];
+            u = fmaf(cc.x, pg.g[1], u);
+            u = fmaf(cc.y, pg.g[2], u);
+            u = fmaf(bq.z, pg.g[3], u);
+            u = fmaf(cc.z, pg.g[4], u);
+            u = fmaf(cc.w, pg.g[5], u);
+            u = fmaf(d.x, pg.g[6], u);
+            u = fmaf(d.y, pg.g[7], u);
+            u = fmaf(d.z, pg.g[8], u);
+            u = fmaf(d.w, pg.g[9], u);
+            u = fmaf(s2, pg.g[10], u);
+            U = fmaf(wgt, u, U);
+            p = p * (1.0f - alpha);
+        }
+    }
+    Ubuf[(size_t)b * SEG + threadIdx.x] = U;
+}
+
+// ---- B': per tile, in place: Ubuf[seg][pix] <- sum of U over the LATER segments of the tile
+__global__ void __launch_bounds__(256)
+k_seg_suffix(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_needed, float* __restrict__ Ubuf)
+{
+    const int tile = blockIdx.x;
+    const uint32_t s0 = seg_off[tile];
+    const int needed = (int)seg_needed[tile];
+    float run = 0.0f;
+    for (int s = needed - 1; s >= 0; --s) {
+        const size_t at = (size_t)(s0 + s) * SEG + threadIdx.x;
+        const float U = Ubuf[at];
+        Ubuf[at] = run;
+        run += U;
+    }
+}
+
+// ---- C': gradients of one (tile, segment)
+__global__ void __launch_bounds__(256)
+k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
+          const uint32_t* __restrict__ seg_needed, const uint32_t* __restrict__ point_list,
+          const Splat* __restrict__ rec, const float* __restrict__ Tbuf, const float* __restrict__ Ubuf,
+          const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+          const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dquat,
+          const float* __restrict__ dL_dscale, const float* __restrict__ dL_dalpha, float* __restrict__ gacc,
+          float* __restrict__ gmean2D)
 {
     __shared__ float red[4][64 * NACC];
     __shared__ uint32_t ids[64];
-    __shared__ int wmax[4];
     const int ntiles = cam.gx * cam.gy;
-    const int tile = xcd_tile(blockIdx.x, ntiles);
-    const int tx = tile % cam.gx, ty = tile / cam.gx;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x;
+    if (b >= seg_off[ntiles]) return;
+    const int tile = seg_find_tile_b(seg_off, ntiles, b);
+    const int sl = (int)(b - seg_off[tile]);
+    const int needed = (int)seg_needed[tile];
+    if (sl >= needed) return;
     const int2 range = ranges[tile];
     const int nlist = range.y - range.x;
+    const int tx = tile % cam.gx, ty = tile / cam.gx;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 
     // ---- pixel state, lane = pixel of this wave's 16x4 strip
     const int px = tx * TILE + (lane & 15), py = ty * TILE + w * 4 + (lane >> 4);
@@ -73,44 +215,34 @@ k_render_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __rest
     const size_t N = (size_t)cam.H * cam.W;
     const size_t pix = (size_t)py * cam.W + px;
     const float v_pxf = (float)px, v_pyf = (float)py;
-    float v_g[NCH];
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) v_g[k] = 0.0f;
-    float v_galpha = 0.0f, v_Tf = 1.0f;
+    PixGrad pg;
+    load_pixgrad(inside, pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, dL_dalpha, pg);
+    float v_Tf = 1.0f;
     int v_nc = 0;
-    if (inside) {
-        if (dL_dcolor) { v_g[0] = dL_dcolor[pix]; v_g[1] = dL_dcolor[N + pix]; v_g[2] = dL_dcolor[2 * N + pix]; }
-        if (dL_ddepth) v_g[3] = dL_ddepth[pix];
-        if (dL_dquat) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v_g[4 + k] = dL_dquat[k * N + pix];
-        }
-        if (dL_dscale) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) v_g[8 + k] = dL_dscale[k * N + pix];
-        }
-        if (dL_dalpha) v_galpha = dL_dalpha[pix];
-        v_Tf = final_T[pix];
-        v_nc = (int)n_contrib[pix];
-    }
+    if (inside) { v_Tf = final_T[pix]; v_nc = (int)n_contrib[pix]; }
     const float v_bgterm =
-        v_Tf * (fmaf(cam.bg[2], v_g[2], fmaf(cam.bg[1], v_g[1], cam.bg[0] * v_g[0])) - v_galpha);
-    float v_Tcar = v_Tf;  // transmittance after the last processed (later) chunk
-    float v_Scar = 0.0f;  // sum of w*u over all later chunks
+        v_Tf * (fmaf(cam.bg[2], pg.g[2], fmaf(cam.bg[1], pg.g[1], cam.bg[0] * pg.g[0])) - pg.galpha);
+    // carries at the END of this segment: transmittance behind its last entry, and the w*u sum of
+    // everything behind the segment
+    float v_Tcar = v_Tf;
+    if (sl + 1 < needed) {
+        const float Tn = Tbuf[(size_t)(b + 1) * SEG + threadIdx.x];
+        if (!(Tn < 0.0f)) v_Tcar = Tn;   // pixel still alive at the next segment
+    }
+    float v_Scar = Ubuf[(size_t)b * SEG + threadIdx.x];
+    const int seg_lo = sl * SEG;         // first list entry (tile-relative) of this segment
 
     int m = v_nc;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
     const int wave_maxc = m;
-    if (lane == 0) wmax[w] = m;
-    __syncthreads();
-    const int tile_maxc = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
-    const int nchunks = (tile_maxc + 63) >> 6;
+    const int seg_cnt = min(SEG, nlist - seg_lo);
+    const int nchunks = (seg_cnt + 63) >> 6;
 
     for (int c = nchunks - 1; c >= 0; --c) {
-        // ---- lane l owns list entry c*64 + (63-l): back-to-front over lanes
-        const int e = c * 64 + (63 - lane);
-        const bool has = e < nlist;
+        // ---- lane l owns list entry seg_lo + c*64 + (63-l): back-to-front over lanes
+        const int e = seg_lo + c * 64 + (63 - lane);
+        const bool has = e < nlist && e < seg_lo + SEG;
         uint32_t id = 0;
         float sx = 0.f, sy = 0.f, cA = 0.f, cB = 0.f, cC = 0.f, op = 0.f;
         float at[NCH];
@@ -128,17 +260,18 @@ k_render_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __rest
         float acc[NACC];
 #pragma unroll
         for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+        const int chunk_lo = seg_lo + c * 64;
 
-        if (c * 64 < wave_maxc) {
+        if (chunk_lo < wave_maxc) {
             for (int p = 0; p < 64; ++p) {
                 const int nc = __builtin_amdgcn_readlane(v_nc, p);
-                if (nc <= c * 64) continue;  // pixel p has no contributor in this chunk (wave-uniform)
+                if (nc <= chunk_lo) continue;  // pixel p has no contributor in this chunk (wave-uniform)
                 const float pxf = readlane_f(v_pxf, p), pyf = readlane_f(v_pyf, p);
                 const float Tc = readlane_f(v_Tcar, p), Sc = readlane_f(v_Scar, p);
                 const float bgterm = readlane_f(v_bgterm, p);
                 float g[NCH];
 #pragma unroll
-                for (int k = 0; k < NCH; ++k) g[k] = readlane_f(v_g[k], p);
+                for (int k = 0; k < NCH; ++k) g[k] = readlane_f(pg.g[k], p);
 
                 float dx, dy;
                 const float power = splat_power(sx, sy, cA, cB, cC, pxf, pyf, dx, dy);
@@ -147,14 +280,14 @@ k_render_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __rest
                 const bool contrib = has && (e < nc) && !(power > 0.0f) && !(alpha < ALPHA_MIN);
                 const float a_eff = contrib ? alpha : 0.0f;
                 const float om = 1.0f - a_eff;
-                const float pprod = wave_prefix_mul(om, lane);           // prod over entries >= mine
+                const float pprod = wave_prefix_mul(om);                 // prod over entries >= mine
                 const float Tl = Tc * __builtin_amdgcn_rcpf(pprod);      // T in front of my splat
                 const float wgt = a_eff * Tl;
                 float u = 0.0f;
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) u = fmaf(at[k], g[k], u);
                 const float wu = wgt * u;
-                const float psum = wave_prefix_add(wu, lane);            // sum over entries >= mine
+                const float psum = wave_prefix_add(wu);                  // sum over entries >= mine
                 const float behind = Sc + (psum - wu);
                 // carries for the next (nearer) chunk: values at the chunk's first entry = lane 63
                 v_Tcar = (lane == p) ? readlane_f(Tl, 63) : v_Tcar;
@@ -192,16 +325,30 @@ k_render_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __rest
     }
 }
 
-int launch_render_bwd(const Camera& cam, const int2* ranges, const uint32_t* point_list, const Splat* rec,
+size_t render_bwd_scratch_bytes(long R, int ntiles)
+{
+    return align_up(seg_capacity(R, ntiles) * SEG * sizeof(float), 256);
+}
+
+int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint32_t* point_list, const Splat* rec,
+                      const uint32_t* seg_off, const uint32_t* seg_needed, const float* Tbuf, void* scratch,
                       const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                       const float* dL_ddepth, const float* dL_dquat, const float* dL_dscale,
                       const float* dL_dalpha, float* gacc, float* gmean2D, hipStream_t s, bool debug)
 {
-    int ntiles = cam.gx * cam.gy;
-    if (ntiles == 0) return 0;
-    hipLaunchKernelGGL(k_render_bwd, dim3(ntiles), dim3(256), 0, s, cam, ranges, point_list, rec, final_T,
-                       n_contrib, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, dL_dalpha, gacc, gmean2D);
-    VR_KERNEL_CHECK("render_bwd", s, debug);
+    const int ntiles = cam.gx * cam.gy;
+    if (ntiles == 0 || R == 0) return 0;
+    const unsigned nseg = (unsigned)seg_capacity(R, ntiles);
+    float* Ubuf = (float*)scratch;
+    hipLaunchKernelGGL(k_seg_wu, dim3(nseg), dim3(256), 0, s, cam, ranges, seg_off, seg_needed, point_list, rec, Tbuf,
+                       n_contrib, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, Ubuf);
+    VR_KERNEL_CHECK("seg_wu", s, debug);
+    hipLaunchKernelGGL(k_seg_suffix, dim3(ntiles), dim3(256), 0, s, seg_off, seg_needed, Ubuf);
+    VR_KERNEL_CHECK("seg_suffix", s, debug);
+    hipLaunchKernelGGL(k_seg_bwd, dim3(nseg), dim3(256), 0, s, cam, ranges, seg_off, seg_needed, point_list, rec, Tbuf,
+                       (const float*)Ubuf, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, dL_dalpha,
+                       gacc, gmean2D);
+    VR_KERNEL_CHECK("seg_bwd", s, debug);
     return 0;
 }
 

@@ -5,114 +5,266 @@
 // gaussian_renderer/__init__.py:86-94; the 6-tuple it returns is consumed at :109-119 and by
 // loss/normal_guidance.py:3-22).  Semantics: SURVEY.md A.4 with fork assumptions A-1..A-5.
 //
-// Mapping: one 256-thread workgroup per 16x16 tile = 4 wave64, each wave owning a 16x4 pixel strip,
-// one lane per pixel (the reduction target of the forward pass is the pixel, so the pixel owns the
-// lane and accumulates in registers).  Splat records are gathered by id with five dwordx4 loads per
-// lane and staged in LDS in batches of 256; the inner loop reads them back as wave-uniform
-// broadcasts.  The gather of batch k+1 is issued before batch k is blended (register staging) so
-// HBM/L2 latency hides behind the blend loop.  Waves whose 64 pixels are all saturated skip the
-// blend loop (wave-uniform branch) but keep staging for the others.
+// MI355X design -- SEGMENTED compositing (a chunked scan over each tile's list), not one
+// sequential loop per tile.  KITTI-shaped scenes pile tens of thousands of far splats onto the
+// vanishing-point tiles (lists of 10^5 entries while the mean is 10^3); a loop per tile leaves
+// 255 CUs idle behind the longest tile.  The list of every tile is cut into segments of 256
+// entries and the unit of work is (tile, segment), ~R/256 + T workgroups of equal size:
+//   A  k_seg_alpha   every (tile, segment): per pixel, P = product of (1 - alpha) over the segment
+//   B  k_seg_scan    per tile: Tb[s+1] = Tb[s] * P[s] per pixel (the only sequential step: one
+//                    multiply per segment); a pixel is finished in the first segment with
+//                    Tb*P < 1e-4 (fp32 products by factors <= 1 are monotone, so this is exactly
+//                    "the stop test fires inside this segment"); segments behind that are skipped
+//   C  k_seg_blend   every needed (tile, segment): blend the segment from its known Tb into
+//                    segment-local sums
+//   D  k_seg_combine per tile: add the segment-local sums in order, write the images
+// The arithmetic (local product / local sums per segment, added in order) is the one the spec
+// fixes (oracle: or_render_fwd), so the images stay bit-identical to the sequential oracle.
+// One 256-thread workgroup = one 16x16 tile = 4 wave64, lane = pixel (16x4 strip per wave); splat
+// records are gathered with dwordx4 loads into LDS and read back as wave-uniform broadcasts.
 #include "vr_host.h"
 
 namespace vr {
 
-constexpr int BATCH = 256;
+constexpr int SEG = 256;
 
-__global__ void __launch_bounds__(256)
-k_render_fwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-             const Splat* __restrict__ rec, float* __restrict__ out_color, float* __restrict__ out_depth,
-             float* __restrict__ out_quat, float* __restrict__ out_scale, float* __restrict__ out_alpha,
-             float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
+__device__ __forceinline__ int seg_find_tile(const uint32_t* __restrict__ seg_off, int ntiles, uint32_t b)
 {
-    __shared__ float4 lds[5][BATCH];
+    // largest t with seg_off[t] <= b  (seg_off is non-decreasing, seg_off[ntiles] = total)
+    int lo = 0, hi = ntiles;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (seg_off[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// seg_off[t] = first global segment id of tile t; seg_off[T] = total.  Single workgroup.
+__global__ void __launch_bounds__(256)
+k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict__ seg_off)
+{
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int base = 0; base < ntiles; base += 256) {
+        const int t = base + threadIdx.x;
+        uint32_t n = 0;
+        if (t < ntiles) { const int2 r = ranges[t]; n = (uint32_t)((r.y - r.x + SEG - 1) / SEG); }
+        uint32_t incl = n;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        const uint32_t carry = carry_s;
+        if (t < ntiles) seg_off[t] = carry + woff + incl - n;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) seg_off[ntiles] = carry_s;
+}
+
+struct SegCtx {
+    int tile, sl;        // tile id, segment index inside the tile
+    int first, count;    // first list entry of the segment (absolute index into point_list), entries
+    float pxf, pyf;
+    bool inside;
+    size_t pix;
+};
+
+__device__ __forceinline__ bool seg_setup(const Camera& cam, const int2* __restrict__ ranges,
+                                          const uint32_t* __restrict__ seg_off, SegCtx& c)
+{
     const int ntiles = cam.gx * cam.gy;
-    const int tile = xcd_tile(blockIdx.x, ntiles);
+    const uint32_t b = blockIdx.x;
+    if (b >= seg_off[ntiles]) return false;
+    c.tile = seg_find_tile(seg_off, ntiles, b);
+    c.sl = (int)(b - seg_off[c.tile]);
+    const int2 r = ranges[c.tile];
+    c.first = r.x + c.sl * SEG;
+    c.count = min(SEG, r.y - c.first);
+    const int tx = c.tile % cam.gx, ty = c.tile / cam.gx;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int px = tx * TILE + (lane & 15), py = ty * TILE + w * 4 + (lane >> 4);
+    c.inside = px < cam.W && py < cam.H;
+    c.pxf = (float)px;
+    c.pyf = (float)py;
+    c.pix = (size_t)py * cam.W + px;
+    return true;
+}
+
+// ---- A: per (tile, segment, pixel) product of (1 - alpha)
+__global__ void __launch_bounds__(256)
+k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
+            const uint32_t* __restrict__ point_list, const Splat* __restrict__ rec, float* __restrict__ Pbuf)
+{
+    __shared__ float4 lds[2][SEG];
+    SegCtx c;
+    if (!seg_setup(cam, ranges, seg_off, c)) return;
+    if ((int)threadIdx.x < c.count) {
+        const float4* src = reinterpret_cast<const float4*>(rec + point_list[c.first + threadIdx.x]);
+        lds[0][threadIdx.x] = src[0];
+        lds[1][threadIdx.x] = src[1];
+    }
+    __syncthreads();
+    float p = 1.0f;
+    for (int k = 0; k < c.count; ++k) {
+        const float4 a = lds[0][k];  // x y A B
+        const float4 b = lds[1][k];  // C opacity depth r
+        float dx, dy;
+        const float power = splat_power(a.x, a.y, a.z, a.w, b.x, c.pxf, c.pyf, dx, dy);
+        const float alpha = fminf(ALPHA_MAX, b.y * vr_exp(power));
+        const bool valid = !(power > 0.0f) && !(alpha < ALPHA_MIN);
+        p = valid ? p * (1.0f - alpha) : p;
+    }
+    Pbuf[(size_t)blockIdx.x * SEG + threadIdx.x] = p;
+}
+
+// ---- B: per tile, boundary transmittances.  Tbuf[seg][pix] = Tb at the segment start, or -1 when
+// the pixel is finished before that segment; seg_needed[tile] = number of segments any pixel needs.
+__global__ void __launch_bounds__(256)
+k_seg_scan(Camera cam, const uint32_t* __restrict__ seg_off, const float* __restrict__ Pbuf,
+           float* __restrict__ Tbuf, uint32_t* __restrict__ seg_needed)
+{
+    const int tile = blockIdx.x;
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int px = tx * TILE + (lane & 15), py = ty * TILE + w * 4 + (lane >> 4);
-    const bool inside = px < cam.W && py < cam.H;
-    const float pxf = (float)px, pyf = (float)py;
-    const int2 range = ranges[tile];
+    bool alive = px < cam.W && py < cam.H;
+    const uint32_t s0 = seg_off[tile], s1 = seg_off[tile + 1];
+    float Tb = 1.0f;
+    uint32_t needed = 0;
+    for (uint32_t s = s0; s < s1; ++s) {
+        if (__syncthreads_or(alive) == 0) break;
+        needed = s - s0 + 1;
+        const size_t at = (size_t)s * SEG + threadIdx.x;
+        const float P = Pbuf[at];
+        Tbuf[at] = alive ? Tb : -1.0f;
+        if (alive) {
+            const float Tn = Tb * P;
+            if (Tn < T_EPS) alive = false;  // the stop test fires inside this segment
+            else Tb = Tn;
+        }
+    }
+    if (threadIdx.x == 0) seg_needed[tile] = needed;
+}
 
-    float T = 1.0f;
+// ---- C: blend one segment from its boundary transmittance into segment-local sums.
+// part[seg][k][pix], k = 0..10 channel sums, 11 = local product p, 12 = local last-contributor | done<<31
+constexpr int NPART = 13;
+
+__global__ void __launch_bounds__(256)
+k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
+            const uint32_t* __restrict__ seg_needed, const uint32_t* __restrict__ point_list,
+            const Splat* __restrict__ rec, const float* __restrict__ Tbuf, float* __restrict__ part)
+{
+    __shared__ float4 lds[5][SEG];
+    SegCtx c;
+    if (!seg_setup(cam, ranges, seg_off, c)) return;
+    if ((uint32_t)c.sl >= seg_needed[c.tile]) return;
+    if ((int)threadIdx.x < c.count) {
+        const float4* src = reinterpret_cast<const float4*>(rec + point_list[c.first + threadIdx.x]);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) lds[k][threadIdx.x] = src[k];
+    }
+    __syncthreads();
+    const float Tb = Tbuf[(size_t)blockIdx.x * SEG + threadIdx.x];
+    bool done = Tb < 0.0f;
+    if (__ballot(!done) == 0ull) return;  // nothing alive in this wave's strip
+    float p = 1.0f;
+    float Cs[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) Cs[k] = 0.0f;
+    uint32_t last = 0;
+    bool stopped = false;
+    for (int k = 0; k < c.count; ++k) {
+        if (done) continue;
+        const float4 a = lds[0][k];  // x y A B
+        const float4 b = lds[1][k];  // C opacity depth r
+        float dx, dy;
+        const float power = splat_power(a.x, a.y, a.z, a.w, b.x, c.pxf, c.pyf, dx, dy);
+        if (power > 0.0f) continue;
+        const float alpha = fminf(ALPHA_MAX, b.y * vr_exp(power));
+        if (alpha < ALPHA_MIN) continue;
+        const float pn = p * (1.0f - alpha);
+        if (Tb * pn < T_EPS) { done = true; stopped = true; continue; }
+        const float wgt = alpha * (Tb * p);
+        const float4 cc = lds[2][k];  // g b qw qx
+        const float4 d = lds[3][k];   // qy qz s0 s1
+        const float s2 = lds[4][k].x;
+        Cs[0] = fmaf(b.w, wgt, Cs[0]);
+        Cs[1] = fmaf(cc.x, wgt, Cs[1]);
+        Cs[2] = fmaf(cc.y, wgt, Cs[2]);
+        Cs[3] = fmaf(b.z, wgt, Cs[3]);
+        Cs[4] = fmaf(cc.z, wgt, Cs[4]);
+        Cs[5] = fmaf(cc.w, wgt, Cs[5]);
+        Cs[6] = fmaf(d.x, wgt, Cs[6]);
+        Cs[7] = fmaf(d.y, wgt, Cs[7]);
+        Cs[8] = fmaf(d.z, wgt, Cs[8]);
+        Cs[9] = fmaf(d.w, wgt, Cs[9]);
+        Cs[10] = fmaf(s2, wgt, Cs[10]);
+        p = pn;
+        last = (uint32_t)(c.sl * SEG + k + 1);
+    }
+    if (!(Tb < 0.0f)) {
+        float* dst = part + (size_t)blockIdx.x * (NPART * SEG) + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) dst[k * SEG] = Cs[k];
+        dst[11 * SEG] = p;
+        dst[12 * SEG] = __uint_as_float(last | (stopped ? 0x80000000u : 0u));
+    }
+}
+
+// ---- D: per tile, add the segment sums in order and write the images
+__global__ void __launch_bounds__(256)
+k_seg_combine(Camera cam, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_needed,
+              const float* __restrict__ Tbuf, const float* __restrict__ part, float* __restrict__ out_color,
+              float* __restrict__ out_depth, float* __restrict__ out_quat, float* __restrict__ out_scale,
+              float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
+{
+    const int tile = xcd_tile(blockIdx.x, cam.gx * cam.gy);
+    const int tx = tile % cam.gx, ty = tile / cam.gx;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int px = tx * TILE + (lane & 15), py = ty * TILE + w * 4 + (lane >> 4);
+    if (!(px < cam.W && py < cam.H)) return;
+    const uint32_t s0 = seg_off[tile];
+    const uint32_t needed = seg_needed[tile];
     float C[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) C[k] = 0.0f;
-    uint32_t contributor = 0, last = 0;
-    bool done = !inside;
-
-    // register-staged prefetch of the first batch
-    float4 st[5];
-    int j = range.x + threadIdx.x;
-    if (j < range.y) {
-        const float4* src = reinterpret_cast<const float4*>(rec + point_list[j]);
+    float T = 1.0f;
+    uint32_t last = 0;
+    for (uint32_t s = 0; s < needed; ++s) {
+        const size_t at = (size_t)(s0 + s) * SEG + threadIdx.x;
+        const float Tb = Tbuf[at];
+        if (Tb < 0.0f) break;
+        const float* src = part + (size_t)(s0 + s) * (NPART * SEG) + threadIdx.x;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) st[k] = src[k];
+        for (int k = 0; k < NCH; ++k) C[k] += src[k * SEG];
+        T = Tb * src[11 * SEG];
+        const uint32_t l = __float_as_uint(src[12 * SEG]) & 0x7FFFFFFFu;
+        if (l) last = l;
     }
-    for (int base = range.x; base < range.y; base += BATCH) {
-        // all pixels of the tile saturated -> stop (the barrier also protects LDS reuse)
-        if (__syncthreads_and(done)) break;
-        if (base + (int)threadIdx.x < range.y) {
+    const size_t N = (size_t)cam.H * cam.W;
+    const size_t pix = (size_t)py * cam.W + px;
+    final_T[pix] = T;
+    n_contrib[pix] = last;
+    out_color[pix] = fmaf(T, cam.bg[0], C[0]);
+    out_color[N + pix] = fmaf(T, cam.bg[1], C[1]);
+    out_color[2 * N + pix] = fmaf(T, cam.bg[2], C[2]);
+    out_depth[pix] = C[3];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) lds[k][threadIdx.x] = st[k];
-        }
-        __syncthreads();
-        // issue the gather of the next batch now; it lands while this batch is blended
-        j = base + BATCH + threadIdx.x;
-        if (j < range.y) {
-            const float4* src = reinterpret_cast<const float4*>(rec + point_list[j]);
+    for (int k = 0; k < 4; ++k) out_quat[k * N + pix] = C[4 + k];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) st[k] = src[k];
-        }
-        const int n = min(BATCH, range.y - base);
-        if (__ballot(!done) != 0ull) {
-            for (int k = 0; k < n; ++k) {
-                if (done) continue;
-                ++contributor;
-                const float4 a = lds[0][k];  // x y A B
-                const float4 b = lds[1][k];  // C opacity depth r
-                float dx, dy;
-                const float power = splat_power(a.x, a.y, a.z, a.w, b.x, pxf, pyf, dx, dy);
-                if (power > 0.0f) continue;
-                const float alpha = fminf(ALPHA_MAX, b.y * vr_exp(power));
-                if (alpha < ALPHA_MIN) continue;
-                const float test_T = T * (1.0f - alpha);
-                if (test_T < T_EPS) { done = true; continue; }
-                const float wgt = alpha * T;
-                const float4 c = lds[2][k];  // g b qw qx
-                const float4 d = lds[3][k];  // qy qz s0 s1
-                const float s2 = lds[4][k].x;
-                C[0] = fmaf(b.w, wgt, C[0]);
-                C[1] = fmaf(c.x, wgt, C[1]);
-                C[2] = fmaf(c.y, wgt, C[2]);
-                C[3] = fmaf(b.z, wgt, C[3]);
-                C[4] = fmaf(c.z, wgt, C[4]);
-                C[5] = fmaf(c.w, wgt, C[5]);
-                C[6] = fmaf(d.x, wgt, C[6]);
-                C[7] = fmaf(d.y, wgt, C[7]);
-                C[8] = fmaf(d.z, wgt, C[8]);
-                C[9] = fmaf(d.w, wgt, C[9]);
-                C[10] = fmaf(s2, wgt, C[10]);
-                T = test_T;
-                last = contributor;
-            }
-        }
-    }
-    if (inside) {
-        const size_t N = (size_t)cam.H * cam.W;
-        const size_t pix = (size_t)py * cam.W + px;
-        final_T[pix] = T;
-        n_contrib[pix] = last;
-        out_color[pix] = fmaf(T, cam.bg[0], C[0]);
-        out_color[N + pix] = fmaf(T, cam.bg[1], C[1]);
-        out_color[2 * N + pix] = fmaf(T, cam.bg[2], C[2]);
-        out_depth[pix] = C[3];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out_quat[k * N + pix] = C[4 + k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) out_scale[k * N + pix] = C[8 + k];
-        out_alpha[pix] = 1.0f - T;
-    }
+    for (int k = 0; k < 3; ++k) out_scale[k * N + pix] = C[8 + k];
+    out_alpha[pix] = 1.0f - T;
 }
 
 __global__ void __launch_bounds__(256)
@@ -125,15 +277,41 @@ k_count_fragments(const uint32_t* __restrict__ n_contrib, long N, unsigned long 
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
 
-int launch_render_fwd(const Camera& cam, const int2* ranges, const uint32_t* point_list, const Splat* rec,
-                      float* out_color, float* out_depth, float* out_quat, float* out_scale, float* out_alpha,
-                      float* final_T, uint32_t* n_contrib, hipStream_t s, bool debug)
+size_t render_fwd_scratch_bytes(long R, int ntiles)
 {
-    int ntiles = cam.gx * cam.gy;
+    const size_t nseg = seg_capacity(R, ntiles);
+    return align_up(nseg * SEG * sizeof(float), 256) + align_up(nseg * (size_t)NPART * SEG * sizeof(float), 256);
+}
+
+int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint32_t* point_list, const Splat* rec,
+                      uint32_t* seg_off, uint32_t* seg_needed, float* Tbuf, void* scratch, float* out_color,
+                      float* out_depth, float* out_quat, float* out_scale, float* out_alpha, float* final_T,
+                      uint32_t* n_contrib, hipStream_t s, bool debug)
+{
+    const int ntiles = cam.gx * cam.gy;
     if (ntiles == 0) return 0;
-    hipLaunchKernelGGL(k_render_fwd, dim3(ntiles), dim3(256), 0, s, cam, ranges, point_list, rec, out_color,
-                       out_depth, out_quat, out_scale, out_alpha, final_T, n_contrib);
-    VR_KERNEL_CHECK("render_fwd", s, debug);
+    const size_t nseg = seg_capacity(R, ntiles);
+    float* Pbuf = (float*)scratch;
+    float* part = (float*)((char*)scratch + align_up(nseg * SEG * sizeof(float), 256));
+    hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(256), 0, s, ranges, ntiles, seg_off);
+    VR_KERNEL_CHECK("seg_offsets", s, debug);
+    if (R > 0) {
+        hipLaunchKernelGGL(k_seg_alpha, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
+                           point_list, rec, Pbuf);
+        VR_KERNEL_CHECK("seg_alpha", s, debug);
+    }
+    hipLaunchKernelGGL(k_seg_scan, dim3(ntiles), dim3(256), 0, s, cam, (const uint32_t*)seg_off, (const float*)Pbuf,
+                       Tbuf, seg_needed);
+    VR_KERNEL_CHECK("seg_scan", s, debug);
+    if (R > 0) {
+        hipLaunchKernelGGL(k_seg_blend, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
+                           (const uint32_t*)seg_needed, point_list, rec, (const float*)Tbuf, part);
+        VR_KERNEL_CHECK("seg_blend", s, debug);
+    }
+    hipLaunchKernelGGL(k_seg_combine, dim3(ntiles), dim3(256), 0, s, cam, (const uint32_t*)seg_off,
+                       (const uint32_t*)seg_needed, (const float*)Tbuf, (const float*)part, out_color, out_depth,
+                       out_quat, out_scale, out_alpha, final_T, n_contrib);
+    VR_KERNEL_CHECK("seg_combine", s, debug);
     return 0;
 }
 

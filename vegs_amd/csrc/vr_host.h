@@ -64,15 +64,20 @@ int launch_binning(const Camera& cam, int V, long R, uint32_t* vis_key, uint32_t
                    const int* radii, const uint32_t* tiles_touched, void* scratch, uint32_t* point_list,
                    int2* ranges, hipStream_t s, bool debug);
 
-// ---- render_fwd.hip
-int launch_render_fwd(const Camera& cam, const int2* ranges, const uint32_t* point_list, const Splat* rec,
-                      float* out_color, float* out_depth, float* out_quat, float* out_scale, float* out_alpha,
-                      float* final_T, uint32_t* n_contrib, hipStream_t s, bool debug);
+// ---- render_fwd.hip / render_bwd.hip (segmented compositing)
+// upper bound on the number of 256-entry segments: sum_t ceil(n_t/256) <= R/256 + T
+static inline size_t seg_capacity(long R, int ntiles) { return (size_t)(R / 256 + ntiles); }
+size_t render_fwd_scratch_bytes(long R, int ntiles);
+int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint32_t* point_list, const Splat* rec,
+                      uint32_t* seg_off, uint32_t* seg_needed, float* Tbuf, void* scratch, float* out_color,
+                      float* out_depth, float* out_quat, float* out_scale, float* out_alpha, float* final_T,
+                      uint32_t* n_contrib, hipStream_t s, bool debug);
 int launch_count_fragments(const uint32_t* n_contrib, long N, unsigned long long* out_dev, hipStream_t s);
 
-// ---- render_bwd.hip
 // gacc: [P][16] floats = conic dA,dB,dC | opacity | attr[11] | pad ; gmean2D: [P][3] (x,y used)
-int launch_render_bwd(const Camera& cam, const int2* ranges, const uint32_t* point_list, const Splat* rec,
+size_t render_bwd_scratch_bytes(long R, int ntiles);
+int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint32_t* point_list, const Splat* rec,
+                      const uint32_t* seg_off, const uint32_t* seg_needed, const float* Tbuf, void* scratch,
                       const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                       const float* dL_ddepth, const float* dL_dquat, const float* dL_dscale,
                       const float* dL_dalpha, float* gacc, float* gmean2D, hipStream_t s, bool debug);

@@ -1,0 +1,74 @@
+"""CPU: the view-sharded exchange step (vegs_amd/dist.py) on the gloo backend, world_size 2."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from vegs_amd import dist as vdist
+    r, w, _ = vdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    P = 1000
+    g = torch.Generator().manual_seed(100 + rank)
+    shapes = [(P, 3), (P, 16, 3), (P, 1), (P, 3), (P, 4)]     # the 59 floats per Gaussian
+    params = [torch.zeros(s, requires_grad=True) for s in shapes]
+    local = [torch.randn(s, generator=g) for s in shapes]
+    for p, l in zip(params, local):
+        p.grad = l.clone()
+    # small bucket threshold so both the in-place and the flat-bucket paths are exercised
+    vdist.allreduce_grads(params, world, flat_bucket_bytes=20000)
+    vg = torch.randn(P, 3, generator=g)
+    vis = torch.rand(P, generator=g) > 0.5
+    radii = torch.randint(0, 50, (P,), generator=g, dtype=torch.int32)
+    gsum, den, mr = vdist.allreduce_densification_stats(vg, vis, radii)
+    torch.save(dict(grads=[p.grad for p in params], local=local, gsum=gsum, den=den, mr=mr, vg=vg, vis=vis,
+                    radii=radii, view=[vdist.view_for_rank(s, rank, world, 16) for s in range(4)]),
+               os.path.join(outdir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_view_sharded_gradient_exchange_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    R = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
+    for k in range(5):
+        want = (R[0]["local"][k] + R[1]["local"][k]) / world          # loss = mean over the views
+        for r in range(world):
+            assert torch.allclose(R[r]["grads"][k], want, atol=1e-6)
+    want_g = sum(torch.norm(R[r]["vg"][:, :2], dim=-1, keepdim=True) * R[r]["vis"][:, None].float() for r in range(world))
+    want_d = sum(R[r]["vis"][:, None].float() for r in range(world))
+    want_m = torch.maximum(R[0]["radii"], R[1]["radii"])
+    for r in range(world):
+        assert torch.allclose(R[r]["gsum"], want_g, atol=1e-6)
+        assert torch.equal(R[r]["den"], want_d)
+        assert torch.equal(R[r]["mr"], want_m)
+    # consecutive views go to consecutive ranks, every view visited once per cycle
+    assert R[0]["view"] == [0, 2, 4, 6] and R[1]["view"] == [1, 3, 5, 7]
+
+
+def test_single_process_is_a_no_op():
+    from vegs_amd import dist as vdist
+    p = torch.zeros(4, 3, requires_grad=True)
+    p.grad = torch.ones(4, 3)
+    vdist.allreduce_grads([p], world=1)
+    assert torch.equal(p.grad, torch.ones(4, 3))
+    g, d, m = vdist.allreduce_densification_stats(torch.ones(4, 3), torch.tensor([True, False, True, True]),
+                                                  torch.tensor([1, 2, 3, 4], dtype=torch.int32))
+    assert torch.allclose(g[:, 0], torch.tensor([2 ** 0.5, 0, 2 ** 0.5, 2 ** 0.5]))
+    assert torch.equal(d[:, 0], torch.tensor([1.0, 0, 1, 1]))

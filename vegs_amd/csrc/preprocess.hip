@@ -83,11 +83,12 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
                     rgb[0] = fmaxf(acc0, 0.0f); rgb[1] = fmaxf(acc1, 0.0f); rgb[2] = fmaxf(acc2, 0.0f);
                 }
                 Splat s;
+                const float opac = opacities[i];
                 s.x = px; s.y = py; s.conA = cv.c * det_inv; s.conB = -cv.b * det_inv;
-                s.conC = cv.a * det_inv; s.opacity = opacities[i]; s.depth = t2; s.r = rgb[0];
-                s.g = rgb[1]; s.b = rgb[2]; s.qw = q[0]; s.qx = q[1];
-                s.qy = q[2]; s.qz = q[3]; s.s0 = sc[0]; s.s1 = sc[1];
-                s.s2 = sc[2]; s.clamped = clampbits; s.pad0 = 0; s.pad1 = 0;
+                s.conC = cv.a * det_inv; s.opacity = opac; s.thr = splat_thr(opac); s.depth = t2;
+                s.r = rgb[0]; s.g = rgb[1]; s.b = rgb[2]; s.qw = q[0];
+                s.qx = q[1]; s.qy = q[2]; s.qz = q[3]; s.s0 = sc[0];
+                s.s1 = sc[1]; s.s2 = sc[2]; s.clamped = clampbits; s.pad0 = 0;
                 float4* dst = reinterpret_cast<float4*>(rec + i);
                 const float4* src = reinterpret_cast<const float4*>(&s);
 #pragma unroll

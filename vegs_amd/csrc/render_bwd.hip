@@ -139,31 +139,32 @@ k_seg_wu(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict
         const float Tb = Tbuf[(size_t)b * SEG + threadIdx.x];
         float p = 1.0f;
         for (int k = 0; k < count; ++k) {
-            if (k >= lim) continue;
-            const float4 a = lds[0][k];
-            const float4 bq = lds[1][k];
+            const float4 a = lds[0][k];   // x y A B
+            const float4 bq = lds[1][k];  // C opacity thr depth
             float dx, dy;
             const float power = splat_power(a.x, a.y, a.z, a.w, bq.x, (float)px, (float)py, dx, dy);
-            if (power > 0.0f) continue;
+            const bool pre = (k < lim) && !(power > 0.0f) && power >= bq.z;
+            if (__ballot(pre) == 0ull) continue;
             const float alpha = fminf(ALPHA_MAX, bq.y * vr_exp(power));
-            if (alpha < ALPHA_MIN) continue;
-            const float wgt = alpha * (Tb * p);
-            const float4 cc = lds[2][k];
-            const float4 d = lds[3][k];
-            const float s2 = lds[4][k].x;
-            float u = bq.w * pg.g[0];
-            u = fmaf(cc.x, pg.g[1], u);
-            u = fmaf(cc.y, pg.g[2], u);
-            u = fmaf(bq.z, pg.g[3], u);
-            u = fmaf(cc.z, pg.g[4], u);
-            u = fmaf(cc.w, pg.g[5], u);
-            u = fmaf(d.x, pg.g[6], u);
-            u = fmaf(d.y, pg.g[7], u);
-            u = fmaf(d.z, pg.g[8], u);
-            u = fmaf(d.w, pg.g[9], u);
-            u = fmaf(s2, pg.g[10], u);
+            const bool valid = pre && !(alpha < ALPHA_MIN);
+            if (__ballot(valid) == 0ull) continue;
+            const float wgt = valid ? alpha * (Tb * p) : 0.0f;
+            const float4 cc = lds[2][k];  // r g b qw
+            const float4 d = lds[3][k];   // qx qy qz s0
+            const float4 e4 = lds[4][k];  // s1 s2 - -
+            float u = cc.x * pg.g[0];
+            u = fmaf(cc.y, pg.g[1], u);
+            u = fmaf(cc.z, pg.g[2], u);
+            u = fmaf(bq.w, pg.g[3], u);
+            u = fmaf(cc.w, pg.g[4], u);
+            u = fmaf(d.x, pg.g[5], u);
+            u = fmaf(d.y, pg.g[6], u);
+            u = fmaf(d.z, pg.g[7], u);
+            u = fmaf(d.w, pg.g[8], u);
+            u = fmaf(e4.x, pg.g[9], u);
+            u = fmaf(e4.y, pg.g[10], u);
             U = fmaf(wgt, u, U);
-            p = p * (1.0f - alpha);
+            p = valid ? p * (1.0f - alpha) : p;
         }
     }
     Ubuf[(size_t)b * SEG + threadIdx.x] = U;
@@ -244,7 +245,7 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
         const int e = seg_lo + c * 64 + (63 - lane);
         const bool has = e < nlist && e < seg_lo + SEG;
         uint32_t id = 0;
-        float sx = 0.f, sy = 0.f, cA = 0.f, cB = 0.f, cC = 0.f, op = 0.f;
+        float sx = 0.f, sy = 0.f, cA = 0.f, cB = 0.f, cC = 0.f, op = 0.f, thr = 1.0f;
         float at[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) at[k] = 0.0f;
@@ -252,10 +253,10 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
             id = point_list[range.x + e];
             const float4* src = reinterpret_cast<const float4*>(rec + id);
             const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4];
-            sx = q0.x; sy = q0.y; cA = q0.z; cB = q0.w; cC = q1.x; op = q1.y;
-            at[0] = q1.w; at[1] = q2.x; at[2] = q2.y; at[3] = q1.z;
-            at[4] = q2.z; at[5] = q2.w; at[6] = q3.x; at[7] = q3.y;
-            at[8] = q3.z; at[9] = q3.w; at[10] = q4.x;
+            sx = q0.x; sy = q0.y; cA = q0.z; cB = q0.w; cC = q1.x; op = q1.y; thr = q1.z;
+            at[0] = q2.x; at[1] = q2.y; at[2] = q2.z; at[3] = q1.w;
+            at[4] = q2.w; at[5] = q3.x; at[6] = q3.y; at[7] = q3.z;
+            at[8] = q3.w; at[9] = q4.x; at[10] = q4.y;
         }
         float acc[NACC];
 #pragma unroll
@@ -267,17 +268,19 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                 const int nc = __builtin_amdgcn_readlane(v_nc, p);
                 if (nc <= chunk_lo) continue;  // pixel p has no contributor in this chunk (wave-uniform)
                 const float pxf = readlane_f(v_pxf, p), pyf = readlane_f(v_pyf, p);
+                float dx, dy;
+                const float power = splat_power(sx, sy, cA, cB, cC, pxf, pyf, dx, dy);
+                const bool pre = has && (e < nc) && !(power > 0.0f) && power >= thr;
+                if (__ballot(pre) == 0ull) continue;  // no splat of the chunk reaches this pixel: carries unchanged
+                const float G = vr_exp(power);
+                const float alpha = fminf(ALPHA_MAX, op * G);
+                const bool contrib = pre && !(alpha < ALPHA_MIN);
                 const float Tc = readlane_f(v_Tcar, p), Sc = readlane_f(v_Scar, p);
                 const float bgterm = readlane_f(v_bgterm, p);
                 float g[NCH];
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) g[k] = readlane_f(pg.g[k], p);
 
-                float dx, dy;
-                const float power = splat_power(sx, sy, cA, cB, cC, pxf, pyf, dx, dy);
-                const float G = vr_exp(power);
-                const float alpha = fminf(ALPHA_MAX, op * G);
-                const bool contrib = has && (e < nc) && !(power > 0.0f) && !(alpha < ALPHA_MIN);
                 const float a_eff = contrib ? alpha : 0.0f;
                 const float om = 1.0f - a_eff;
                 const float pprod = wave_prefix_mul(om);                 // prod over entries >= mine

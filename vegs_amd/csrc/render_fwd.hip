@@ -117,11 +117,13 @@ k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     float p = 1.0f;
     for (int k = 0; k < c.count; ++k) {
         const float4 a = lds[0][k];  // x y A B
-        const float4 b = lds[1][k];  // C opacity depth r
+        const float4 b = lds[1][k];  // C opacity thr depth
         float dx, dy;
         const float power = splat_power(a.x, a.y, a.z, a.w, b.x, c.pxf, c.pyf, dx, dy);
+        const bool pre = !(power > 0.0f) && power >= b.z;
+        if (__ballot(pre) == 0ull) continue;  // the splat cannot reach 1/255 anywhere in this 16x4 strip
         const float alpha = fminf(ALPHA_MAX, b.y * vr_exp(power));
-        const bool valid = !(power > 0.0f) && !(alpha < ALPHA_MIN);
+        const bool valid = pre && !(alpha < ALPHA_MIN);
         p = valid ? p * (1.0f - alpha) : p;
     }
     Pbuf[(size_t)blockIdx.x * SEG + threadIdx.x] = p;
@@ -184,34 +186,43 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     for (int k = 0; k < NCH; ++k) Cs[k] = 0.0f;
     uint32_t last = 0;
     bool stopped = false;
+    // Branch-free per lane (predicated); only wave-uniform branches: skip the exp when no pixel of the
+    // strip can reach alpha >= 1/255, skip the channel update when no pixel applies the splat.
     for (int k = 0; k < c.count; ++k) {
-        if (done) continue;
         const float4 a = lds[0][k];  // x y A B
-        const float4 b = lds[1][k];  // C opacity depth r
+        const float4 b = lds[1][k];  // C opacity thr depth
         float dx, dy;
         const float power = splat_power(a.x, a.y, a.z, a.w, b.x, c.pxf, c.pyf, dx, dy);
-        if (power > 0.0f) continue;
+        const bool pre = !done && !(power > 0.0f) && power >= b.z;
+        if (__ballot(pre) == 0ull) {
+            if (__ballot(!done) == 0ull) break;  // every pixel of the strip is finished
+            continue;
+        }
         const float alpha = fminf(ALPHA_MAX, b.y * vr_exp(power));
-        if (alpha < ALPHA_MIN) continue;
+        const bool valid = pre && !(alpha < ALPHA_MIN);
         const float pn = p * (1.0f - alpha);
-        if (Tb * pn < T_EPS) { done = true; stopped = true; continue; }
-        const float wgt = alpha * (Tb * p);
-        const float4 cc = lds[2][k];  // g b qw qx
-        const float4 d = lds[3][k];   // qy qz s0 s1
-        const float s2 = lds[4][k].x;
-        Cs[0] = fmaf(b.w, wgt, Cs[0]);
-        Cs[1] = fmaf(cc.x, wgt, Cs[1]);
-        Cs[2] = fmaf(cc.y, wgt, Cs[2]);
-        Cs[3] = fmaf(b.z, wgt, Cs[3]);
-        Cs[4] = fmaf(cc.z, wgt, Cs[4]);
-        Cs[5] = fmaf(cc.w, wgt, Cs[5]);
-        Cs[6] = fmaf(d.x, wgt, Cs[6]);
-        Cs[7] = fmaf(d.y, wgt, Cs[7]);
-        Cs[8] = fmaf(d.z, wgt, Cs[8]);
-        Cs[9] = fmaf(d.w, wgt, Cs[9]);
-        Cs[10] = fmaf(s2, wgt, Cs[10]);
-        p = pn;
-        last = (uint32_t)(c.sl * SEG + k + 1);
+        const bool stop = valid && (Tb * pn < T_EPS);
+        const bool apply = valid && !stop;
+        done = done || stop;
+        stopped = stopped || stop;
+        if (__ballot(apply) == 0ull) continue;
+        const float wgt = apply ? alpha * (Tb * p) : 0.0f;
+        const float4 cc = lds[2][k];  // r g b qw
+        const float4 d = lds[3][k];   // qx qy qz s0
+        const float4 e4 = lds[4][k];  // s1 s2 - -
+        Cs[0] = fmaf(cc.x, wgt, Cs[0]);
+        Cs[1] = fmaf(cc.y, wgt, Cs[1]);
+        Cs[2] = fmaf(cc.z, wgt, Cs[2]);
+        Cs[3] = fmaf(b.w, wgt, Cs[3]);
+        Cs[4] = fmaf(cc.w, wgt, Cs[4]);
+        Cs[5] = fmaf(d.x, wgt, Cs[5]);
+        Cs[6] = fmaf(d.y, wgt, Cs[6]);
+        Cs[7] = fmaf(d.z, wgt, Cs[7]);
+        Cs[8] = fmaf(d.w, wgt, Cs[8]);
+        Cs[9] = fmaf(e4.x, wgt, Cs[9]);
+        Cs[10] = fmaf(e4.y, wgt, Cs[10]);
+        p = apply ? pn : p;
+        last = apply ? (uint32_t)(c.sl * SEG + k + 1) : last;
     }
     if (!(Tb < 0.0f)) {
         float* dst = part + (size_t)blockIdx.x * (NPART * SEG) + threadIdx.x;

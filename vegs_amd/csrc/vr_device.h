@@ -20,13 +20,13 @@ constexpr float T_EPS = 0.0001f;
 // Per-Gaussian record written by preprocess for visible Gaussians and gathered by the render
 // kernels: 5 x 16 B so a record is fetched with five dwordx4 loads.
 struct __attribute__((aligned(16))) Splat {
-    float x, y, conA, conB;          // pixel centre, conic A,B
-    float conC, opacity, depth, r;   // conic C, opacity, view depth, red
-    float g, b, qw, qx;              // green, blue, quaternion w,x  (input rotation row, A-2)
-    float qy, qz, s0, s1;            // quaternion y,z, scale 0,1    (input scale row, A-3)
-    float s2;                        // scale 2
-    uint32_t clamped;                // bit c set: colour channel c was clamped at 0
-    uint32_t pad0, pad1;
+    float x, y, conA, conB;          // q0: pixel centre, conic A,B
+    float conC, opacity, thr, depth; // q1: conic C, opacity, power threshold (see splat_thr), view depth
+    float r, g, b, qw;               // q2: colour, quaternion w       (input rotation row, A-2)
+    float qx, qy, qz, s0;            // q3: quaternion x,y,z, scale 0  (input scale row, A-3)
+    float s1, s2;                    // q4: scale 1,2
+    uint32_t clamped;                //     bit c set: colour channel c was clamped at 0
+    uint32_t pad0;
 };
 static_assert(sizeof(Splat) == 80, "Splat must be 80 bytes");
 
@@ -84,6 +84,11 @@ __device__ __forceinline__ void tile_rect(float px, float py, int rad, int gx, i
     x1 = clampi((int)((px + (float)rad + (float)(TILE - 1)) / (float)TILE), 0, gx);
     y1 = clampi((int)((py + (float)rad + (float)(TILE - 1)) / (float)TILE), 0, gy);
 }
+
+// Conservative lower bound on the exponent below which alpha = opacity*exp(power) is certainly
+// < 1/255 (1 % slack in the exponent >> the error of vr_exp): lets a whole wave skip a splat without
+// evaluating exp.  Never decides anything by itself -- the exact alpha test still follows.
+__device__ __forceinline__ float splat_thr(float opacity) { return -__logf(255.0f * opacity) - 0.01f; }
 
 // Gaussian exponent at a pixel; identical expression in forward and backward.
 __device__ __forceinline__ float splat_power(float sx, float sy, float A, float B, float C, float pxf, float pyf,

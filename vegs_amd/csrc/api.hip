@@ -290,7 +290,8 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
     prof_begin(VR_STAGE_BWD_ZERO, s);
     VR_HIP(hipMemsetAsync(gacc, 0, (size_t)P * 16 * sizeof(float), s));
     VR_HIP(hipMemsetAsync(gin->dL_dmeans2D, 0, (size_t)P * 3 * sizeof(float), s));
-    if (gin->dL_dshs) VR_HIP(hipMemsetAsync(gin->dL_dshs, 0, (size_t)P * in->M * 3 * sizeof(float), s));
+    if (gin->dL_dshs && !preprocess_bwd_writes_all_sh(in->M, in->shs, gin->dL_dshs))
+        VR_HIP(hipMemsetAsync(gin->dL_dshs, 0, (size_t)P * in->M * 3 * sizeof(float), s));
     prof_end(VR_STAGE_BWD_ZERO, s);
     if (saved->num_rendered > 0) {
         void* scr = alloc(user, VR_BUF_SCRATCH, render_bwd_scratch_bytes((long)saved->num_rendered, (int)T) + 256);

@@ -6,9 +6,28 @@
 // gaussian_renderer/__init__.py:86-94).  In-repo definitions of the same math: SH colour
 // utils/sh_utils.py:57-112 and the +0.5 / clamp at gaussian_renderer/__init__.py:79-80; cov3D
 // utils/general_utils.py:97-129; camera matrices scene/cameras.py:76-88.
+//
+// Memory: the SH block is the bulk of the bytes (192 B per Gaussian at 16 coefficients).  A lane
+// reading its own row would stride 192 B across the wave and over-fetch 2.5x (measured with
+// FETCH_SIZE), so each wave stages the 64 contiguous rows of its Gaussians through LDS with fully
+// coalesced dwordx4 loads and every lane then reads its row back from LDS.
 #include "vr_host.h"
 
 namespace vr {
+
+constexpr int SH_ROW_MAX = 48;  // floats per Gaussian staged through LDS (M <= 16 coefficients x 3)
+
+// colour_c = sum_k basis[k] * sh[k][c]   (fixed fma order: part of the numerics contract)
+__device__ __forceinline__ void sh_dot(const float* bas, int K, const float* sh, float* acc)
+{
+    float a0 = bas[0] * sh[0], a1 = bas[0] * sh[1], a2 = bas[0] * sh[2];
+    for (int k = 1; k < K; ++k) {
+        a0 = fmaf(bas[k], sh[3 * k + 0], a0);
+        a1 = fmaf(bas[k], sh[3 * k + 1], a1);
+        a2 = fmaf(bas[k], sh[3 * k + 2], a2);
+    }
+    acc[0] = a0; acc[1] = a1; acc[2] = a2;
+}
 
 __global__ void __launch_bounds__(256)
 k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
@@ -17,91 +36,120 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
              const float* __restrict__ cov3D_precomp, Splat* __restrict__ rec, int* __restrict__ radii,
              uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    __shared__ __attribute__((aligned(16))) float sh_lds[4][64 * SH_ROW_MAX];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool in_range = i < P;
     // culled unless proven visible
-    int rad_out = 0;
-    uint32_t tiles_out = 0;
-    uint32_t key_out = 0;
-
-    float px3 = means3D[3 * i], py3 = means3D[3 * i + 1], pz3 = means3D[3 * i + 2];
-    float t0, t1, t2;
-    xform43(cam.view, px3, py3, pz3, t0, t1, t2);
-    if (t2 > NEAR_Z) {
-        float h0, h1, h2;
-        xform43(cam.proj, px3, py3, pz3, h0, h1, h2);
-        float hw = xform_w(cam.proj, px3, py3, pz3);
-        float pw = 1.0f / (hw + 0.0000001f);
-        float ndcx = h0 * pw, ndcy = h1 * pw;
-        float c6[6];
-        float q[4] = {0.f, 0.f, 0.f, 0.f}, sc[3] = {0.f, 0.f, 0.f};
-        if (cov3D_precomp) {
+    bool vis = false;
+    int rad = 0, ntiles = 0;
+    float px = 0.f, py = 0.f, t2 = 0.f, conA = 0.f, conB = 0.f, conC = 0.f;
+    float q[4] = {0.f, 0.f, 0.f, 0.f}, sc[3] = {0.f, 0.f, 0.f};
+    float px3 = 0.f, py3 = 0.f, pz3 = 0.f;
+    if (in_range) {
+        px3 = means3D[3 * (size_t)i];
+        py3 = means3D[3 * (size_t)i + 1];
+        pz3 = means3D[3 * (size_t)i + 2];
+        float t0, t1;
+        xform43(cam.view, px3, py3, pz3, t0, t1, t2);
+        if (t2 > NEAR_Z) {
+            float h0, h1, h2;
+            xform43(cam.proj, px3, py3, pz3, h0, h1, h2);
+            const float hw = xform_w(cam.proj, px3, py3, pz3);
+            const float pw = 1.0f / (hw + 0.0000001f);
+            const float ndcx = h0 * pw, ndcy = h1 * pw;
+            float c6[6];
+            if (cov3D_precomp) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * (size_t)i + k];
-        } else {
+                for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * (size_t)i + k];
+            } else {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) sc[k] = scales[3 * (size_t)i + k];
+                for (int k = 0; k < 3; ++k) sc[k] = scales[3 * (size_t)i + k];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) q[k] = rotations[4 * (size_t)i + k];
-            cov3d_from_scale_rot(sc, cam.mod, q, c6);
-        }
-        Cov2D cv;
-        cov2d(cam, cam.view, t0, t1, t2, c6, cv);
-        float det = cv.a * cv.c - cv.b * cv.b;
-        if (det != 0.0f) {
-            float det_inv = 1.0f / det;
-            float mid = 0.5f * (cv.a + cv.c);
-            float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
-            float lam = fmaxf(mid + sq, mid - sq);
-            int rad = (int)ceilf(3.0f * sqrtf(lam));
-            float px = ndc2pix(ndcx, cam.W), py = ndc2pix(ndcy, cam.H);
-            int x0, y0, x1, y1;
-            tile_rect(px, py, rad, cam.gx, cam.gy, x0, y0, x1, y1);
-            int ntiles = (x1 - x0) * (y1 - y0);
-            if (ntiles != 0) {
-                float rgb[3];
-                uint32_t clampbits = 0;
-                if (colors_precomp) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) rgb[c] = colors_precomp[3 * (size_t)i + c];
-                } else {
-                    float dx = px3 - cam.campos[0], dy = py3 - cam.campos[1], dz = pz3 - cam.campos[2];
-                    float len = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-                    dx = dx / len; dy = dy / len; dz = dz / len;
-                    float b[16];
-                    sh_basis(cam.deg, dx, dy, dz, b);
-                    int K = (cam.deg + 1) * (cam.deg + 1);
-                    const float* sh = shs + (size_t)i * cam.M * 3;
-                    float acc0 = b[0] * sh[0], acc1 = b[0] * sh[1], acc2 = b[0] * sh[2];
-                    for (int k = 1; k < K; ++k) {
-                        acc0 = fmaf(b[k], sh[3 * k + 0], acc0);
-                        acc1 = fmaf(b[k], sh[3 * k + 1], acc1);
-                        acc2 = fmaf(b[k], sh[3 * k + 2], acc2);
-                    }
-                    acc0 += 0.5f; acc1 += 0.5f; acc2 += 0.5f;
-                    clampbits = (acc0 < 0.0f ? 1u : 0u) | (acc1 < 0.0f ? 2u : 0u) | (acc2 < 0.0f ? 4u : 0u);
-                    rgb[0] = fmaxf(acc0, 0.0f); rgb[1] = fmaxf(acc1, 0.0f); rgb[2] = fmaxf(acc2, 0.0f);
-                }
-                Splat s;
-                const float opac = opacities[i];
-                s.x = px; s.y = py; s.conA = cv.c * det_inv; s.conB = -cv.b * det_inv;
-                s.conC = cv.a * det_inv; s.opacity = opac; s.thr = splat_thr(opac); s.depth = t2;
-                s.r = rgb[0]; s.g = rgb[1]; s.b = rgb[2]; s.qw = q[0];
-                s.qx = q[1]; s.qy = q[2]; s.qz = q[3]; s.s0 = sc[0];
-                s.s1 = sc[1]; s.s2 = sc[2]; s.clamped = clampbits; s.pad0 = 0;
-                float4* dst = reinterpret_cast<float4*>(rec + i);
-                const float4* src = reinterpret_cast<const float4*>(&s);
-#pragma unroll
-                for (int k = 0; k < 5; ++k) dst[k] = src[k];
-                rad_out = rad;
-                tiles_out = (uint32_t)ntiles;
-                key_out = __float_as_uint(t2);
+                for (int k = 0; k < 4; ++k) q[k] = rotations[4 * (size_t)i + k];
+                cov3d_from_scale_rot(sc, cam.mod, q, c6);
+            }
+            Cov2D cv;
+            cov2d(cam, cam.view, t0, t1, t2, c6, cv);
+            const float det = cv.a * cv.c - cv.b * cv.b;
+            if (det != 0.0f) {
+                const float det_inv = 1.0f / det;
+                const float mid = 0.5f * (cv.a + cv.c);
+                const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float lam = fmaxf(mid + sq, mid - sq);
+                rad = (int)ceilf(3.0f * sqrtf(lam));
+                px = ndc2pix(ndcx, cam.W);
+                py = ndc2pix(ndcy, cam.H);
+                int x0, y0, x1, y1;
+                tile_rect(px, py, rad, cam.gx, cam.gy, x0, y0, x1, y1);
+                ntiles = (x1 - x0) * (y1 - y0);
+                vis = ntiles != 0;
+                conA = cv.c * det_inv;
+                conB = -cv.b * det_inv;
+                conC = cv.a * det_inv;
             }
         }
     }
-    radii[i] = rad_out;
-    tiles_touched[i] = tiles_out;
-    depth_key[i] = key_out;
+
+    // ---- colour
+    float rgb[3] = {0.f, 0.f, 0.f};
+    uint32_t clampbits = 0;
+    if (colors_precomp) {
+        if (vis) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rgb[c] = colors_precomp[3 * (size_t)i + c];
+        }
+    } else if (__ballot(vis) != 0ull) {
+        // stage this wave's 64 SH rows (contiguous in memory) through LDS, coalesced
+        const int row = cam.M * 3;                             // floats per Gaussian
+        const bool staged = row <= SH_ROW_MAX && (row & 3) == 0 && (reinterpret_cast<size_t>(shs) & 15) == 0;
+        const size_t wave_first = (size_t)(blockIdx.x * blockDim.x + w * 64);
+        float acc[3] = {0.f, 0.f, 0.f};
+        float bas[16];
+        const int K = (cam.deg + 1) * (cam.deg + 1);
+        if (vis) {
+            float dx = px3 - cam.campos[0], dy = py3 - cam.campos[1], dz = pz3 - cam.campos[2];
+            const float len = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+            dx = dx / len; dy = dy / len; dz = dz / len;
+            sh_basis(cam.deg, dx, dy, dz, bas);
+        }
+        if (staged) {
+            const float* src = shs + wave_first * row;
+            const int rows_here = min(64, P - (int)wave_first);
+            const int nvec = rows_here * row / 4;               // float4s to move
+            float4* dst4 = reinterpret_cast<float4*>(sh_lds[w]);
+            const float4* src4 = reinterpret_cast<const float4*>(src);
+            for (int v = lane; v < nvec; v += 64) dst4[v] = src4[v];
+            __builtin_amdgcn_wave_barrier();
+            if (vis) sh_dot(bas, K, sh_lds[w] + lane * row, acc);
+        } else if (vis) {
+            sh_dot(bas, K, shs + (size_t)i * row, acc);        // unusual M / alignment: direct row reads
+        }
+        if (vis) {
+            acc[0] += 0.5f; acc[1] += 0.5f; acc[2] += 0.5f;
+            clampbits = (acc[0] < 0.0f ? 1u : 0u) | (acc[1] < 0.0f ? 2u : 0u) | (acc[2] < 0.0f ? 4u : 0u);
+            rgb[0] = fmaxf(acc[0], 0.0f); rgb[1] = fmaxf(acc[1], 0.0f); rgb[2] = fmaxf(acc[2], 0.0f);
+        }
+    }
+
+    if (vis) {
+        Splat s;
+        const float opac = opacities[i];
+        s.x = px; s.y = py; s.conA = conA; s.conB = conB;
+        s.conC = conC; s.opacity = opac; s.thr = splat_thr(opac); s.depth = t2;
+        s.r = rgb[0]; s.g = rgb[1]; s.b = rgb[2]; s.qw = q[0];
+        s.qx = q[1]; s.qy = q[2]; s.qz = q[3]; s.s0 = sc[0];
+        s.s1 = sc[1]; s.s2 = sc[2]; s.clamped = clampbits; s.pad0 = 0;
+        float4* dst = reinterpret_cast<float4*>(rec + i);
+        const float4* src = reinterpret_cast<const float4*>(&s);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dst[k] = src[k];
+    }
+    if (in_range) {
+        radii[i] = vis ? rad : 0;
+        tiles_touched[i] = vis ? (uint32_t)ntiles : 0u;
+        depth_key[i] = vis ? __float_as_uint(t2) : 0u;
+    }
 }
 
 __global__ void __launch_bounds__(256)

@@ -35,8 +35,43 @@ __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z
     bx[15] = SH_C3[6] * (3.0f * xx - 3.0f * yy); by[15] = SH_C3[6] * -6.0f * x * y;
 }
 
+constexpr int SH_ROW_MAX = 48;  // floats per Gaussian staged through LDS (M <= 16 coefficients x 3)
+
+// One Gaussian's SH backward: gsh[k][c] = basis[k] * dL/drgb_c (zero where the colour was clamped) and
+// the gradient through the view direction into the mean.  `sh` and `gsh` may alias (in-place in LDS).
+__device__ __forceinline__ void sh_backward_row(const Camera& cam, float px3, float py3, float pz3, uint32_t clampbits,
+                                                float g0, float g1, float g2, const float* sh, float* gsh, float* dmean)
+{
+    const float d0 = px3 - cam.campos[0], d1 = py3 - cam.campos[1], d2v = pz3 - cam.campos[2];
+    const float len = sqrtf(d0 * d0 + d1 * d1 + d2v * d2v);
+    const float il = 1.0f / len;
+    const float dir[3] = {d0 * il, d1 * il, d2v * il};
+    float bas[16], bx[16], by[16], bz[16];
+    sh_basis(cam.deg, dir[0], dir[1], dir[2], bas);
+    sh_basis_grad(cam.deg, dir[0], dir[1], dir[2], bx, by, bz);
+    const int K = (cam.deg + 1) * (cam.deg + 1);
+    const float gc0 = (clampbits & 1u) ? 0.f : g0;
+    const float gc1 = (clampbits & 2u) ? 0.f : g1;
+    const float gc2 = (clampbits & 4u) ? 0.f : g2;
+    float ddir[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) {
+        const float s0 = sh[3 * k], s1 = sh[3 * k + 1], s2 = sh[3 * k + 2];
+        gsh[3 * k + 0] = bas[k] * gc0;
+        gsh[3 * k + 1] = bas[k] * gc1;
+        gsh[3 * k + 2] = bas[k] * gc2;
+        const float sg = s0 * gc0 + s1 * gc1 + s2 * gc2;
+        ddir[0] += bx[k] * sg;
+        ddir[1] += by[k] * sg;
+        ddir[2] += bz[k] * sg;
+    }
+    for (int k = K; k < cam.M; ++k) { gsh[3 * k] = 0.f; gsh[3 * k + 1] = 0.f; gsh[3 * k + 2] = 0.f; }
+    const float dot = dir[0] * ddir[0] + dir[1] * ddir[1] + dir[2] * ddir[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dmean[k] += (ddir[k] - dir[k] * dot) * il;
+}
+
 __global__ void __launch_bounds__(256)
-k_preprocess_bwd(Camera cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
+k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ means3D, const float* __restrict__ shs,
                  const float* __restrict__ colors_precomp, const float* __restrict__ scales,
                  const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
                  const int* __restrict__ radii, const Splat* __restrict__ rec, const float* __restrict__ gacc,
@@ -44,13 +79,53 @@ k_preprocess_bwd(Camera cam, int P, const float* __restrict__ means3D, const flo
                  float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
                  float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    __shared__ __attribute__((aligned(16))) float sh_lds[4][64 * SH_ROW_MAX];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool in_range = i < P;
+    const bool vis = in_range && radii[i] > 0;
     float dmean[3] = {0.f, 0.f, 0.f};
     float dsc[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f}, dcol[3] = {0.f, 0.f, 0.f};
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dop = 0.f;
-    if (radii[i] > 0) {
+
+    // ---- SH backward, wave-cooperative: the wave's 64 SH rows are contiguous in memory, so they are
+    // staged through LDS with coalesced dwordx4 loads, every lane turns its row into its dL/dsh row in
+    // place, and the 64 rows are stored back coalesced (zeros for culled Gaussians: the kernel writes
+    // every row of dL_dshs itself, no separate memset).
+    if (shs && sh_staged) {
+        const int row = cam.M * 3;
+        const size_t wave_first = (size_t)(blockIdx.x * blockDim.x + w * 64);
+        const int rows_here = max(0, min(64, P - (int)wave_first));
+        const int nvec = rows_here * row / 4;
+        float4* lds4 = reinterpret_cast<float4*>(sh_lds[w]);
+        const bool any = __ballot(vis) != 0ull;
+        if (any) {
+            const float4* src4 = reinterpret_cast<const float4*>(shs + wave_first * row);
+            for (int v = lane; v < nvec; v += 64) lds4[v] = src4[v];
+            __builtin_amdgcn_wave_barrier();
+            float* myrow = sh_lds[w] + lane * row;
+            if (vis) {
+                const float4 a1 = reinterpret_cast<const float4*>(gacc + (size_t)i * 16)[1];
+                const float px3 = means3D[3 * (size_t)i], py3 = means3D[3 * (size_t)i + 1], pz3 = means3D[3 * (size_t)i + 2];
+                sh_backward_row(cam, px3, py3, pz3, rec[i].clamped, a1.x, a1.y, a1.z, myrow, myrow, dmean);
+            } else if (lane < rows_here) {
+                for (int k = 0; k < row; ++k) myrow[k] = 0.0f;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        float4* dst4 = reinterpret_cast<float4*>(dL_dshs + wave_first * row);
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int v = lane; v < nvec; v += 64) dst4[v] = any ? lds4[v] : zero4;
+    } else if (shs && vis) {
+        // unusual coefficient count / alignment: direct row access, dL_dshs pre-zeroed by the caller
+        const float4 a1 = reinterpret_cast<const float4*>(gacc + (size_t)i * 16)[1];
+        const float px3 = means3D[3 * (size_t)i], py3 = means3D[3 * (size_t)i + 1], pz3 = means3D[3 * (size_t)i + 2];
+        sh_backward_row(cam, px3, py3, pz3, rec[i].clamped, a1.x, a1.y, a1.z, shs + (size_t)i * cam.M * 3,
+                        dL_dshs + (size_t)i * cam.M * 3, dmean);
+    }
+
+    if (vis) {
         const float* V = cam.view;
         const float* Pm = cam.proj;
         const float4* ga4 = reinterpret_cast<const float4*>(gacc + (size_t)i * 16);
@@ -130,37 +205,9 @@ k_preprocess_bwd(Camera cam, int P, const float* __restrict__ means3D, const flo
             dmean[k] += mul1 * gx2 + mul2 * gy2;
         }
 
-        // ---- colour
+        // ---- colour (the SH part was handled wave-cooperatively above)
         if (colors_precomp) {
             dcol[0] = ga[0]; dcol[1] = ga[1]; dcol[2] = ga[2];
-        } else {
-            const float d0 = px3 - cam.campos[0], d1 = py3 - cam.campos[1], d2v = pz3 - cam.campos[2];
-            const float len = sqrtf(d0 * d0 + d1 * d1 + d2v * d2v);
-            const float il = 1.0f / len;
-            const float dir[3] = {d0 * il, d1 * il, d2v * il};
-            float bas[16], bx[16], by[16], bz[16];
-            sh_basis(cam.deg, dir[0], dir[1], dir[2], bas);
-            sh_basis_grad(cam.deg, dir[0], dir[1], dir[2], bx, by, bz);
-            const int K = (cam.deg + 1) * (cam.deg + 1);
-            const float* sh = shs + (size_t)i * cam.M * 3;
-            float* gsh = dL_dshs + (size_t)i * cam.M * 3;
-            const uint32_t clampbits = rec[i].clamped;
-            const float gc0 = (clampbits & 1u) ? 0.f : ga[0];
-            const float gc1 = (clampbits & 2u) ? 0.f : ga[1];
-            const float gc2 = (clampbits & 4u) ? 0.f : ga[2];
-            float ddir[3] = {0.f, 0.f, 0.f};
-            for (int k = 0; k < K; ++k) {
-                gsh[3 * k + 0] = bas[k] * gc0;
-                gsh[3 * k + 1] = bas[k] * gc1;
-                gsh[3 * k + 2] = bas[k] * gc2;
-                const float sg = sh[3 * k] * gc0 + sh[3 * k + 1] * gc1 + sh[3 * k + 2] * gc2;
-                ddir[0] += bx[k] * sg;
-                ddir[1] += by[k] * sg;
-                ddir[2] += bz[k] * sg;
-            }
-            const float dot = dir[0] * ddir[0] + dir[1] * ddir[1] + dir[2] * ddir[2];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) dmean[k] += (ddir[k] - dir[k] * dot) * il;
         }
 
         // ---- cov3D -> scale / rotation, plus the directly blended rows
@@ -195,6 +242,7 @@ k_preprocess_bwd(Camera cam, int P, const float* __restrict__ means3D, const flo
             drot[3] = 2.f * (r * (D[3] - D[1]) + x * (D[2] + D[6]) + y * (D[5] + D[7])) - 4.f * z * (D[0] + D[4]) + ga[7];
         }
     }
+    if (!in_range) return;
 #pragma unroll
     for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * (size_t)i + k] = dmean[k];
     dL_dopacities[i] = dop;
@@ -216,6 +264,14 @@ k_preprocess_bwd(Camera cam, int P, const float* __restrict__ means3D, const flo
     }
 }
 
+// true when k_preprocess_bwd takes the LDS-staged SH path and therefore writes EVERY row of dL_dshs
+bool preprocess_bwd_writes_all_sh(int M, const float* shs, const float* dL_dshs)
+{
+    const int row = 3 * M;
+    return shs && dL_dshs && row <= SH_ROW_MAX && (row & 3) == 0 && (reinterpret_cast<size_t>(shs) & 15) == 0 &&
+           (reinterpret_cast<size_t>(dL_dshs) & 15) == 0;
+}
+
 int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const float* shs,
                           const float* colors_precomp, const float* scales, const float* rotations,
                           const float* cov3D_precomp, const int* radii, const Splat* rec, const float* gacc,
@@ -224,7 +280,8 @@ int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const 
                           hipStream_t s, bool debug)
 {
     if (P == 0) return 0;
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, means3D, shs, colors_precomp,
+    const int sh_staged = preprocess_bwd_writes_all_sh(cam.M, shs, dL_dshs) ? 1 : 0;
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, sh_staged, means3D, shs, colors_precomp,
                        scales, rotations, cov3D_precomp, radii, rec, gacc, gmean2D, dL_dmeans3D, dL_dshs, dL_dcolors,
                        dL_dopacities, dL_dscales, dL_drots, dL_dcov3D);
     VR_KERNEL_CHECK("preprocess_bwd", s, debug);

@@ -83,6 +83,7 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
                       const float* dL_dalpha, float* gacc, float* gmean2D, hipStream_t s, bool debug);
 
 // ---- preprocess_bwd.hip
+bool preprocess_bwd_writes_all_sh(int M, const float* shs, const float* dL_dshs);
 int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const float* shs,
                           const float* colors_precomp, const float* scales, const float* rotations,
                           const float* cov3D_precomp, const int* radii, const Splat* rec, const float* gacc,

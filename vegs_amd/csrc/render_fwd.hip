@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(256)
 k_seg_scan(Camera cam, const uint32_t* __restrict__ seg_off, const float* __restrict__ Pbuf,
            float* __restrict__ Tbuf, uint32_t* __restrict__ seg_needed)
 {
+    __shared__ uint32_t wneed[4];
     const int tile = blockIdx.x;
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -142,19 +143,32 @@ k_seg_scan(Camera cam, const uint32_t* __restrict__ seg_off, const float* __rest
     bool alive = px < cam.W && py < cam.H;
     const uint32_t s0 = seg_off[tile], s1 = seg_off[tile + 1];
     float Tb = 1.0f;
-    uint32_t needed = 0;
-    for (uint32_t s = s0; s < s1; ++s) {
-        if (__syncthreads_or(alive) == 0) break;
-        needed = s - s0 + 1;
-        const size_t at = (size_t)s * SEG + threadIdx.x;
-        const float P = Pbuf[at];
-        Tbuf[at] = alive ? Tb : -1.0f;
-        if (alive) {
-            const float Tn = Tb * P;
-            if (Tn < T_EPS) alive = false;  // the stop test fires inside this segment
-            else Tb = Tn;
+    // Each wave walks the segment chain of its own 64 pixels without block barriers; the P values of
+    // UNROLL segments are fetched together so the chain is not bound by one memory latency per segment.
+    constexpr int UNROLL = 8;
+    uint32_t mine = 0;  // segments this wave needs (some pixel alive at the segment start)
+    bool wave_alive = __ballot(alive) != 0ull;
+    for (uint32_t s = s0; s < s1 && wave_alive; s += UNROLL) {
+        float Pv[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k)
+            Pv[k] = (s + k < s1) ? Pbuf[(size_t)(s + k) * SEG + threadIdx.x] : 1.0f;
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) {
+            if (s + k < s1 && wave_alive) {
+                mine = s + k - s0 + 1;
+                Tbuf[(size_t)(s + k) * SEG + threadIdx.x] = alive ? Tb : -1.0f;
+                const float Tn = Tb * Pv[k];
+                if (alive && Tn < T_EPS) alive = false;  // the stop test fires inside this segment
+                else if (alive) Tb = Tn;
+                wave_alive = __ballot(alive) != 0ull;
+            }
         }
     }
+    if (lane == 0) wneed[w] = mine;
+    __syncthreads();
+    const uint32_t needed = max(max(wneed[0], wneed[1]), max(wneed[2], wneed[3]));
+    for (uint32_t s = s0 + mine; s < s0 + needed; ++s) Tbuf[(size_t)s * SEG + threadIdx.x] = -1.0f;
     if (threadIdx.x == 0) seg_needed[tile] = needed;
 }
 
@@ -252,15 +266,33 @@ k_seg_combine(Camera cam, const uint32_t* __restrict__ seg_off, const uint32_t* 
     for (int k = 0; k < NCH; ++k) C[k] = 0.0f;
     float T = 1.0f;
     uint32_t last = 0;
-    for (uint32_t s = 0; s < needed; ++s) {
-        const size_t at = (size_t)(s0 + s) * SEG + threadIdx.x;
-        const float Tb = Tbuf[at];
-        if (Tb < 0.0f) break;
-        const float* src = part + (size_t)(s0 + s) * (NPART * SEG) + threadIdx.x;
+    // two segments per iteration, every load issued before the first use (order of the adds is the spec's)
+    bool dead = false;
+    for (uint32_t s = 0; s < needed && !dead; s += 2) {
+        const bool two = s + 1 < needed;
+        const size_t at0 = (size_t)(s0 + s) * SEG + threadIdx.x;
+        const size_t at1 = two ? at0 + SEG : at0;
+        const float Tb0 = Tbuf[at0];
+        const float Tb1 = two ? Tbuf[at1] : -1.0f;
+        const float* src0 = part + (size_t)(s0 + s) * (NPART * SEG) + threadIdx.x;
+        const float* src1 = two ? src0 + NPART * SEG : src0;
+        float v0[NPART], v1[NPART];
+        const bool use0 = !(Tb0 < 0.0f), use1 = use0 && !(Tb1 < 0.0f);
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) C[k] += src[k * SEG];
-        T = Tb * src[11 * SEG];
-        const uint32_t l = __float_as_uint(src[12 * SEG]) & 0x7FFFFFFFu;
+        for (int k = 0; k < NPART; ++k) v0[k] = use0 ? src0[k * SEG] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < NPART; ++k) v1[k] = use1 ? src1[k * SEG] : 0.0f;
+        if (!use0) { dead = true; break; }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) C[k] += v0[k];
+        T = Tb0 * v0[11];
+        uint32_t l = __float_as_uint(v0[12]) & 0x7FFFFFFFu;
+        if (l) last = l;
+        if (!use1) { dead = true; break; }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) C[k] += v1[k];
+        T = Tb1 * v1[11];
+        l = __float_as_uint(v1[12]) & 0x7FFFFFFFu;
         if (l) last = l;
     }
     const size_t N = (size_t)cam.H * cam.W;

@@ -25,10 +25,10 @@
 // of the tile are reduced through LDS and one coalesced set of global atomics per (tile, splat) is
 // issued -- 256x fewer atomics than one per fragment.
 #include "vr_host.h"
+#include "vr_segment.h"
 
 namespace vr {
 
-constexpr int SEG = 256;
 constexpr int NACC = 17;  // conic(3) opacity(1) attr(11) mean2D(2)
 
 __device__ __forceinline__ float readlane_f(float v, int l)
@@ -63,16 +63,6 @@ __device__ __forceinline__ float wave_prefix_add(float v)
     v += dpp_f<0x142, 0xa>(0.0f, v);
     v += dpp_f<0x143, 0xc>(0.0f, v);
     return v;
-}
-
-__device__ __forceinline__ int seg_find_tile_b(const uint32_t* __restrict__ seg_off, int ntiles, uint32_t b)
-{
-    int lo = 0, hi = ntiles;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (seg_off[mid] <= b) lo = mid; else hi = mid - 1;
-    }
-    return lo;
 }
 
 // per-pixel upstream gradients of the 11 blended channels
@@ -110,64 +100,71 @@ k_seg_wu(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict
          const float* __restrict__ dL_dscale, float* __restrict__ Ubuf)
 {
     __shared__ float4 lds[5][SEG];
-    const int ntiles = cam.gx * cam.gy;
-    const uint32_t b = blockIdx.x;
-    if (b >= seg_off[ntiles]) return;
-    const int tile = seg_find_tile_b(seg_off, ntiles, b);
-    const int sl = (int)(b - seg_off[tile]);
-    if ((uint32_t)sl >= seg_needed[tile]) return;
-    const int2 r = ranges[tile];
-    const int first = r.x + sl * SEG;
-    const int count = min(SEG, r.y - first);
-    const int tx = tile % cam.gx, ty = tile / cam.gx;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int px = tx * TILE + (lane & 15), py = ty * TILE + w * 4 + (lane >> 4);
-    const bool inside = px < cam.W && py < cam.H;
-    const size_t N = (size_t)cam.H * cam.W, pix = (size_t)py * cam.W + px;
-    if ((int)threadIdx.x < count) {
-        const float4* src = reinterpret_cast<const float4*>(rec + point_list[first + threadIdx.x]);
+    __shared__ unsigned long long masks[4][4];
+    SegCtx c;
+    if (!seg_setup(cam, ranges, seg_off, c)) return;
+    if ((uint32_t)c.sl >= seg_needed[c.tile]) return;
+    {
+        const bool have = (int)threadIdx.x < c.count;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t ext = 0;
+        if (have) {
+            const float4* src = reinterpret_cast<const float4*>(rec + point_list[c.first + threadIdx.x]);
+            q0 = src[0];
+            const float4 q4 = src[4];
+            lds[0][threadIdx.x] = q0;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) lds[k][threadIdx.x] = src[k];
+            for (int k = 1; k < 4; ++k) lds[k][threadIdx.x] = src[k];
+            lds[4][threadIdx.x] = q4;
+            ext = __float_as_uint(q4.w);
+        }
+        seg_build_masks(c, have, q0.x, q0.y, ext, masks);
     }
     __syncthreads();
+    const int w = threadIdx.x >> 6;
+    const size_t N = (size_t)cam.H * cam.W;
     PixGrad pg;
-    load_pixgrad(inside, pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, nullptr, pg);
-    const int nc = inside ? (int)n_contrib[pix] : 0;
-    const int lim = min(count, nc - sl * SEG);  // entries of this segment in front of the pixel's last contributor
+    load_pixgrad(c.inside, c.pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, nullptr, pg);
+    const int nc = c.inside ? (int)n_contrib[c.pix] : 0;
+    const int lim = min(c.count, nc - c.sl * SEG);  // entries of this segment in front of the pixel's last contributor
+    const float pxf = (float)c.px, pyf = (float)c.py;
     float U = 0.0f;
     if (__ballot(lim > 0) != 0ull) {
-        const float Tb = Tbuf[(size_t)b * SEG + threadIdx.x];
+        const float Tb = Tbuf[(size_t)blockIdx.x * SEG + threadIdx.x];
         float p = 1.0f;
-        for (int k = 0; k < count; ++k) {
-            const float4 a = lds[0][k];   // x y A B
-            const float4 bq = lds[1][k];  // C opacity thr depth
-            float dx, dy;
-            const float power = splat_power(a.x, a.y, a.z, a.w, bq.x, (float)px, (float)py, dx, dy);
-            const bool pre = (k < lim) && !(power > 0.0f) && power >= bq.z;
-            if (__ballot(pre) == 0ull) continue;
-            const float alpha = fminf(ALPHA_MAX, bq.y * vr_exp(power));
-            const bool valid = pre && !(alpha < ALPHA_MIN);
-            if (__ballot(valid) == 0ull) continue;
-            const float wgt = valid ? alpha * (Tb * p) : 0.0f;
-            const float4 cc = lds[2][k];  // r g b qw
-            const float4 d = lds[3][k];   // qx qy qz s0
-            const float4 e4 = lds[4][k];  // s1 s2 - -
-            float u = cc.x * pg.g[0];
-            u = fmaf(cc.y, pg.g[1], u);
-            u = fmaf(cc.z, pg.g[2], u);
-            u = fmaf(bq.w, pg.g[3], u);
-            u = fmaf(cc.w, pg.g[4], u);
-            u = fmaf(d.x, pg.g[5], u);
-            u = fmaf(d.y, pg.g[6], u);
-            u = fmaf(d.z, pg.g[7], u);
-            u = fmaf(d.w, pg.g[8], u);
-            u = fmaf(e4.x, pg.g[9], u);
-            u = fmaf(e4.y, pg.g[10], u);
-            U = fmaf(wgt, u, U);
-            p = valid ? p * (1.0f - alpha) : p;
+        for (int part = 0; part < 4; ++part) {
+            for (unsigned long long m = uniform64(masks[w][part]); m; m &= m - 1) {
+                const int k = part * 64 + __builtin_ctzll(m);
+                const float4 a = lds[0][k];   // x y A B
+                const float4 bq = lds[1][k];  // C opacity thr depth
+                float dx, dy;
+                const float power = splat_power(a.x, a.y, a.z, a.w, bq.x, pxf, pyf, dx, dy);
+                const bool pre = (k < lim) && !(power > 0.0f) && power >= bq.z;
+                if (__ballot(pre) == 0ull) continue;
+                const float alpha = fminf(ALPHA_MAX, bq.y * vr_exp(power));
+                const bool valid = pre && !(alpha < ALPHA_MIN);
+                if (__ballot(valid) == 0ull) continue;
+                const float wgt = valid ? alpha * (Tb * p) : 0.0f;
+                const float4 cc = lds[2][k];  // r g b qw
+                const float4 d = lds[3][k];   // qx qy qz s0
+                const float4 e4 = lds[4][k];  // s1 s2 - -
+                float u = cc.x * pg.g[0];
+                u = fmaf(cc.y, pg.g[1], u);
+                u = fmaf(cc.z, pg.g[2], u);
+                u = fmaf(bq.w, pg.g[3], u);
+                u = fmaf(cc.w, pg.g[4], u);
+                u = fmaf(d.x, pg.g[5], u);
+                u = fmaf(d.y, pg.g[6], u);
+                u = fmaf(d.z, pg.g[7], u);
+                u = fmaf(d.w, pg.g[8], u);
+                u = fmaf(e4.x, pg.g[9], u);
+                u = fmaf(e4.y, pg.g[10], u);
+                U = fmaf(wgt, u, U);
+                p = valid ? p * (1.0f - alpha) : p;
+            }
         }
     }
-    Ubuf[(size_t)b * SEG + threadIdx.x] = U;
+    Ubuf[(size_t)blockIdx.x * SEG + threadIdx.x] = U;
 }
 
 // ---- B': per tile, in place: Ubuf[seg][pix] <- sum of U over the LATER segments of the tile
@@ -196,62 +193,89 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
           const float* __restrict__ dL_dscale, const float* __restrict__ dL_dalpha, float* __restrict__ gacc,
           float* __restrict__ gmean2D)
 {
-    __shared__ float red[4][64 * NACC];
-    __shared__ uint32_t ids[64];
-    const int ntiles = cam.gx * cam.gy;
-    const uint32_t b = blockIdx.x;
-    if (b >= seg_off[ntiles]) return;
-    const int tile = seg_find_tile_b(seg_off, ntiles, b);
-    const int sl = (int)(b - seg_off[tile]);
-    const int needed = (int)seg_needed[tile];
-    if (sl >= needed) return;
-    const int2 range = ranges[tile];
-    const int nlist = range.y - range.x;
-    const int tx = tile % cam.gx, ty = tile / cam.gx;
+    __shared__ float gsum[SEG * NACC];            // per-entry gradient sums of this (tile, segment)
+    __shared__ uint32_t ids[SEG];                 // Gaussian id of every entry
+    __shared__ unsigned short ridx[4][SEG];       // per strip: the relevant entries, ascending
+    __shared__ unsigned long long masks[4][4];
+    SegCtx c;
+    if (!seg_setup(cam, ranges, seg_off, c)) return;
+    const int needed = (int)seg_needed[c.tile];
+    if (c.sl >= needed) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 
+    // ---- entry j of the segment: id, strip relevance, compacted per-strip lists
+    bool rel[4] = {false, false, false, false};
+    {
+        const bool have = (int)threadIdx.x < c.count;
+        float sx = 0.f, sy = 0.f;
+        uint32_t ext = 0, id = 0xFFFFFFFFu;
+        if (have) {
+            id = point_list[c.first + threadIdx.x];
+            const Splat* sp = rec + id;
+            sx = sp->x; sy = sp->y; ext = sp->ext;
+        }
+        ids[threadIdx.x] = id;
+        float hx, hy;
+        splat_extent_unpack(ext, hx, hy);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            rel[s] = have && strip_relevant(sx, sy, hx, hy, c.x0, c.y0, s);
+            const unsigned long long m = __ballot(rel[s]);
+            if (lane == 0) masks[s][w] = m;
+        }
+        for (int v = threadIdx.x; v < SEG * NACC; v += 256) gsum[v] = 0.0f;
+    }
+    __syncthreads();
+    {
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            int before = 0;
+            for (int q = 0; q < w; ++q) before += __popcll(masks[s][q]);
+            if (rel[s]) ridx[s][before + __popcll(masks[s][w] & lt)] = (unsigned short)threadIdx.x;
+        }
+    }
+    __syncthreads();
+    const int nrel = __popcll(masks[w][0]) + __popcll(masks[w][1]) + __popcll(masks[w][2]) + __popcll(masks[w][3]);
+
     // ---- pixel state, lane = pixel of this wave's 16x4 strip
-    const int px = tx * TILE + (lane & 15), py = ty * TILE + w * 4 + (lane >> 4);
-    const bool inside = px < cam.W && py < cam.H;
     const size_t N = (size_t)cam.H * cam.W;
-    const size_t pix = (size_t)py * cam.W + px;
-    const float v_pxf = (float)px, v_pyf = (float)py;
+    const float v_pxf = (float)c.px, v_pyf = (float)c.py;
     PixGrad pg;
-    load_pixgrad(inside, pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, dL_dalpha, pg);
+    load_pixgrad(c.inside, c.pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, dL_dalpha, pg);
     float v_Tf = 1.0f;
     int v_nc = 0;
-    if (inside) { v_Tf = final_T[pix]; v_nc = (int)n_contrib[pix]; }
+    if (c.inside) { v_Tf = final_T[c.pix]; v_nc = (int)n_contrib[c.pix]; }
     const float v_bgterm =
         v_Tf * (fmaf(cam.bg[2], pg.g[2], fmaf(cam.bg[1], pg.g[1], cam.bg[0] * pg.g[0])) - pg.galpha);
     // carries at the END of this segment: transmittance behind its last entry, and the w*u sum of
     // everything behind the segment
     float v_Tcar = v_Tf;
-    if (sl + 1 < needed) {
-        const float Tn = Tbuf[(size_t)(b + 1) * SEG + threadIdx.x];
+    if (c.sl + 1 < needed) {
+        const float Tn = Tbuf[(size_t)(blockIdx.x + 1) * SEG + threadIdx.x];
         if (!(Tn < 0.0f)) v_Tcar = Tn;   // pixel still alive at the next segment
     }
-    float v_Scar = Ubuf[(size_t)b * SEG + threadIdx.x];
-    const int seg_lo = sl * SEG;         // first list entry (tile-relative) of this segment
+    float v_Scar = Ubuf[(size_t)blockIdx.x * SEG + threadIdx.x];
+    const int seg_lo = c.sl * SEG;       // first list entry (tile-relative) of this segment
 
-    int m = v_nc;
+    int mx = v_nc;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
-    const int wave_maxc = m;
-    const int seg_cnt = min(SEG, nlist - seg_lo);
-    const int nchunks = (seg_cnt + 63) >> 6;
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
+    const int wave_maxc = mx;
+    const int nchunks = (nrel + 63) >> 6;
 
-    for (int c = nchunks - 1; c >= 0; --c) {
-        // ---- lane l owns list entry seg_lo + c*64 + (63-l): back-to-front over lanes
-        const int e = seg_lo + c * 64 + (63 - lane);
-        const bool has = e < nlist && e < seg_lo + SEG;
-        uint32_t id = 0;
+    for (int ch = nchunks - 1; ch >= 0; --ch) {
+        // ---- lane l owns the strip's relevant entry number ch*64 + (63-l): back-to-front over lanes
+        const int r = ch * 64 + (63 - lane);
+        const bool has = r < nrel;
+        const int ej = has ? (int)ridx[w][r] : 0;      // entry index inside the segment
+        const int e = seg_lo + ej;                      // tile-relative list index
         float sx = 0.f, sy = 0.f, cA = 0.f, cB = 0.f, cC = 0.f, op = 0.f, thr = 1.0f;
         float at[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) at[k] = 0.0f;
         if (has) {
-            id = point_list[range.x + e];
-            const float4* src = reinterpret_cast<const float4*>(rec + id);
+            const float4* src = reinterpret_cast<const float4*>(rec + ids[ej]);
             const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4];
             sx = q0.x; sy = q0.y; cA = q0.z; cB = q0.w; cC = q1.x; op = q1.y; thr = q1.z;
             at[0] = q2.x; at[1] = q2.y; at[2] = q2.z; at[3] = q1.w;
@@ -261,7 +285,9 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
         float acc[NACC];
 #pragma unroll
         for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
-        const int chunk_lo = seg_lo + c * 64;
+        // nearest list index held by this chunk (its first relevant entry): pixels whose last
+        // contributor lies in front of it have nothing to do here
+        const int chunk_lo = seg_lo + (int)ridx[w][ch * 64];
 
         if (chunk_lo < wave_maxc) {
             for (int p = 0; p < 64; ++p) {
@@ -280,7 +306,6 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                 float g[NCH];
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) g[k] = readlane_f(pg.g[k], p);
-
                 const float a_eff = contrib ? alpha : 0.0f;
                 const float om = 1.0f - a_eff;
                 const float pprod = wave_prefix_mul(om);                 // prod over entries >= mine
@@ -309,22 +334,23 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                     acc[16] = fmaf(dLdG, -gdy * cC - gdx * cB, acc[16]);
                 }
             }
-        }
-        // ---- reduce the four waves through LDS, then one coalesced atomic set per (tile, splat)
-        __syncthreads();  // previous chunk's readers are done with red/ids
+            // the strips of a tile share entries: combine them in LDS (ds_add_f32)
+            if (has) {
 #pragma unroll
-        for (int k = 0; k < NACC; ++k) red[w][lane * NACC + k] = acc[k];
-        if (w == 0) ids[lane] = has ? id : 0xFFFFFFFFu;
-        __syncthreads();
-        for (int v = threadIdx.x; v < 64 * NACC; v += 256) {
-            const int l = v / NACC, k = v - l * NACC;
-            const uint32_t gid = ids[l];
-            if (gid == 0xFFFFFFFFu) continue;
-            float sum = (red[0][v] + red[1][v]) + (red[2][v] + red[3][v]);
-            if (sum == 0.0f) continue;
-            if (k < 15) atomicAdd(&gacc[(size_t)gid * 16 + k], sum);
-            else atomicAdd(&gmean2D[(size_t)gid * 3 + (k - 15)], sum * (k == 15 ? 0.5f * (float)cam.W : 0.5f * (float)cam.H));
+                for (int k = 0; k < NACC; ++k)
+                    if (acc[k] != 0.0f) atomicAdd(&gsum[ej * NACC + k], acc[k]);
+            }
         }
+    }
+    // ---- one coalesced set of global atomics per (tile, entry)
+    __syncthreads();
+    for (int v = threadIdx.x; v < SEG * NACC; v += 256) {
+        const int l = v / NACC, k = v - l * NACC;
+        const uint32_t gid = ids[l];
+        const float sum = gsum[v];
+        if (gid == 0xFFFFFFFFu || sum == 0.0f) continue;
+        if (k < 15) atomicAdd(&gacc[(size_t)gid * 16 + k], sum);
+        else atomicAdd(&gmean2D[(size_t)gid * 3 + (k - 15)], sum * (k == 15 ? 0.5f * (float)cam.W : 0.5f * (float)cam.H));
     }
 }
 

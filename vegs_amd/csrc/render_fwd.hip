@@ -23,21 +23,9 @@
 // One 256-thread workgroup = one 16x16 tile = 4 wave64, lane = pixel (16x4 strip per wave); splat
 // records are gathered with dwordx4 loads into LDS and read back as wave-uniform broadcasts.
 #include "vr_host.h"
+#include "vr_segment.h"
 
 namespace vr {
-
-constexpr int SEG = 256;
-
-__device__ __forceinline__ int seg_find_tile(const uint32_t* __restrict__ seg_off, int ntiles, uint32_t b)
-{
-    // largest t with seg_off[t] <= b  (seg_off is non-decreasing, seg_off[ntiles] = total)
-    int lo = 0, hi = ntiles;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (seg_off[mid] <= b) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
 
 // seg_off[t] = first global segment id of tile t; seg_off[T] = total.  Single workgroup.
 __global__ void __launch_bounds__(256)
@@ -71,60 +59,46 @@ k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict_
     if (threadIdx.x == 0) seg_off[ntiles] = carry_s;
 }
 
-struct SegCtx {
-    int tile, sl;        // tile id, segment index inside the tile
-    int first, count;    // first list entry of the segment (absolute index into point_list), entries
-    float pxf, pyf;
-    bool inside;
-    size_t pix;
-};
-
-__device__ __forceinline__ bool seg_setup(const Camera& cam, const int2* __restrict__ ranges,
-                                          const uint32_t* __restrict__ seg_off, SegCtx& c)
-{
-    const int ntiles = cam.gx * cam.gy;
-    const uint32_t b = blockIdx.x;
-    if (b >= seg_off[ntiles]) return false;
-    c.tile = seg_find_tile(seg_off, ntiles, b);
-    c.sl = (int)(b - seg_off[c.tile]);
-    const int2 r = ranges[c.tile];
-    c.first = r.x + c.sl * SEG;
-    c.count = min(SEG, r.y - c.first);
-    const int tx = c.tile % cam.gx, ty = c.tile / cam.gx;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int px = tx * TILE + (lane & 15), py = ty * TILE + w * 4 + (lane >> 4);
-    c.inside = px < cam.W && py < cam.H;
-    c.pxf = (float)px;
-    c.pyf = (float)py;
-    c.pix = (size_t)py * cam.W + px;
-    return true;
-}
-
 // ---- A: per (tile, segment, pixel) product of (1 - alpha)
 __global__ void __launch_bounds__(256)
 k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
             const uint32_t* __restrict__ point_list, const Splat* __restrict__ rec, float* __restrict__ Pbuf)
 {
     __shared__ float4 lds[2][SEG];
+    __shared__ unsigned long long masks[4][4];
     SegCtx c;
     if (!seg_setup(cam, ranges, seg_off, c)) return;
-    if ((int)threadIdx.x < c.count) {
-        const float4* src = reinterpret_cast<const float4*>(rec + point_list[c.first + threadIdx.x]);
-        lds[0][threadIdx.x] = src[0];
-        lds[1][threadIdx.x] = src[1];
+    {
+        const bool have = (int)threadIdx.x < c.count;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t ext = 0;
+        if (have) {
+            const Splat* sp = rec + point_list[c.first + threadIdx.x];
+            const float4* src = reinterpret_cast<const float4*>(sp);
+            q0 = src[0];
+            lds[0][threadIdx.x] = q0;
+            lds[1][threadIdx.x] = src[1];
+            ext = sp->ext;
+        }
+        seg_build_masks(c, have, q0.x, q0.y, ext, masks);
     }
     __syncthreads();
+    const int w = threadIdx.x >> 6;
+    const float pxf = (float)c.px, pyf = (float)c.py;
     float p = 1.0f;
-    for (int k = 0; k < c.count; ++k) {
-        const float4 a = lds[0][k];  // x y A B
-        const float4 b = lds[1][k];  // C opacity thr depth
-        float dx, dy;
-        const float power = splat_power(a.x, a.y, a.z, a.w, b.x, c.pxf, c.pyf, dx, dy);
-        const bool pre = !(power > 0.0f) && power >= b.z;
-        if (__ballot(pre) == 0ull) continue;  // the splat cannot reach 1/255 anywhere in this 16x4 strip
-        const float alpha = fminf(ALPHA_MAX, b.y * vr_exp(power));
-        const bool valid = pre && !(alpha < ALPHA_MIN);
-        p = valid ? p * (1.0f - alpha) : p;
+    for (int part = 0; part < 4; ++part) {
+        for (unsigned long long m = uniform64(masks[w][part]); m; m &= m - 1) {
+            const int k = part * 64 + __builtin_ctzll(m);
+            const float4 a = lds[0][k];  // x y A B
+            const float4 b = lds[1][k];  // C opacity thr depth
+            float dx, dy;
+            const float power = splat_power(a.x, a.y, a.z, a.w, b.x, pxf, pyf, dx, dy);
+            const bool pre = !(power > 0.0f) && power >= b.z;
+            if (__ballot(pre) == 0ull) continue;  // cannot reach 1/255 anywhere in this strip
+            const float alpha = fminf(ALPHA_MAX, b.y * vr_exp(power));
+            const bool valid = pre && !(alpha < ALPHA_MIN);
+            p = valid ? p * (1.0f - alpha) : p;
+        }
     }
     Pbuf[(size_t)blockIdx.x * SEG + threadIdx.x] = p;
 }
@@ -182,15 +156,29 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
             const Splat* __restrict__ rec, const float* __restrict__ Tbuf, float* __restrict__ part)
 {
     __shared__ float4 lds[5][SEG];
+    __shared__ unsigned long long masks[4][4];
     SegCtx c;
     if (!seg_setup(cam, ranges, seg_off, c)) return;
     if ((uint32_t)c.sl >= seg_needed[c.tile]) return;
-    if ((int)threadIdx.x < c.count) {
-        const float4* src = reinterpret_cast<const float4*>(rec + point_list[c.first + threadIdx.x]);
+    {
+        const bool have = (int)threadIdx.x < c.count;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t ext = 0;
+        if (have) {
+            const float4* src = reinterpret_cast<const float4*>(rec + point_list[c.first + threadIdx.x]);
+            q0 = src[0];
+            const float4 q4 = src[4];
+            lds[0][threadIdx.x] = q0;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) lds[k][threadIdx.x] = src[k];
+            for (int k = 1; k < 4; ++k) lds[k][threadIdx.x] = src[k];
+            lds[4][threadIdx.x] = q4;
+            ext = __float_as_uint(q4.w);
+        }
+        seg_build_masks(c, have, q0.x, q0.y, ext, masks);
     }
     __syncthreads();
+    const int w = threadIdx.x >> 6;
+    const float pxf = (float)c.px, pyf = (float)c.py;
     const float Tb = Tbuf[(size_t)blockIdx.x * SEG + threadIdx.x];
     bool done = Tb < 0.0f;
     if (__ballot(!done) == 0ull) return;  // nothing alive in this wave's strip
@@ -202,41 +190,42 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     bool stopped = false;
     // Branch-free per lane (predicated); only wave-uniform branches: skip the exp when no pixel of the
     // strip can reach alpha >= 1/255, skip the channel update when no pixel applies the splat.
-    for (int k = 0; k < c.count; ++k) {
-        const float4 a = lds[0][k];  // x y A B
-        const float4 b = lds[1][k];  // C opacity thr depth
-        float dx, dy;
-        const float power = splat_power(a.x, a.y, a.z, a.w, b.x, c.pxf, c.pyf, dx, dy);
-        const bool pre = !done && !(power > 0.0f) && power >= b.z;
-        if (__ballot(pre) == 0ull) {
-            if (__ballot(!done) == 0ull) break;  // every pixel of the strip is finished
-            continue;
+    for (int part_i = 0; part_i < 4; ++part_i) {
+        for (unsigned long long m = uniform64(masks[w][part_i]); m; m &= m - 1) {
+            const int k = part_i * 64 + __builtin_ctzll(m);
+            const float4 a = lds[0][k];  // x y A B
+            const float4 b = lds[1][k];  // C opacity thr depth
+            float dx, dy;
+            const float power = splat_power(a.x, a.y, a.z, a.w, b.x, pxf, pyf, dx, dy);
+            const bool pre = !done && !(power > 0.0f) && power >= b.z;
+            if (__ballot(pre) == 0ull) continue;
+            const float alpha = fminf(ALPHA_MAX, b.y * vr_exp(power));
+            const bool valid = pre && !(alpha < ALPHA_MIN);
+            const float pn = p * (1.0f - alpha);
+            const bool stop = valid && (Tb * pn < T_EPS);
+            const bool apply = valid && !stop;
+            done = done || stop;
+            stopped = stopped || stop;
+            if (__ballot(apply) == 0ull) continue;
+            const float wgt = apply ? alpha * (Tb * p) : 0.0f;
+            const float4 cc = lds[2][k];  // r g b qw
+            const float4 d = lds[3][k];   // qx qy qz s0
+            const float4 e4 = lds[4][k];  // s1 s2 - -
+            Cs[0] = fmaf(cc.x, wgt, Cs[0]);
+            Cs[1] = fmaf(cc.y, wgt, Cs[1]);
+            Cs[2] = fmaf(cc.z, wgt, Cs[2]);
+            Cs[3] = fmaf(b.w, wgt, Cs[3]);
+            Cs[4] = fmaf(cc.w, wgt, Cs[4]);
+            Cs[5] = fmaf(d.x, wgt, Cs[5]);
+            Cs[6] = fmaf(d.y, wgt, Cs[6]);
+            Cs[7] = fmaf(d.z, wgt, Cs[7]);
+            Cs[8] = fmaf(d.w, wgt, Cs[8]);
+            Cs[9] = fmaf(e4.x, wgt, Cs[9]);
+            Cs[10] = fmaf(e4.y, wgt, Cs[10]);
+            p = apply ? pn : p;
+            last = apply ? (uint32_t)(c.sl * SEG + k + 1) : last;
         }
-        const float alpha = fminf(ALPHA_MAX, b.y * vr_exp(power));
-        const bool valid = pre && !(alpha < ALPHA_MIN);
-        const float pn = p * (1.0f - alpha);
-        const bool stop = valid && (Tb * pn < T_EPS);
-        const bool apply = valid && !stop;
-        done = done || stop;
-        stopped = stopped || stop;
-        if (__ballot(apply) == 0ull) continue;
-        const float wgt = apply ? alpha * (Tb * p) : 0.0f;
-        const float4 cc = lds[2][k];  // r g b qw
-        const float4 d = lds[3][k];   // qx qy qz s0
-        const float4 e4 = lds[4][k];  // s1 s2 - -
-        Cs[0] = fmaf(cc.x, wgt, Cs[0]);
-        Cs[1] = fmaf(cc.y, wgt, Cs[1]);
-        Cs[2] = fmaf(cc.z, wgt, Cs[2]);
-        Cs[3] = fmaf(b.w, wgt, Cs[3]);
-        Cs[4] = fmaf(cc.w, wgt, Cs[4]);
-        Cs[5] = fmaf(d.x, wgt, Cs[5]);
-        Cs[6] = fmaf(d.y, wgt, Cs[6]);
-        Cs[7] = fmaf(d.z, wgt, Cs[7]);
-        Cs[8] = fmaf(d.w, wgt, Cs[8]);
-        Cs[9] = fmaf(e4.x, wgt, Cs[9]);
-        Cs[10] = fmaf(e4.y, wgt, Cs[10]);
-        p = apply ? pn : p;
-        last = apply ? (uint32_t)(c.sl * SEG + k + 1) : last;
+        if (__ballot(!done) == 0ull) break;  // every pixel of the strip is finished
     }
     if (!(Tb < 0.0f)) {
         float* dst = part + (size_t)blockIdx.x * (NPART * SEG) + threadIdx.x;

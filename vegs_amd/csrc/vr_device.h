@@ -5,6 +5,7 @@
 // fused multiply-add is an explicit fmaf(), so that radii, tile rectangles, sort keys and
 // forward images are bit-reproducible against the CPU oracle used by the tests.
 #pragma once
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -26,7 +27,7 @@ struct __attribute__((aligned(16))) Splat {
     float qx, qy, qz, s0;            // q3: quaternion x,y,z, scale 0  (input scale row, A-3)
     float s1, s2;                    // q4: scale 1,2
     uint32_t clamped;                //     bit c set: colour channel c was clamped at 0
-    uint32_t pad0;
+    uint32_t ext;                    //     half2 (hx, hy): conservative half-extent of the alpha >= 1/255 footprint
 };
 static_assert(sizeof(Splat) == 80, "Splat must be 80 bytes");
 
@@ -89,6 +90,35 @@ __device__ __forceinline__ void tile_rect(float px, float py, int rad, int gx, i
 // < 1/255 (1 % slack in the exponent >> the error of vr_exp): lets a whole wave skip a splat without
 // evaluating exp.  Never decides anything by itself -- the exact alpha test still follows.
 __device__ __forceinline__ float splat_thr(float opacity) { return -__logf(255.0f * opacity) - 0.01f; }
+
+// Conservative axis-aligned half-extent (pixels) of the region where alpha can reach 1/255:
+// power >= thr  <=>  d^T conic d <= -2 thr, an ellipse whose bounding box is sqrt(-2 thr * cov2D_xx/yy).
+// Rounded UP into a half2; (-1,-1) = never visible.  Only used to skip work, never to decide a result.
+__device__ __forceinline__ uint32_t splat_extent(float thr, float cov_a, float cov_c)
+{
+    const float k = -2.0f * thr;
+    float hx = -1.0f, hy = -1.0f;
+    if (k > 0.0f) {
+        hx = fminf(sqrtf(k * cov_a) * 1.002f + 0.01f, 60000.0f);
+        hy = fminf(sqrtf(k * cov_c) * 1.002f + 0.01f, 60000.0f);
+    }
+    const uint32_t lo = __half_as_ushort(__float2half_ru(hx)), hi = __half_as_ushort(__float2half_ru(hy));
+    return lo | (hi << 16);
+}
+__device__ __forceinline__ void splat_extent_unpack(uint32_t e, float& hx, float& hy)
+{
+    hx = __half2float(__ushort_as_half((unsigned short)(e & 0xFFFFu)));
+    hy = __half2float(__ushort_as_half((unsigned short)(e >> 16)));
+}
+
+// Segment helpers shared by the render kernels.  The 256 staged entries of a segment are tested once
+// against the tile's column range and the four 16x4 pixel strips; wave w then visits only the set
+// bits of its strip's 256-bit mask (4 x u64, wave-uniform), in ascending entry order.
+__device__ __forceinline__ bool strip_relevant(float sx, float sy, float hx, float hy, float x0, float y0, int strip)
+{
+    const float ys = y0 + 4.0f * (float)strip;
+    return (sx + hx >= x0) && (sx - hx <= x0 + 15.0f) && (sy + hy >= ys) && (sy - hy <= ys + 3.0f);
+}
 
 // Gaussian exponent at a pixel; identical expression in forward and backward.
 __device__ __forceinline__ float splat_power(float sx, float sy, float A, float B, float C, float pxf, float pyf,

@@ -1,0 +1,79 @@
+// vr_segment.h -- device helpers shared by the segmented compositing kernels (render_fwd.hip,
+// render_bwd.hip).  Unit of work: (tile, segment of SEG = 256 consecutive tile-list entries);
+// workgroup = 256 threads = 4 wave64; wave w owns the 16x4 pixel strip w of the tile, lane = pixel.
+#pragma once
+#include "vr_device.h"
+
+namespace vr {
+
+constexpr int SEG = 256;
+
+// largest t with seg_off[t] <= b  (seg_off non-decreasing, seg_off[ntiles] = number of segments)
+__device__ __forceinline__ int seg_find_tile(const uint32_t* __restrict__ seg_off, int ntiles, uint32_t b)
+{
+    int lo = 0, hi = ntiles;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (seg_off[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+struct SegCtx {
+    int tile, sl;      // tile id, segment index inside the tile
+    int first, count;  // first list entry of the segment (absolute index into point_list), entries
+    int nlist;         // entries in the whole tile list
+    int px, py;        // this lane's pixel
+    float x0, y0;      // tile origin (pixel coordinates of its first column / row)
+    bool inside;
+    size_t pix;
+};
+
+__device__ __forceinline__ bool seg_setup(const Camera& cam, const int2* __restrict__ ranges,
+                                          const uint32_t* __restrict__ seg_off, SegCtx& c)
+{
+    const int ntiles = cam.gx * cam.gy;
+    const uint32_t b = blockIdx.x;
+    if (b >= seg_off[ntiles]) return false;
+    c.tile = seg_find_tile(seg_off, ntiles, b);
+    c.sl = (int)(b - seg_off[c.tile]);
+    const int2 r = ranges[c.tile];
+    c.nlist = r.y - r.x;
+    c.first = r.x + c.sl * SEG;
+    c.count = min(SEG, r.y - c.first);
+    const int tx = c.tile % cam.gx, ty = c.tile / cam.gx;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    c.px = tx * TILE + (lane & 15);
+    c.py = ty * TILE + w * 4 + (lane >> 4);
+    c.x0 = (float)(tx * TILE);
+    c.y0 = (float)(ty * TILE);
+    c.inside = c.px < cam.W && c.py < cam.H;
+    c.pix = (size_t)c.py * cam.W + c.px;
+    return true;
+}
+
+// Relevance masks of the segment's entries: masks[strip][part] bit j set <=> entry part*64+j can reach
+// alpha >= 1/255 somewhere in that 16x4 strip (conservative bounding-box test on the record's extent).
+// Thread j tests entry j; the caller must __syncthreads() before reading the masks.
+__device__ __forceinline__ void seg_build_masks(const SegCtx& c, bool have, float sx, float sy, uint32_t ext,
+                                                unsigned long long (*masks)[4])
+{
+    float hx, hy;
+    splat_extent_unpack(ext, hx, hy);
+    const int part = threadIdx.x >> 6;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const unsigned long long m = __ballot(have && strip_relevant(sx, sy, hx, hy, c.x0, c.y0, s));
+        if ((threadIdx.x & 63) == 0) masks[s][part] = m;
+    }
+}
+
+// wave-uniform 64-bit value held in SGPRs
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+}  // namespace vr

@@ -255,34 +255,31 @@ k_seg_combine(Camera cam, const uint32_t* __restrict__ seg_off, const uint32_t* 
     for (int k = 0; k < NCH; ++k) C[k] = 0.0f;
     float T = 1.0f;
     uint32_t last = 0;
-    // two segments per iteration, every load issued before the first use (order of the adds is the spec's)
+    // CU segments per iteration: every load (unconditional, addresses are always inside the buffers) is
+    // issued before the first use, so the chain pays one memory latency per CU segments; the adds
+    // keep the spec's order.  Values of segments in which the pixel is already finished are ignored.
+    constexpr int CU = 6;
     bool dead = false;
-    for (uint32_t s = 0; s < needed && !dead; s += 2) {
-        const bool two = s + 1 < needed;
-        const size_t at0 = (size_t)(s0 + s) * SEG + threadIdx.x;
-        const size_t at1 = two ? at0 + SEG : at0;
-        const float Tb0 = Tbuf[at0];
-        const float Tb1 = two ? Tbuf[at1] : -1.0f;
-        const float* src0 = part + (size_t)(s0 + s) * (NPART * SEG) + threadIdx.x;
-        const float* src1 = two ? src0 + NPART * SEG : src0;
-        float v0[NPART], v1[NPART];
-        const bool use0 = !(Tb0 < 0.0f), use1 = use0 && !(Tb1 < 0.0f);
+    for (uint32_t s = 0; s < needed && !dead; s += CU) {
+        float Tbv[CU], v[CU][NPART];
 #pragma unroll
-        for (int k = 0; k < NPART; ++k) v0[k] = use0 ? src0[k * SEG] : 0.0f;
+        for (int j = 0; j < CU; ++j) {
+            const uint32_t sj = min(s + j, needed - 1);   // clamp: duplicates are never used
+            Tbv[j] = Tbuf[(size_t)(s0 + sj) * SEG + threadIdx.x];
+            const float* src = part + (size_t)(s0 + sj) * (NPART * SEG) + threadIdx.x;
 #pragma unroll
-        for (int k = 0; k < NPART; ++k) v1[k] = use1 ? src1[k * SEG] : 0.0f;
-        if (!use0) { dead = true; break; }
+            for (int k = 0; k < NPART; ++k) v[j][k] = src[k * SEG];
+        }
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) C[k] += v0[k];
-        T = Tb0 * v0[11];
-        uint32_t l = __float_as_uint(v0[12]) & 0x7FFFFFFFu;
-        if (l) last = l;
-        if (!use1) { dead = true; break; }
+        for (int j = 0; j < CU; ++j) {
+            if (dead || s + j >= needed) continue;
+            if (Tbv[j] < 0.0f) { dead = true; continue; }
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) C[k] += v1[k];
-        T = Tb1 * v1[11];
-        l = __float_as_uint(v1[12]) & 0x7FFFFFFFu;
-        if (l) last = l;
+            for (int k = 0; k < NCH; ++k) C[k] += v[j][k];
+            T = Tbv[j] * v[j][11];
+            const uint32_t l = __float_as_uint(v[j][12]) & 0x7FFFFFFFu;
+            if (l) last = l;
+        }
     }
     const size_t N = (size_t)cam.H * cam.W;
     const size_t pix = (size_t)py * cam.W + px;

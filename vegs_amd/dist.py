@@ -27,7 +27,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # VEGS_DIST_BACKEND=gloo lets the N>1 path be exercised on a single-GPU box (several ranks
+            # sharing one device, which RCCL refuses); production default is nccl (= RCCL over xGMI)
+            backend = os.environ.get("VEGS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

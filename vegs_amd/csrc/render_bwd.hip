@@ -91,95 +91,50 @@ __device__ __forceinline__ void load_pixgrad(bool inside, size_t pix, size_t N, 
     if (dL_dalpha) o.galpha = dL_dalpha[pix];
 }
 
-// ---- A': U[seg][pix] = sum over the segment's applied entries of w*u (pixel-parallel, lane = pixel)
+// ---- A'+B': per tile, Ubuf[seg][pix] = sum over the LATER segments of the tile of U, where
+// U[seg][pix] = sum over the segment's applied entries of w*u = <dL/dout(pix), segment-local channel
+// sums> -- the sums the forward already produced (`part`), so no second pass over the splats.
+constexpr int NPART_B = 13;
 __global__ void __launch_bounds__(256)
-k_seg_wu(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
-         const uint32_t* __restrict__ seg_needed, const uint32_t* __restrict__ point_list,
-         const Splat* __restrict__ rec, const float* __restrict__ Tbuf, const uint32_t* __restrict__ n_contrib,
-         const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dquat,
-         const float* __restrict__ dL_dscale, float* __restrict__ Ubuf)
-{
-    __shared__ float4 lds[5][SEG];
-    __shared__ unsigned long long masks[4][4];
-    SegCtx c;
-    if (!seg_setup(cam, ranges, seg_off, c)) return;
-    if ((uint32_t)c.sl >= seg_needed[c.tile]) return;
-    {
-        const bool have = (int)threadIdx.x < c.count;
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        uint32_t ext = 0;
-        if (have) {
-            const float4* src = reinterpret_cast<const float4*>(rec + point_list[c.first + threadIdx.x]);
-            q0 = src[0];
-            const float4 q4 = src[4];
-            lds[0][threadIdx.x] = q0;
-#pragma unroll
-            for (int k = 1; k < 4; ++k) lds[k][threadIdx.x] = src[k];
-            lds[4][threadIdx.x] = q4;
-            ext = __float_as_uint(q4.w);
-        }
-        seg_build_masks(c, have, q0.x, q0.y, ext, masks);
-    }
-    __syncthreads();
-    const int w = threadIdx.x >> 6;
-    const size_t N = (size_t)cam.H * cam.W;
-    PixGrad pg;
-    load_pixgrad(c.inside, c.pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, nullptr, pg);
-    const int nc = c.inside ? (int)n_contrib[c.pix] : 0;
-    const int lim = min(c.count, nc - c.sl * SEG);  // entries of this segment in front of the pixel's last contributor
-    const float pxf = (float)c.px, pyf = (float)c.py;
-    float U = 0.0f;
-    if (__ballot(lim > 0) != 0ull) {
-        const float Tb = Tbuf[(size_t)blockIdx.x * SEG + threadIdx.x];
-        float p = 1.0f;
-        for (int part = 0; part < 4; ++part) {
-            for (unsigned long long m = uniform64(masks[w][part]); m; m &= m - 1) {
-                const int k = part * 64 + __builtin_ctzll(m);
-                const float4 a = lds[0][k];   // x y A B
-                const float4 bq = lds[1][k];  // C opacity thr depth
-                float dx, dy;
-                const float power = splat_power(a.x, a.y, a.z, a.w, bq.x, pxf, pyf, dx, dy);
-                const bool pre = (k < lim) && !(power > 0.0f) && power >= bq.z;
-                if (__ballot(pre) == 0ull) continue;
-                const float alpha = fminf(ALPHA_MAX, bq.y * vr_exp(power));
-                const bool valid = pre && !(alpha < ALPHA_MIN);
-                if (__ballot(valid) == 0ull) continue;
-                const float wgt = valid ? alpha * (Tb * p) : 0.0f;
-                const float4 cc = lds[2][k];  // r g b qw
-                const float4 d = lds[3][k];   // qx qy qz s0
-                const float4 e4 = lds[4][k];  // s1 s2 - -
-                float u = cc.x * pg.g[0];
-                u = fmaf(cc.y, pg.g[1], u);
-                u = fmaf(cc.z, pg.g[2], u);
-                u = fmaf(bq.w, pg.g[3], u);
-                u = fmaf(cc.w, pg.g[4], u);
-                u = fmaf(d.x, pg.g[5], u);
-                u = fmaf(d.y, pg.g[6], u);
-                u = fmaf(d.z, pg.g[7], u);
-                u = fmaf(d.w, pg.g[8], u);
-                u = fmaf(e4.x, pg.g[9], u);
-                u = fmaf(e4.y, pg.g[10], u);
-                U = fmaf(wgt, u, U);
-                p = valid ? p * (1.0f - alpha) : p;
-            }
-        }
-    }
-    Ubuf[(size_t)blockIdx.x * SEG + threadIdx.x] = U;
-}
-
-// ---- B': per tile, in place: Ubuf[seg][pix] <- sum of U over the LATER segments of the tile
-__global__ void __launch_bounds__(256)
-k_seg_suffix(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_needed, float* __restrict__ Ubuf)
+k_seg_usuffix(Camera cam, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_needed,
+              const float* __restrict__ part, const uint32_t* __restrict__ n_contrib,
+              const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+              const float* __restrict__ dL_dquat, const float* __restrict__ dL_dscale, float* __restrict__ Ubuf)
 {
     const int tile = blockIdx.x;
+    const int tx = tile % cam.gx, ty = tile / cam.gx;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int px = tx * TILE + (lane & 15), py = ty * TILE + w * 4 + (lane >> 4);
+    const bool inside = px < cam.W && py < cam.H;
+    const size_t N = (size_t)cam.H * cam.W, pix = (size_t)py * cam.W + px;
+    PixGrad pg;
+    load_pixgrad(inside, pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, nullptr, pg);
+    const int nc = inside ? (int)n_contrib[pix] : 0;
     const uint32_t s0 = seg_off[tile];
     const int needed = (int)seg_needed[tile];
+    constexpr int CU = 4;
     float run = 0.0f;
-    for (int s = needed - 1; s >= 0; --s) {
-        const size_t at = (size_t)(s0 + s) * SEG + threadIdx.x;
-        const float U = Ubuf[at];
-        Ubuf[at] = run;
-        run += U;
+    for (int s = needed - 1; s >= 0; s -= CU) {
+        float v[CU][NCH];
+#pragma unroll
+        for (int j = 0; j < CU; ++j) {
+            const int sj = max(s - j, 0);
+            const float* src = part + (size_t)(s0 + sj) * (NPART_B * SEG) + threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) v[j][k] = src[k * SEG];
+        }
+#pragma unroll
+        for (int j = 0; j < CU; ++j) {
+            const int sj = s - j;
+            if (sj < 0) continue;
+            float U = 0.0f;
+            if (sj * SEG < nc) {   // the pixel applied entries of this segment (otherwise `part` is not defined for it)
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) U = fmaf(v[j][k], pg.g[k], U);
+            }
+            Ubuf[(size_t)(s0 + sj) * SEG + threadIdx.x] = run;
+            run += U;
+        }
     }
 }
 
@@ -360,8 +315,8 @@ size_t render_bwd_scratch_bytes(long R, int ntiles)
 }
 
 int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint32_t* point_list, const Splat* rec,
-                      const uint32_t* seg_off, const uint32_t* seg_needed, const float* Tbuf, void* scratch,
-                      const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
+                      const uint32_t* seg_off, const uint32_t* seg_needed, const float* Tbuf, const float* part,
+                      void* scratch, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                       const float* dL_ddepth, const float* dL_dquat, const float* dL_dscale,
                       const float* dL_dalpha, float* gacc, float* gmean2D, hipStream_t s, bool debug)
 {
@@ -369,11 +324,9 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
     if (ntiles == 0 || R == 0) return 0;
     const unsigned nseg = (unsigned)seg_capacity(R, ntiles);
     float* Ubuf = (float*)scratch;
-    hipLaunchKernelGGL(k_seg_wu, dim3(nseg), dim3(256), 0, s, cam, ranges, seg_off, seg_needed, point_list, rec, Tbuf,
-                       n_contrib, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, Ubuf);
-    VR_KERNEL_CHECK("seg_wu", s, debug);
-    hipLaunchKernelGGL(k_seg_suffix, dim3(ntiles), dim3(256), 0, s, seg_off, seg_needed, Ubuf);
-    VR_KERNEL_CHECK("seg_suffix", s, debug);
+    hipLaunchKernelGGL(k_seg_usuffix, dim3(ntiles), dim3(256), 0, s, cam, seg_off, seg_needed, part, n_contrib,
+                       dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, Ubuf);
+    VR_KERNEL_CHECK("seg_usuffix", s, debug);
     hipLaunchKernelGGL(k_seg_bwd, dim3(nseg), dim3(256), 0, s, cam, ranges, seg_off, seg_needed, point_list, rec, Tbuf,
                        (const float*)Ubuf, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, dL_dalpha,
                        gacc, gmean2D);

@@ -309,11 +309,11 @@ k_count_fragments(const uint32_t* __restrict__ n_contrib, long N, unsigned long 
 size_t render_fwd_scratch_bytes(long R, int ntiles)
 {
     const size_t nseg = seg_capacity(R, ntiles);
-    return align_up(nseg * SEG * sizeof(float), 256) + align_up(nseg * (size_t)NPART * SEG * sizeof(float), 256);
+    return align_up(nseg * SEG * sizeof(float), 256);
 }
 
 int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint32_t* point_list, const Splat* rec,
-                      uint32_t* seg_off, uint32_t* seg_needed, float* Tbuf, void* scratch, float* out_color,
+                      uint32_t* seg_off, uint32_t* seg_needed, float* Tbuf, float* part, void* scratch, float* out_color,
                       float* out_depth, float* out_quat, float* out_scale, float* out_alpha, float* final_T,
                       uint32_t* n_contrib, hipStream_t s, bool debug)
 {
@@ -321,7 +321,6 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     if (ntiles == 0) return 0;
     const size_t nseg = seg_capacity(R, ntiles);
     float* Pbuf = (float*)scratch;
-    float* part = (float*)((char*)scratch + align_up(nseg * SEG * sizeof(float), 256));
     hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(256), 0, s, ranges, ntiles, seg_off);
     VR_KERNEL_CHECK("seg_offsets", s, debug);
     if (R > 0) {

@@ -196,34 +196,40 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     // ---- transient, P-sized
     const size_t s1 = binning_stage1_scratch_bytes(P);
     const size_t arr = align_up(p1 * 4, 256);
-    void* scr = alloc(user, VR_BUF_SCRATCH, 4 * arr + s1 + 256);
+    void* scr = alloc(user, VR_BUF_SCRATCH, 5 * arr + s1 + 256);
     if (!geom || !image || !scr) return fail(VR_ERR_ALLOC, "allocator returned NULL");
     Splat* rec = (Splat*)geom;
     float* final_T = (float*)((char*)image + IL.final_T);
     uint32_t* n_contrib = (uint32_t*)((char*)image + IL.n_contrib);
-    uint32_t* tiles_touched = (uint32_t*)scr;
-    uint32_t* depth_key = (uint32_t*)((char*)scr + arr);
-    uint32_t* vis_key = (uint32_t*)((char*)scr + 2 * arr);
-    uint32_t* vis_id = (uint32_t*)((char*)scr + 3 * arr);
-    void* scan_scr = (char*)scr + 4 * arr;
-    uint32_t* totals_dev = (uint32_t*)((char*)scr + 4 * arr + s1);
+    uint2* rect = (uint2*)scr;                                   // 8 B per Gaussian
+    uint32_t* depth_key = (uint32_t*)((char*)scr + 2 * arr);
+    uint32_t* vis_key = (uint32_t*)((char*)scr + 3 * arr);
+    uint32_t* vis_id = (uint32_t*)((char*)scr + 4 * arr);
+    void* scan_scr = (char*)scr + 5 * arr;
+    uint32_t* totals_dev = (uint32_t*)((char*)scr + 5 * arr + s1);
 
-    uint32_t V = 0, R = 0;
+    uint32_t V = 0, R = 0, key_min = 0;
+    int key_bits = 0;
     if (P > 0) {
         prof_begin(VR_STAGE_PREPROCESS, s);
         rc = launch_preprocess(cam, P, in->means3D, in->shs, in->colors_precomp, in->opacities, in->scales,
-                               in->rotations, in->cov3D_precomp, rec, out->radii, tiles_touched, depth_key, s, debug);
+                               in->rotations, in->cov3D_precomp, rec, out->radii, rect, depth_key, s, debug);
         prof_end(VR_STAGE_PREPROCESS, s);
         if (rc) return rc;
         prof_begin(VR_STAGE_COMPACT, s);
-        rc = launch_compact_visible(P, tiles_touched, depth_key, scan_scr, vis_key, vis_id, totals_dev, s, debug);
+        rc = launch_compact_visible(P, rect, depth_key, scan_scr, vis_key, vis_id, totals_dev, s, debug);
         prof_end(VR_STAGE_COMPACT, s);
         if (rc) return rc;
         // the one host<->device round trip of the forward pass: sizes of the data-dependent lists
-        VR_HIP(hipMemcpyAsync(g_pinned, totals_dev, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        VR_HIP(hipMemcpyAsync(g_pinned, totals_dev, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         VR_HIP(hipStreamSynchronize(s));
         V = g_pinned[0];
         R = g_pinned[1];
+        if (V > 0) {
+            key_min = g_pinned[2];
+            uint32_t span = g_pinned[3] - g_pinned[2];
+            while (span) { ++key_bits; span >>= 1; }
+        }
     }
     const BinLayout BL = bin_layout(T, R);
     void* binning = alloc(user, VR_BUF_BINNING, BL.total);
@@ -231,8 +237,8 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     if (!binning || !scr2) return fail(VR_ERR_ALLOC, "allocator returned NULL");
     int2* ranges = (int2*)((char*)binning + BL.ranges);
     uint32_t* point_list = (uint32_t*)((char*)binning + BL.point_list);
-    rc = launch_binning(cam, (int)V, (long)R, vis_key, vis_id, rec, out->radii, tiles_touched, scr2, point_list,
-                        ranges, s, debug);
+    rc = launch_binning(cam, (int)V, (long)R, key_min, key_bits, vis_key, vis_id, rect, scr2, point_list, ranges, s,
+                        debug);
     if (rc) return rc;
     void* scr3 = alloc(user, VR_BUF_SCRATCH, render_fwd_scratch_bytes((long)R, (int)T) + 256);
     if (!scr3) return fail(VR_ERR_ALLOC, "allocator returned NULL");

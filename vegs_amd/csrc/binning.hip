@@ -22,8 +22,6 @@ constexpr int SCAN_ITEMS = 8;                   // per thread
 constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;    // elements per block
 constexpr int RADIX_ITEMS = 16;                 // per thread
 constexpr int RADIX_BLOCK = 256 * RADIX_ITEMS;  // elements per block
-constexpr int RADIX_BITS = 8;
-constexpr int RADIX_SIZE = 1 << RADIX_BITS;
 
 // ---------------------------------------------------------------- wave / block primitives
 
@@ -53,25 +51,32 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
 
 // ---------------------------------------------------------------- generic 3-kernel scan
 
-struct SrcFlagTiles {  // 1 for visible Gaussians; secondary value = tiles_touched (summed only)
-    const uint32_t* tiles;
-    __device__ uint32_t operator()(long i) const { return tiles[i] ? 1u : 0u; }
-    __device__ uint32_t second(long i) const { return tiles[i]; }
+__device__ __forceinline__ uint32_t rect_area(uint2 r) { return (r.y & 0xFFFFu) * (r.y >> 16); }
+
+struct SrcFlagTiles {  // 1 for visible Gaussians; secondary value = tiles touched (summed only);
+    const uint2* rect;  // also the min / max depth key of the visible ones (range of the depth sort)
+    const uint32_t* depth_key;
+    static constexpr bool MINMAX = true;
+    __device__ uint32_t operator()(long i) const { return rect_area(rect[i]) ? 1u : 0u; }
+    __device__ uint32_t second(long i) const { return rect_area(rect[i]); }
+    __device__ uint32_t key(long i) const { return depth_key[i]; }
 };
-struct SrcGather {  // tiles_touched in depth-sorted order
-    const uint32_t* tiles;
-    const uint32_t* ids;
-    __device__ uint32_t operator()(long i) const { return tiles[ids[i]]; }
+struct SrcRectSorted {  // tiles touched, in depth-sorted order (rectangles already gathered: coalesced reads)
+    const uint2* rect_sorted;
+    static constexpr bool MINMAX = false;
+    __device__ uint32_t operator()(long i) const { return rect_area(rect_sorted[i]); }
     __device__ uint32_t second(long) const { return 0; }
+    __device__ uint32_t key(long) const { return 0; }
 };
 struct SrcPlain {
     const uint32_t* v;
+    static constexpr bool MINMAX = false;
     __device__ uint32_t operator()(long i) const { return v[i]; }
     __device__ uint32_t second(long) const { return 0; }
+    __device__ uint32_t key(long) const { return 0; }
 };
 
 struct SinkCompact {
-    const uint32_t* tiles;
     const uint32_t* depth_key;
     uint32_t* vis_key;
     uint32_t* vis_id;
@@ -85,35 +90,61 @@ struct SinkStore {
     __device__ void operator()(long i, uint32_t, uint32_t excl) const { out[i] = excl; }
 };
 
+// bsum2 (optional): per-block sums of the secondary value; for MINMAX sources bsum2[nb..3nb) also
+// receives the per-block min / max of key(i) over the elements with a non-zero value.
 template <class Src>
 __global__ void __launch_bounds__(256) k_scan_reduce(Src src, long n, uint32_t* bsum, uint32_t* bsum2)
 {
-    __shared__ uint32_t lds[8];
+    __shared__ uint32_t lds[16];
     long base = (long)blockIdx.x * SCAN_BLOCK + (long)threadIdx.x * SCAN_ITEMS;
-    uint32_t a = 0, b = 0;
+    uint32_t a = 0, b = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (base + k < n) { a += src(base + k); b += src.second(base + k); }
+        if (base + k < n) {
+            const uint32_t v = src(base + k);
+            a += v;
+            b += src.second(base + k);
+            if (Src::MINMAX && v) { const uint32_t key = src.key(base + k); kmin = min(kmin, key); kmax = max(kmax, key); }
+        }
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { a += __shfl_down(a, d, 64); b += __shfl_down(b, d, 64); }
-    if (lane == 0) { lds[w] = a; lds[4 + w] = b; }
+    for (int d = 32; d > 0; d >>= 1) {
+        a += __shfl_down(a, d, 64);
+        b += __shfl_down(b, d, 64);
+        if (Src::MINMAX) {
+            kmin = min(kmin, (uint32_t)__shfl_down((int)kmin, d, 64));
+            kmax = max(kmax, (uint32_t)__shfl_down((int)kmax, d, 64));
+        }
+    }
+    if (lane == 0) { lds[w] = a; lds[4 + w] = b; lds[8 + w] = kmin; lds[12 + w] = kmax; }
     __syncthreads();
     if (threadIdx.x == 0) {
         bsum[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
-        if (bsum2) bsum2[blockIdx.x] = lds[4] + lds[5] + lds[6] + lds[7];
+        if (bsum2) {
+            bsum2[blockIdx.x] = lds[4] + lds[5] + lds[6] + lds[7];
+            if (Src::MINMAX) {
+                bsum2[gridDim.x + blockIdx.x] = min(min(lds[8], lds[9]), min(lds[10], lds[11]));
+                bsum2[2 * gridDim.x + blockIdx.x] = max(max(lds[12], lds[13]), max(lds[14], lds[15]));
+            }
+        }
     }
 }
 
-// single block: in-place exclusive scan of bsum[0..nb), total -> totals[0]; sum of bsum2 -> totals[1]
-__global__ void __launch_bounds__(256) k_scan_sums(uint32_t* bsum, const uint32_t* bsum2, int nb, uint32_t* totals)
+// single block: in-place exclusive scan of bsum[0..nb), total -> totals[0]; sum of bsum2 -> totals[1];
+// with minmax: min of bsum2[nb..2nb) -> totals[2], max of bsum2[2nb..3nb) -> totals[3]
+__global__ void __launch_bounds__(256)
+k_scan_sums(uint32_t* bsum, const uint32_t* bsum2, int nb, uint32_t* totals, int minmax)
 {
     __shared__ uint32_t lds4[4];
-    uint32_t carry = 0, acc2 = 0;
+    __shared__ uint32_t mm[8];
+    uint32_t carry = 0, acc2 = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
     for (int base = 0; base < nb; base += 256) {
         int i = base + threadIdx.x;
         uint32_t v = i < nb ? bsum[i] : 0;
-        if (bsum2 && i < nb) acc2 += bsum2[i];
+        if (bsum2 && i < nb) {
+            acc2 += bsum2[i];
+            if (minmax) { kmin = min(kmin, bsum2[nb + i]); kmax = max(kmax, bsum2[2 * nb + i]); }
+        }
         uint32_t total;
         uint32_t ex = block_excl_scan(v, total, lds4);
         if (i < nb) bsum[i] = carry + ex;
@@ -125,6 +156,19 @@ __global__ void __launch_bounds__(256) k_scan_sums(uint32_t* bsum, const uint32_
             uint32_t t2;
             (void)block_excl_scan(acc2, t2, lds4);
             if (threadIdx.x == 0) totals[1] = t2;
+            if (minmax) {
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    kmin = min(kmin, (uint32_t)__shfl_down((int)kmin, d, 64));
+                    kmax = max(kmax, (uint32_t)__shfl_down((int)kmax, d, 64));
+                }
+                if ((threadIdx.x & 63) == 0) { mm[threadIdx.x >> 6] = kmin; mm[4 + (threadIdx.x >> 6)] = kmax; }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    totals[2] = min(min(mm[0], mm[1]), min(mm[2], mm[3]));
+                    totals[3] = max(max(mm[4], mm[5]), max(mm[6], mm[7]));
+                }
+            }
         }
     }
 }
@@ -158,7 +202,8 @@ static int run_scan(Src src, Sink sink, long n, uint32_t* bsum, uint32_t* bsum2,
     int nb = cdiv(n, SCAN_BLOCK);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_reduce<Src>), dim3(nb), dim3(256), 0, s, src, n, bsum, bsum2);
     VR_KERNEL_CHECK(what, s, debug);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, s, bsum, (const uint32_t*)bsum2, nb, totals);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, s, bsum, (const uint32_t*)bsum2, nb, totals,
+                       Src::MINMAX ? 1 : 0);
     VR_KERNEL_CHECK(what, s, debug);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<Src, Sink>), dim3(nb), dim3(256), 0, s, src, sink, n,
                        (const uint32_t*)bsum);
@@ -171,28 +216,29 @@ static int run_scan(Src src, Sink sink, long n, uint32_t* bsum, uint32_t* bsum2,
 size_t binning_stage1_scratch_bytes(int P)
 {
     size_t nb = (size_t)cdiv(P > 0 ? P : 1, SCAN_BLOCK);
-    return align_up(2 * nb * sizeof(uint32_t), 256);
+    return align_up(4 * nb * sizeof(uint32_t), 256);
 }
 
-int launch_compact_visible(int P, const uint32_t* tiles_touched, const uint32_t* depth_key, void* scratch,
+int launch_compact_visible(int P, const uint2* rect, const uint32_t* depth_key, void* scratch,
                            uint32_t* vis_key, uint32_t* vis_id, uint32_t* totals_dev, hipStream_t s, bool debug)
 {
     int nb = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
     uint32_t* bsum = (uint32_t*)scratch;
     uint32_t* bsum2 = bsum + nb;
-    SrcFlagTiles src{tiles_touched};
-    SinkCompact sink{tiles_touched, depth_key, vis_key, vis_id};
+    SrcFlagTiles src{rect, depth_key};
+    SinkCompact sink{depth_key, vis_key, vis_id};
     return run_scan(src, sink, P, bsum, bsum2, totals_dev, s, debug, "compact_visible");
 }
 
 // ---------------------------------------------------------------- radix sort pass (stable LSD)
 
-// lanes of the wave (restricted to `valid`) holding the same 8-bit digit as this lane
+// lanes of the wave (restricted to `valid`) holding the same BITS-bit digit as this lane
+template <int BITS>
 __device__ __forceinline__ unsigned long long match_digit(uint32_t d, unsigned long long valid)
 {
     unsigned long long m = valid;
 #pragma unroll
-    for (int b = 0; b < RADIX_BITS; ++b) {
+    for (int b = 0; b < BITS; ++b) {
         unsigned long long bal = __ballot((d >> b) & 1u);
         m &= ((d >> b) & 1u) ? bal : ~bal;
     }
@@ -204,12 +250,23 @@ __device__ __forceinline__ unsigned long long lanemask_lt()
     return (1ull << (threadIdx.x & 63)) - 1ull;
 }
 
-// hist layout: digit-major [RADIX_SIZE][nblk]
-__global__ void __launch_bounds__(256)
-k_radix_hist(const uint32_t* __restrict__ keys, long n, int shift, uint32_t* __restrict__ hist, int nblk)
+// digit of a key: keys are first shifted down by `kmin` (monotone), so only the bits that actually
+// vary across the input have to be sorted
+template <int BITS>
+__device__ __forceinline__ uint32_t digit_of(uint32_t key, uint32_t kmin, int shift)
 {
-    __shared__ uint32_t h[RADIX_SIZE];
-    h[threadIdx.x] = 0;
+    return ((key - kmin) >> shift) & ((1u << BITS) - 1u);
+}
+
+// hist layout: digit-major [1<<BITS][nblk]
+template <int BITS>
+__global__ void __launch_bounds__(256)
+k_radix_hist(const uint32_t* __restrict__ keys, long n, uint32_t kmin, int shift, uint32_t* __restrict__ hist,
+             int nblk)
+{
+    constexpr int SIZE = 1 << BITS;
+    __shared__ uint32_t h[SIZE];
+    for (int d = threadIdx.x; d < SIZE; d += 256) h[d] = 0;
     __syncthreads();
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     long wbase = (long)blockIdx.x * RADIX_BLOCK + (long)w * (64 * RADIX_ITEMS);
@@ -217,27 +274,29 @@ k_radix_hist(const uint32_t* __restrict__ keys, long n, int shift, uint32_t* __r
     for (int i = 0; i < RADIX_ITEMS; ++i) {
         long idx = wbase + i * 64 + lane;
         bool ok = idx < n;
-        uint32_t d = ok ? ((keys[idx] >> shift) & (RADIX_SIZE - 1)) : 0;
+        uint32_t d = ok ? digit_of<BITS>(keys[idx], kmin, shift) : 0;
         unsigned long long valid = __ballot(ok);
-        unsigned long long m = match_digit(d, valid);
+        unsigned long long m = match_digit<BITS>(d, valid);
         if (ok && (m & lanemask_lt()) == 0) atomicAdd(&h[d], (uint32_t)__popcll(m));
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+    for (int d = threadIdx.x; d < SIZE; d += 256) hist[(size_t)d * nblk + blockIdx.x] = h[d];
 }
 
-// IDENT: values are the element indices (first pass over freshly generated keys)
-template <bool IDENT>
+template <int BITS>
 __global__ void __launch_bounds__(256)
 k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, long n, int shift,
+                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, long n, uint32_t kmin, int shift,
                 const uint32_t* __restrict__ hist_scanned, int nblk)
 {
-    __shared__ uint32_t cnt[4][RADIX_SIZE];
-    __shared__ uint32_t off[4][RADIX_SIZE];
+    constexpr int SIZE = 1 << BITS;
+    __shared__ uint32_t cnt[4][SIZE];
+    __shared__ uint32_t off[4][SIZE];
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int d = threadIdx.x; d < SIZE; d += 256) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) cnt[k][threadIdx.x] = 0;
+        for (int k = 0; k < 4; ++k) cnt[k][d] = 0;
+    }
     __syncthreads();
     long wbase = (long)blockIdx.x * RADIX_BLOCK + (long)w * (64 * RADIX_ITEMS);
     uint32_t key[RADIX_ITEMS], rank[RADIX_ITEMS];
@@ -247,17 +306,16 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
         long idx = wbase + i * 64 + lane;
         bool ok = idx < n;
         key[i] = ok ? keys_in[idx] : 0xFFFFFFFFu;
-        uint32_t d = (key[i] >> shift) & (RADIX_SIZE - 1);
+        uint32_t d = digit_of<BITS>(key[i], kmin, shift);
         unsigned long long valid = __ballot(ok);
-        unsigned long long m = match_digit(d, valid);
+        unsigned long long m = match_digit<BITS>(d, valid);
         uint32_t prior = ok ? cnt[w][d] : 0;
         rank[i] = prior + (uint32_t)__popcll(m & lt);
         if (ok && (m & lt) == 0) cnt[w][d] = prior + (uint32_t)__popcll(m);
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    {
-        int d = threadIdx.x;
+    for (int d = threadIdx.x; d < SIZE; d += 256) {
         uint32_t g = hist_scanned[(size_t)d * nblk + blockIdx.x];
         uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d];
         off[0][d] = g;
@@ -270,38 +328,87 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
     for (int i = 0; i < RADIX_ITEMS; ++i) {
         long idx = wbase + i * 64 + lane;
         if (idx < n) {
-            uint32_t d = (key[i] >> shift) & (RADIX_SIZE - 1);
+            uint32_t d = digit_of<BITS>(key[i], kmin, shift);
             uint32_t dst = off[w][d] + rank[i];
             keys_out[dst] = key[i];
-            vals_out[dst] = IDENT ? (uint32_t)idx : vals_in[idx];
+            vals_out[dst] = vals_in[idx];
         }
     }
 }
 
-static int radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, long n, int shift,
-                      uint32_t* hist, uint32_t* bsum, hipStream_t s, bool debug)
+template <int BITS>
+static int radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, long n, uint32_t kmin,
+                      int shift, uint32_t* hist, uint32_t* bsum, hipStream_t s, bool debug)
 {
     int nblk = cdiv(n, RADIX_BLOCK);
-    hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(256), 0, s, kin, n, shift, hist, nblk);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<BITS>), dim3(nblk), dim3(256), 0, s, kin, n, kmin, shift, hist,
+                       nblk);
     VR_KERNEL_CHECK("radix_hist", s, debug);
-    long hn = (long)RADIX_SIZE * nblk;
+    long hn = (long)(1 << BITS) * nblk;
     int rc = run_scan(SrcPlain{hist}, SinkStore{hist}, hn, bsum, (uint32_t*)nullptr, (uint32_t*)nullptr, s, debug,
                       "radix_scan");
     if (rc) return rc;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<false>), dim3(nblk), dim3(256), 0, s, kin, vin, kout, vout,
-                       n, shift, (const uint32_t*)hist, nblk);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<BITS>), dim3(nblk), dim3(256), 0, s, kin, vin, kout, vout, n,
+                       kmin, shift, (const uint32_t*)hist, nblk);
     VR_KERNEL_CHECK("radix_scatter", s, debug);
     return 0;
+}
+
+// digit width for sorting `nbits` key bits: fewest passes first, then the narrowest digit (cheaper ranking)
+static int radix_digit(int nbits)
+{
+    if (nbits <= 12) return 6;   // 1-2 passes
+    if (nbits <= 16) return 8;   // 2
+    if (nbits <= 18) return 9;   // 2
+    if (nbits <= 24) return 8;   // 3
+    if (nbits <= 27) return 9;   // 3
+    return 8;                    // 4
+}
+
+// Stable LSD sort of (key, val) pairs on the low `nbits` bits of (key - kmin).  Ping-pongs between
+// (k0,v0) and (k1,v1); returns in *res which pair holds the result (0 or 1).  Digit width is chosen
+// per call: few wide passes for many bits, narrow digits (cheaper ballot ranking) for few bits.
+static int radix_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long n, uint32_t kmin, int nbits,
+                      uint32_t* hist, uint32_t* bsum, hipStream_t s, bool debug, int* res)
+{
+    const int digit = radix_digit(nbits);
+    const int passes = nbits <= 0 ? 0 : cdiv(nbits, digit);
+    uint32_t *ka = k0, *va = v0, *kb = k1, *vb = v1;
+    int where = 0;
+    for (int pass = 0; pass < passes; ++pass) {
+        int rc;
+        if (digit == 6) rc = radix_pass<6>(ka, va, kb, vb, n, kmin, pass * digit, hist, bsum, s, debug);
+        else if (digit == 9) rc = radix_pass<9>(ka, va, kb, vb, n, kmin, pass * digit, hist, bsum, s, debug);
+        else rc = radix_pass<8>(ka, va, kb, vb, n, kmin, pass * digit, hist, bsum, s, debug);
+        if (rc) return rc;
+        uint32_t* t = ka; ka = kb; kb = t;
+        t = va; va = vb; vb = t;
+        where ^= 1;
+    }
+    *res = where;
+    return 0;
+}
+int radix_sort_passes(int nbits)
+{
+    return nbits <= 0 ? 0 : cdiv(nbits, radix_digit(nbits));
 }
 
 // ---------------------------------------------------------------- emission + ranges
 
 // One block per 256 depth-sorted Gaussians; lanes are spread over OUTPUT entries (binary search in
 // the block's LDS prefix), so long rectangles do not serialise a lane and writes are coalesced.
+// the only gather of the binning stage: rectangles of the depth-sorted Gaussians (8 B each)
 __global__ void __launch_bounds__(256)
-k_emit(int V, int gx, int gy, const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ offs,
-       const uint32_t* __restrict__ tiles_touched, const Splat* __restrict__ rec, const int* __restrict__ radii,
-       uint32_t* __restrict__ tkeys, uint32_t* __restrict__ tvals)
+k_gather_rect(int V, const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ rect,
+              uint2* __restrict__ rect_sorted)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < V) rect_sorted[r] = rect[sorted_id[r]];
+}
+
+__global__ void __launch_bounds__(256)
+k_emit(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ offs,
+       const uint2* __restrict__ rect_sorted, uint32_t* __restrict__ tkeys, uint32_t* __restrict__ tvals)
 {
     __shared__ uint32_t l_off[257];
     __shared__ uint32_t l_id[256];
@@ -309,15 +416,13 @@ k_emit(int V, int gx, int gy, const uint32_t* __restrict__ sorted_id, const uint
     int r = blockIdx.x * 256 + threadIdx.x;
     uint32_t myoff = 0, cnt = 0;
     if (r < V) {
-        uint32_t id = sorted_id[r];
+        const uint2 rc = rect_sorted[r];
         myoff = offs[r];
-        cnt = tiles_touched[id];
-        int x0, y0, x1, y1;
-        tile_rect(rec[id].x, rec[id].y, radii[id], gx, gy, x0, y0, x1, y1);
-        l_id[threadIdx.x] = id;
-        l_x0[threadIdx.x] = x0;
-        l_y0[threadIdx.x] = y0;
-        l_w[threadIdx.x] = x1 - x0;
+        cnt = rect_area(rc);
+        l_id[threadIdx.x] = sorted_id[r];
+        l_x0[threadIdx.x] = (int)(rc.x & 0xFFFFu);
+        l_y0[threadIdx.x] = (int)(rc.x >> 16);
+        l_w[threadIdx.x] = (int)(rc.y & 0xFFFFu);
     }
     int last = min(V - blockIdx.x * 256, 256) - 1;  // last valid thread of this block
     l_off[threadIdx.x] = myoff;
@@ -357,7 +462,7 @@ k_tile_ranges(const uint32_t* __restrict__ tkeys, long R, int2* __restrict__ ran
 // ---------------------------------------------------------------- stage 2 driver
 
 struct Stage2Layout {
-    size_t tmp_key, tmp_id, offs, tkeysA, tkeysB, tvalsB, hist, bsum, total;
+    size_t tmp_key, tmp_id, offs, rect_sorted, tkeysA, tkeysB, tvalsB, hist, bsum, total;
 };
 
 static Stage2Layout stage2_layout(int V, long R)
@@ -369,13 +474,14 @@ static Stage2Layout stage2_layout(int V, long R)
     L.tmp_key = take(v * 4);
     L.tmp_id = take(v * 4);
     L.offs = take(v * 4);
+    L.rect_sorted = take(v * 8);
     L.tkeysA = take(r * 4);
     L.tkeysB = take(r * 4);
     L.tvalsB = take(r * 4);
     size_t nmax = r > v ? r : v;
     size_t nblk = (size_t)cdiv((long)nmax, RADIX_BLOCK);
-    L.hist = take(nblk * RADIX_SIZE * 4);
-    size_t scan_n = nblk * RADIX_SIZE > nmax ? nblk * RADIX_SIZE : nmax;
+    L.hist = take(nblk * 512 * 4);
+    size_t scan_n = nblk * 512 > nmax ? nblk * 512 : nmax;
     L.bsum = take((size_t)cdiv((long)scan_n, SCAN_BLOCK) * 4 + 256);
     L.total = o;
     return L;
@@ -383,9 +489,8 @@ static Stage2Layout stage2_layout(int V, long R)
 
 size_t binning_stage2_scratch_bytes(int V, long R, int) { return stage2_layout(V, R).total; }
 
-int launch_binning(const Camera& cam, int V, long R, uint32_t* vis_key, uint32_t* vis_id, const Splat* rec,
-                   const int* radii, const uint32_t* tiles_touched, void* scratch, uint32_t* point_list,
-                   int2* ranges, hipStream_t s, bool debug)
+int launch_binning(const Camera& cam, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
+                   uint32_t* vis_id, const uint2* rect, void* scratch, uint32_t* point_list, int2* ranges, hipStream_t s, bool debug)
 {
     int ntiles = cam.gx * cam.gy;
     VR_HIP(hipMemsetAsync(ranges, 0, sizeof(int2) * (size_t)ntiles, s));
@@ -395,48 +500,50 @@ int launch_binning(const Camera& cam, int V, long R, uint32_t* vis_key, uint32_t
     uint32_t* tmp_key = (uint32_t*)(base + L.tmp_key);
     uint32_t* tmp_id = (uint32_t*)(base + L.tmp_id);
     uint32_t* offs = (uint32_t*)(base + L.offs);
+    uint2* rect_sorted = (uint2*)(base + L.rect_sorted);
     uint32_t* tkeysA = (uint32_t*)(base + L.tkeysA);
     uint32_t* tkeysB = (uint32_t*)(base + L.tkeysB);
     uint32_t* tvalsB = (uint32_t*)(base + L.tvalsB);
     uint32_t* hist = (uint32_t*)(base + L.hist);
     uint32_t* bsum = (uint32_t*)(base + L.bsum);
 
-    // 2. depth sort of the visible Gaussians (ping-pong; 4 passes end in vis_key/vis_id)
+    // 2. depth sort of the visible Gaussians on the bits of (key - kmin) that vary
+    uint32_t* sorted_id = vis_id;
     {
         ProfScope ps(VR_STAGE_DEPTH_SORT, s);
-        uint32_t *ka = vis_key, *va = vis_id, *kb = tmp_key, *vb = tmp_id;
-        for (int pass = 0; pass < 4; ++pass) {
-            int rc = radix_pass(ka, va, kb, vb, V, pass * RADIX_BITS, hist, bsum, s, debug);
-            if (rc) return rc;
-            uint32_t* t = ka; ka = kb; kb = t;
-            t = va; va = vb; vb = t;
-        }
+        int where = 0;
+        int rc = radix_sort(vis_key, vis_id, tmp_key, tmp_id, V, key_min, key_bits, hist, bsum, s, debug, &where);
+        if (rc) return rc;
+        sorted_id = where ? tmp_id : vis_id;
     }
     // 3. offsets in depth order, then emission
     prof_begin(VR_STAGE_EMIT, s);
     {
-        int rc = run_scan(SrcGather{tiles_touched, vis_id}, SinkStore{offs}, V, bsum, (uint32_t*)nullptr,
+        hipLaunchKernelGGL(k_gather_rect, dim3(cdiv(V, 256)), dim3(256), 0, s, V, (const uint32_t*)sorted_id, rect,
+                           rect_sorted);
+        VR_KERNEL_CHECK("gather_rect", s, debug);
+        int rc = run_scan(SrcRectSorted{rect_sorted}, SinkStore{offs}, V, bsum, (uint32_t*)nullptr,
                           (uint32_t*)nullptr, s, debug, "offset_scan");
         if (rc) return rc;
     }
     int bits = 0;
     while ((1 << bits) < ntiles) ++bits;
-    int passes = bits == 0 ? 0 : cdiv(bits, RADIX_BITS);
+    const int passes = radix_sort_passes(bits);
     // choose the starting value buffer so that the last pass lands in point_list
     uint32_t* va = (passes % 2 == 0) ? point_list : tvalsB;
     uint32_t* vb = (passes % 2 == 0) ? tvalsB : point_list;
     uint32_t *ka = tkeysA, *kb = tkeysB;
-    hipLaunchKernelGGL(k_emit, dim3(cdiv(V, 256)), dim3(256), 0, s, V, cam.gx, cam.gy, (const uint32_t*)vis_id,
-                       (const uint32_t*)offs, tiles_touched, rec, radii, ka, va);
+    hipLaunchKernelGGL(k_emit, dim3(cdiv(V, 256)), dim3(256), 0, s, V, cam.gx, (const uint32_t*)sorted_id,
+                       (const uint32_t*)offs, (const uint2*)rect_sorted, ka, va);
     VR_KERNEL_CHECK("emit", s, debug);
     prof_end(VR_STAGE_EMIT, s);
     // 4. stable sort by tile id
     prof_begin(VR_STAGE_TILE_SORT, s);
-    for (int pass = 0; pass < passes; ++pass) {
-        int rc = radix_pass(ka, va, kb, vb, R, pass * RADIX_BITS, hist, bsum, s, debug);
+    {
+        int where = 0;
+        int rc = radix_sort(ka, va, kb, vb, R, 0u, bits, hist, bsum, s, debug, &where);
         if (rc) return rc;
-        uint32_t* t = ka; ka = kb; kb = t;
-        t = va; va = vb; vb = t;
+        if (where) { uint32_t* t = ka; ka = kb; kb = t; }
     }
     prof_end(VR_STAGE_TILE_SORT, s);
     // 5. ranges

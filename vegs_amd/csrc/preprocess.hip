@@ -34,7 +34,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
              const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
              const float* __restrict__ scales, const float* __restrict__ rotations,
              const float* __restrict__ cov3D_precomp, Splat* __restrict__ rec, int* __restrict__ radii,
-             uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key)
+             uint2* __restrict__ rect, uint32_t* __restrict__ depth_key)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4][64 * SH_ROW_MAX];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -42,7 +42,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
     const bool in_range = i < P;
     // culled unless proven visible
     bool vis = false;
-    int rad = 0, ntiles = 0;
+    int rad = 0, ntiles = 0, rx0 = 0, ry0 = 0, rw = 0, rh = 0;
     float px = 0.f, py = 0.f, t2 = 0.f, conA = 0.f, conB = 0.f, conC = 0.f, cova = 0.f, covc = 0.f;
     float q[4] = {0.f, 0.f, 0.f, 0.f}, sc[3] = {0.f, 0.f, 0.f};
     float px3 = 0.f, py3 = 0.f, pz3 = 0.f;
@@ -83,6 +83,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
                 int x0, y0, x1, y1;
                 tile_rect(px, py, rad, cam.gx, cam.gy, x0, y0, x1, y1);
                 ntiles = (x1 - x0) * (y1 - y0);
+                rx0 = x0; ry0 = y0; rw = x1 - x0; rh = y1 - y0;
                 vis = ntiles != 0;
                 conA = cv.c * det_inv;
                 conB = -cv.b * det_inv;
@@ -149,7 +150,9 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
     }
     if (in_range) {
         radii[i] = vis ? rad : 0;
-        tiles_touched[i] = vis ? (uint32_t)ntiles : 0u;
+        // tile rectangle (x0, y0 | width, height), 16 bit each; width*height = tiles touched (0 when culled)
+        rect[i] = vis ? make_uint2((uint32_t)rx0 | ((uint32_t)ry0 << 16), (uint32_t)rw | ((uint32_t)rh << 16))
+                      : make_uint2(0u, 0u);
         depth_key[i] = vis ? __float_as_uint(t2) : 0u;
     }
 }
@@ -166,12 +169,12 @@ k_mark_visible(const float* __restrict__ xyz, int P, const float* __restrict__ v
 
 int launch_preprocess(const Camera& cam, int P, const float* means3D, const float* shs, const float* colors_precomp,
                       const float* opacities, const float* scales, const float* rotations,
-                      const float* cov3D_precomp, Splat* rec, int* radii, uint32_t* tiles_touched,
+                      const float* cov3D_precomp, Splat* rec, int* radii, uint2* rect,
                       uint32_t* depth_key, hipStream_t s, bool debug)
 {
     if (P == 0) return 0;
     hipLaunchKernelGGL(k_preprocess, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, means3D, shs, colors_precomp,
-                       opacities, scales, rotations, cov3D_precomp, rec, radii, tiles_touched, depth_key);
+                       opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key);
     VR_KERNEL_CHECK("preprocess", s, debug);
     return 0;
 }

@@ -45,7 +45,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // ---- preprocess.hip
 int launch_preprocess(const Camera& cam, int P, const float* means3D, const float* shs, const float* colors_precomp,
                       const float* opacities, const float* scales, const float* rotations,
-                      const float* cov3D_precomp, Splat* rec, int* radii, uint32_t* tiles_touched,
+                      const float* cov3D_precomp, Splat* rec, int* radii, uint2* rect,
                       uint32_t* depth_key, hipStream_t s, bool debug);
 int launch_mark_visible(const float* xyz, int P, const float* view, uint8_t* present, hipStream_t s);
 
@@ -56,13 +56,12 @@ struct BinningPlan {
 };
 // stage 1 (P-sized): compaction of visible Gaussians in id order + totals.  totals_dev[0]=V, [1]=R.
 size_t binning_stage1_scratch_bytes(int P);
-int launch_compact_visible(int P, const uint32_t* tiles_touched, const uint32_t* depth_key, void* scratch,
+int launch_compact_visible(int P, const uint2* rect, const uint32_t* depth_key, void* scratch,
                            uint32_t* vis_key, uint32_t* vis_id, uint32_t* totals_dev, hipStream_t s, bool debug);
 // stage 2 (V- and R-sized): depth sort, emission, tile sort, ranges.
 size_t binning_stage2_scratch_bytes(int V, long R, int ntiles);
-int launch_binning(const Camera& cam, int V, long R, uint32_t* vis_key, uint32_t* vis_id, const Splat* rec,
-                   const int* radii, const uint32_t* tiles_touched, void* scratch, uint32_t* point_list,
-                   int2* ranges, hipStream_t s, bool debug);
+int launch_binning(const Camera& cam, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
+                   uint32_t* vis_id, const uint2* rect, void* scratch, uint32_t* point_list, int2* ranges, hipStream_t s, bool debug);
 
 // ---- render_fwd.hip / render_bwd.hip (segmented compositing)
 // upper bound on the number of 256-entry segments: sum_t ceil(n_t/256) <= R/256 + T

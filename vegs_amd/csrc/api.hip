@@ -140,7 +140,7 @@ static ImageLayout image_layout(size_t N)
 }
 // binning buffer: tile ranges | segment table | point list | boundary transmittances per (segment, pixel) |
 // segment-local channel sums per (segment, channel, pixel) -- the backward derives its w*u sums from them
-struct BinLayout { size_t ranges, seg_off, seg_needed, point_list, tbuf, part, total; };
+struct BinLayout { size_t ranges, seg_off, seg_needed, point_list, tbuf, part, segmask, total; };
 static BinLayout bin_layout(size_t T, size_t R)
 {
     BinLayout L;
@@ -150,7 +150,8 @@ static BinLayout bin_layout(size_t T, size_t R)
     L.point_list = L.seg_needed + align_up(T * 4, 256);
     L.tbuf = L.point_list + align_up((R > 0 ? R : 1) * 4, 256);
     L.part = L.tbuf + align_up(seg_capacity((long)R, (int)T) * 256 * sizeof(float), 256);
-    L.total = L.part + align_up(seg_capacity((long)R, (int)T) * 13 * 256 * sizeof(float), 256);
+    L.segmask = L.part + align_up(seg_capacity((long)R, (int)T) * 13 * 256 * sizeof(float), 256);
+    L.total = L.segmask + align_up(seg_capacity((long)R, (int)T) * 16 * sizeof(unsigned long long), 256);
     return L;
 }
 
@@ -245,7 +246,8 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     prof_begin(VR_STAGE_RENDER_FWD, s);
     rc = launch_render_fwd(cam, (long)R, ranges, point_list, rec, (uint32_t*)((char*)binning + BL.seg_off),
                            (uint32_t*)((char*)binning + BL.seg_needed), (float*)((char*)binning + BL.tbuf),
-                           (float*)((char*)binning + BL.part), scr3,
+                           (float*)((char*)binning + BL.part),
+                           (unsigned long long*)((char*)binning + BL.segmask), scr3,
                            out->color, out->depth, out->cov_quat, out->cov_scale, out->alpha, final_T, n_contrib, s,
                            debug);
     prof_end(VR_STAGE_RENDER_FWD, s);
@@ -310,7 +312,9 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
                                (const uint32_t*)((const char*)saved->binning + BL.seg_off),
                                (const uint32_t*)((const char*)saved->binning + BL.seg_needed),
                                (const float*)((const char*)saved->binning + BL.tbuf),
-                               (const float*)((const char*)saved->binning + BL.part), scr, final_T, n_contrib,
+                               (const float*)((const char*)saved->binning + BL.part),
+                               (const unsigned long long*)((const char*)saved->binning + BL.segmask), scr, final_T,
+                               n_contrib,
                                gout->dL_dcolor, gout->dL_ddepth, gout->dL_dcov_quat, gout->dL_dcov_scale,
                                gout->dL_dalpha, gacc, gin->dL_dmeans2D, s, debug);
         if (rc) return rc;

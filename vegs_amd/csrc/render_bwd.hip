@@ -146,52 +146,35 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
           const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
           const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dquat,
           const float* __restrict__ dL_dscale, const float* __restrict__ dL_dalpha, float* __restrict__ gacc,
-          float* __restrict__ gmean2D)
+          float* __restrict__ gmean2D, const unsigned long long* __restrict__ segmask)
 {
     __shared__ float gsum[SEG * NACC];            // per-entry gradient sums of this (tile, segment)
     __shared__ uint32_t ids[SEG];                 // Gaussian id of every entry
     __shared__ unsigned short ridx[4][SEG];       // per strip: the relevant entries, ascending
-    __shared__ unsigned long long masks[4][4];
     SegCtx c;
     if (!seg_setup(cam, ranges, seg_off, c)) return;
     const int needed = (int)seg_needed[c.tile];
     if (c.sl >= needed) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 
-    // ---- entry j of the segment: id, strip relevance, compacted per-strip lists
-    bool rel[4] = {false, false, false, false};
+    // ---- entry j of the segment: id; per-strip lists of the relevant entries (masks from the forward)
+    const unsigned long long* masks = segmask + (size_t)blockIdx.x * 16;
     {
         const bool have = (int)threadIdx.x < c.count;
-        float sx = 0.f, sy = 0.f;
-        uint32_t ext = 0, id = 0xFFFFFFFFu;
-        if (have) {
-            id = point_list[c.first + threadIdx.x];
-            const Splat* sp = rec + id;
-            sx = sp->x; sy = sp->y; ext = sp->ext;
-        }
-        ids[threadIdx.x] = id;
-        float hx, hy;
-        splat_extent_unpack(ext, hx, hy);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            rel[s] = have && strip_relevant(sx, sy, hx, hy, c.x0, c.y0, s);
-            const unsigned long long m = __ballot(rel[s]);
-            if (lane == 0) masks[s][w] = m;
-        }
+        ids[threadIdx.x] = have ? point_list[c.first + threadIdx.x] : 0xFFFFFFFFu;
         for (int v = threadIdx.x; v < SEG * NACC; v += 256) gsum[v] = 0.0f;
-    }
-    __syncthreads();
-    {
         const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             int before = 0;
-            for (int q = 0; q < w; ++q) before += __popcll(masks[s][q]);
-            if (rel[s]) ridx[s][before + __popcll(masks[s][w] & lt)] = (unsigned short)threadIdx.x;
+            for (int q = 0; q < w; ++q) before += __popcll(masks[s * 4 + q]);
+            const unsigned long long mine = masks[s * 4 + w];
+            if ((mine >> lane) & 1ull) ridx[s][before + __popcll(mine & lt)] = (unsigned short)threadIdx.x;
         }
     }
     __syncthreads();
-    const int nrel = __popcll(masks[w][0]) + __popcll(masks[w][1]) + __popcll(masks[w][2]) + __popcll(masks[w][3]);
+    const int nrel = __popcll(masks[w * 4]) + __popcll(masks[w * 4 + 1]) + __popcll(masks[w * 4 + 2]) +
+                     __popcll(masks[w * 4 + 3]);
 
     // ---- pixel state, lane = pixel of this wave's 16x4 strip
     const size_t N = (size_t)cam.H * cam.W;
@@ -316,7 +299,7 @@ size_t render_bwd_scratch_bytes(long R, int ntiles)
 
 int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint32_t* point_list, const Splat* rec,
                       const uint32_t* seg_off, const uint32_t* seg_needed, const float* Tbuf, const float* part,
-                      void* scratch, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
+                      const unsigned long long* segmask, void* scratch, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                       const float* dL_ddepth, const float* dL_dquat, const float* dL_dscale,
                       const float* dL_dalpha, float* gacc, float* gmean2D, hipStream_t s, bool debug)
 {
@@ -329,7 +312,7 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
     VR_KERNEL_CHECK("seg_usuffix", s, debug);
     hipLaunchKernelGGL(k_seg_bwd, dim3(nseg), dim3(256), 0, s, cam, ranges, seg_off, seg_needed, point_list, rec, Tbuf,
                        (const float*)Ubuf, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, dL_dalpha,
-                       gacc, gmean2D);
+                       gacc, gmean2D, segmask);
     VR_KERNEL_CHECK("seg_bwd", s, debug);
     return 0;
 }

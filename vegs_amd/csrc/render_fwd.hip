@@ -62,32 +62,32 @@ k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict_
 // ---- A: per (tile, segment, pixel) product of (1 - alpha)
 __global__ void __launch_bounds__(256)
 k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
-            const uint32_t* __restrict__ point_list, const Splat* __restrict__ rec, float* __restrict__ Pbuf)
+            const uint32_t* __restrict__ point_list, const Splat* __restrict__ rec, float* __restrict__ Pbuf,
+            unsigned long long* __restrict__ segmask)
 {
     __shared__ float4 lds[2][SEG];
-    __shared__ unsigned long long masks[4][4];
+    __shared__ unsigned long long masks[16];
     SegCtx c;
     if (!seg_setup(cam, ranges, seg_off, c)) return;
     {
         const bool have = (int)threadIdx.x < c.count;
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        uint32_t ext = 0;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
         if (have) {
-            const Splat* sp = rec + point_list[c.first + threadIdx.x];
-            const float4* src = reinterpret_cast<const float4*>(sp);
+            const float4* src = reinterpret_cast<const float4*>(rec + point_list[c.first + threadIdx.x]);
             q0 = src[0];
+            q1 = src[1];
             lds[0][threadIdx.x] = q0;
-            lds[1][threadIdx.x] = src[1];
-            ext = sp->ext;
+            lds[1][threadIdx.x] = q1;
         }
-        seg_build_masks(c, have, q0.x, q0.y, ext, masks);
+        seg_build_masks(c, have, q0, q1, masks);
     }
     __syncthreads();
+    if (threadIdx.x < 16) segmask[(size_t)blockIdx.x * 16 + threadIdx.x] = masks[threadIdx.x];
     const int w = threadIdx.x >> 6;
     const float pxf = (float)c.px, pyf = (float)c.py;
     float p = 1.0f;
     for (int part = 0; part < 4; ++part) {
-        for (unsigned long long m = uniform64(masks[w][part]); m; m &= m - 1) {
+        for (unsigned long long m = uniform64(masks[w * 4 + part]); m; m &= m - 1) {
             const int k = part * 64 + __builtin_ctzll(m);
             const float4 a = lds[0][k];  // x y A B
             const float4 b = lds[1][k];  // C opacity thr depth
@@ -153,30 +153,23 @@ constexpr int NPART = 13;
 __global__ void __launch_bounds__(256)
 k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
             const uint32_t* __restrict__ seg_needed, const uint32_t* __restrict__ point_list,
-            const Splat* __restrict__ rec, const float* __restrict__ Tbuf, float* __restrict__ part)
+            const Splat* __restrict__ rec, const float* __restrict__ Tbuf, float* __restrict__ part,
+            const unsigned long long* __restrict__ segmask)
 {
     __shared__ float4 lds[5][SEG];
-    __shared__ unsigned long long masks[4][4];
     SegCtx c;
     if (!seg_setup(cam, ranges, seg_off, c)) return;
     if ((uint32_t)c.sl >= seg_needed[c.tile]) return;
     {
         const bool have = (int)threadIdx.x < c.count;
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        uint32_t ext = 0;
         if (have) {
             const float4* src = reinterpret_cast<const float4*>(rec + point_list[c.first + threadIdx.x]);
-            q0 = src[0];
-            const float4 q4 = src[4];
-            lds[0][threadIdx.x] = q0;
 #pragma unroll
-            for (int k = 1; k < 4; ++k) lds[k][threadIdx.x] = src[k];
-            lds[4][threadIdx.x] = q4;
-            ext = __float_as_uint(q4.w);
+            for (int k = 0; k < 5; ++k) lds[k][threadIdx.x] = src[k];
         }
-        seg_build_masks(c, have, q0.x, q0.y, ext, masks);
     }
     __syncthreads();
+    const unsigned long long* masks = segmask + (size_t)blockIdx.x * 16;
     const int w = threadIdx.x >> 6;
     const float pxf = (float)c.px, pyf = (float)c.py;
     const float Tb = Tbuf[(size_t)blockIdx.x * SEG + threadIdx.x];
@@ -191,7 +184,7 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     // Branch-free per lane (predicated); only wave-uniform branches: skip the exp when no pixel of the
     // strip can reach alpha >= 1/255, skip the channel update when no pixel applies the splat.
     for (int part_i = 0; part_i < 4; ++part_i) {
-        for (unsigned long long m = uniform64(masks[w][part_i]); m; m &= m - 1) {
+        for (unsigned long long m = uniform64(masks[w * 4 + part_i]); m; m &= m - 1) {
             const int k = part_i * 64 + __builtin_ctzll(m);
             const float4 a = lds[0][k];  // x y A B
             const float4 b = lds[1][k];  // C opacity thr depth
@@ -313,7 +306,8 @@ size_t render_fwd_scratch_bytes(long R, int ntiles)
 }
 
 int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint32_t* point_list, const Splat* rec,
-                      uint32_t* seg_off, uint32_t* seg_needed, float* Tbuf, float* part, void* scratch, float* out_color,
+                      uint32_t* seg_off, uint32_t* seg_needed, float* Tbuf, float* part, unsigned long long* segmask,
+                      void* scratch, float* out_color,
                       float* out_depth, float* out_quat, float* out_scale, float* out_alpha, float* final_T,
                       uint32_t* n_contrib, hipStream_t s, bool debug)
 {
@@ -325,7 +319,7 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     VR_KERNEL_CHECK("seg_offsets", s, debug);
     if (R > 0) {
         hipLaunchKernelGGL(k_seg_alpha, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
-                           point_list, rec, Pbuf);
+                           point_list, rec, Pbuf, segmask);
         VR_KERNEL_CHECK("seg_alpha", s, debug);
     }
     hipLaunchKernelGGL(k_seg_scan, dim3(ntiles), dim3(256), 0, s, cam, (const uint32_t*)seg_off, (const float*)Pbuf,
@@ -333,7 +327,8 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     VR_KERNEL_CHECK("seg_scan", s, debug);
     if (R > 0) {
         hipLaunchKernelGGL(k_seg_blend, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
-                           (const uint32_t*)seg_needed, point_list, rec, (const float*)Tbuf, part);
+                           (const uint32_t*)seg_needed, point_list, rec, (const float*)Tbuf, part,
+                           (const unsigned long long*)segmask);
         VR_KERNEL_CHECK("seg_blend", s, debug);
     }
     hipLaunchKernelGGL(k_seg_combine, dim3(ntiles), dim3(256), 0, s, cam, (const uint32_t*)seg_off,

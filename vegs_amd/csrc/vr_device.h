@@ -120,6 +120,42 @@ __device__ __forceinline__ bool strip_relevant(float sx, float sy, float hx, flo
     return (sx + hx >= x0) && (sx - hx <= x0 + 15.0f) && (sy + hy >= ys) && (sy - hy <= ys + 3.0f);
 }
 
+// Exact (up to a safety margin) version: does the footprint ellipse  A dx^2 + 2B dx dy + C dy^2 <= k,
+// k = -2 thr, intersect the strip's rectangle of pixel centres?  Minimum of the convex quadratic over
+// the rectangle: 0 if the centre is inside, otherwise on one of the four edges (1-D clamped minimum).
+// Thin diagonal splats (VEGS discs seen edge-on) have a bounding box several times their footprint.
+__device__ __forceinline__ float quad_edge_min(float a, float inv_a, float b, float c, float fixed, float lo, float hi)
+{
+    // min over t in [lo,hi] of  a t^2 + 2 b t fixed + c fixed^2   (inv_a ~ 1/a: an inexact minimiser only
+    // raises the value by a*delta^2, far below the safety margin of the caller)
+    const float t = fminf(hi, fmaxf(lo, -b * fixed * inv_a));
+    return fmaf(fmaf(a, t, 2.0f * b * fixed), t, c * fixed * fixed);
+}
+// relevance of one splat for the four 16x4 strips of a tile (bit s of the result = strip s)
+__device__ __forceinline__ uint32_t strips_relevant_exact(float sx, float sy, float A, float B, float C, float thr,
+                                                          float x0, float y0)
+{
+    const float k = -2.0f * thr;
+    if (!(k > 0.0f)) return 0u;
+    const float lim = k * 1.001f + 0.001f;
+    const float inv_A = __builtin_amdgcn_rcpf(A), inv_C = __builtin_amdgcn_rcpf(C);
+    const float xl = x0 - sx, xh = x0 + 15.0f - sx;
+    const bool x_in = xl <= 0.0f && xh >= 0.0f;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float yl = y0 + 4.0f * (float)s - sy, yh = yl + 3.0f;
+        bool rel = x_in && yl <= 0.0f && yh >= 0.0f;
+        float q = quad_edge_min(A, inv_A, B, C, yl, xl, xh);
+        q = fminf(q, quad_edge_min(A, inv_A, B, C, yh, xl, xh));
+        q = fminf(q, quad_edge_min(C, inv_C, B, A, xl, yl, yh));
+        q = fminf(q, quad_edge_min(C, inv_C, B, A, xh, yl, yh));
+        rel = rel || q <= lim;
+        bits |= rel ? (1u << s) : 0u;
+    }
+    return bits;
+}
+
 // Gaussian exponent at a pixel; identical expression in forward and backward.
 __device__ __forceinline__ float splat_power(float sx, float sy, float A, float B, float C, float pxf, float pyf,
                                              float& dx, float& dy)

@@ -68,7 +68,8 @@ int launch_binning(const Camera& cam, int V, long R, uint32_t key_min, int key_b
 static inline size_t seg_capacity(long R, int ntiles) { return (size_t)(R / 256 + ntiles); }
 size_t render_fwd_scratch_bytes(long R, int ntiles);
 int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint32_t* point_list, const Splat* rec,
-                      uint32_t* seg_off, uint32_t* seg_needed, float* Tbuf, float* part, void* scratch, float* out_color,
+                      uint32_t* seg_off, uint32_t* seg_needed, float* Tbuf, float* part, unsigned long long* segmask,
+                      void* scratch, float* out_color,
                       float* out_depth, float* out_quat, float* out_scale, float* out_alpha, float* final_T,
                       uint32_t* n_contrib, hipStream_t s, bool debug);
 int launch_count_fragments(const uint32_t* n_contrib, long N, unsigned long long* out_dev, hipStream_t s);
@@ -77,7 +78,7 @@ int launch_count_fragments(const uint32_t* n_contrib, long N, unsigned long long
 size_t render_bwd_scratch_bytes(long R, int ntiles);
 int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint32_t* point_list, const Splat* rec,
                       const uint32_t* seg_off, const uint32_t* seg_needed, const float* Tbuf, const float* part,
-                      void* scratch, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
+                      const unsigned long long* segmask, void* scratch, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                       const float* dL_ddepth, const float* dL_dquat, const float* dL_dscale,
                       const float* dL_dalpha, float* gacc, float* gmean2D, hipStream_t s, bool debug);
 

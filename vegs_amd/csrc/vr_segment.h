@@ -52,19 +52,19 @@ __device__ __forceinline__ bool seg_setup(const Camera& cam, const int2* __restr
     return true;
 }
 
-// Relevance masks of the segment's entries: masks[strip][part] bit j set <=> entry part*64+j can reach
-// alpha >= 1/255 somewhere in that 16x4 strip (conservative bounding-box test on the record's extent).
-// Thread j tests entry j; the caller must __syncthreads() before reading the masks.
-__device__ __forceinline__ void seg_build_masks(const SegCtx& c, bool have, float sx, float sy, uint32_t ext,
-                                                unsigned long long (*masks)[4])
+// Relevance masks of the segment's entries: mask[strip*4 + part] bit j set <=> entry part*64+j can reach
+// alpha >= 1/255 somewhere in that 16x4 strip (conservative ellipse-vs-rectangle test).  Built once per
+// segment by k_seg_alpha (thread j tests entry j; q0 = x y A B, q1 = C opacity thr depth), kept in the
+// binning buffer (16 x u64 per segment) and reused by the blend and backward kernels.
+__device__ __forceinline__ void seg_build_masks(const SegCtx& c, bool have, float4 q0, float4 q1,
+                                                unsigned long long* __restrict__ gmask)
 {
-    float hx, hy;
-    splat_extent_unpack(ext, hx, hy);
+    const uint32_t bits = have ? strips_relevant_exact(q0.x, q0.y, q0.z, q0.w, q1.x, q1.z, c.x0, c.y0) : 0u;
     const int part = threadIdx.x >> 6;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const unsigned long long m = __ballot(have && strip_relevant(sx, sy, hx, hy, c.x0, c.y0, s));
-        if ((threadIdx.x & 63) == 0) masks[s][part] = m;
+        const unsigned long long m = __ballot((bits >> s) & 1u);
+        if ((threadIdx.x & 63) == 0) gmask[s * 4 + part] = m;
     }
 }
 

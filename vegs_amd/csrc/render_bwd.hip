@@ -36,32 +36,34 @@ __device__ __forceinline__ float readlane_f(float v, int l)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_f(float identity, float v)
-{
-    // lanes whose DPP source is out of range (or whose row is masked off) read `identity`
-    return __int_as_float(
-        __builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-}
-// wave64 inclusive prefix scans: row_shr 1,2,4,8 inside each 16-lane row, then row_bcast 15 / 31
+// wave64 inclusive prefix scans in DPP: row_shr 1,2,4,8 inside each 16-lane row, then row_bcast 15 / 31.
+// VOP2-DPP semantics do the masking for free: a lane whose DPP source is out of range (or whose row is
+// masked off) is simply not written, i.e. keeps its value -- one instruction per scan step.  The
+// "s_nop 1" are the two wait states a DPP read needs after the VALU write of the same VGPR.
 __device__ __forceinline__ float wave_prefix_mul(float v)
 {
-    v *= dpp_f<0x111, 0xf>(1.0f, v);
-    v *= dpp_f<0x112, 0xf>(1.0f, v);
-    v *= dpp_f<0x114, 0xf>(1.0f, v);
-    v *= dpp_f<0x118, 0xf>(1.0f, v);
-    v *= dpp_f<0x142, 0xa>(1.0f, v);
-    v *= dpp_f<0x143, 0xc>(1.0f, v);
+    asm volatile(
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return v;
 }
 __device__ __forceinline__ float wave_prefix_add(float v)
 {
-    v += dpp_f<0x111, 0xf>(0.0f, v);
-    v += dpp_f<0x112, 0xf>(0.0f, v);
-    v += dpp_f<0x114, 0xf>(0.0f, v);
-    v += dpp_f<0x118, 0xf>(0.0f, v);
-    v += dpp_f<0x142, 0xa>(0.0f, v);
-    v += dpp_f<0x143, 0xc>(0.0f, v);
+    asm volatile(
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return v;
 }
 
@@ -151,6 +153,7 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     __shared__ float gsum[SEG * NACC];            // per-entry gradient sums of this (tile, segment)
     __shared__ uint32_t ids[SEG];                 // Gaussian id of every entry
     __shared__ unsigned short ridx[4][SEG];       // per strip: the relevant entries, ascending
+    __shared__ float4 pixrec[4][64][4];           // per strip, per pixel: coords, bg term, 11 upstream grads, carries
     SegCtx c;
     if (!seg_setup(cam, ranges, seg_off, c)) return;
     const int needed = (int)seg_needed[c.tile];
@@ -195,6 +198,13 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     }
     float v_Scar = Ubuf[(size_t)blockIdx.x * SEG + threadIdx.x];
     const int seg_lo = c.sl * SEG;       // first list entry (tile-relative) of this segment
+    // Per-pixel record in LDS: in the pixel loop it is read back as wave-uniform broadcasts (LDS pipe)
+    // instead of 16 v_readlane (VALU pipe); the two carries live there too and are updated by one lane.
+    pixrec[w][lane][0] = make_float4(v_pxf, v_pyf, v_bgterm, pg.g[0]);
+    pixrec[w][lane][1] = make_float4(pg.g[1], pg.g[2], pg.g[3], pg.g[4]);
+    pixrec[w][lane][2] = make_float4(pg.g[5], pg.g[6], pg.g[7], pg.g[8]);
+    pixrec[w][lane][3] = make_float4(pg.g[9], pg.g[10], v_Tcar, v_Scar);
+    __builtin_amdgcn_wave_barrier();
 
     int mx = v_nc;
 #pragma unroll
@@ -231,7 +241,8 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
             for (int p = 0; p < 64; ++p) {
                 const int nc = __builtin_amdgcn_readlane(v_nc, p);
                 if (nc <= chunk_lo) continue;  // pixel p has no contributor in this chunk (wave-uniform)
-                const float pxf = readlane_f(v_pxf, p), pyf = readlane_f(v_pyf, p);
+                const float4 r0 = pixrec[w][p][0];   // pxf pyf bgterm g0
+                const float pxf = r0.x, pyf = r0.y;
                 float dx, dy;
                 const float power = splat_power(sx, sy, cA, cB, cC, pxf, pyf, dx, dy);
                 const bool pre = has && (e < nc) && !(power > 0.0f) && power >= thr;
@@ -239,11 +250,9 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                 const float G = vr_exp(power);
                 const float alpha = fminf(ALPHA_MAX, op * G);
                 const bool contrib = pre && !(alpha < ALPHA_MIN);
-                const float Tc = readlane_f(v_Tcar, p), Sc = readlane_f(v_Scar, p);
-                const float bgterm = readlane_f(v_bgterm, p);
-                float g[NCH];
-#pragma unroll
-                for (int k = 0; k < NCH; ++k) g[k] = readlane_f(pg.g[k], p);
+                const float4 r1 = pixrec[w][p][1], r2 = pixrec[w][p][2], r3 = pixrec[w][p][3];
+                const float bgterm = r0.z, Tc = r3.z, Sc = r3.w;
+                const float g[NCH] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y};
                 const float a_eff = contrib ? alpha : 0.0f;
                 const float om = 1.0f - a_eff;
                 const float pprod = wave_prefix_mul(om);                 // prod over entries >= mine
@@ -256,8 +265,10 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                 const float psum = wave_prefix_add(wu);                  // sum over entries >= mine
                 const float behind = Sc + (psum - wu);
                 // carries for the next (nearer) chunk: values at the chunk's first entry = lane 63
-                v_Tcar = (lane == p) ? readlane_f(Tl, 63) : v_Tcar;
-                v_Scar = (lane == p) ? Sc + readlane_f(psum, 63) : v_Scar;
+                if (lane == 63) {
+                    float2* car = reinterpret_cast<float2*>(&pixrec[w][p][3].z);
+                    *car = make_float2(Tl, Sc + psum);
+                }
                 if (contrib) {
                     const float dLda = fmaf(Tl, u, -(behind + bgterm) * __builtin_amdgcn_rcpf(om));
                     const float dLdG = op * dLda;

@@ -102,7 +102,7 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
         const bool any = __ballot(vis) != 0ull;
         if (any) {
             const float4* src4 = reinterpret_cast<const float4*>(shs + wave_first * row);
-            for (int v = lane; v < nvec; v += 64) lds4[v] = src4[v];
+            for (int v = lane; v < nvec; v += 64) lds4[v] = nt_load4(&src4[v]);  // streamed once
             __builtin_amdgcn_wave_barrier();
             float* myrow = sh_lds[w] + lane * row;
             if (vis) {
@@ -116,7 +116,7 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
         }
         float4* dst4 = reinterpret_cast<float4*>(dL_dshs + wave_first * row);
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int v = lane; v < nvec; v += 64) dst4[v] = any ? lds4[v] : zero4;
+        for (int v = lane; v < nvec; v += 64) nt_store4(any ? lds4[v] : zero4, &dst4[v]);
     } else if (shs && vis) {
         // unusual coefficient count / alignment: direct row access, dL_dshs pre-zeroed by the caller
         const float4 a1 = reinterpret_cast<const float4*>(gacc + (size_t)i * 16)[1];

@@ -42,6 +42,19 @@ struct Camera {
     const float* bg;
 };
 
+// non-temporal 16-byte accesses for data that is streamed exactly once (SH rows, dL/dSH rows)
+typedef float vr_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4* p)
+{
+    const vr_f4 v = __builtin_nontemporal_load(reinterpret_cast<const vr_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float4 v, float4* p)
+{
+    vr_f4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<vr_f4*>(p));
+}
+
 // exp(x), x <= 0, from IEEE basic operations only: bit-identical on host and device.
 __device__ __forceinline__ float vr_exp(float x)
 {

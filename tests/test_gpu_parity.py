@@ -261,3 +261,39 @@ def test_debug_mode_runs(dev):
     pkg = harness.render(scenes.camera_c1(64, 64), T, deg, torch.zeros(3, device=dev), debug=True)
     pkg["render"].sum().backward()
     assert torch.isfinite(T["means3D"].grad).all()
+
+
+@pytest.mark.parametrize("M,deg", [(4, 1), (9, 2), (9, 1), (1, 0)])
+def test_sh_storage_widths(M, deg, dev):
+    """shs with fewer stored coefficients than 16: rows of 12 floats take the LDS-staged path,
+    rows of 27 / 3 floats (not a multiple of 4) take the direct path; both must match the oracle."""
+    from oracle import oracle as orc
+    from vegs_amd import scenes
+    sc, _ = scenes.scene_random(P=3000, sh_degree=deg, seed=21 + M, scale=0.04)
+    shs = np.ascontiguousarray(sc["shs"][:, :M, :])
+    inputs = dict(means3D=sc["means3D"], shs=shs, colors_precomp=None, opacities=sc["opacities"],
+                  scales=sc["scales"], rotations=sc["rotations"], cov3D_precomp=None)
+    cam = scenes.camera_c1(96, 80)
+    oc = orc.make_cam(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy, [0.1, 0.1, 0.1], 1.0,
+                      cam.world_view_transform, cam.full_proj_transform, cam.camera_center, deg, M)
+    o_out, st = orc.forward(oc, **inputs)
+    rng = np.random.default_rng(M)
+    gouts = [rng.normal(size=s).astype(np.float32) for s in [(3, 80, 96), (1, 80, 96), (4, 80, 96), (3, 80, 96), (1, 80, 96)]]
+    h_out, h_grads, _ = _run_hip(_settings(cam, [0.1, 0.1, 0.1], deg, 1.0, dev), inputs, dev, gouts)
+    for n in OUT_NAMES:
+        assert np.array_equal(h_out[n], o_out[n]), n
+    og = orc.backward(oc, st, *gouts)
+    for k in ("means3D", "shs", "opacities", "scales", "rotations"):
+        assert h_grads[k].shape == og[k].shape
+        assert rel_err(h_grads[k], og[k]) < GRAD_RTOL, (k, rel_err(h_grads[k], og[k]))
+    K = (deg + 1) ** 2
+    assert np.all(h_grads["shs"][:, K:, :] == 0)       # inactive coefficients receive exact zeros
+
+
+def test_many_tiles_large_image(dev):
+    """2048x1200 = 9600 tiles (14 key bits: 8-bit radix digits, 2 passes) with a sparse scene."""
+    from vegs_amd import scenes
+    sc, deg = scenes.scene_random(P=4000, sh_degree=1, seed=77, extent=1.2, scale=0.03)
+    inputs = dict(means3D=sc["means3D"], shs=sc["shs"], colors_precomp=None, opacities=sc["opacities"],
+                  scales=sc["scales"], rotations=sc["rotations"], cov3D_precomp=None)
+    _check_against_oracle(inputs, scenes.camera_c1(2048, 1200), [0, 0, 0], deg, 1.0, dev, grad_rtol=5e-4)

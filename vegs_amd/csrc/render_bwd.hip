@@ -161,7 +161,7 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 
     // ---- entry j of the segment: id; per-strip lists of the relevant entries (masks from the forward)
-    const unsigned long long* masks = segmask + (size_t)blockIdx.x * 16;
+    const unsigned long long* masks = segmask + (size_t)c.seg * 16;
     {
         const bool have = (int)threadIdx.x < c.count;
         ids[threadIdx.x] = have ? point_list[c.first + threadIdx.x] : 0xFFFFFFFFu;
@@ -193,10 +193,10 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     // everything behind the segment
     float v_Tcar = v_Tf;
     if (c.sl + 1 < needed) {
-        const float Tn = Tbuf[(size_t)(blockIdx.x + 1) * SEG + threadIdx.x];
+        const float Tn = Tbuf[(size_t)(c.seg + 1) * SEG + threadIdx.x];
         if (!(Tn < 0.0f)) v_Tcar = Tn;   // pixel still alive at the next segment
     }
-    float v_Scar = Ubuf[(size_t)blockIdx.x * SEG + threadIdx.x];
+    float v_Scar = Ubuf[(size_t)c.seg * SEG + threadIdx.x];
     const int seg_lo = c.sl * SEG;       // first list entry (tile-relative) of this segment
     // Per-pixel record in LDS: in the pixel loop it is read back as wave-uniform broadcasts (LDS pipe)
     // instead of 16 v_readlane (VALU pipe); the two carries live there too and are updated by one lane.

@@ -82,7 +82,7 @@ k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
         seg_build_masks(c, have, q0, q1, masks);
     }
     __syncthreads();
-    if (threadIdx.x < 16) segmask[(size_t)blockIdx.x * 16 + threadIdx.x] = masks[threadIdx.x];
+    if (threadIdx.x < 16) segmask[(size_t)c.seg * 16 + threadIdx.x] = masks[threadIdx.x];
     const int w = threadIdx.x >> 6;
     const float pxf = (float)c.px, pyf = (float)c.py;
     float p = 1.0f;
@@ -100,7 +100,7 @@ k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
             p = valid ? p * (1.0f - alpha) : p;
         }
     }
-    Pbuf[(size_t)blockIdx.x * SEG + threadIdx.x] = p;
+    Pbuf[(size_t)c.seg * SEG + threadIdx.x] = p;
 }
 
 // ---- B: per tile, boundary transmittances.  Tbuf[seg][pix] = Tb at the segment start, or -1 when
@@ -169,10 +169,10 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
         }
     }
     __syncthreads();
-    const unsigned long long* masks = segmask + (size_t)blockIdx.x * 16;
+    const unsigned long long* masks = segmask + (size_t)c.seg * 16;
     const int w = threadIdx.x >> 6;
     const float pxf = (float)c.px, pyf = (float)c.py;
-    const float Tb = Tbuf[(size_t)blockIdx.x * SEG + threadIdx.x];
+    const float Tb = Tbuf[(size_t)c.seg * SEG + threadIdx.x];
     bool done = Tb < 0.0f;
     if (__ballot(!done) == 0ull) return;  // nothing alive in this wave's strip
     float p = 1.0f;
@@ -221,7 +221,7 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
         if (__ballot(!done) == 0ull) break;  // every pixel of the strip is finished
     }
     if (!(Tb < 0.0f)) {
-        float* dst = part + (size_t)blockIdx.x * (NPART * SEG) + threadIdx.x;
+        float* dst = part + (size_t)c.seg * (NPART * SEG) + threadIdx.x;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) dst[k * SEG] = Cs[k];
         dst[11 * SEG] = p;

@@ -20,6 +20,7 @@ __device__ __forceinline__ int seg_find_tile(const uint32_t* __restrict__ seg_of
 }
 
 struct SegCtx {
+    uint32_t seg;      // global segment id handled by this workgroup
     int tile, sl;      // tile id, segment index inside the tile
     int first, count;  // first list entry of the segment (absolute index into point_list), entries
     int nlist;         // entries in the whole tile list
@@ -33,8 +34,14 @@ __device__ __forceinline__ bool seg_setup(const Camera& cam, const int2* __restr
                                           const uint32_t* __restrict__ seg_off, SegCtx& c)
 {
     const int ntiles = cam.gx * cam.gy;
+    // Identity block -> segment map on purpose: the dispatcher deals consecutive blocks round-robin to
+    // the 8 XCDs, which spreads the (contiguous) segments of the heavy vanishing-point tiles over the
+    // whole chip.  Giving each XCD a contiguous run of segments for L2 locality was measured 1.4-2x
+    // SLOWER (one XCD ends up with all the long tiles).
+    const uint32_t nseg = seg_off[ntiles];
+    if (blockIdx.x >= nseg) return false;
     const uint32_t b = blockIdx.x;
-    if (b >= seg_off[ntiles]) return false;
+    c.seg = b;
     c.tile = seg_find_tile(seg_off, ntiles, b);
     c.sl = (int)(b - seg_off[c.tile]);
     const int2 r = ranges[c.tile];

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VR_ABI_VERSION 1
+#define VR_ABI_VERSION 2
 
 typedef enum VrStatus {
     VR_OK = 0,
@@ -91,13 +91,18 @@ typedef struct VrOutputs {
     int32_t* radii;   /* [P] */
 } VrOutputs;
 
-/* Filled by vr_forward; pass it unchanged to vr_backward. */
+/* Filled by vr_forward; pass it unchanged to vr_backward.
+ * On ENTRY to vr_forward, binning_capacity may hold a hint: the expected number of tile-list entries
+ * (e.g. the previous call's num_rendered plus some headroom; 0 = no hint).  With a hint the library
+ * requests its R-sized buffers BEFORE the host synchronisation, so the device does not idle while the
+ * host allocates; if the hint turns out too small the buffers are simply requested again. */
 typedef struct VrSaved {
     void* geom;
     void* binning;
     void* image;
-    int64_t num_rendered; /* R: tile-list entries */
-    int64_t num_visible;  /* V: Gaussians with radii > 0 */
+    int64_t num_rendered;     /* R: tile-list entries */
+    int64_t num_visible;      /* V: Gaussians with radii > 0 */
+    int64_t binning_capacity; /* entries the binning buffer was laid out for (>= R) */
 } VrSaved;
 
 /* Incoming gradients, one per differentiable output (NULL = zero). */

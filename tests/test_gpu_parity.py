@@ -69,12 +69,11 @@ def _export_binning(res, H, W, dev):
     """(point_list, ranges) of the forward that produced `res`, through vr_debug_export_binning."""
     from vegs_amd import _capi
     fn = res[0].grad_fn
-    geom, binning, image = fn.buffers
     R = fn.num_rendered
     T = ((W + 15) // 16) * ((H + 15) // 16)
     pl = torch.zeros(max(R, 1), dtype=torch.int32, device=dev)
     rg = torch.zeros((T, 2), dtype=torch.int32, device=dev)
-    saved = _capi.VrSaved(geom.data_ptr(), binning.data_ptr(), image.data_ptr(), R, fn.num_visible)
+    saved = _capi.saved_of(fn)
     rc = _capi.load().vr_debug_export_binning(C.byref(saved), H, W, pl.data_ptr(), rg.data_ptr(),
                                               torch.cuda.current_stream(dev).cuda_stream)
     _capi.check(rc)

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libvegsrast.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH = 0, 1, 2, 3
 
@@ -42,7 +42,7 @@ class VrOutputs(C.Structure):
 
 class VrSaved(C.Structure):
     _fields_ = [("geom", C.c_void_p), ("binning", C.c_void_p), ("image", C.c_void_p), ("num_rendered", C.c_int64),
-                ("num_visible", C.c_int64)]
+                ("num_visible", C.c_int64), ("binning_capacity", C.c_int64)]
 
 
 class VrOutGrads(C.Structure):
@@ -171,10 +171,17 @@ def counters():
     return dict(P=c.P, V=c.num_visible, R=c.num_rendered, T=c.num_tiles, N=c.num_pixels)
 
 
+def saved_of(grad_fn):
+    """VrSaved of the forward behind `grad_fn` (the op's autograd node)."""
+    geom, binning, image = grad_fn.buffers
+    return VrSaved(geom.data_ptr(), binning.data_ptr(), image.data_ptr(), grad_fn.num_rendered, grad_fn.num_visible,
+                   grad_fn.binning_capacity)
+
+
 def count_fragments(grad_fn, H, W, device):
     """F = sum of n_contrib of the forward behind `grad_fn` (the op's autograd node)."""
     geom, binning, image = grad_fn.buffers
-    saved = VrSaved(geom.data_ptr(), binning.data_ptr(), image.data_ptr(), grad_fn.num_rendered, grad_fn.num_visible)
+    saved = saved_of(grad_fn)
     out = C.c_int64(0)
     with torch.cuda.device(device):
         check(load().vr_count_fragments(C.byref(saved), H, W, torch.cuda.current_stream(device).cuda_stream,

@@ -211,6 +211,17 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
 
     uint32_t V = 0, R = 0, key_min = 0;
     int key_bits = 0;
+    // R-sized buffers: requested up front when the caller supplied a capacity hint (see VrSaved)
+    size_t Rcap = saved->binning_capacity > 0 ? (size_t)saved->binning_capacity : 0;
+    void *binning = nullptr, *scr2 = nullptr, *scr3 = nullptr;
+    if (Rcap > 0 && P > 0) {
+        binning = alloc(user, VR_BUF_BINNING, bin_layout(T, Rcap).total);
+        scr2 = alloc(user, VR_BUF_SCRATCH, binning_stage2_scratch_bytes(P, (long)Rcap, (int)T));
+        scr3 = alloc(user, VR_BUF_SCRATCH, render_fwd_scratch_bytes((long)Rcap, (int)T) + 256);
+        if (!binning || !scr2 || !scr3) return fail(VR_ERR_ALLOC, "allocator returned NULL");
+    } else {
+        Rcap = 0;
+    }
     if (P > 0) {
         prof_begin(VR_STAGE_PREPROCESS, s);
         rc = launch_preprocess(cam, P, in->means3D, in->shs, in->colors_precomp, in->opacities, in->scales,
@@ -232,17 +243,19 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
             while (span) { ++key_bits; span >>= 1; }
         }
     }
-    const BinLayout BL = bin_layout(T, R);
-    void* binning = alloc(user, VR_BUF_BINNING, BL.total);
-    void* scr2 = alloc(user, VR_BUF_SCRATCH, binning_stage2_scratch_bytes((int)V, (long)R, (int)T));
-    if (!binning || !scr2) return fail(VR_ERR_ALLOC, "allocator returned NULL");
+    if (Rcap == 0 || R > Rcap) {   // no hint, or the hint was too small: size for the actual R
+        Rcap = R;
+        binning = alloc(user, VR_BUF_BINNING, bin_layout(T, Rcap).total);
+        scr2 = alloc(user, VR_BUF_SCRATCH, binning_stage2_scratch_bytes(P, (long)Rcap, (int)T));
+        scr3 = alloc(user, VR_BUF_SCRATCH, render_fwd_scratch_bytes((long)Rcap, (int)T) + 256);
+    }
+    if (!binning || !scr2 || !scr3) return fail(VR_ERR_ALLOC, "allocator returned NULL");
+    const BinLayout BL = bin_layout(T, Rcap);
     int2* ranges = (int2*)((char*)binning + BL.ranges);
     uint32_t* point_list = (uint32_t*)((char*)binning + BL.point_list);
     rc = launch_binning(cam, (int)V, (long)R, key_min, key_bits, vis_key, vis_id, rect, scr2, point_list, ranges, s,
                         debug);
     if (rc) return rc;
-    void* scr3 = alloc(user, VR_BUF_SCRATCH, render_fwd_scratch_bytes((long)R, (int)T) + 256);
-    if (!scr3) return fail(VR_ERR_ALLOC, "allocator returned NULL");
     prof_begin(VR_STAGE_RENDER_FWD, s);
     rc = launch_render_fwd(cam, (long)R, ranges, point_list, rec, (uint32_t*)((char*)binning + BL.seg_off),
                            (uint32_t*)((char*)binning + BL.seg_needed), (float*)((char*)binning + BL.tbuf),
@@ -258,6 +271,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     saved->image = image;
     saved->num_rendered = (int64_t)R;
     saved->num_visible = (int64_t)V;
+    saved->binning_capacity = (int64_t)Rcap;
     g_counters.P = P;
     g_counters.num_visible = V;
     g_counters.num_rendered = R;
@@ -289,7 +303,8 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
     const bool debug = st->debug != 0;
     const size_t N = (size_t)cam.H * cam.W, T = (size_t)cam.gx * cam.gy;
     const ImageLayout IL = image_layout(N);
-    const BinLayout BL = bin_layout(T, (size_t)saved->num_rendered);
+    const size_t Rcap = saved->binning_capacity > 0 ? (size_t)saved->binning_capacity : (size_t)saved->num_rendered;
+    const BinLayout BL = bin_layout(T, Rcap);
     const Splat* rec = (const Splat*)saved->geom;
     const float* final_T = (const float*)((const char*)saved->image + IL.final_T);
     const uint32_t* n_contrib = (const uint32_t*)((const char*)saved->image + IL.n_contrib);
@@ -385,7 +400,7 @@ int vr_debug_export_binning(const VrSaved* saved, int32_t H, int32_t W, uint32_t
         return fail(VR_ERR_INVALID_ARGUMENT, "debug_export_binning: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-    const BinLayout BL = bin_layout(T, (size_t)saved->num_rendered);
+    const BinLayout BL = bin_layout(T, saved->binning_capacity > 0 ? (size_t)saved->binning_capacity : (size_t)saved->num_rendered);
     if (ranges)
         VR_HIP(hipMemcpyAsync(ranges, (const char*)saved->binning + BL.ranges, T * 8, hipMemcpyDeviceToDevice, s));
     if (point_list && saved->num_rendered > 0)

@@ -77,6 +77,11 @@ def _cpu_args_copy(args):
     return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
 
 
+# last number of tile-list entries per device: handed to the library as a capacity hint so that it can
+# request its R-sized buffers before the forward's single host synchronisation
+_LAST_R = {}
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -119,6 +124,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                   alpha.data_ptr(), _capi.ptr(radii))
             arena = _capi.Arena(device)
             saved = _capi.VrSaved()
+            hint = _LAST_R.get(device.index, 0)
+            saved.binning_capacity = int(hint * 1.125) + 65536 if hint > 0 else 0
             stream = torch.cuda.current_stream(device).cuda_stream
             cpu_args = _cpu_args_copy((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)) \
                 if rs.debug else None
@@ -134,6 +141,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = int(saved.num_rendered)
         ctx.num_visible = int(saved.num_visible)
+        ctx.binning_capacity = int(saved.binning_capacity)
+        _LAST_R[device.index] = ctx.num_rendered
         ctx.buffers = (arena.kept[_capi.VR_BUF_GEOM], arena.kept[_capi.VR_BUF_BINNING], arena.kept[_capi.VR_BUF_IMAGE])
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
         ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii)
@@ -170,7 +179,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             gin = _capi.VrInGrads(_capi.ptr(d_means3D), _capi.ptr(d_means2D), _capi.ptr(d_sh), _capi.ptr(d_col),
                                   _capi.ptr(d_opac), _capi.ptr(d_scales), _capi.ptr(d_rot), _capi.ptr(d_cov))
             saved = _capi.VrSaved(geom.data_ptr(), binning.data_ptr(), image.data_ptr(), ctx.num_rendered,
-                                  ctx.num_visible)
+                                  ctx.num_visible, ctx.binning_capacity)
             arena = _capi.Arena(device)
             stream = torch.cuda.current_stream(device).cuda_stream
             cpu_args = _cpu_args_copy((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

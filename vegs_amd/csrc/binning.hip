@@ -270,11 +270,17 @@ k_radix_hist(const uint32_t* __restrict__ keys, long n, uint32_t kmin, int shift
     __syncthreads();
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     long wbase = (long)blockIdx.x * RADIX_BLOCK + (long)w * (64 * RADIX_ITEMS);
-#pragma unroll 4
+    uint32_t key[RADIX_ITEMS];
+#pragma unroll
+    for (int i = 0; i < RADIX_ITEMS; ++i) {
+        long idx = wbase + i * 64 + lane;
+        key[i] = idx < n ? keys[idx] : 0u;
+    }
+#pragma unroll
     for (int i = 0; i < RADIX_ITEMS; ++i) {
         long idx = wbase + i * 64 + lane;
         bool ok = idx < n;
-        uint32_t d = ok ? digit_of<BITS>(keys[idx], kmin, shift) : 0;
+        uint32_t d = ok ? digit_of<BITS>(key[i], kmin, shift) : 0;
         unsigned long long valid = __ballot(ok);
         unsigned long long m = match_digit<BITS>(d, valid);
         if (ok && (m & lanemask_lt()) == 0) atomicAdd(&h[d], (uint32_t)__popcll(m));
@@ -299,13 +305,23 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
     }
     __syncthreads();
     long wbase = (long)blockIdx.x * RADIX_BLOCK + (long)w * (64 * RADIX_ITEMS);
-    uint32_t key[RADIX_ITEMS], rank[RADIX_ITEMS];
+    uint32_t key[RADIX_ITEMS], val[RADIX_ITEMS], rank[RADIX_ITEMS];
     unsigned long long lt = lanemask_lt();
+    // all loads first (32 in flight per lane), ranking afterwards: the pass is latency-bound otherwise
+#pragma unroll
+    for (int i = 0; i < RADIX_ITEMS; ++i) {
+        long idx = wbase + i * 64 + lane;
+        key[i] = idx < n ? keys_in[idx] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int i = 0; i < RADIX_ITEMS; ++i) {
+        long idx = wbase + i * 64 + lane;
+        val[i] = idx < n ? vals_in[idx] : 0u;
+    }
 #pragma unroll
     for (int i = 0; i < RADIX_ITEMS; ++i) {
         long idx = wbase + i * 64 + lane;
         bool ok = idx < n;
-        key[i] = ok ? keys_in[idx] : 0xFFFFFFFFu;
         uint32_t d = digit_of<BITS>(key[i], kmin, shift);
         unsigned long long valid = __ballot(ok);
         unsigned long long m = match_digit<BITS>(d, valid);
@@ -331,7 +347,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
             uint32_t d = digit_of<BITS>(key[i], kmin, shift);
             uint32_t dst = off[w][d] + rank[i];
             keys_out[dst] = key[i];
-            vals_out[dst] = vals_in[idx];
+            vals_out[dst] = val[i];
         }
     }
 }

@@ -422,42 +422,47 @@ k_gather_rect(int V, const uint32_t* __restrict__ sorted_id, const uint2* __rest
     if (r < V) rect_sorted[r] = rect[sorted_id[r]];
 }
 
+// Emission of the (tile, id) pairs of 256 depth-sorted Gaussians per workgroup.  Small rectangles
+// (<= EMIT_SMALL tiles: the vast majority, far splats touch 1-4 tiles) are written by their own lane --
+// consecutive lanes own consecutive output ranges, so the stores stay nearly coalesced; a large
+// rectangle is written by its whole wave, 64 entries per step.
+constexpr int EMIT_SMALL = 8;
 __global__ void __launch_bounds__(256)
 k_emit(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ offs,
        const uint2* __restrict__ rect_sorted, uint32_t* __restrict__ tkeys, uint32_t* __restrict__ tvals)
 {
-    __shared__ uint32_t l_off[257];
-    __shared__ uint32_t l_id[256];
-    __shared__ int l_x0[256], l_y0[256], l_w[256];
-    int r = blockIdx.x * 256 + threadIdx.x;
-    uint32_t myoff = 0, cnt = 0;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t off = 0, cnt = 0, id = 0;
+    int x0 = 0, y0 = 0, w = 1;
     if (r < V) {
         const uint2 rc = rect_sorted[r];
-        myoff = offs[r];
+        off = offs[r];
         cnt = rect_area(rc);
-        l_id[threadIdx.x] = sorted_id[r];
-        l_x0[threadIdx.x] = (int)(rc.x & 0xFFFFu);
-        l_y0[threadIdx.x] = (int)(rc.x >> 16);
-        l_w[threadIdx.x] = (int)(rc.y & 0xFFFFu);
+        id = sorted_id[r];
+        x0 = (int)(rc.x & 0xFFFFu);
+        y0 = (int)(rc.x >> 16);
+        w = max((int)(rc.y & 0xFFFFu), 1);
     }
-    int last = min(V - blockIdx.x * 256, 256) - 1;  // last valid thread of this block
-    l_off[threadIdx.x] = myoff;
-    if (threadIdx.x == last) l_off[256] = myoff + cnt;
-    __syncthreads();
-    uint32_t base = l_off[0];
-    uint32_t total = l_off[256] - base;
-    for (uint32_t e = threadIdx.x; e < total; e += 256) {
-        uint32_t target = base + e;
-        int lo = 0, hi = last;  // largest j with l_off[j] <= target
-        while (lo < hi) {
-            int mid = (lo + hi + 1) >> 1;
-            if (l_off[mid] <= target) lo = mid; else hi = mid - 1;
+    if (cnt <= EMIT_SMALL) {
+        int rx = 0, ry = 0;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            tkeys[off + k] = (uint32_t)((y0 + ry) * gx + x0 + rx);
+            tvals[off + k] = id;
+            if (++rx == w) { rx = 0; ++ry; }
         }
-        uint32_t k = target - l_off[lo];
-        int w = l_w[lo];
-        int ry = (int)(k / (uint32_t)w), rx = (int)(k - (uint32_t)ry * (uint32_t)w);
-        tkeys[target] = (uint32_t)((l_y0[lo] + ry) * gx + l_x0[lo] + rx);
-        tvals[target] = l_id[lo];
+    }
+    // large rectangles: one at a time, all 64 lanes of the wave
+    for (unsigned long long big = __ballot(cnt > EMIT_SMALL); big; big &= big - 1) {
+        const int src = __builtin_ctzll(big);
+        const uint32_t b_off = (uint32_t)__shfl((int)off, src, 64), b_cnt = (uint32_t)__shfl((int)cnt, src, 64);
+        const uint32_t b_id = (uint32_t)__shfl((int)id, src, 64);
+        const int b_x0 = __shfl(x0, src, 64), b_y0 = __shfl(y0, src, 64), b_w = __shfl(w, src, 64);
+        for (uint32_t k = lane; k < b_cnt; k += 64) {
+            const int ry = (int)(k / (uint32_t)b_w), rx = (int)(k - (uint32_t)ry * (uint32_t)b_w);
+            tkeys[b_off + k] = (uint32_t)((b_y0 + ry) * gx + b_x0 + rx);
+            tvals[b_off + k] = b_id;
+        }
     }
 }
 

@@ -93,49 +93,51 @@ __device__ __forceinline__ void load_pixgrad(bool inside, size_t pix, size_t N, 
     if (dL_dalpha) o.galpha = dL_dalpha[pix];
 }
 
-// ---- A'+B': per tile, Ubuf[seg][pix] = sum over the LATER segments of the tile of U, where
-// U[seg][pix] = sum over the segment's applied entries of w*u = <dL/dout(pix), segment-local channel
-// sums> -- the sums the forward already produced (`part`), so no second pass over the splats.
+// ---- A': U[seg][pix] = sum over the segment's applied entries of w*u = <dL/dout(pix), segment-local
+// channel sums> -- the sums the forward already produced (`part`), so no second pass over the splats.
+// Fully parallel over (segment, pixel); the sequential part (B') then only touches one float per segment.
 constexpr int NPART_B = 13;
 __global__ void __launch_bounds__(256)
-k_seg_usuffix(Camera cam, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_needed,
-              const float* __restrict__ part, const uint32_t* __restrict__ n_contrib,
-              const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-              const float* __restrict__ dL_dquat, const float* __restrict__ dL_dscale, float* __restrict__ Ubuf)
+k_seg_u(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
+        const uint32_t* __restrict__ seg_needed, const float* __restrict__ part,
+        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
+        const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dquat, const float* __restrict__ dL_dscale,
+        float* __restrict__ Ubuf)
+{
+    SegCtx c;
+    if (!seg_setup(cam, ranges, seg_off, c)) return;
+    if ((uint32_t)c.sl >= seg_needed[c.tile]) return;
+    const size_t N = (size_t)cam.H * cam.W;
+    PixGrad pg;
+    load_pixgrad(c.inside, c.pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, nullptr, pg);
+    const int nc = c.inside ? (int)n_contrib[c.pix] : 0;
+    float U = 0.0f;
+    if (c.sl * SEG < nc) {   // the pixel applied entries of this segment (otherwise `part` is not defined for it)
+        const float* src = part + (size_t)c.seg * (NPART_B * SEG) + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) U = fmaf(src[k * SEG], pg.g[k], U);
+    }
+    Ubuf[(size_t)c.seg * SEG + threadIdx.x] = U;
+}
+
+// ---- B': per tile, in place: Ubuf[seg][pix] <- sum of U over the LATER segments of the tile
+__global__ void __launch_bounds__(256)
+k_seg_suffix(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_needed, float* __restrict__ Ubuf)
 {
     const int tile = blockIdx.x;
-    const int tx = tile % cam.gx, ty = tile / cam.gx;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int px = tx * TILE + (lane & 15), py = ty * TILE + w * 4 + (lane >> 4);
-    const bool inside = px < cam.W && py < cam.H;
-    const size_t N = (size_t)cam.H * cam.W, pix = (size_t)py * cam.W + px;
-    PixGrad pg;
-    load_pixgrad(inside, pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, nullptr, pg);
-    const int nc = inside ? (int)n_contrib[pix] : 0;
     const uint32_t s0 = seg_off[tile];
     const int needed = (int)seg_needed[tile];
-    constexpr int CU = 4;
+    constexpr int CU = 8;
     float run = 0.0f;
     for (int s = needed - 1; s >= 0; s -= CU) {
-        float v[CU][NCH];
+        float v[CU];
+#pragma unroll
+        for (int j = 0; j < CU; ++j) v[j] = Ubuf[(size_t)(s0 + max(s - j, 0)) * SEG + threadIdx.x];
 #pragma unroll
         for (int j = 0; j < CU; ++j) {
-            const int sj = max(s - j, 0);
-            const float* src = part + (size_t)(s0 + sj) * (NPART_B * SEG) + threadIdx.x;
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) v[j][k] = src[k * SEG];
-        }
-#pragma unroll
-        for (int j = 0; j < CU; ++j) {
-            const int sj = s - j;
-            if (sj < 0) continue;
-            float U = 0.0f;
-            if (sj * SEG < nc) {   // the pixel applied entries of this segment (otherwise `part` is not defined for it)
-#pragma unroll
-                for (int k = 0; k < NCH; ++k) U = fmaf(v[j][k], pg.g[k], U);
-            }
-            Ubuf[(size_t)(s0 + sj) * SEG + threadIdx.x] = run;
-            run += U;
+            if (s - j < 0) continue;
+            Ubuf[(size_t)(s0 + s - j) * SEG + threadIdx.x] = run;
+            run += v[j];
         }
     }
 }
@@ -318,9 +320,11 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
     if (ntiles == 0 || R == 0) return 0;
     const unsigned nseg = (unsigned)seg_capacity(R, ntiles);
     float* Ubuf = (float*)scratch;
-    hipLaunchKernelGGL(k_seg_usuffix, dim3(ntiles), dim3(256), 0, s, cam, seg_off, seg_needed, part, n_contrib,
+    hipLaunchKernelGGL(k_seg_u, dim3(nseg), dim3(256), 0, s, cam, ranges, seg_off, seg_needed, part, n_contrib,
                        dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, Ubuf);
-    VR_KERNEL_CHECK("seg_usuffix", s, debug);
+    VR_KERNEL_CHECK("seg_u", s, debug);
+    hipLaunchKernelGGL(k_seg_suffix, dim3(ntiles), dim3(256), 0, s, seg_off, seg_needed, Ubuf);
+    VR_KERNEL_CHECK("seg_suffix", s, debug);
     hipLaunchKernelGGL(k_seg_bwd, dim3(nseg), dim3(256), 0, s, cam, ranges, seg_off, seg_needed, point_list, rec, Tbuf,
                        (const float*)Ubuf, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, dL_dalpha,
                        gacc, gmean2D, segmask);

@@ -150,6 +150,8 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    mallocs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
+    reserved0 = torch.cuda.memory_reserved(device)
     t0 = time.perf_counter()
     views_done = []
     for i in range(args.warmup, args.warmup + args.steps):
@@ -209,6 +211,9 @@ def main():
                      "whole_view_frac": round(b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
     }
     if args.stages:
+        print("hipMalloc calls inside the timed region:",
+              torch.cuda.memory_stats(device).get("num_device_alloc", 0) - mallocs0, "reserved MB before/after:",
+              reserved0 >> 20, torch.cuda.memory_reserved(device) >> 20, file=sys.stderr)
         print("stage breakdown (ms per step):", {k: round(v[0] / args.steps, 4) for k, v in stage.items()},
               file=sys.stderr)
     if world == 1 and not args.no_cpu_baseline:

@@ -73,3 +73,24 @@ def test_product_never_imports_the_oracle():
                 if f.endswith((".py", ".hip", ".h")):
                     txt = open(os.path.join(dirpath, f)).read()
                     assert "import oracle" not in txt and "from oracle" not in txt and "vr_oracle" not in txt, f
+
+
+def test_arena_is_freed_by_refcount_not_by_gc():
+    """The allocator arena must not sit in a reference cycle: a cycle kept ~0.5 GB of per-call buffers
+    alive until the cyclic GC ran, which sent the caching allocator back to hipMalloc every other step."""
+    import gc
+    import weakref
+    from vegs_amd import _capi
+    gc.disable()
+    try:
+        arena = _capi.Arena(torch.device("cpu"))
+        cb = arena.callback()
+        assert cb(None, _capi.VR_BUF_SCRATCH, 64) != 0 and cb(None, _capi.VR_BUF_GEOM, 64) != 0
+        ref = weakref.ref(arena)
+        del cb
+        kept = arena.kept
+        del arena
+        assert ref() is None, "Arena is part of a reference cycle"
+        assert _capi.VR_BUF_GEOM in kept
+    finally:
+        gc.enable()

@@ -134,7 +134,13 @@ class Arena:
         self.kept = {}
         self.scratch = []
         self.error = None
-        self.callback = VrAllocFn(self._alloc)
+
+    def callback(self):
+        """A fresh C callback bound to this arena.  Deliberately NOT stored on the arena: arena ->
+        callback -> bound method -> arena would be a reference cycle that keeps hundreds of MB of
+        buffers alive until the cyclic GC happens to run (and sends the caching allocator back to
+        hipMalloc in the meantime)."""
+        return VrAllocFn(self._alloc)
 
     def _alloc(self, _user, kind, nbytes):
         try:

@@ -320,7 +320,7 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
         VR_HIP(hipMemsetAsync(gin->dL_dshs, 0, (size_t)P * in->M * 3 * sizeof(float), s));
     prof_end(VR_STAGE_BWD_ZERO, s);
     if (saved->num_rendered > 0) {
-        void* scr = alloc(user, VR_BUF_SCRATCH, render_bwd_scratch_bytes((long)saved->num_rendered, (int)T) + 256);
+        void* scr = alloc(user, VR_BUF_SCRATCH, render_bwd_scratch_bytes((long)Rcap, (int)T) + 256);
         if (!scr) return fail(VR_ERR_ALLOC, "allocator returned NULL");
         ProfScope ps(VR_STAGE_RENDER_BWD, s);
         rc = launch_render_bwd(cam, (long)saved->num_rendered, ranges, point_list, rec,

@@ -77,8 +77,10 @@ def _cpu_args_copy(args):
     return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
 
 
-# last number of tile-list entries per device: handed to the library as a capacity hint so that it can
-# request its R-sized buffers before the forward's single host synchronisation
+# largest number of tile-list entries seen per device: handed to the library as a capacity hint so that
+# it can request its R-sized buffers before the forward's single host synchronisation.  A running
+# maximum (not the last value) keeps every request the same size from step to step, so PyTorch's
+# caching allocator serves them from its pool instead of going back to hipMalloc.
 _LAST_R = {}
 
 
@@ -129,7 +131,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             stream = torch.cuda.current_stream(device).cuda_stream
             cpu_args = _cpu_args_copy((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)) \
                 if rs.debug else None
-            rc = lib.vr_forward(C.byref(st), C.byref(inp), C.byref(out), arena.callback, None, stream, C.byref(saved))
+            cb = arena.callback()
+            rc = lib.vr_forward(C.byref(st), C.byref(inp), C.byref(out), cb, None, stream, C.byref(saved))
+            del cb
             arena.release_scratch()
             if rc != 0:
                 if rs.debug:
@@ -142,7 +146,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = int(saved.num_rendered)
         ctx.num_visible = int(saved.num_visible)
         ctx.binning_capacity = int(saved.binning_capacity)
-        _LAST_R[device.index] = ctx.num_rendered
+        _LAST_R[device.index] = max(_LAST_R.get(device.index, 0), ctx.num_rendered)
         ctx.buffers = (arena.kept[_capi.VR_BUF_GEOM], arena.kept[_capi.VR_BUF_BINNING], arena.kept[_capi.VR_BUF_IMAGE])
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
         ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii)
@@ -184,8 +188,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             stream = torch.cuda.current_stream(device).cuda_stream
             cpu_args = _cpu_args_copy((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                        radii, g_color, g_depth, g_quat, g_scale, g_alpha)) if rs.debug else None
+            cb = arena.callback()
             rc = lib.vr_backward(C.byref(st), C.byref(inp), _capi.ptr(radii), C.byref(saved), C.byref(gout),
-                                 C.byref(gin), arena.callback, None, stream)
+                                 C.byref(gin), cb, None, stream)
+            del cb
             arena.release_scratch()
             if rc != 0:
                 if rs.debug:

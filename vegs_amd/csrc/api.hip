@@ -191,7 +191,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
 
     // ---- buffers that survive until backward
     const size_t p1 = (size_t)(P > 0 ? P : 1);
-    void* geom = alloc(user, VR_BUF_GEOM, align_up(p1 * sizeof(Splat), 256));
+    void* geom = alloc(user, VR_BUF_GEOM, align_up(p1 * sizeof(Splat), 256) + align_up(p1, 256));   // records | clamp bits
     const ImageLayout IL = image_layout(N);
     void* image = alloc(user, VR_BUF_IMAGE, IL.total);
     // ---- transient, P-sized
@@ -225,7 +225,8 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     if (P > 0) {
         prof_begin(VR_STAGE_PREPROCESS, s);
         rc = launch_preprocess(cam, P, in->means3D, in->shs, in->colors_precomp, in->opacities, in->scales,
-                               in->rotations, in->cov3D_precomp, rec, out->radii, rect, depth_key, s, debug);
+                               in->rotations, in->cov3D_precomp, rec, out->radii, rect, depth_key,
+                               (uint8_t*)geom + align_up(p1 * sizeof(Splat), 256), s, debug);
         prof_end(VR_STAGE_PREPROCESS, s);
         if (rc) return rc;
         prof_begin(VR_STAGE_COMPACT, s);
@@ -336,7 +337,8 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
     }
     ProfScope ps2(VR_STAGE_PREPROCESS_BWD, s);
     rc = launch_preprocess_bwd(cam, P, in->means3D, in->shs, in->colors_precomp, in->scales, in->rotations,
-                               in->cov3D_precomp, radii, rec, gacc, gin->dL_dmeans2D, gin->dL_dmeans3D, gin->dL_dshs,
+                               in->cov3D_precomp, radii,
+                               (const uint8_t*)saved->geom + align_up((size_t)P * sizeof(Splat), 256), gacc, gin->dL_dmeans2D, gin->dL_dmeans3D, gin->dL_dshs,
                                gin->dL_dcolors_precomp, gin->dL_dopacities, gin->dL_dscales, gin->dL_drotations,
                                gin->dL_dcov3D_precomp, s, debug);
     return rc;

@@ -34,7 +34,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
              const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
              const float* __restrict__ scales, const float* __restrict__ rotations,
              const float* __restrict__ cov3D_precomp, Splat* __restrict__ rec, int* __restrict__ radii,
-             uint2* __restrict__ rect, uint32_t* __restrict__ depth_key)
+             uint2* __restrict__ rect, uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clampb)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4][64 * SH_ROW_MAX];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,6 +154,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
         rect[i] = vis ? make_uint2((uint32_t)rx0 | ((uint32_t)ry0 << 16), (uint32_t)rw | ((uint32_t)rh << 16))
                       : make_uint2(0u, 0u);
         depth_key[i] = vis ? __float_as_uint(t2) : 0u;
+        clampb[i] = (uint8_t)clampbits;   // dense copy for the backward (a 4-byte gather out of the 80-byte records costs a line each)
     }
 }
 
@@ -170,11 +171,11 @@ k_mark_visible(const float* __restrict__ xyz, int P, const float* __restrict__ v
 int launch_preprocess(const Camera& cam, int P, const float* means3D, const float* shs, const float* colors_precomp,
                       const float* opacities, const float* scales, const float* rotations,
                       const float* cov3D_precomp, Splat* rec, int* radii, uint2* rect,
-                      uint32_t* depth_key, hipStream_t s, bool debug)
+                      uint32_t* depth_key, uint8_t* clampb, hipStream_t s, bool debug)
 {
     if (P == 0) return 0;
     hipLaunchKernelGGL(k_preprocess, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, means3D, shs, colors_precomp,
-                       opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key);
+                       opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, clampb);
     VR_KERNEL_CHECK("preprocess", s, debug);
     return 0;
 }

@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256)
 k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ means3D, const float* __restrict__ shs,
                  const float* __restrict__ colors_precomp, const float* __restrict__ scales,
                  const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
-                 const int* __restrict__ radii, const Splat* __restrict__ rec, const float* __restrict__ gacc,
+                 const int* __restrict__ radii, const uint8_t* __restrict__ clampb, const float* __restrict__ gacc,
                  const float* __restrict__ gmean2D, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dshs,
                  float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
                  float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D)
@@ -108,7 +108,7 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
             if (vis) {
                 const float4 a1 = reinterpret_cast<const float4*>(gacc + (size_t)i * 16)[1];
                 const float px3 = means3D[3 * (size_t)i], py3 = means3D[3 * (size_t)i + 1], pz3 = means3D[3 * (size_t)i + 2];
-                sh_backward_row(cam, px3, py3, pz3, rec[i].clamped, a1.x, a1.y, a1.z, myrow, myrow, dmean);
+                sh_backward_row(cam, px3, py3, pz3, (uint32_t)clampb[i], a1.x, a1.y, a1.z, myrow, myrow, dmean);
             } else if (lane < rows_here) {
                 for (int k = 0; k < row; ++k) myrow[k] = 0.0f;
             }
@@ -121,7 +121,7 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
         // unusual coefficient count / alignment: direct row access, dL_dshs pre-zeroed by the caller
         const float4 a1 = reinterpret_cast<const float4*>(gacc + (size_t)i * 16)[1];
         const float px3 = means3D[3 * (size_t)i], py3 = means3D[3 * (size_t)i + 1], pz3 = means3D[3 * (size_t)i + 2];
-        sh_backward_row(cam, px3, py3, pz3, rec[i].clamped, a1.x, a1.y, a1.z, shs + (size_t)i * cam.M * 3,
+        sh_backward_row(cam, px3, py3, pz3, (uint32_t)clampb[i], a1.x, a1.y, a1.z, shs + (size_t)i * cam.M * 3,
                         dL_dshs + (size_t)i * cam.M * 3, dmean);
     }
 
@@ -274,7 +274,7 @@ bool preprocess_bwd_writes_all_sh(int M, const float* shs, const float* dL_dshs)
 
 int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const float* shs,
                           const float* colors_precomp, const float* scales, const float* rotations,
-                          const float* cov3D_precomp, const int* radii, const Splat* rec, const float* gacc,
+                          const float* cov3D_precomp, const int* radii, const uint8_t* clampb, const float* gacc,
                           const float* gmean2D, float* dL_dmeans3D, float* dL_dshs, float* dL_dcolors,
                           float* dL_dopacities, float* dL_dscales, float* dL_drots, float* dL_dcov3D,
                           hipStream_t s, bool debug)
@@ -282,7 +282,7 @@ int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const 
     if (P == 0) return 0;
     const int sh_staged = preprocess_bwd_writes_all_sh(cam.M, shs, dL_dshs) ? 1 : 0;
     hipLaunchKernelGGL(k_preprocess_bwd, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, sh_staged, means3D, shs, colors_precomp,
-                       scales, rotations, cov3D_precomp, radii, rec, gacc, gmean2D, dL_dmeans3D, dL_dshs, dL_dcolors,
+                       scales, rotations, cov3D_precomp, radii, clampb, gacc, gmean2D, dL_dmeans3D, dL_dshs, dL_dcolors,
                        dL_dopacities, dL_dscales, dL_drots, dL_dcov3D);
     VR_KERNEL_CHECK("preprocess_bwd", s, debug);
     return 0;

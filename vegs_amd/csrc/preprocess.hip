@@ -122,7 +122,14 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
             const int nvec = rows_here * row / 4;               // float4s to move
             float4* dst4 = reinterpret_cast<float4*>(sh_lds[w]);
             const float4* src4 = reinterpret_cast<const float4*>(src);
-            for (int v = lane; v < nvec; v += 64) dst4[v] = nt_load4(&src4[v]);  // streamed once
+            // all (up to 12) loads of the lane in flight before the first LDS store
+            float4 tmp[SH_ROW_MAX / 4];
+#pragma unroll
+            for (int j = 0; j < SH_ROW_MAX / 4; ++j)
+                if (lane + 64 * j < nvec) tmp[j] = nt_load4(&src4[lane + 64 * j]);  // streamed once
+#pragma unroll
+            for (int j = 0; j < SH_ROW_MAX / 4; ++j)
+                if (lane + 64 * j < nvec) dst4[lane + 64 * j] = tmp[j];
             __builtin_amdgcn_wave_barrier();
             if (vis) sh_dot(bas, K, sh_lds[w] + lane * row, acc);
         } else if (vis) {

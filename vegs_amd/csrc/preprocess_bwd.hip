@@ -102,7 +102,13 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
         const bool any = __ballot(vis) != 0ull;
         if (any) {
             const float4* src4 = reinterpret_cast<const float4*>(shs + wave_first * row);
-            for (int v = lane; v < nvec; v += 64) lds4[v] = nt_load4(&src4[v]);  // streamed once
+            float4 tmp[SH_ROW_MAX / 4];   // all (up to 12) loads of the lane in flight before the first LDS store
+#pragma unroll
+            for (int j = 0; j < SH_ROW_MAX / 4; ++j)
+                if (lane + 64 * j < nvec) tmp[j] = nt_load4(&src4[lane + 64 * j]);  // streamed once
+#pragma unroll
+            for (int j = 0; j < SH_ROW_MAX / 4; ++j)
+                if (lane + 64 * j < nvec) lds4[lane + 64 * j] = tmp[j];
             __builtin_amdgcn_wave_barrier();
             float* myrow = sh_lds[w] + lane * row;
             if (vis) {
@@ -116,7 +122,9 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
         }
         float4* dst4 = reinterpret_cast<float4*>(dL_dshs + wave_first * row);
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int v = lane; v < nvec; v += 64) nt_store4(any ? lds4[v] : zero4, &dst4[v]);
+#pragma unroll
+        for (int j = 0; j < SH_ROW_MAX / 4; ++j)
+            if (lane + 64 * j < nvec) nt_store4(any ? lds4[lane + 64 * j] : zero4, &dst4[lane + 64 * j]);
     } else if (shs && vis) {
         // unusual coefficient count / alignment: direct row access, dL_dshs pre-zeroed by the caller
         const float4 a1 = reinterpret_cast<const float4*>(gacc + (size_t)i * 16)[1];

@@ -130,53 +130,58 @@ __global__ void __launch_bounds__(256) k_scan_reduce(Src src, long n, uint32_t* 
     }
 }
 
-// single block: in-place exclusive scan of bsum[0..nb), total -> totals[0]; sum of bsum2 -> totals[1];
-// with minmax: min of bsum2[nb..2nb) -> totals[2], max of bsum2[2nb..3nb) -> totals[3]
-__global__ void __launch_bounds__(256)
-k_scan_sums(uint32_t* bsum, const uint32_t* bsum2, int nb, uint32_t* totals, int minmax)
+// block-wide sum of one value per thread (256 threads)
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* lds4)
 {
-    __shared__ uint32_t lds4[4];
-    __shared__ uint32_t mm[8];
-    uint32_t carry = 0, acc2 = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
-    for (int base = 0; base < nb; base += 256) {
-        int i = base + threadIdx.x;
-        uint32_t v = i < nb ? bsum[i] : 0;
-        if (bsum2 && i < nb) {
-            acc2 += bsum2[i];
-            if (minmax) { kmin = min(kmin, bsum2[nb + i]); kmax = max(kmax, bsum2[2 * nb + i]); }
-        }
-        uint32_t total;
-        uint32_t ex = block_excl_scan(v, total, lds4);
-        if (i < nb) bsum[i] = carry + ex;
-        carry += total;
-    }
-    if (totals) {
-        if (threadIdx.x == 0) totals[0] = carry;
-        if (bsum2) {
-            uint32_t t2;
-            (void)block_excl_scan(acc2, t2, lds4);
-            if (threadIdx.x == 0) totals[1] = t2;
-            if (minmax) {
 #pragma unroll
-                for (int d = 32; d > 0; d >>= 1) {
-                    kmin = min(kmin, (uint32_t)__shfl_down((int)kmin, d, 64));
-                    kmax = max(kmax, (uint32_t)__shfl_down((int)kmax, d, 64));
-                }
-                if ((threadIdx.x & 63) == 0) { mm[threadIdx.x >> 6] = kmin; mm[4 + (threadIdx.x >> 6)] = kmax; }
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    totals[2] = min(min(mm[0], mm[1]), min(mm[2], mm[3]));
-                    totals[3] = max(max(mm[4], mm[5]), max(mm[6], mm[7]));
-                }
-            }
-        }
-    }
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return lds4[0] + lds4[1] + lds4[2] + lds4[3];
 }
 
+// Second (last) kernel of a scan.  Every workgroup derives its own exclusive prefix from the per-block
+// sums of the reduce kernel (a few KB, L2-resident) instead of waiting for a separate single-block scan
+// kernel; workgroup 0 also publishes the grand totals (sum, secondary sum, min/max key) when asked.
 template <class Src, class Sink>
-__global__ void __launch_bounds__(256) k_scan_apply(Src src, Sink sink, long n, const uint32_t* bsum_excl)
+__global__ void __launch_bounds__(256)
+k_scan_apply(Src src, Sink sink, long n, const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ bsum2,
+             int nb, uint32_t* __restrict__ totals)
 {
     __shared__ uint32_t lds4[4];
+    uint32_t acc = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) acc += bsum[j];
+    const uint32_t prefix = block_sum(acc, lds4);
+    if (totals && blockIdx.x == 0) {
+        uint32_t t0 = 0, t1 = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+        for (int j = threadIdx.x; j < nb; j += 256) {
+            t0 += bsum[j];
+            if (bsum2) {
+                t1 += bsum2[j];
+                if (Src::MINMAX) { kmin = min(kmin, bsum2[nb + j]); kmax = max(kmax, bsum2[2 * nb + j]); }
+            }
+        }
+        t0 = block_sum(t0, lds4);
+        t1 = block_sum(t1, lds4);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d, 64));
+            kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d, 64));
+        }
+        __shared__ uint32_t mm[8];
+        if ((threadIdx.x & 63) == 0) { mm[threadIdx.x >> 6] = kmin; mm[4 + (threadIdx.x >> 6)] = kmax; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            totals[0] = t0;
+            totals[1] = t1;
+            if (Src::MINMAX) {
+                totals[2] = min(min(mm[0], mm[1]), min(mm[2], mm[3]));
+                totals[3] = max(max(mm[4], mm[5]), max(mm[6], mm[7]));
+            }
+        }
+        __syncthreads();
+    }
     long base = (long)blockIdx.x * SCAN_BLOCK + (long)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     uint32_t tsum = 0;
@@ -186,7 +191,7 @@ __global__ void __launch_bounds__(256) k_scan_apply(Src src, Sink sink, long n, 
         tsum += v[k];
     }
     uint32_t total;
-    uint32_t ex = block_excl_scan(tsum, total, lds4) + bsum_excl[blockIdx.x];
+    uint32_t ex = block_excl_scan(tsum, total, lds4) + prefix;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         if (base + k < n) sink(base + k, v[k], ex);
@@ -202,11 +207,8 @@ static int run_scan(Src src, Sink sink, long n, uint32_t* bsum, uint32_t* bsum2,
     int nb = cdiv(n, SCAN_BLOCK);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_reduce<Src>), dim3(nb), dim3(256), 0, s, src, n, bsum, bsum2);
     VR_KERNEL_CHECK(what, s, debug);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, s, bsum, (const uint32_t*)bsum2, nb, totals,
-                       Src::MINMAX ? 1 : 0);
-    VR_KERNEL_CHECK(what, s, debug);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<Src, Sink>), dim3(nb), dim3(256), 0, s, src, sink, n,
-                       (const uint32_t*)bsum);
+                       (const uint32_t*)bsum, (const uint32_t*)bsum2, nb, totals);
     VR_KERNEL_CHECK(what, s, debug);
     return 0;
 }

@@ -43,7 +43,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
     // culled unless proven visible
     bool vis = false;
     int rad = 0, ntiles = 0, rx0 = 0, ry0 = 0, rw = 0, rh = 0;
-    float px = 0.f, py = 0.f, t2 = 0.f, conA = 0.f, conB = 0.f, conC = 0.f, cova = 0.f, covc = 0.f;
+    float px = 0.f, py = 0.f, t2 = 0.f, conA = 0.f, conB = 0.f, conC = 0.f;
     float q[4] = {0.f, 0.f, 0.f, 0.f}, sc[3] = {0.f, 0.f, 0.f};
     float px3 = 0.f, py3 = 0.f, pz3 = 0.f;
     if (in_range) {
@@ -88,8 +88,6 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
                 conA = cv.c * det_inv;
                 conB = -cv.b * det_inv;
                 conC = cv.a * det_inv;
-                cova = cv.a;
-                covc = cv.c;
             }
         }
     }
@@ -149,7 +147,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
         s.conC = conC; s.opacity = opac; s.thr = splat_thr(opac); s.depth = t2;
         s.r = rgb[0]; s.g = rgb[1]; s.b = rgb[2]; s.qw = q[0];
         s.qx = q[1]; s.qy = q[2]; s.qz = q[3]; s.s0 = sc[0];
-        s.s1 = sc[1]; s.s2 = sc[2]; s.clamped = clampbits; s.ext = splat_extent(s.thr, cova, covc);
+        s.s1 = sc[1]; s.s2 = sc[2]; s.clamped = clampbits; s.pad0 = 0;
         float4* dst = reinterpret_cast<float4*>(rec + i);
         const float4* src = reinterpret_cast<const float4*>(&s);
 #pragma unroll

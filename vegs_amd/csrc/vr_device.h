@@ -5,7 +5,6 @@
 // fused multiply-add is an explicit fmaf(), so that radii, tile rectangles, sort keys and
 // forward images are bit-reproducible against the CPU oracle used by the tests.
 #pragma once
-#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -27,7 +26,7 @@ struct __attribute__((aligned(16))) Splat {
     float qx, qy, qz, s0;            // q3: quaternion x,y,z, scale 0  (input scale row, A-3)
     float s1, s2;                    // q4: scale 1,2
     uint32_t clamped;                //     bit c set: colour channel c was clamped at 0
-    uint32_t ext;                    //     half2 (hx, hy): conservative half-extent of the alpha >= 1/255 footprint
+    uint32_t pad0;
 };
 static_assert(sizeof(Splat) == 80, "Splat must be 80 bytes");
 
@@ -104,39 +103,13 @@ __device__ __forceinline__ void tile_rect(float px, float py, int rad, int gx, i
 // evaluating exp.  Never decides anything by itself -- the exact alpha test still follows.
 __device__ __forceinline__ float splat_thr(float opacity) { return -__logf(255.0f * opacity) - 0.01f; }
 
-// Conservative axis-aligned half-extent (pixels) of the region where alpha can reach 1/255:
-// power >= thr  <=>  d^T conic d <= -2 thr, an ellipse whose bounding box is sqrt(-2 thr * cov2D_xx/yy).
-// Rounded UP into a half2; (-1,-1) = never visible.  Only used to skip work, never to decide a result.
-__device__ __forceinline__ uint32_t splat_extent(float thr, float cov_a, float cov_c)
-{
-    const float k = -2.0f * thr;
-    float hx = -1.0f, hy = -1.0f;
-    if (k > 0.0f) {
-        hx = fminf(sqrtf(k * cov_a) * 1.002f + 0.01f, 60000.0f);
-        hy = fminf(sqrtf(k * cov_c) * 1.002f + 0.01f, 60000.0f);
-    }
-    const uint32_t lo = __half_as_ushort(__float2half_ru(hx)), hi = __half_as_ushort(__float2half_ru(hy));
-    return lo | (hi << 16);
-}
-__device__ __forceinline__ void splat_extent_unpack(uint32_t e, float& hx, float& hy)
-{
-    hx = __half2float(__ushort_as_half((unsigned short)(e & 0xFFFFu)));
-    hy = __half2float(__ushort_as_half((unsigned short)(e >> 16)));
-}
-
-// Segment helpers shared by the render kernels.  The 256 staged entries of a segment are tested once
-// against the tile's column range and the four 16x4 pixel strips; wave w then visits only the set
-// bits of its strip's 256-bit mask (4 x u64, wave-uniform), in ascending entry order.
-__device__ __forceinline__ bool strip_relevant(float sx, float sy, float hx, float hy, float x0, float y0, int strip)
-{
-    const float ys = y0 + 4.0f * (float)strip;
-    return (sx + hx >= x0) && (sx - hx <= x0 + 15.0f) && (sy + hy >= ys) && (sy - hy <= ys + 3.0f);
-}
-
-// Exact (up to a safety margin) version: does the footprint ellipse  A dx^2 + 2B dx dy + C dy^2 <= k,
-// k = -2 thr, intersect the strip's rectangle of pixel centres?  Minimum of the convex quadratic over
-// the rectangle: 0 if the centre is inside, otherwise on one of the four edges (1-D clamped minimum).
-// Thin diagonal splats (VEGS discs seen edge-on) have a bounding box several times their footprint.
+// Strip relevance.  The reference's tile rectangle comes from the 3-sigma radius of the LARGER axis, so
+// most tile-list entries never reach alpha >= 1/255 inside a given 16x4 pixel strip (VEGS discs are
+// thin ellipses).  Does the footprint ellipse  A dx^2 + 2B dx dy + C dy^2 <= k,  k = -2 thr, intersect
+// the strip's rectangle of pixel centres?  Minimum of the convex quadratic over the rectangle: 0 if the
+// centre is inside, otherwise on one of the four edges (1-D clamped minimum).  Conservative by
+// construction (thr already carries slack; the comparison adds a margin): a strip is only skipped when
+// the splat provably contributes nothing to it, so skipping never changes a result.
 __device__ __forceinline__ float quad_edge_min(float a, float inv_a, float b, float c, float fixed, float lo, float hi)
 {
     // min over t in [lo,hi] of  a t^2 + 2 b t fixed + c fixed^2   (inv_a ~ 1/a: an inexact minimiser only

@@ -65,6 +65,13 @@ def part_a():
     q = rng.normal(size=(32, 4)).astype(np.float32)
     cams["quat"] = q
     cams["quat_matrix"] = gu.quaternion_to_matrix(torch.tensor(q)).numpy()
+    # matrix_to_quaternion (utils/graphics_utils.py:140-201) on proper rotations, incl. near-180-degree ones
+    qn = q / np.linalg.norm(q, axis=1, keepdims=True)
+    qn[:4] = np.array([[1e-4, 1, 0, 0], [1e-4, 0, 1, 0], [1e-4, 0, 0, 1], [0.5, 0.5, 0.5, 0.5]], np.float32)
+    qn = (qn / np.linalg.norm(qn, axis=1, keepdims=True)).astype(np.float32)
+    rm = gu.quaternion_to_matrix(torch.tensor(qn))
+    cams["rotmat"] = rm.numpy()
+    cams["rotmat_quat"] = gu.matrix_to_quaternion(rm).numpy()
     np.savez_compressed(os.path.join(HERE, "ref_camera.npz"), **cams)
 
     # normal-guidance loss (the consumer of cov_quat / cov_scale): value and gradients

@@ -42,3 +42,69 @@ def render(cam, tensors, sh_degree, bg_color, scaling_modifier=1.0, debug=False,
     return {"render": rendered_image, "render_depth": depth_image, "render_cov_quat": cov_quat,
             "render_cov_scale": cov_scale, "alpha": alpha, "viewspace_points": screenspace_points,
             "visibility_filter": radii > 0, "radii": radii}
+
+
+# ---------------------------------------------------------------------------------------------
+# render_all-shaped driver: static Gaussians + dynamic box instances (reference
+# gaussian_renderer/__init__.py:121-186 prepare_rasterization / merge_kwargs, :263-333 render_all).
+# Every op input is a torch.cat of per-model tensors after a differentiable box2world transform,
+# so gradients w.r.t. means3D, scales AND rotations must be right (they flow on into
+# model/boxmodel.py:30-42).  Device-agnostic on purpose: the tests run the same graph on the CPU to
+# carry the oracle's op-input gradients back to the parameters.
+
+def quaternion_to_matrix(q):
+    """(w,x,y,z) -> rotation matrix, normalising by |q|^2 (convention of utils/graphics_utils.py:204-248)."""
+    r, i, j, k = torch.unbind(q, -1)
+    two_s = 2.0 / (q * q).sum(-1)
+    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return o.reshape(q.shape[:-1] + (3, 3))
+
+
+def matrix_to_quaternion(m):
+    """Rotation matrix -> (w,x,y,z): of the four algebraically equivalent candidates (each is the
+    quaternion scaled by one of its own components) take the best conditioned one, i.e. the one whose
+    defining component sqrt(1 +- m00 +- m11 +- m22)/2 is largest (utils/graphics_utils.py:140-201)."""
+    m00, m01, m02 = m[..., 0, 0], m[..., 0, 1], m[..., 0, 2]
+    m10, m11, m12 = m[..., 1, 0], m[..., 1, 1], m[..., 1, 2]
+    m20, m21, m22 = m[..., 2, 0], m[..., 2, 1], m[..., 2, 2]
+    sq = torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22, 1 - m00 - m11 + m22], -1)
+    q_abs = torch.sqrt(torch.clamp(sq, min=0.0) + (sq <= 0) * 1e-30) * (sq > 0)
+    cand = torch.stack([
+        torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], -1),
+        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], -1),
+        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], -1),
+        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], -1)], -2)
+    cand = cand / (2.0 * torch.clamp(q_abs, min=0.1)[..., None])
+    best = q_abs.argmax(-1)
+    return torch.gather(cand, -2, best[..., None, None].expand(best.shape + (1, 4))).squeeze(-2)
+
+
+def prepare_rasterization(t, box2world=None):
+    """Op inputs of one Gaussian model (dict means3D, shs, opacities, scales, rotations); with a 4x4
+    `box2world` the means, rotations and scales are carried into the world frame, differentiably."""
+    means3D, scales, rotations = t["means3D"], t["scales"], t["rotations"]
+    if box2world is not None:
+        ones = torch.ones(means3D.shape[0], 1, dtype=means3D.dtype, device=means3D.device)
+        hom = (box2world @ torch.cat((means3D, ones), 1).t()).t()
+        means3D = hom[:, :3] / hom[:, 3:]
+        lin = box2world[:3, :3]
+        box_scale = torch.norm(lin, dim=0, keepdim=True)
+        box_rot = lin / box_scale
+        rotations = matrix_to_quaternion(box_rot[None] @ quaternion_to_matrix(rotations))
+        scales = scales * box_scale
+    return {"means3D": means3D, "shs": t["shs"], "opacities": t["opacities"], "scales": scales, "rotations": rotations}
+
+
+def merge_kwargs(a, b):
+    return {k: torch.cat((a[k], b[k]), 0).contiguous() for k in a}
+
+
+def render_all(cam, static, boxes, box2worlds, sh_degree, bg_color, scaling_modifier=1.0, cam_t=None):
+    kw = prepare_rasterization(static)
+    for t, b2w in zip(boxes, box2worlds):
+        kw = merge_kwargs(kw, prepare_rasterization(t, b2w))
+    pkg = render(cam, kw, sh_degree, bg_color, scaling_modifier, cam_t=cam_t)
+    pkg["op_inputs"] = kw
+    return pkg

@@ -159,7 +159,7 @@ int vr_count_fragments(const VrSaved* saved, int32_t image_height, int32_t image
                        int64_t* fragments);
 
 /* ---- stage timing (HIP events recorded on `stream` around the kernels of each stage).
- * level 0 = off (default), 1 = only the two render kernels, 2 = every stage.
+ * level 0 = off (default), 1 = only the render stages (+ the k_seg_bwd kernel), 2 = every stage.
  * vr_profile_collect synchronises the recorded events, ADDS the elapsed milliseconds and launch
  * counts of each stage to ms[VR_STAGE_COUNT] / count[VR_STAGE_COUNT], and clears the record. */
 typedef enum VrStage {
@@ -173,7 +173,8 @@ typedef enum VrStage {
     VR_STAGE_BWD_ZERO = 7,
     VR_STAGE_RENDER_BWD = 8,
     VR_STAGE_PREPROCESS_BWD = 9,
-    VR_STAGE_COUNT = 10
+    VR_STAGE_K_SEG_BWD = 10, /* the single kernel k_seg_bwd inside RENDER_BWD (the dominant kernel) */
+    VR_STAGE_COUNT = 11
 } VrStage;
 int vr_profile_level(int level);
 int vr_profile_collect(double* ms, int64_t* count);

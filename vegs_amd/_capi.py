@@ -19,7 +19,7 @@ VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH = 0, 1, 2, 3
 EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_mark_visible", "vr_get_counters",
            "vr_count_fragments", "vr_debug_export_binning", "vr_profile_level", "vr_profile_collect"]
 STAGES = ["preprocess", "compact", "depth_sort", "emit", "tile_sort", "ranges", "render_fwd", "bwd_zero",
-          "render_bwd", "preprocess_bwd"]
+          "render_bwd", "preprocess_bwd", "k_seg_bwd"]
 
 
 class VrSettings(C.Structure):

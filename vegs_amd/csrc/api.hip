@@ -37,7 +37,7 @@ static bool prof_on(int stage)
 {
     int lvl = g_prof_level.load(std::memory_order_relaxed);
     if (lvl >= 2) return true;
-    return lvl == 1 && (stage == VR_STAGE_RENDER_FWD || stage == VR_STAGE_RENDER_BWD);
+    return lvl == 1 && (stage == VR_STAGE_RENDER_FWD || stage == VR_STAGE_RENDER_BWD || stage == VR_STAGE_K_SEG_BWD);
 }
 static hipEvent_t prof_event()
 {

@@ -24,6 +24,7 @@
 // Per-splat gradients stay in registers until the chunk is finished; the four waves (pixel strips)
 // of the tile are reduced through LDS and one coalesced set of global atomics per (tile, splat) is
 // issued -- 256x fewer atomics than one per fragment.
+#include "../../include/vegs_rast.h"
 #include "vr_host.h"
 #include "vr_segment.h"
 
@@ -325,9 +326,11 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
     VR_KERNEL_CHECK("seg_u", s, debug);
     hipLaunchKernelGGL(k_seg_suffix, dim3(ntiles), dim3(256), 0, s, seg_off, seg_needed, Ubuf);
     VR_KERNEL_CHECK("seg_suffix", s, debug);
+    prof_begin(VR_STAGE_K_SEG_BWD, s);
     hipLaunchKernelGGL(k_seg_bwd, dim3(nseg), dim3(256), 0, s, cam, ranges, seg_off, seg_needed, point_list, rec, Tbuf,
                        (const float*)Ubuf, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, dL_dalpha,
                        gacc, gmean2D, segmask);
+    prof_end(VR_STAGE_K_SEG_BWD, s);
     VR_KERNEL_CHECK("seg_bwd", s, debug);
     return 0;
 }

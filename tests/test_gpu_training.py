@@ -1,0 +1,52 @@
+"""GPU (-m gpu): the operator is usable for what VEGS uses it for -- gradient-based fitting.  A small
+scene is optimised with Adam (the optimiser of scene/gaussian_model.py:154-172, same activations as
+scene/gaussian_model.py:38-46,100-120) against images rendered from a ground-truth scene; the
+photometric loss must fall substantially and stay finite, the densification statistics must be filled."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fitting_a_small_scene_reduces_the_loss():
+    from vegs_amd import harness, scenes
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    gt, deg = scenes.scene_random(P=1500, sh_degree=1, seed=5, scale=0.05)
+    cams = [scenes.lookat_camera([2.0 * np.cos(a), 2.0 * np.sin(a), 0.3], [0, 0, 0], [0, 0, 1.0], 96, 80, 45.0)
+            for a in np.linspace(0, 2 * np.pi, 6, endpoint=False)]
+    bg = torch.zeros(3, device=dev)
+    gt_t = {k: torch.tensor(v, device=dev) for k, v in gt.items()}
+    with torch.no_grad():
+        targets = [harness.render(c, gt_t, deg, bg)["render"].clone() for c in cams]
+
+    # trainable copy, perturbed; raw parameters + the reference's activations
+    g = torch.Generator(device="cpu").manual_seed(0)
+    xyz = (gt_t["means3D"] + 0.03 * torch.randn(1500, 3, generator=g).to(dev)).requires_grad_(True)
+    shs = (gt_t["shs"] * 0.0).requires_grad_(True)                       # start grey
+    scal = torch.log(gt_t["scales"] * 1.3).requires_grad_(True)           # exp activation
+    rot = (gt_t["rotations"] + 0.1 * torch.randn(1500, 4, generator=g).to(dev)).requires_grad_(True)
+    opa = torch.logit(gt_t["opacities"].clamp(0.05, 0.95)).requires_grad_(True)
+    opt = torch.optim.Adam([{"params": [xyz], "lr": 1e-3}, {"params": [shs], "lr": 2e-2}, {"params": [scal], "lr": 5e-3},
+                            {"params": [rot], "lr": 1e-3}, {"params": [opa], "lr": 2e-2}], eps=1e-15)
+    grad_accum = torch.zeros(1500, 1, device=dev)
+    denom = torch.zeros(1500, 1, device=dev)
+    losses = []
+    for it in range(120):
+        v = it % len(cams)
+        t = {"means3D": xyz, "shs": shs, "scales": torch.exp(scal),
+             "rotations": torch.nn.functional.normalize(rot), "opacities": torch.sigmoid(opa)}
+        pkg = harness.render(cams[v], t, deg, bg)
+        loss = (pkg["render"] - targets[v]).abs().mean()
+        loss.backward()
+        vis = pkg["visibility_filter"]
+        grad_accum[vis] += torch.norm(pkg["viewspace_points"].grad[vis, :2], dim=-1, keepdim=True)   # gaussian_model.py:411-413
+        denom[vis] += 1
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        losses.append(loss.item())
+    first, last = np.mean(losses[:6]), np.mean(losses[-6:])
+    assert np.isfinite(losses).all()
+    assert last < 0.5 * first, (first, last)
+    assert (denom > 0).sum() > 1000 and torch.isfinite(grad_accum).all() and grad_accum.sum() > 0

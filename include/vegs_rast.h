@@ -151,6 +151,11 @@ int vr_backward(const VrSettings* settings, const VrInputs* in, const int32_t* r
 int vr_mark_visible(const float* xyz, int32_t P, const float* viewmatrix, const float* projmatrix,
                     uint8_t* present, void* stream);
 
+/* Replacement for the reference's second native dependency, simple_knn._C.distCUDA2 (imported at
+ * scene/gaussian_model.py:21, called at :140 and :517): out[i] = mean of the squared distances from
+ * points[i] to its three nearest other points (exact).  points [N,3], out [N]; scratch via `alloc`. */
+int vr_knn3_mean_dist2(const float* points, int32_t N, float* out, VrAllocFn alloc, void* alloc_user, void* stream);
+
 void vr_get_counters(VrCounters* out);
 
 /* F = sum over pixels of n_contrib (fragments traversed by the forward blend loop) of the

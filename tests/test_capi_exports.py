@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_functions():
     src = open(os.path.join(ROOT, "include", "vegs_rast.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"\b(vr_[a-z_]+)\s*\(", src)
+    names = re.findall(r"\b(vr_[a-z0-9_]+)\s*\(", src)
     return sorted(set(names))
 
 

@@ -17,7 +17,8 @@ VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH = 0, 1, 2, 3
 
 # every symbol include/vegs_rast.h declares
 EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_mark_visible", "vr_get_counters",
-           "vr_count_fragments", "vr_debug_export_binning", "vr_profile_level", "vr_profile_collect"]
+           "vr_count_fragments", "vr_debug_export_binning", "vr_profile_level", "vr_profile_collect",
+           "vr_knn3_mean_dist2"]
 STAGES = ["preprocess", "compact", "depth_sort", "emit", "tile_sort", "ranges", "render_fwd", "bwd_zero",
           "render_bwd", "preprocess_bwd", "k_seg_bwd"]
 
@@ -95,6 +96,8 @@ def load():
     lib.vr_debug_export_binning.restype = C.c_int
     lib.vr_debug_export_binning.argtypes = [C.POINTER(VrSaved), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_void_p]
+    lib.vr_knn3_mean_dist2.restype = C.c_int
+    lib.vr_knn3_mean_dist2.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, VrAllocFn, C.c_void_p, C.c_void_p]
     lib.vr_profile_level.restype = C.c_int
     lib.vr_profile_level.argtypes = [C.c_int]
     lib.vr_profile_collect.restype = C.c_int

@@ -376,6 +376,16 @@ int vr_mark_visible(const float* xyz, int32_t P, const float* viewmatrix, const 
     return launch_mark_visible(xyz, P, viewmatrix, present, (hipStream_t)stream);
 }
 
+int vr_knn3_mean_dist2(const float* points, int32_t N, float* out, VrAllocFn alloc, void* user, void* stream)
+{
+    g_err[0] = 0;
+    if (N < 0 || (N > 0 && (!points || !out || !alloc))) return fail(VR_ERR_INVALID_ARGUMENT, "knn3: bad arguments");
+    if (N == 0) return VR_OK;
+    void* scr = alloc(user, VR_BUF_SCRATCH, knn3_scratch_bytes(N));
+    if (!scr) return fail(VR_ERR_ALLOC, "allocator returned NULL");
+    return launch_knn3(points, N, out, scr, (hipStream_t)stream, false);
+}
+
 int vr_count_fragments(const VrSaved* saved, int32_t H, int32_t W, void* stream, int64_t* fragments)
 {
     g_err[0] = 0;

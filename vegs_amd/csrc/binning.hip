@@ -411,6 +411,24 @@ int radix_sort_passes(int nbits)
     return nbits <= 0 ? 0 : cdiv(nbits, radix_digit(nbits));
 }
 
+// generic entry for other translation units (knn.hip): sort (key,val) pairs on the low nbits of key - kmin
+size_t sort_pairs_scratch_bytes(long n)
+{
+    const size_t nblk = (size_t)cdiv(n > 0 ? n : 1, RADIX_BLOCK);
+    const size_t scan_n = nblk * 512 > (size_t)n ? nblk * 512 : (size_t)n;
+    return align_up(nblk * 512 * 4, 256) + align_up((size_t)cdiv((long)scan_n, SCAN_BLOCK) * 4 + 256, 256);
+}
+int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long n, uint32_t kmin, int nbits,
+                      void* scratch, hipStream_t s, bool debug, int* where)
+{
+    const size_t nblk = (size_t)cdiv(n > 0 ? n : 1, RADIX_BLOCK);
+    uint32_t* hist = (uint32_t*)scratch;
+    uint32_t* bsum = (uint32_t*)((char*)scratch + align_up(nblk * 512 * 4, 256));
+    *where = 0;
+    if (n <= 0) return 0;
+    return radix_sort(k0, v0, k1, v1, n, kmin, nbits, hist, bsum, s, debug, where);
+}
+
 // ---------------------------------------------------------------- emission + ranges
 
 // One block per 256 depth-sorted Gaussians; lanes are spread over OUTPUT entries (binary search in

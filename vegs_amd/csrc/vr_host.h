@@ -63,6 +63,16 @@ size_t binning_stage2_scratch_bytes(int V, long R, int ntiles);
 int launch_binning(const Camera& cam, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
                    uint32_t* vis_id, const uint2* rect, void* scratch, uint32_t* point_list, int2* ranges, hipStream_t s, bool debug);
 
+// stable LSD radix sort of (key,val) u32 pairs on the low nbits of (key - kmin); ping-pongs between the two
+// pairs, *where = 0/1 tells which pair holds the result
+size_t sort_pairs_scratch_bytes(long n);
+int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long n, uint32_t kmin, int nbits,
+                      void* scratch, hipStream_t s, bool debug, int* where);
+
+// ---- knn.hip (simple-knn replacement)
+size_t knn3_scratch_bytes(int N);
+int launch_knn3(const float* points, int N, float* out, void* scratch, hipStream_t s, bool debug);
+
 // ---- render_fwd.hip / render_bwd.hip (segmented compositing)
 // upper bound on the number of 256-entry segments: sum_t ceil(n_t/256) <= R/256 + T
 static inline size_t seg_capacity(long R, int ntiles) { return (size_t)(R / 256 + ntiles); }

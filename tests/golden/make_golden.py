@@ -9,6 +9,7 @@ nothing of it is copied -- only inputs and outputs are stored):
     :305-337 getProjectionMatrixwithPrincipalPointOffset, :342-343 focal2fov -> ref_camera.npz
   * loss/normal_guidance.py:3-22 loss_normal_guidance (value + gradients w.r.t.
     cov_quat / cov_scale)                        -> ref_normal_guidance.npz
+  * utils/loss_utils.py:18-22 l1_loss, :39-79 ssim (values + gradients)  -> ref_photometric.npz
 Part B runs the independent float64 autograd restatement oracle/torch_ref.py on tiny
 seeded scenes (vegs_amd/scenes.py) and stores inputs, forward images and input gradients
 -> raster_case*.npz.  These pin vr_oracle.c and, on the GPU box, the HIP kernels.
@@ -89,6 +90,27 @@ def part_a():
     np.savez_compressed(os.path.join(HERE, "ref_normal_guidance.npz"), normal=cam.original_normal.numpy(), R=cam.R,
                         cov_quat=cq.detach().numpy(), cov_scale=cs.detach().numpy(), loss=loss.item(),
                         grad_cov_quat=cq.grad.numpy(), grad_cov_scale=cs.grad.numpy())
+
+    # photometric losses (utils/loss_utils.py:18-22 l1_loss, :39-79 ssim) exactly as train.py:162-164 combines
+    # them: values and d/d(image) by torch autograd, on small images with all border cases
+    import utils.loss_utils as lu
+    blob = {}
+    for tag, (H, W) in {"a": (37, 53), "b": (16, 16), "c": (9, 40)}.items():     # c: image smaller than the window
+        img = torch.tensor(rng.uniform(0, 1, (3, H, W)).astype(np.float32), requires_grad=True)
+        gt = torch.tensor(np.clip(img.detach().numpy() + rng.normal(0, 0.15, (3, H, W)), 0, 1).astype(np.float32))
+        gt[:, :3, :5] = img.detach()[:, :3, :5]                                   # exact zeros of |x-y|
+        l1 = lu.l1_loss(img, gt)
+        ss = lu.ssim(img, gt)
+        g_l1, = torch.autograd.grad(l1, img, retain_graph=True)
+        g_ss, = torch.autograd.grad(ss, img, retain_graph=True)
+        lam = 0.2                                                                 # arguments/__init__.py:90
+        loss = (1.0 - lam) * l1 + lam * (1.0 - ss)
+        g_loss, = torch.autograd.grad(loss, img)
+        blob.update({f"img_{tag}": img.detach().numpy(), f"gt_{tag}": gt.numpy(), f"l1_{tag}": l1.item(),
+                     f"ssim_{tag}": ss.item(), f"grad_l1_{tag}": g_l1.numpy(), f"grad_ssim_{tag}": g_ss.numpy(),
+                     f"loss_{tag}": loss.item(), f"grad_loss_{tag}": g_loss.numpy()})
+    blob["window"] = lu.gaussian(11, 1.5).numpy()
+    np.savez_compressed(os.path.join(HERE, "ref_photometric.npz"), **blob)
 
 
 CASES = {

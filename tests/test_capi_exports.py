@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_functions():
-    src = open(os.path.join(ROOT, "include", "vegs_rast.h")).read()
+    inc = os.path.join(ROOT, "include")
+    src = "".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = re.findall(r"\b(vr_[a-z0-9_]+)\s*\(", src)
     return sorted(set(names))

@@ -117,3 +117,33 @@ def test_oracle_mark_visible():
     far = np.abs(z - 0.2) > 1e-5
     assert np.array_equal(vis[far], (z > 0.2)[far])
     assert 0 < vis.sum() < len(vis)
+
+
+# ---- row N1: per-pixel losses.  oracle/loss_oracle.py against outputs of the reference's own functions.
+def test_loss_oracle_photometric_matches_reference_outputs():
+    from oracle import loss_oracle as lo
+    z = np.load(os.path.join(GOLDEN, "ref_photometric.npz"))
+    assert np.abs(lo.gaussian_window() - z["window"]).max() < 3e-8        # utils/loss_utils.py:30-32 (1 ulp: sum order)
+    for tag in "abc":
+        x, y = z[f"img_{tag}"], z[f"gt_{tag}"]
+        l1, ss, _ = lo.photometric(x, y)
+        assert abs(l1 - z[f"l1_{tag}"]) < 2e-7 and abs(ss - z[f"ssim_{tag}"]) < 2e-6
+        n = x.size
+        for (gl, gs), key in {(1.0, 0.0): "grad_l1", (0.0, 1.0): "grad_ssim", (0.8, -0.2): "grad_loss"}.items():
+            g = lo.photometric(x, y, gl, gs)[2]
+            want = z[f"{key}_{tag}"]
+            assert np.abs(g - want).max() < 2e-5 / n + 2e-4 * np.abs(want).max(), (tag, key)
+        assert abs((0.8 * l1 + 0.2 * (1 - ss)) - z[f"loss_{tag}"]) < 1e-6       # train.py:164, lambda_dssim = 0.2
+
+
+def test_loss_oracle_normal_guidance_matches_reference_outputs():
+    from oracle import loss_oracle as lo
+    z = np.load(os.path.join(GOLDEN, "ref_normal_guidance.npz"))
+    loss, dq, ds = lo.normal_guidance(z["cov_quat"], z["cov_scale"], z["normal"], z["R"])
+    assert abs(loss - z["loss"]) < 1e-6
+    assert np.abs(dq - z["grad_cov_quat"]).max() < 1e-6 * max(1.0, np.abs(z["grad_cov_quat"]).max() * 1e2)
+    assert rel_err(dq, z["grad_cov_quat"]) < 1e-4 and rel_err(ds, z["grad_cov_scale"]) < 1e-5
+    # an uncovered pixel (cov_quat = 0) poisons the reference's loss with NaN (2/|q|^2 = inf); the restatement keeps that
+    q0 = z["cov_quat"].copy()
+    q0[:, 0, 0] = 0
+    assert np.isnan(lo.normal_guidance(q0, z["cov_scale"], z["normal"], z["R"])[0])

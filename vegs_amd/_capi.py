@@ -18,7 +18,8 @@ VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH = 0, 1, 2, 3
 # every symbol include/vegs_rast.h declares
 EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_mark_visible", "vr_get_counters",
            "vr_count_fragments", "vr_debug_export_binning", "vr_profile_level", "vr_profile_collect",
-           "vr_knn3_mean_dist2"]
+           "vr_knn3_mean_dist2", "vr_photometric_forward", "vr_photometric_backward",
+           "vr_normal_guidance_forward", "vr_normal_guidance_backward"]
 STAGES = ["preprocess", "compact", "depth_sort", "emit", "tile_sort", "ranges", "render_fwd", "bwd_zero",
           "render_bwd", "preprocess_bwd", "k_seg_bwd"]
 
@@ -98,6 +99,15 @@ def load():
                                             C.c_void_p]
     lib.vr_knn3_mean_dist2.restype = C.c_int
     lib.vr_knn3_mean_dist2.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, VrAllocFn, C.c_void_p, C.c_void_p]
+    vp, i32 = C.c_void_p, C.c_int32
+    lib.vr_photometric_forward.restype = C.c_int
+    lib.vr_photometric_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, VrAllocFn, vp, vp]
+    lib.vr_photometric_backward.restype = C.c_int
+    lib.vr_photometric_backward.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.vr_normal_guidance_forward.restype = C.c_int
+    lib.vr_normal_guidance_forward.argtypes = [vp, vp, vp, C.POINTER(C.c_float), i32, i32, vp, VrAllocFn, vp, vp]
+    lib.vr_normal_guidance_backward.restype = C.c_int
+    lib.vr_normal_guidance_backward.argtypes = [vp, vp, vp, C.POINTER(C.c_float), i32, i32, vp, vp, vp, vp]
     lib.vr_profile_level.restype = C.c_int
     lib.vr_profile_level.argtypes = [C.c_int]
     lib.vr_profile_collect.restype = C.c_int

@@ -7,7 +7,7 @@
 #include <mutex>
 #include <vector>
 
-#include "../../include/vegs_rast.h"
+#include "../../include/vegs_loss.h"
 #include "vr_host.h"
 
 namespace vr {
@@ -384,6 +384,50 @@ int vr_knn3_mean_dist2(const float* points, int32_t N, float* out, VrAllocFn all
     void* scr = alloc(user, VR_BUF_SCRATCH, knn3_scratch_bytes(N));
     if (!scr) return fail(VR_ERR_ALLOC, "allocator returned NULL");
     return launch_knn3(points, N, out, scr, (hipStream_t)stream, false);
+}
+
+int vr_photometric_forward(const float* image, const float* gt, int32_t C, int32_t H, int32_t W, float* sums, float* dmaps,
+                           VrAllocFn alloc, void* user, void* stream)
+{
+    g_err[0] = 0;
+    if (C <= 0 || H <= 0 || W <= 0) return fail(VR_ERR_INVALID_ARGUMENT, "image must be [C,H,W] with positive sizes");
+    if (!image || !gt || !sums || !alloc) return fail(VR_ERR_INVALID_ARGUMENT, "image, gt, sums and alloc are required");
+    void* scr = alloc(user, VR_BUF_SCRATCH, photometric_scratch_bytes(C, H, W));
+    if (!scr) return fail(VR_ERR_ALLOC, "allocator returned NULL");
+    return launch_photometric_fwd(image, gt, C, H, W, sums, dmaps, scr, (hipStream_t)stream, false);
+}
+
+int vr_photometric_backward(const float* image, const float* gt, int32_t C, int32_t H, int32_t W, const float* dmaps,
+                            const float* g_l1, const float* g_ssim, float* dL_dimage, void* stream)
+{
+    g_err[0] = 0;
+    if (C <= 0 || H <= 0 || W <= 0) return fail(VR_ERR_INVALID_ARGUMENT, "image must be [C,H,W] with positive sizes");
+    if (!image || !gt || !dmaps || !dL_dimage)
+        return fail(VR_ERR_INVALID_ARGUMENT, "image, gt, dmaps and dL_dimage are required");
+    return launch_photometric_bwd(image, gt, C, H, W, dmaps, g_l1, g_ssim, dL_dimage, (hipStream_t)stream, false);
+}
+
+int vr_normal_guidance_forward(const float* cov_quat, const float* cov_scale, const float* normal, const float* R,
+                               int32_t H, int32_t W, float* loss, VrAllocFn alloc, void* user, void* stream)
+{
+    g_err[0] = 0;
+    if (H <= 0 || W <= 0) return fail(VR_ERR_INVALID_ARGUMENT, "maps must be [k,H,W] with positive sizes");
+    if (!cov_quat || !cov_scale || !normal || !R || !loss || !alloc)
+        return fail(VR_ERR_INVALID_ARGUMENT, "cov_quat, cov_scale, normal, R_cam2world, loss and alloc are required");
+    void* scr = alloc(user, VR_BUF_SCRATCH, normal_guidance_scratch_bytes(H, W));
+    if (!scr) return fail(VR_ERR_ALLOC, "allocator returned NULL");
+    return launch_normal_guidance_fwd(cov_quat, cov_scale, normal, R, H, W, loss, scr, (hipStream_t)stream, false);
+}
+
+int vr_normal_guidance_backward(const float* cov_quat, const float* cov_scale, const float* normal, const float* R,
+                                int32_t H, int32_t W, const float* g, float* dL_dquat, float* dL_dscale, void* stream)
+{
+    g_err[0] = 0;
+    if (H <= 0 || W <= 0) return fail(VR_ERR_INVALID_ARGUMENT, "maps must be [k,H,W] with positive sizes");
+    if (!cov_quat || !cov_scale || !normal || !R || !g || !dL_dquat || !dL_dscale)
+        return fail(VR_ERR_INVALID_ARGUMENT, "all pointers are required");
+    return launch_normal_guidance_bwd(cov_quat, cov_scale, normal, R, H, W, g, dL_dquat, dL_dscale, (hipStream_t)stream,
+                                      false);
 }
 
 int vr_count_fragments(const VrSaved* saved, int32_t H, int32_t W, void* stream, int64_t* fragments)

@@ -73,6 +73,18 @@ int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, lo
 size_t knn3_scratch_bytes(int N);
 int launch_knn3(const float* points, int N, float* out, void* scratch, hipStream_t s, bool debug);
 
+// losses.hip
+size_t photometric_scratch_bytes(int C, int H, int W);
+int launch_photometric_fwd(const float* image, const float* gt, int C, int H, int W, float* sums, float* dmaps,
+                           void* scratch, hipStream_t s, bool debug);
+int launch_photometric_bwd(const float* image, const float* gt, int C, int H, int W, const float* dmaps,
+                           const float* g_l1, const float* g_ssim, float* dL_dimage, hipStream_t s, bool debug);
+size_t normal_guidance_scratch_bytes(int H, int W);
+int launch_normal_guidance_fwd(const float* cov_quat, const float* cov_scale, const float* normal, const float* R9, int H,
+                               int W, float* loss, void* scratch, hipStream_t s, bool debug);
+int launch_normal_guidance_bwd(const float* cov_quat, const float* cov_scale, const float* normal, const float* R9, int H,
+                               int W, const float* g, float* dL_dquat, float* dL_dscale, hipStream_t s, bool debug);
+
 // ---- render_fwd.hip / render_bwd.hip (segmented compositing)
 // upper bound on the number of 256-entry segments: sum_t ceil(n_t/256) <= R/256 + T
 static inline size_t seg_capacity(long R, int ntiles) { return (size_t)(R / 256 + ntiles); }

@@ -1,0 +1,160 @@
+"""Host-side mirror of the reference's per-pixel training losses, computed by fused HIP kernels
+(vegs_amd/csrc/losses.hip through the C ABI of include/vegs_loss.h).  Same names, argument meaning
+and results as the reference functions they replace, so VEGS' train.py:162-167 can import them
+unchanged:
+
+    from vegs_amd.losses import l1_loss, ssim, loss_normal_guidance
+
+  l1_loss(network_output, gt)                       utils/loss_utils.py:18-22
+  ssim(img1, img2, window_size=11, size_average=True)  utils/loss_utils.py:39-79
+  loss_normal_guidance(viewpoint_cam, cov_quat, cov_scale)   loss/normal_guidance.py:3-22
+  photometric_loss(image, gt, lambda_dssim)         the combination of train.py:162-164 in one call
+
+Both l1_loss and ssim of the same (image, gt) pair share ONE forward kernel and ONE backward kernel:
+the pair (l1 mean, ssim mean) is computed once and cached on the image tensor's identity/version, so
+train.py's two separate calls cost one launch.  GPU tensors only; there is no CPU path.
+"""
+import ctypes as C
+import weakref
+
+import torch
+
+from . import _capi
+
+
+def _check_image_pair(a, b):
+    if not (isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor)):
+        raise TypeError("image and gt must be tensors")
+    if not a.is_cuda or not b.is_cuda:
+        raise ValueError("image and gt must be GPU tensors (the fused losses have no CPU path)")
+    if a.shape != b.shape or a.dim() not in (3, 4):
+        raise ValueError(f"image {tuple(a.shape)} and gt {tuple(b.shape)} must have the same [C,H,W] shape")
+    if a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise ValueError("image and gt must be float32")
+
+
+def _scratch_call(device, fn):
+    arena = _capi.Arena(device)
+    cb = arena.callback()
+    try:
+        with torch.cuda.device(device):
+            rc = fn(cb)
+    finally:
+        del cb
+        arena.release_scratch()
+    if arena.error is not None:
+        raise arena.error
+    _capi.check(rc)
+
+
+class _PhotometricSums(torch.autograd.Function):
+    """(image, gt) -> tensor [2] = (mean |image - gt|, mean SSIM map)."""
+
+    @staticmethod
+    def forward(ctx, image, gt):
+        lib = _capi.load()
+        img = image.contiguous()
+        ref = gt.contiguous()
+        Cn, H, W = (img.shape[-3] * (img.shape[0] if img.dim() == 4 else 1)), img.shape[-2], img.shape[-1]
+        sums = torch.empty(2, dtype=torch.float32, device=img.device)
+        need_grad = ctx.needs_input_grad[0]
+        dmaps = torch.empty((3,) + tuple(img.shape), dtype=torch.float32, device=img.device) if need_grad else None
+        stream = torch.cuda.current_stream(img.device).cuda_stream
+        _scratch_call(img.device, lambda cb: lib.vr_photometric_forward(
+            _capi.ptr(img), _capi.ptr(ref), Cn, H, W, _capi.ptr(sums), _capi.ptr(dmaps), cb, None, stream))
+        ctx.save_for_backward(img, ref, dmaps)
+        ctx.dims = (Cn, H, W)
+        return sums
+
+    @staticmethod
+    def backward(ctx, g_sums):
+        lib = _capi.load()
+        img, ref, dmaps = ctx.saved_tensors
+        Cn, H, W = ctx.dims
+        g = g_sums.to(torch.float32).contiguous()
+        grad = torch.empty_like(img)
+        with torch.cuda.device(img.device):
+            rc = lib.vr_photometric_backward(_capi.ptr(img), _capi.ptr(ref), Cn, H, W, _capi.ptr(dmaps), g.data_ptr(),
+                                             g.data_ptr() + 4, _capi.ptr(grad),
+                                             torch.cuda.current_stream(img.device).cuda_stream)
+        _capi.check(rc)
+        return grad, None
+
+
+_last = {"key": None, "sums": None}
+
+
+def _sums(image, gt):
+    """(l1 mean, ssim mean) of the pair, sharing one kernel launch between train.py's two calls."""
+    key = (id(image), image._version, id(gt), gt._version, image.data_ptr(), gt.data_ptr(), torch.is_grad_enabled())
+    if _last["key"] == key and _last["img"]() is image:
+        return _last["sums"]
+    sums = _PhotometricSums.apply(image, gt)
+    _last.update(key=key, sums=sums, img=weakref.ref(image))
+    return sums
+
+
+def l1_loss(network_output, gt, mask=None):
+    if mask is not None:
+        raise NotImplementedError("masked l1_loss is not on the training path (train.py:162) and is not fused")
+    _check_image_pair(network_output, gt)
+    return _sums(network_output, gt)[0]
+
+
+def ssim(img1, img2, window_size=11, size_average=True, inst_mask=None):
+    if window_size != 11 or not size_average or inst_mask is not None:
+        raise NotImplementedError("only the training-path call ssim(image, gt) (train.py:164) is fused")
+    _check_image_pair(img1, img2)
+    return _sums(img1, img2)[1]
+
+
+def photometric_loss(image, gt, lambda_dssim):
+    """(1 - lambda) * Ll1 + lambda * (1 - ssim)   (train.py:162-164).  Returns (loss, Ll1)."""
+    _check_image_pair(image, gt)
+    s = _PhotometricSums.apply(image, gt)
+    return (1.0 - lambda_dssim) * s[0] + lambda_dssim * (1.0 - s[1]), s[0]
+
+
+class _NormalGuidance(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cov_quat, cov_scale, normal, R9):
+        lib = _capi.load()
+        q, s, n = cov_quat.contiguous(), cov_scale.contiguous(), normal.contiguous()
+        H, W = n.shape[-2], n.shape[-1]
+        loss = torch.empty((), dtype=torch.float32, device=q.device)
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+        _scratch_call(q.device, lambda cb: lib.vr_normal_guidance_forward(
+            _capi.ptr(q), _capi.ptr(s), _capi.ptr(n), R9, H, W, _capi.ptr(loss), cb, None, stream))
+        ctx.save_for_backward(q, s, n)
+        ctx.R9 = R9
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _capi.load()
+        q, s, n = ctx.saved_tensors
+        H, W = n.shape[-2], n.shape[-1]
+        g = g.to(torch.float32).contiguous()
+        dq, ds = torch.empty_like(q), torch.empty_like(s)
+        with torch.cuda.device(q.device):
+            rc = lib.vr_normal_guidance_backward(_capi.ptr(q), _capi.ptr(s), _capi.ptr(n), ctx.R9, H, W, g.data_ptr(),
+                                                 _capi.ptr(dq), _capi.ptr(ds),
+                                                 torch.cuda.current_stream(q.device).cuda_stream)
+        _capi.check(rc)
+        return dq, ds, None, None
+
+
+def loss_normal_guidance(viewpoint_cam, cov_quat, cov_scale):
+    """loss/normal_guidance.py:3-22: `viewpoint_cam` needs .original_normal [3,H,W] (camera frame, GPU) and
+    .R (3x3 cam->world, numpy/array-like, host)."""
+    normal = viewpoint_cam.original_normal
+    for name, t, k in (("cov_quat", cov_quat, 4), ("cov_scale", cov_scale, 3), ("original_normal", normal, 3)):
+        if not t.is_cuda:
+            raise ValueError(f"{name} must be a GPU tensor (the fused losses have no CPU path)")
+        if t.dim() != 3 or t.shape[0] != k or t.shape[1:] != normal.shape[1:] or t.dtype != torch.float32:
+            raise ValueError(f"{name} must be float32 [{k},H,W] (got {tuple(t.shape)}, {t.dtype})")
+    Rflat = [float(v) for row in viewpoint_cam.R for v in row]
+    if len(Rflat) != 9:
+        raise ValueError("viewpoint_cam.R must be 3x3")
+    R9 = (C.c_float * 9)(*Rflat)
+    return _NormalGuidance.apply(cov_quat, cov_scale, normal, R9)

@@ -19,7 +19,7 @@ VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH = 0, 1, 2, 3
 EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_mark_visible", "vr_get_counters",
            "vr_count_fragments", "vr_debug_export_binning", "vr_profile_level", "vr_profile_collect",
            "vr_knn3_mean_dist2", "vr_photometric_forward", "vr_photometric_backward",
-           "vr_normal_guidance_forward", "vr_normal_guidance_backward"]
+           "vr_normal_guidance_forward", "vr_normal_guidance_backward", "vr_adam_step", "vr_densify_stats"]
 STAGES = ["preprocess", "compact", "depth_sort", "emit", "tile_sort", "ranges", "render_fwd", "bwd_zero",
           "render_bwd", "preprocess_bwd", "k_seg_bwd"]
 
@@ -56,6 +56,11 @@ class VrInGrads(C.Structure):
     _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
                 ("dL_dcolors_precomp", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
                 ("dL_drotations", C.c_void_p), ("dL_dcov3D_precomp", C.c_void_p)]
+
+
+class VrAdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_int64), ("lr", C.c_double), ("step", C.c_int64)]
 
 
 class VrCounters(C.Structure):
@@ -108,6 +113,10 @@ def load():
     lib.vr_normal_guidance_forward.argtypes = [vp, vp, vp, C.POINTER(C.c_float), i32, i32, vp, VrAllocFn, vp, vp]
     lib.vr_normal_guidance_backward.restype = C.c_int
     lib.vr_normal_guidance_backward.argtypes = [vp, vp, vp, C.POINTER(C.c_float), i32, i32, vp, vp, vp, vp]
+    lib.vr_adam_step.restype = C.c_int
+    lib.vr_adam_step.argtypes = [C.POINTER(VrAdamTensor), i32, C.c_double, C.c_double, C.c_double, vp]
+    lib.vr_densify_stats.restype = C.c_int
+    lib.vr_densify_stats.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     lib.vr_profile_level.restype = C.c_int
     lib.vr_profile_level.argtypes = [C.c_int]
     lib.vr_profile_collect.restype = C.c_int

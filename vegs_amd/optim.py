@@ -1,0 +1,89 @@
+"""Host-side mirror of the per-Gaussian update that follows loss.backward() in a VEGS iteration, computed
+by fused HIP kernels (vegs_amd/csrc/optim.hip, C ABI include/vegs_optim.h):
+
+  Adam(params, lr, betas, eps)          drop-in for torch.optim.Adam as scene/gaussian_model.py:159-168 builds it
+                                        (six named groups, eps=1e-15) and train.py:319-320 steps it
+  add_densification_stats(...)          scene/gaussian_model.py:411-413 + the max_radii2D line of train.py:299
+
+`Adam` is a torch.optim.Optimizer: param_groups (with the reference's extra "name" keys) and the per-parameter
+state dict {"step", "exp_avg", "exp_avg_sq"} have torch's layout, because the reference's densification code
+edits them in place (scene/gaussian_model.py:263-331: _prune_optimizer, cat_tensors_to_optimizer,
+replace_tensor_to_optimizer) and checkpoints them with state_dict().  One kernel launch updates all groups.
+GPU tensors only; there is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0 or amsgrad:
+            raise NotImplementedError("the fused Adam covers the reference's configuration: no weight decay, no amsgrad")
+        if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
+            raise ValueError("invalid Adam hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _capi.load()
+        by_cfg = {}
+        keep = []                                            # keeps contiguous gradient copies alive until launch
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise ValueError("fused Adam expects GPU parameters (there is no CPU path)")
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse:
+                    raise ValueError("fused Adam expects dense float32 parameters and gradients")
+                if not p.is_contiguous():
+                    raise ValueError("fused Adam expects contiguous parameters")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                m, v = st["exp_avg"], st["exp_avg_sq"]
+                if m.shape != p.shape or v.shape != p.shape or not m.is_contiguous() or not v.is_contiguous():
+                    raise ValueError("optimizer state does not match its parameter")
+                keep.append(g)
+                by_cfg.setdefault((p.device, float(b1), float(b2), float(group["eps"])), []).append(
+                    _capi.VrAdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                                       float(group["lr"]), int(st["step"].item())))
+        for (device, b1, b2, eps), items in by_cfg.items():
+            arr = (_capi.VrAdamTensor * len(items))(*items)
+            with torch.cuda.device(device):
+                rc = lib.vr_adam_step(arr, len(items), b1, b2, eps, torch.cuda.current_stream(device).cuda_stream)
+            _capi.check(rc)
+        return loss
+
+
+def add_densification_stats(viewspace_point_grad, radii, xyz_gradient_accum, denom, max_radii2D):
+    """In place, for every Gaussian with radii > 0 (the reference's visibility_filter, gaussian_renderer/__init__.py:117):
+    xyz_gradient_accum += ||viewspace_point_grad[:, :2]||, denom += 1 (scene/gaussian_model.py:411-413) and
+    max_radii2D = max(max_radii2D, radii) (train.py:299)."""
+    P = radii.shape[0]
+    for name, t, shape, dt in (("viewspace_point_grad", viewspace_point_grad, (P, 3), torch.float32),
+                               ("radii", radii, (P,), torch.int32),
+                               ("xyz_gradient_accum", xyz_gradient_accum, (P, 1), torch.float32),
+                               ("denom", denom, (P, 1), torch.float32), ("max_radii2D", max_radii2D, (P,), torch.float32)):
+        if not t.is_cuda:
+            raise ValueError(f"{name} must be a GPU tensor (there is no CPU path)")
+        if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous {dt} {shape} (got {t.dtype} {tuple(t.shape)})")
+    lib = _capi.load()
+    with torch.cuda.device(radii.device):
+        rc = lib.vr_densify_stats(_capi.ptr(viewspace_point_grad), _capi.ptr(radii), P, _capi.ptr(xyz_gradient_accum),
+                                  _capi.ptr(denom), _capi.ptr(max_radii2D),
+                                  torch.cuda.current_stream(radii.device).cuda_stream)
+    _capi.check(rc)

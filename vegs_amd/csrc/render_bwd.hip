@@ -68,6 +68,34 @@ __device__ __forceinline__ float wave_prefix_add(float v)
     return v;
 }
 
+// two independent scans interleaved: the other chain's instruction fills one of the two DPP wait states
+#define VR_DPP2(op, ctl)                                                        \
+    op " %0, %0, %0 " ctl "\n\t" op " %1, %1, %1 " ctl "\n\ts_nop 0\n\t"
+__device__ __forceinline__ void wave_prefix_mul_x2(float& a, float& b)
+{
+    asm volatile("s_nop 1\n\t"
+                 VR_DPP2("v_mul_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")
+                 VR_DPP2("v_mul_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
+                 VR_DPP2("v_mul_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf")
+                 VR_DPP2("v_mul_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
+                 VR_DPP2("v_mul_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 VR_DPP2("v_mul_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 0"
+                 : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void wave_prefix_add_x2(float& a, float& b)
+{
+    asm volatile("s_nop 1\n\t"
+                 VR_DPP2("v_add_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")
+                 VR_DPP2("v_add_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
+                 VR_DPP2("v_add_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf")
+                 VR_DPP2("v_add_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
+                 VR_DPP2("v_add_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 VR_DPP2("v_add_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 0"
+                 : "+v"(a), "+v"(b));
+}
+
 // per-pixel upstream gradients of the 11 blended channels
 struct PixGrad {
     float g[NCH];
@@ -156,7 +184,7 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     __shared__ float gsum[SEG * NACC];            // per-entry gradient sums of this (tile, segment)
     __shared__ uint32_t ids[SEG];                 // Gaussian id of every entry
     __shared__ unsigned short ridx[4][SEG];       // per strip: the relevant entries, ascending
-    __shared__ float4 pixrec[4][64][4];           // per strip, per pixel: coords, bg term, 11 upstream grads, carries
+    __shared__ float4 pixrec[4][32][8];           // per strip, per PIXEL PAIR: coords, bg term, 11 upstream grads, carries
     SegCtx c;
     if (!seg_setup(cam, ranges, seg_off, c)) return;
     const int needed = (int)seg_needed[c.tile];
@@ -201,12 +229,18 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     }
     float v_Scar = Ubuf[(size_t)c.seg * SEG + threadIdx.x];
     const int seg_lo = c.sl * SEG;       // first list entry (tile-relative) of this segment
-    // Per-pixel record in LDS: in the pixel loop it is read back as wave-uniform broadcasts (LDS pipe)
-    // instead of 16 v_readlane (VALU pipe); the two carries live there too and are updated by one lane.
-    pixrec[w][lane][0] = make_float4(v_pxf, v_pyf, v_bgterm, pg.g[0]);
-    pixrec[w][lane][1] = make_float4(pg.g[1], pg.g[2], pg.g[3], pg.g[4]);
-    pixrec[w][lane][2] = make_float4(pg.g[5], pg.g[6], pg.g[7], pg.g[8]);
-    pixrec[w][lane][3] = make_float4(pg.g[9], pg.g[10], v_Tcar, v_Scar);
+    // Per-pixel record in LDS, interleaved by PIXEL PAIR (a = even pixel, b = odd pixel of the strip): the
+    // pixel loop reads it back as wave-uniform broadcasts (LDS pipe, not 16 v_readlane on the VALU pipe) and
+    // gets every quantity as a ready-made (a,b) register pair for packed fp32 math.  float4 slots:
+    //   0 {px_a px_b py_a py_b}  1 {bg_a bg_b g0_a g0_b}  2 {g1 g2}  3 {g3 g4}  4 {g5 g6}  5 {g7 g8}
+    //   6 {g9 g10}  7 {Tcar_a Tcar_b Scar_a Scar_b} -- the two carries, updated in place by lane 63.
+    {
+        float* rec2 = reinterpret_cast<float*>(&pixrec[w][lane >> 1][0]) + (lane & 1);
+        rec2[0] = v_pxf; rec2[2] = v_pyf; rec2[4] = v_bgterm;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) rec2[6 + 2 * k] = pg.g[k];
+        rec2[28] = v_Tcar; rec2[30] = v_Scar;
+    }
     __builtin_amdgcn_wave_barrier();
 
     int mx = v_nc;
@@ -233,64 +267,85 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
             at[4] = q2.w; at[5] = q3.x; at[6] = q3.y; at[7] = q3.z;
             at[8] = q3.w; at[9] = q4.x; at[10] = q4.y;
         }
-        float acc[NACC];
+        // accumulators: .x sums over the even pixels, .y over the odd ones (added at the end of the chunk)
+        f2 acc[NACC];
 #pragma unroll
-        for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+        for (int k = 0; k < NACC; ++k) acc[k] = f2_splat(0.0f);
         // nearest list index held by this chunk (its first relevant entry): pixels whose last
         // contributor lies in front of it have nothing to do here
         const int chunk_lo = seg_lo + (int)ridx[w][ch * 64];
 
         if (chunk_lo < wave_maxc) {
-            for (int p = 0; p < 64; ++p) {
-                const int nc = __builtin_amdgcn_readlane(v_nc, p);
-                if (nc <= chunk_lo) continue;  // pixel p has no contributor in this chunk (wave-uniform)
-                const float4 r0 = pixrec[w][p][0];   // pxf pyf bgterm g0
-                const float pxf = r0.x, pyf = r0.y;
-                float dx, dy;
-                const float power = splat_power(sx, sy, cA, cB, cC, pxf, pyf, dx, dy);
-                const bool pre = has && (e < nc) && !(power > 0.0f) && power >= thr;
-                if (__ballot(pre) == 0ull) continue;  // no splat of the chunk reaches this pixel: carries unchanged
-                const float G = vr_exp(power);
-                const float alpha = fminf(ALPHA_MAX, op * G);
-                const bool contrib = pre && !(alpha < ALPHA_MIN);
-                const float4 r1 = pixrec[w][p][1], r2 = pixrec[w][p][2], r3 = pixrec[w][p][3];
-                const float bgterm = r0.z, Tc = r3.z, Sc = r3.w;
-                const float g[NCH] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y};
-                const float a_eff = contrib ? alpha : 0.0f;
-                const float om = 1.0f - a_eff;
-                const float pprod = wave_prefix_mul(om);                 // prod over entries >= mine
-                const float Tl = Tc * __builtin_amdgcn_rcpf(pprod);      // T in front of my splat
-                const float wgt = a_eff * Tl;
-                float u = 0.0f;
+            for (int pp = 0; pp < 32; ++pp) {
+                const int nc0 = __builtin_amdgcn_readlane(v_nc, 2 * pp), nc1 = __builtin_amdgcn_readlane(v_nc, 2 * pp + 1);
+                if (max(nc0, nc1) <= chunk_lo) continue;  // neither pixel has a contributor in this chunk (wave-uniform)
+                const float4 r0 = pixrec[w][pp][0];
+                const f2 pxf = {r0.x, r0.y}, pyf = {r0.z, r0.w};
+                f2 dx, dy;
+                const f2 power = splat_power_x2(sx, sy, cA, cB, cC, pxf, pyf, dx, dy);
+                const bool pre0 = has && (e < nc0) && !(power.x > 0.0f) && power.x >= thr;
+                const bool pre1 = has && (e < nc1) && !(power.y > 0.0f) && power.y >= thr;
+                if (__ballot(pre0 || pre1) == 0ull) continue;  // no splat of the chunk reaches the pair: carries unchanged
+                // hardware exp2 here (1 ulp; the forward's bit-exact vr_exp is not needed for gradients: only an
+                // alpha within 1e-7 of the 1/255 threshold could be classified differently, with a 0.4 % weight)
+                f2 G = {__builtin_amdgcn_exp2f(power.x * 1.44269504088896341f), __builtin_amdgcn_exp2f(power.y * 1.44269504088896341f)};
+                const f2 alpha = {fminf(ALPHA_MAX, op * G.x), fminf(ALPHA_MAX, op * G.y)};
+                const bool contrib0 = pre0 && !(alpha.x < ALPHA_MIN), contrib1 = pre1 && !(alpha.y < ALPHA_MIN);
+                const f2 a_eff = {contrib0 ? alpha.x : 0.0f, contrib1 ? alpha.y : 0.0f};
+                G.x = contrib0 ? G.x : 0.0f;              // (exp of a positive exponent may be inf: keep it out of 0*inf)
+                G.y = contrib1 ? G.y : 0.0f;
+                const float4 r1 = pixrec[w][pp][1], r2 = pixrec[w][pp][2], r3 = pixrec[w][pp][3], r4 = pixrec[w][pp][4],
+                             r5 = pixrec[w][pp][5], r6 = pixrec[w][pp][6], r7 = pixrec[w][pp][7];
+                const f2 bgterm = {r1.x, r1.y}, Tc = {r7.x, r7.y}, Sc = {r7.z, r7.w};
+                const f2 g[NCH] = {{r1.z, r1.w}, {r2.x, r2.y}, {r2.z, r2.w}, {r3.x, r3.y}, {r3.z, r3.w}, {r4.x, r4.y},
+                                   {r4.z, r4.w}, {r5.x, r5.y}, {r5.z, r5.w}, {r6.x, r6.y}, {r6.z, r6.w}};
+                const f2 om = f2_splat(1.0f) - a_eff;
+                float pa = om.x, pb = om.y;
+                wave_prefix_mul_x2(pa, pb);                               // prod over entries >= mine
+                const f2 Tl = Tc * (f2){__builtin_amdgcn_rcpf(pa), __builtin_amdgcn_rcpf(pb)};   // T in front of my splat
+                const f2 wgt = a_eff * Tl;
+                // <attr, g> in two independent chains (a dependent v_pk_fma_f32 costs an extra wait state)
+                f2 u0 = f2_splat(at[0]) * g[0], u1 = f2_splat(at[1]) * g[1];
 #pragma unroll
-                for (int k = 0; k < NCH; ++k) u = fmaf(at[k], g[k], u);
-                const float wu = wgt * u;
-                const float psum = wave_prefix_add(wu);                  // sum over entries >= mine
-                const float behind = Sc + (psum - wu);
+                for (int k = 2; k + 1 < NCH; k += 2) {
+                    u0 = f2_fma(f2_splat(at[k]), g[k], u0);
+                    u1 = f2_fma(f2_splat(at[k + 1]), g[k + 1], u1);
+                }
+                const f2 u = f2_fma(f2_splat(at[NCH - 1]), g[NCH - 1], u0) + u1;
+                const f2 wu = wgt * u;
+                float sa = wu.x, sb = wu.y;
+                wave_prefix_add_x2(sa, sb);                               // sum over entries >= mine
+                const f2 psum = {sa, sb};
+                const f2 behind = Sc + (psum - wu);
                 // carries for the next (nearer) chunk: values at the chunk's first entry = lane 63
                 if (lane == 63) {
-                    float2* car = reinterpret_cast<float2*>(&pixrec[w][p][3].z);
-                    *car = make_float2(Tl, Sc + psum);
+                    const f2 Sn = Sc + psum;
+                    pixrec[w][pp][7] = make_float4(Tl.x, Tl.y, Sn.x, Sn.y);
                 }
-                if (contrib) {
-                    const float dLda = fmaf(Tl, u, -(behind + bgterm) * __builtin_amdgcn_rcpf(om));
-                    const float dLdG = op * dLda;
-                    const float gdx = G * dx, gdy = G * dy;
-                    acc[0] = fmaf(-0.5f * gdx * dx, dLdG, acc[0]);
-                    acc[1] = fmaf(-gdx * dy, dLdG, acc[1]);
-                    acc[2] = fmaf(-0.5f * gdy * dy, dLdG, acc[2]);
-                    acc[3] = fmaf(G, dLda, acc[3]);
+                if (contrib0 || contrib1) {
+                    const f2 inv_om = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                    f2 dLda = f2_fma(Tl, u, -(behind + bgterm) * inv_om);
+                    dLda.x = contrib0 ? dLda.x : 0.0f;
+                    dLda.y = contrib1 ? dLda.y : 0.0f;
+                    const f2 dLdG = f2_splat(op) * dLda;
+                    const f2 gdx = G * dx, gdy = G * dy;
+                    acc[0] = f2_fma(f2_splat(-0.5f) * gdx * dx, dLdG, acc[0]);
+                    acc[1] = f2_fma(-gdx * dy, dLdG, acc[1]);
+                    acc[2] = f2_fma(f2_splat(-0.5f) * gdy * dy, dLdG, acc[2]);
+                    acc[3] = f2_fma(G, dLda, acc[3]);
 #pragma unroll
-                    for (int k = 0; k < NCH; ++k) acc[4 + k] = fmaf(wgt, g[k], acc[4 + k]);
-                    acc[15] = fmaf(dLdG, -gdx * cA - gdy * cB, acc[15]);
-                    acc[16] = fmaf(dLdG, -gdy * cC - gdx * cB, acc[16]);
+                    for (int k = 0; k < NCH; ++k) acc[4 + k] = f2_fma(wgt, g[k], acc[4 + k]);
+                    acc[15] = f2_fma(dLdG, -gdx * f2_splat(cA) - gdy * f2_splat(cB), acc[15]);
+                    acc[16] = f2_fma(dLdG, -gdy * f2_splat(cC) - gdx * f2_splat(cB), acc[16]);
                 }
             }
             // the strips of a tile share entries: combine them in LDS (ds_add_f32)
             if (has) {
 #pragma unroll
-                for (int k = 0; k < NACC; ++k)
-                    if (acc[k] != 0.0f) atomicAdd(&gsum[ej * NACC + k], acc[k]);
+                for (int k = 0; k < NACC; ++k) {
+                    const float a = acc[k].x + acc[k].y;
+                    if (a != 0.0f) atomicAdd(&gsum[ej * NACC + k], a);
+                }
             }
         }
     }

@@ -62,7 +62,27 @@ def build(force=False, verbose=False):
     objs = [os.path.join(OBJ_DIR, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _newer(LIB, objs):
         run([_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", LIB])
+    build_c_harness(force or bool(jobs))
     return LIB
+
+
+HARNESS_SRC = os.path.join(os.path.dirname(HERE), "tools", "c_harness", "vr_harness.c")
+HARNESS = os.path.join(OUT_DIR, "vr_harness")
+
+
+def build_c_harness(force=False):
+    """tools/c_harness/vr_harness.c: a plain C11 program (gcc, no hipcc, no Python) that drives the C ABI.
+    Built next to the library so that it travels to the GPU box; tests/test_gpu_c_harness.py runs it."""
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    if not force and not _newer(HARNESS, [HARNESS_SRC, LIB, os.path.join(CSRC, "..", "..", "include", "vegs_rast.h")]):
+        return HARNESS
+    cmd = ["gcc", "-std=c11", "-O2", "-Wall", "-I" + os.path.join(os.path.dirname(HERE), "include"),
+           "-I" + os.path.join(rocm, "include"), HARNESS_SRC, "-o", HARNESS, "-L" + OUT_DIR, "-lvegsrast",
+           "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("gcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    return HARNESS
 
 
 if __name__ == "__main__":

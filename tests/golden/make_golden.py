@@ -10,6 +10,8 @@ nothing of it is copied -- only inputs and outputs are stored):
   * loss/normal_guidance.py:3-22 loss_normal_guidance (value + gradients w.r.t.
     cov_quat / cov_scale)                        -> ref_normal_guidance.npz
   * utils/loss_utils.py:18-22 l1_loss, :39-79 ssim (values + gradients)  -> ref_photometric.npz
+  * utils/graphics_utils.py:49-53 decompose_T_to_RS, :140-201 matrix_to_quaternion, :204-248
+    quaternion_to_matrix composed as gaussian_renderer/__init__.py:122-153 does -> ref_instances.npz
 Part B runs the independent float64 autograd restatement oracle/torch_ref.py on tiny
 seeded scenes (vegs_amd/scenes.py) and stores inputs, forward images and input gradients
 -> raster_case*.npz.  These pin vr_oracle.c and, on the GPU box, the HIP kernels.
@@ -111,6 +113,44 @@ def part_a():
                      f"loss_{tag}": loss.item(), f"grad_loss_{tag}": g_loss.numpy()})
     blob["window"] = lu.gaussian(11, 1.5).numpy()
     np.savez_compressed(os.path.join(HERE, "ref_photometric.npz"), **blob)
+
+    # box-instance branch of prepare_rasterization (gaussian_renderer/__init__.py:122-126,140-153), composed from
+    # the reference's own decompose_T_to_RS / quaternion_to_matrix / matrix_to_quaternion; values + autograd
+    # gradients w.r.t. the instance's Gaussians and the 4x4 box2world
+    blob = {}
+    for b in range(4):
+        n = 60
+        ang = rng.normal(size=4)
+        ang = ang / np.linalg.norm(ang)
+        if b == 1:
+            ang = np.array([1e-3, 0.0, 1.0, 0.0])                      # ~180 degrees about y: another candidate wins
+        Rb = gu.quaternion_to_matrix(torch.tensor(ang)).numpy()
+        sc3 = np.array([1.7, 1.7, 1.7]) if b % 2 == 0 else np.array([0.6, 1.1, 2.3])   # uniform / per-axis scale
+        B = np.eye(4)
+        B[:3, :3] = Rb * sc3[None, :]
+        B[:3, 3] = rng.normal(size=3) * 3
+        box2world = torch.tensor(B.astype(np.float32), requires_grad=True)
+        xyz = torch.tensor(rng.normal(size=(n, 3)).astype(np.float32), requires_grad=True)
+        scales = torch.tensor(rng.uniform(0.01, 0.3, (n, 3)).astype(np.float32), requires_grad=True)
+        q = rng.normal(size=(n, 4))
+        q[:8] = np.eye(4)[[0, 1, 2, 3, 0, 1, 2, 3]] + 1e-3 * rng.normal(size=(8, 4))       # axis-aligned half-turns
+        rot = torch.tensor((q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32), requires_grad=True)
+        means3D = torch.cat((xyz, torch.ones(n, 1)), dim=1)
+        means3D = torch.matmul(box2world, means3D.transpose(1, 0).contiguous()).transpose(1, 0).contiguous()
+        means3D = means3D[:, :3] / means3D[:, 3:]
+        b_scale, b_rot = gu.decompose_T_to_RS(box2world)
+        rotations = gu.matrix_to_quaternion(torch.matmul(b_rot[None, ...], gu.quaternion_to_matrix(rot)))
+        scales_o = scales * b_scale
+        gm, gr, gsc = (torch.tensor(rng.normal(size=t.shape).astype(np.float32)) for t in (means3D, rotations, scales_o))
+        ((means3D * gm).sum() + (rotations * gr).sum() + (scales_o * gsc).sum()).backward()
+        blob.update({f"box2world_{b}": box2world.detach().numpy(), f"xyz_{b}": xyz.detach().numpy(),
+                     f"scales_{b}": scales.detach().numpy(), f"rot_{b}": rot.detach().numpy(),
+                     f"out_means_{b}": means3D.detach().numpy(), f"out_rot_{b}": rotations.detach().numpy(),
+                     f"out_scales_{b}": scales_o.detach().numpy(), f"gout_means_{b}": gm.numpy(),
+                     f"gout_rot_{b}": gr.numpy(), f"gout_scales_{b}": gsc.numpy(),
+                     f"grad_xyz_{b}": xyz.grad.numpy(), f"grad_scales_{b}": scales.grad.numpy(),
+                     f"grad_rot_{b}": rot.grad.numpy(), f"grad_box2world_{b}": box2world.grad.numpy()})
+    np.savez_compressed(os.path.join(HERE, "ref_instances.npz"), **blob)
 
 
 CASES = {

@@ -1,0 +1,108 @@
+"""GPU (-m gpu): fused instance transform + concatenation (row N4) against (1) outputs of the reference's own
+functions + autograd (tests/golden/ref_instances.npz) and (2) the float64 oracle on a render_all-sized frame."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_instance_transform_matches_reference_outputs():
+    from vegs_amd.instances import prepare_and_merge
+    z = np.load(os.path.join(GOLDEN, "ref_instances.npz"))
+    boxes, b2ws = [], []
+    for b in range(4):
+        t = {"means3D": z[f"xyz_{b}"], "scales": z[f"scales_{b}"], "rotations": z[f"rot_{b}"],
+             "shs": np.zeros((60, 4, 3), np.float32), "opacities": np.full((60, 1), 0.5, np.float32)}
+        boxes.append({k: torch.tensor(v, device=DEV, requires_grad=True) for k, v in t.items()})
+        b2ws.append(torch.tensor(z[f"box2world_{b}"], device=DEV, requires_grad=True))
+    kw = prepare_and_merge(None, boxes, b2ws)                       # render_dyn: instances only
+    gm = np.concatenate([z[f"gout_means_{b}"] for b in range(4)])
+    gs = np.concatenate([z[f"gout_scales_{b}"] for b in range(4)])
+    gr = np.concatenate([z[f"gout_rot_{b}"] for b in range(4)])
+    torch.autograd.backward([kw["means3D"], kw["scales"], kw["rotations"]],
+                            [torch.tensor(g, device=DEV) for g in (gm, gs, gr)])
+    for b in range(4):
+        sl = slice(60 * b, 60 * b + 60)
+        assert np.abs(kw["means3D"][sl].detach().cpu().numpy() - z[f"out_means_{b}"]).max() < 5e-6
+        assert np.abs(kw["scales"][sl].detach().cpu().numpy() - z[f"out_scales_{b}"]).max() < 1e-6
+        assert np.abs(kw["rotations"][sl].detach().cpu().numpy() - z[f"out_rot_{b}"]).max() < 2e-6
+        assert rel_err(boxes[b]["means3D"].grad.cpu().numpy(), z[f"grad_xyz_{b}"]) < 2e-5
+        assert rel_err(boxes[b]["scales"].grad.cpu().numpy(), z[f"grad_scales_{b}"]) < 2e-5
+        assert rel_err(boxes[b]["rotations"].grad.cpu().numpy(), z[f"grad_rot_{b}"]) < 5e-5
+        assert rel_err(b2ws[b].grad.cpu().numpy(), z[f"grad_box2world_{b}"]) < 5e-5
+    assert kw["shs"].shape == (240, 4, 3) and kw["opacities"].shape == (240, 1)
+
+
+def test_fused_render_all_equals_the_op_by_op_composition():
+    """C5-shaped: a static model + 20 instances of 8196 Gaussians (more than one launch table), through the
+    rasterizer; forward images bit-identical inputs apart, gradients of every leaf vs the float64 oracle."""
+    from oracle import instance_oracle as io
+    from vegs_amd import harness, scenes
+    sc_static, deg = scenes.scene_random(P=30_000, sh_degree=1, seed=3, scale=0.03)
+    rng = np.random.default_rng(6)
+    nb, n = 20, 8196
+    sc_boxes = [scenes.scene_random(P=n, sh_degree=1, seed=50 + i, extent=0.1, scale=0.02)[0] for i in range(nb)]
+    Bs = []
+    for i in range(nb):
+        q = rng.normal(size=4)
+        R = np.asarray(harness.quaternion_to_matrix(torch.tensor(q)).numpy())
+        B = np.eye(4)
+        B[:3, :3] = R * rng.uniform(0.7, 1.5)
+        B[:3, 3] = rng.uniform(-0.4, 0.4, 3)
+        Bs.append(B.astype(np.float32))
+    cam = scenes.camera_c1(256, 160)
+
+    def leaves():
+        st = {k: torch.tensor(v, device=DEV, requires_grad=True) for k, v in sc_static.items()}
+        bx = [{k: torch.tensor(v, device=DEV, requires_grad=True) for k, v in b.items()} for b in sc_boxes]
+        bw = [torch.tensor(B, device=DEV, requires_grad=True) for B in Bs]
+        return st, bx, bw
+
+    gouts = [torch.tensor(rng.normal(size=s).astype(np.float32), device=DEV) for s in [(3, 160, 256), (4, 160, 256), (3, 160, 256)]]
+    res = []
+    for fused in (False, True):
+        st, bx, bw = leaves()
+        pkg = harness.render_all(cam, st, bx, bw, deg, torch.zeros(3, device=DEV), fused=fused)
+        torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], gouts)
+        res.append((pkg, st, bx, bw))
+    (pa, sta, bxa, bwa), (pb, stb, bxb, bwb) = res
+    for k in ("means3D", "scales", "rotations"):
+        assert rel_err(pb["op_inputs"][k].detach().cpu().numpy(), pa["op_inputs"][k].detach().cpu().numpy()) < 1e-6, k
+    assert torch.equal(pb["op_inputs"]["shs"], pa["op_inputs"]["shs"])
+    # oracle: the fused op's own inputs and upstream gradients
+    kwb = pb["op_inputs"]
+    # (gradients of the op inputs are not retained; recompute them on detached inputs)
+    det = {k: v.detach().clone().requires_grad_(True) for k, v in kwb.items()}
+    p2 = harness.render(cam, det, deg, torch.zeros(3, device=DEV))
+    torch.autograd.backward([p2["render"], p2["render_cov_quat"], p2["render_cov_scale"]], gouts)
+    gm, gs, gr = (det[k].grad.cpu().numpy() for k in ("means3D", "scales", "rotations"))
+    off = 30_000
+    for i in (0, 7, 19):
+        sl = slice(off + i * n, off + (i + 1) * n)
+        want = io.backward(sc_boxes[i]["means3D"], sc_boxes[i]["scales"], sc_boxes[i]["rotations"], Bs[i], gm[sl], gs[sl], gr[sl])
+        got = (bxb[i]["means3D"].grad, bxb[i]["scales"].grad, bxb[i]["rotations"].grad, bwb[i].grad)
+        for g, w, name in zip(got, want, ("means3D", "scales", "rotations", "box2world")):
+            assert rel_err(g.cpu().numpy(), w) < 2e-4, (i, name)
+    for k in ("means3D", "scales", "rotations", "shs", "opacities"):     # static model: plain slices
+        assert rel_err(stb[k].grad.cpu().numpy(), sta[k].grad.cpu().numpy()) < 1e-4, k
+    for ba, bb in zip(bwa, bwb):                                         # and the op-by-op composition agrees
+        assert rel_err(bb.grad.cpu().numpy(), ba.grad.cpu().numpy()) < 2e-3
+
+
+def test_instance_argument_checks():
+    from vegs_amd.instances import prepare_and_merge
+    t = {"means3D": torch.zeros(4, 3), "scales": torch.zeros(4, 3), "rotations": torch.zeros(4, 4),
+         "shs": torch.zeros(4, 1, 3), "opacities": torch.zeros(4, 1)}
+    with pytest.raises(ValueError):
+        prepare_and_merge(t, [], [])
+    g = {k: v.to(DEV) for k, v in t.items()}
+    with pytest.raises(ValueError):
+        prepare_and_merge(g, [g], [torch.eye(3, device=DEV)])
+    with pytest.raises(ValueError):
+        prepare_and_merge(g, [g], [])

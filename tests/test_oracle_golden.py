@@ -147,3 +147,17 @@ def test_loss_oracle_normal_guidance_matches_reference_outputs():
     q0 = z["cov_quat"].copy()
     q0[:, 0, 0] = 0
     assert np.isnan(lo.normal_guidance(q0, z["cov_scale"], z["normal"], z["R"])[0])
+
+
+# ---- row N4: box-instance transform.  oracle/instance_oracle.py against outputs of the reference's own functions.
+def test_instance_oracle_matches_reference_outputs():
+    from oracle import instance_oracle as io
+    z = np.load(os.path.join(GOLDEN, "ref_instances.npz"))
+    for b in range(4):
+        a = [z[f"{k}_{b}"] for k in ("xyz", "scales", "rot", "box2world")]
+        m, s, q = io.forward(*a)
+        assert np.abs(m - z[f"out_means_{b}"]).max() < 2e-6 * max(1.0, np.abs(m).max())
+        assert np.abs(s - z[f"out_scales_{b}"]).max() < 1e-6 and np.abs(q - z[f"out_rot_{b}"]).max() < 2e-6
+        g = io.backward(*a, z[f"gout_means_{b}"], z[f"gout_scales_{b}"], z[f"gout_rot_{b}"])
+        for got, key in zip(g, ("grad_xyz", "grad_scales", "grad_rot", "grad_box2world")):
+            assert rel_err(got, z[f"{key}_{b}"]) < 2e-5, (b, key)

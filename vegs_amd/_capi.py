@@ -19,7 +19,8 @@ VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH = 0, 1, 2, 3
 EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_mark_visible", "vr_get_counters",
            "vr_count_fragments", "vr_debug_export_binning", "vr_profile_level", "vr_profile_collect",
            "vr_knn3_mean_dist2", "vr_photometric_forward", "vr_photometric_backward",
-           "vr_normal_guidance_forward", "vr_normal_guidance_backward", "vr_adam_step", "vr_densify_stats"]
+           "vr_normal_guidance_forward", "vr_normal_guidance_backward", "vr_adam_step", "vr_densify_stats",
+           "vr_instances_forward", "vr_instances_backward"]
 STAGES = ["preprocess", "compact", "depth_sort", "emit", "tile_sort", "ranges", "render_fwd", "bwd_zero",
           "render_bwd", "preprocess_bwd", "k_seg_bwd"]
 
@@ -61,6 +62,16 @@ class VrInGrads(C.Structure):
 class VrAdamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("n", C.c_int64), ("lr", C.c_double), ("step", C.c_int64)]
+
+
+class VrInstance(C.Structure):
+    _fields_ = [("means", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("box2world", C.c_void_p),
+                ("n", C.c_int64), ("offset", C.c_int64)]
+
+
+class VrInstanceGrads(C.Structure):
+    _fields_ = [("dL_dmeans", C.c_void_p), ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p),
+                ("dL_dbox2world", C.c_void_p)]
 
 
 class VrCounters(C.Structure):
@@ -117,6 +128,10 @@ def load():
     lib.vr_adam_step.argtypes = [C.POINTER(VrAdamTensor), i32, C.c_double, C.c_double, C.c_double, vp]
     lib.vr_densify_stats.restype = C.c_int
     lib.vr_densify_stats.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    lib.vr_instances_forward.restype = C.c_int
+    lib.vr_instances_forward.argtypes = [C.POINTER(VrInstance), i32, vp, vp, vp, vp]
+    lib.vr_instances_backward.restype = C.c_int
+    lib.vr_instances_backward.argtypes = [C.POINTER(VrInstance), C.POINTER(VrInstanceGrads), i32, vp, vp, vp, VrAllocFn, vp, vp]
     lib.vr_profile_level.restype = C.c_int
     lib.vr_profile_level.argtypes = [C.c_int]
     lib.vr_profile_collect.restype = C.c_int

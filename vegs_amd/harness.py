@@ -101,10 +101,16 @@ def merge_kwargs(a, b):
     return {k: torch.cat((a[k], b[k]), 0).contiguous() for k in a}
 
 
-def render_all(cam, static, boxes, box2worlds, sh_degree, bg_color, scaling_modifier=1.0, cam_t=None):
-    kw = prepare_rasterization(static)
-    for t, b2w in zip(boxes, box2worlds):
-        kw = merge_kwargs(kw, prepare_rasterization(t, b2w))
+def render_all(cam, static, boxes, box2worlds, sh_degree, bg_color, scaling_modifier=1.0, cam_t=None, fused=False):
+    """fused=False: the reference's op-by-op composition (device-agnostic; what the CPU checks run);
+    fused=True: vegs_amd.instances.prepare_and_merge (one HIP launch for all instances, GPU only)."""
+    if fused:
+        from .instances import prepare_and_merge
+        kw = prepare_and_merge(static, boxes, box2worlds)
+    else:
+        kw = prepare_rasterization(static)
+        for t, b2w in zip(boxes, box2worlds):
+            kw = merge_kwargs(kw, prepare_rasterization(t, b2w))
     pkg = render(cam, kw, sh_degree, bg_color, scaling_modifier, cam_t=cam_t)
     pkg["op_inputs"] = kw
     return pkg

@@ -1,0 +1,108 @@
+"""Fused counterpart of the reference's per-instance `prepare_rasterization(..., box2world=...)` +
+`merge_kwargs` (gaussian_renderer/__init__.py:121-186) as render_all / render_dyn use them (:188-333):
+ONE HIP launch carries the means / scales / rotations of every box instance into the world frame and writes
+them, together with the static model's, straight into the concatenated op inputs; one launch (+ a tiny
+reduction) produces all gradients including dL/d(box2world) (vegs_amd/csrc/instances.hip, C ABI
+include/vegs_instances.h).  shs / opacities need no arithmetic and are concatenated by torch.cat as in the
+reference.  GPU tensors only; there is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi
+
+
+def _check(name, t, cols, device):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name} must be a GPU tensor (there is no CPU path)")
+    if t.device != device or t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != cols:
+        raise ValueError(f"{name} must be float32 [n,{cols}] on {device} (got {t.dtype} {tuple(t.shape)} on {t.device})")
+
+
+class _TransformConcat(torch.autograd.Function):
+    """inputs: (means_0, scales_0, rot_0, box2world_0 | None, means_1, ...) -> (means, scales, rotations)"""
+
+    @staticmethod
+    def forward(ctx, *flat):
+        lib = _capi.load()
+        n_inst = len(flat) // 4
+        device = flat[0].device
+        items, offset, keep = [], 0, []
+        for i in range(n_inst):
+            m, s, r, b = flat[4 * i:4 * i + 4]
+            _check("means3D", m, 3, device); _check("scales", s, 3, device); _check("rotations", r, 4, device)
+            if s.shape[0] != m.shape[0] or r.shape[0] != m.shape[0]:
+                raise ValueError("means3D, scales and rotations of an instance must have the same number of rows")
+            m, s, r = m.contiguous(), s.contiguous(), r.contiguous()
+            if b is not None:
+                if not b.is_cuda or b.shape != (4, 4) or b.dtype != torch.float32:
+                    raise ValueError("box2world must be a float32 GPU tensor of shape (4, 4)")
+                b = b.contiguous()
+            keep.append((m, s, r, b))
+            items.append(_capi.VrInstance(_capi.ptr(m), _capi.ptr(s), _capi.ptr(r), None if b is None else b.data_ptr(),
+                                          m.shape[0], offset))
+            offset += m.shape[0]
+        out_m = torch.empty((offset, 3), dtype=torch.float32, device=device)
+        out_s = torch.empty((offset, 3), dtype=torch.float32, device=device)
+        out_r = torch.empty((offset, 4), dtype=torch.float32, device=device)
+        arr = (_capi.VrInstance * n_inst)(*items)
+        with torch.cuda.device(device):
+            rc = lib.vr_instances_forward(arr, n_inst, _capi.ptr(out_m), _capi.ptr(out_s), _capi.ptr(out_r),
+                                          torch.cuda.current_stream(device).cuda_stream)
+        _capi.check(rc)
+        ctx.keep = keep
+        ctx.device = device
+        return out_m, out_s, out_r
+
+    @staticmethod
+    def backward(ctx, g_m, g_s, g_r):
+        lib = _capi.load()
+        device = ctx.device
+        g_m, g_s, g_r = g_m.contiguous(), g_s.contiguous(), g_r.contiguous()
+        items, gitems, grads, offset = [], [], [], 0
+        for (m, s, r, b) in ctx.keep:
+            n = m.shape[0]
+            if b is None:                       # static model: its gradients ARE rows of the concatenated gradients
+                grads += [g_m[offset:offset + n], g_s[offset:offset + n], g_r[offset:offset + n], None]
+                gi = _capi.VrInstanceGrads(None, None, None, None)
+            else:
+                dm, ds, dr = torch.empty_like(m), torch.empty_like(s), torch.empty_like(r)
+                db = torch.empty((4, 4), dtype=torch.float32, device=device)
+                grads += [dm, ds, dr, db]
+                gi = _capi.VrInstanceGrads(_capi.ptr(dm), _capi.ptr(ds), _capi.ptr(dr), db.data_ptr())
+            items.append(_capi.VrInstance(_capi.ptr(m), _capi.ptr(s), _capi.ptr(r), None if b is None else b.data_ptr(),
+                                          n, offset))
+            gitems.append(gi)
+            offset += n
+        arr = (_capi.VrInstance * len(items))(*items)
+        garr = (_capi.VrInstanceGrads * len(items))(*gitems)
+        arena = _capi.Arena(device)
+        cb = arena.callback()
+        with torch.cuda.device(device):
+            rc = lib.vr_instances_backward(arr, garr, len(items), _capi.ptr(g_m), _capi.ptr(g_s), _capi.ptr(g_r), cb, None,
+                                           torch.cuda.current_stream(device).cuda_stream)
+        del cb
+        arena.release_scratch()
+        if arena.error is not None:
+            raise arena.error
+        _capi.check(rc)
+        return tuple(grads)
+
+
+def prepare_and_merge(static, boxes, box2worlds):
+    """Op inputs for a frame with dynamic instances: the result of
+        kw = prepare_rasterization(static); for each box: kw = merge_kwargs(kw, prepare_rasterization(box, box2world))
+    (gaussian_renderer/__init__.py:274-303).  `static` / `boxes[i]`: dicts with means3D, shs, opacities, scales,
+    rotations; `box2worlds[i]`: differentiable 4x4 tensors.  `static` may be None (render_dyn)."""
+    if len(boxes) != len(box2worlds):
+        raise ValueError("one box2world per box instance")
+    models = ([] if static is None else [(static, None)]) + list(zip(boxes, box2worlds))
+    if not models:
+        raise ValueError("nothing to render")
+    flat = []
+    for t, b in models:
+        flat += [t["means3D"], t["scales"], t["rotations"], b]
+    means, scales, rotations = _TransformConcat.apply(*flat)
+    cat = (lambda k: models[0][0][k]) if len(models) == 1 else (lambda k: torch.cat([t[k] for t, _ in models], 0))
+    return {"means3D": means, "shs": cat("shs"), "opacities": cat("opacities"), "scales": scales, "rotations": rotations}

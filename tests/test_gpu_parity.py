@@ -81,9 +81,9 @@ def _export_binning(res, H, W, dev):
     return pl[:R].cpu().numpy().astype(np.uint32), rg.cpu().numpy()
 
 
-def _check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=0, grad_rtol=GRAD_RTOL, gmask=(1, 1, 1, 1, 1)):
+def _check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=0, grad_rtol=GRAD_RTOL, gmask=(1, 1, 1, 1, 1), M=16):
     from oracle import oracle as orc
-    oc = oracle_cam(cam, bg, deg, mod)
+    oc = oracle_cam(cam, bg, deg, mod, M)
     o_out, st = orc.forward(oc, **inputs)
     rng = np.random.default_rng(seed)
     H, W = cam.image_height, cam.image_width

@@ -300,6 +300,8 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
     constexpr int SIZE = 1 << BITS;
     __shared__ uint32_t cnt[4][SIZE];
     __shared__ uint32_t off[4][SIZE];
+    __shared__ uint32_t loc[SIZE], gl[SIZE];
+    __shared__ uint32_t skey[RADIX_BLOCK], sval[RADIX_BLOCK];
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int d = threadIdx.x; d < SIZE; d += 256) {
 #pragma unroll
@@ -333,13 +335,33 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+    // ---- block-local bucket layout: items are first put in digit order in LDS and then written out by
+    // consecutive threads, so every bucket's run of this block is one contiguous, coalesced global write
+    // (a direct scatter of 8-byte pairs to up to 512 destinations per wave wrote mostly 1/8-used lines)
     for (int d = threadIdx.x; d < SIZE; d += 256) {
-        uint32_t g = hist_scanned[(size_t)d * nblk + blockIdx.x];
-        uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d];
-        off[0][d] = g;
-        off[1][d] = g + c0;
-        off[2][d] = g + c0 + c1;
-        off[3][d] = g + c0 + c1 + c2;
+        const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
+        gl[d] = hist_scanned[(size_t)d * nblk + blockIdx.x];
+        off[0][d] = 0;
+        off[1][d] = c0;
+        off[2][d] = c0 + c1;
+        off[3][d] = c0 + c1 + c2;
+        loc[d] = c0 + c1 + c2 + c3;
+    }
+    __syncthreads();
+    if (w == 0) {   // exclusive scan of the bucket totals: lane handles DPL consecutive digits
+        constexpr int DPL = SIZE / 64;
+        uint32_t t[DPL], sum = 0;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) { t[k] = loc[lane * DPL + k]; sum += t[k]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, dd, 64);
+            if (lane >= dd) incl += o;
+        }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) { loc[lane * DPL + k] = run; run += t[k]; }
     }
     __syncthreads();
 #pragma unroll
@@ -347,10 +369,20 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
         long idx = wbase + i * 64 + lane;
         if (idx < n) {
             uint32_t d = digit_of<BITS>(key[i], kmin, shift);
-            uint32_t dst = off[w][d] + rank[i];
-            keys_out[dst] = key[i];
-            vals_out[dst] = val[i];
+            uint32_t p = loc[d] + off[w][d] + rank[i];
+            skey[p] = key[i];
+            sval[p] = val[i];
         }
+    }
+    __syncthreads();
+    const long bbase = (long)blockIdx.x * RADIX_BLOCK;
+    const int nvalid = (int)((n - bbase) < (long)RADIX_BLOCK ? (n - bbase) : (long)RADIX_BLOCK);
+    for (int j = threadIdx.x; j < nvalid; j += 256) {
+        const uint32_t k = skey[j];
+        const uint32_t d = digit_of<BITS>(k, kmin, shift);
+        const uint32_t dst = gl[d] + ((uint32_t)j - loc[d]);
+        keys_out[dst] = k;
+        vals_out[dst] = sval[j];
     }
 }
 

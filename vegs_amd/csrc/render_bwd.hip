@@ -172,7 +172,7 @@ k_seg_suffix(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ 
 }
 
 // ---- C': gradients of one (tile, segment)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
           const uint32_t* __restrict__ seg_needed, const uint32_t* __restrict__ point_list,
           const Splat* __restrict__ rec, const float* __restrict__ Tbuf, const float* __restrict__ Ubuf,

@@ -27,7 +27,8 @@
 
 namespace vr {
 
-// seg_off[t] = first global segment id of tile t; seg_off[T] = total.  Single workgroup.
+// seg_off[t] = first global segment id of tile t; seg_off[T] = total.  Single workgroup.  (k_seg_tiles then
+// fills seg_tile[s] = tile of segment s, 0xFFFFFFFF beyond the total: the launch grids cover `cap` segments.)
 __global__ void __launch_bounds__(256)
 k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict__ seg_off)
 {
@@ -57,6 +58,22 @@ k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict_
         __syncthreads();
     }
     if (threadIdx.x == 0) seg_off[ntiles] = carry_s;
+}
+
+// seg_tile[s] = largest t with seg_off[t] <= s  (one thread per segment of the launch grid)
+__global__ void __launch_bounds__(256)
+k_seg_tiles(int ntiles, uint32_t* __restrict__ seg_off, uint32_t cap)
+{
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= cap) return;
+    uint32_t* __restrict__ seg_tile = seg_off + seg_tile_offset(ntiles);
+    if (b >= seg_off[ntiles]) { seg_tile[b] = 0xFFFFFFFFu; return; }
+    int lo = 0, hi = ntiles;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg_off[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    seg_tile[b] = (uint32_t)lo;
 }
 
 // ---- A: per (tile, segment, pixel) product of (1 - alpha)
@@ -316,6 +333,7 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     const size_t nseg = seg_capacity(R, ntiles);
     float* Pbuf = (float*)scratch;
     hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(256), 0, s, ranges, ntiles, seg_off);
+    hipLaunchKernelGGL(k_seg_tiles, dim3(cdiv((long)nseg, 256)), dim3(256), 0, s, ntiles, seg_off, (uint32_t)nseg);
     VR_KERNEL_CHECK("seg_offsets", s, debug);
     if (R > 0) {
         hipLaunchKernelGGL(k_seg_alpha, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,

@@ -8,16 +8,11 @@ namespace vr {
 
 constexpr int SEG = 256;
 
-// largest t with seg_off[t] <= b  (seg_off non-decreasing, seg_off[ntiles] = number of segments)
-__device__ __forceinline__ int seg_find_tile(const uint32_t* __restrict__ seg_off, int ntiles, uint32_t b)
-{
-    int lo = 0, hi = ntiles;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (seg_off[mid] <= b) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
+// The segment table lives in one array: seg_off[0..T] (first global segment id of every tile, seg_off[T] =
+// number of segments) followed, at element seg_tile_offset(T), by seg_tile[s] = tile of segment s
+// (0xFFFFFFFF for the unused tail of the launch grid).  A workgroup finds its work with two dependent
+// loads instead of a 12-step binary search over seg_off.
+__host__ __device__ inline int seg_tile_offset(int ntiles) { return (ntiles + 1 + 63) & ~63; }
 
 struct SegCtx {
     uint32_t seg;      // global segment id handled by this workgroup
@@ -38,11 +33,11 @@ __device__ __forceinline__ bool seg_setup(const Camera& cam, const int2* __restr
     // the 8 XCDs, which spreads the (contiguous) segments of the heavy vanishing-point tiles over the
     // whole chip.  Giving each XCD a contiguous run of segments for L2 locality was measured 1.4-2x
     // SLOWER (one XCD ends up with all the long tiles).
-    const uint32_t nseg = seg_off[ntiles];
-    if (blockIdx.x >= nseg) return false;
     const uint32_t b = blockIdx.x;
+    const uint32_t t = seg_off[seg_tile_offset(ntiles) + b];
+    if (t == 0xFFFFFFFFu) return false;
     c.seg = b;
-    c.tile = seg_find_tile(seg_off, ntiles, b);
+    c.tile = (int)t;
     c.sl = (int)(b - seg_off[c.tile]);
     const int2 r = ranges[c.tile];
     c.nlist = r.y - r.x;

@@ -112,7 +112,7 @@ k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
             const float power = splat_power(a.x, a.y, a.z, a.w, b.x, pxf, pyf, dx, dy);
             const bool pre = !(power > 0.0f) && power >= b.z;
             if (__ballot(pre) == 0ull) continue;  // cannot reach 1/255 anywhere in this strip
-            const float alpha = fminf(ALPHA_MAX, b.y * vr_exp(power));
+            const float alpha = fminf(ALPHA_MAX, b.y * vr_exp_unclamped(power));
             const bool valid = pre && !(alpha < ALPHA_MIN);
             p = valid ? p * (1.0f - alpha) : p;
         }
@@ -209,7 +209,7 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
             const float power = splat_power(a.x, a.y, a.z, a.w, b.x, pxf, pyf, dx, dy);
             const bool pre = !done && !(power > 0.0f) && power >= b.z;
             if (__ballot(pre) == 0ull) continue;
-            const float alpha = fminf(ALPHA_MAX, b.y * vr_exp(power));
+            const float alpha = fminf(ALPHA_MAX, b.y * vr_exp_unclamped(power));
             const bool valid = pre && !(alpha < ALPHA_MIN);
             const float pn = p * (1.0f - alpha);
             const bool stop = valid && (Tb * pn < T_EPS);

@@ -71,6 +71,23 @@ __device__ __forceinline__ float vr_exp(float x)
     float v = ldexpf(p, (int)n);
     return x < -87.0f ? 0.0f : v;
 }
+// The same value for every x >= -87 (all the compositing kernels ever USE: they only keep exp(power) for
+// power >= thr > -6); below that the result is unspecified.  Saves the clamp in the inner loops.
+__device__ __forceinline__ float vr_exp_unclamped(float x)
+{
+    float t = x * 1.44269504088896341f;
+    float n = rintf(t);
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.0f / 720.0f;
+    p = fmaf(p, r, 1.0f / 120.0f);
+    p = fmaf(p, r, 1.0f / 24.0f);
+    p = fmaf(p, r, 1.0f / 6.0f);
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    return ldexpf(p, (int)n);
+}
 
 // ---- packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process two floats per lane per issue):
 // two-wide versions of the compositing arithmetic, component-wise identical to the scalar functions

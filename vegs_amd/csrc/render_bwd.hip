@@ -171,8 +171,12 @@ k_seg_suffix(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ 
     }
 }
 
-// ---- C': gradients of one (tile, segment)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// ---- C': gradients of one (tile, segment, 16x4 strip).  ONE WAVE PER WORKGROUP: the four strips of a segment have
+// different numbers of relevant entries and live pixels; as four waves of one workgroup the fast ones idled at
+// the final barrier while still holding their occupancy slot (SQ_WAIT_ANY was 48 % of the wave cycles).  As
+// independent 64-thread workgroups they are scheduled -- and leave -- individually.  An entry is relevant to
+// 1.05 strips on average, so combining the strips in LDS before the global flush bought almost nothing.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
           const uint32_t* __restrict__ seg_needed, const uint32_t* __restrict__ point_list,
           const Splat* __restrict__ rec, const float* __restrict__ Tbuf, const float* __restrict__ Ubuf,
@@ -181,34 +185,39 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
           const float* __restrict__ dL_dscale, const float* __restrict__ dL_dalpha, float* __restrict__ gacc,
           float* __restrict__ gmean2D, const unsigned long long* __restrict__ segmask)
 {
-    __shared__ float gsum[SEG * NACC];            // per-entry gradient sums of this (tile, segment)
-    __shared__ uint32_t ids[SEG];                 // Gaussian id of every entry
-    __shared__ unsigned short ridx[4][SEG];       // per strip: the relevant entries, ascending
-    __shared__ float4 pixrec[4][32][8];           // per strip, per PIXEL PAIR: coords, bg term, 11 upstream grads, carries
+    __shared__ float stage[64 * NACC];            // one chunk's per-entry sums, entry-major, for the coalesced flush
+    __shared__ uint32_t rel_gid[SEG];             // the strip's relevant entries, ascending: Gaussian id ...
+    __shared__ unsigned short rel_j[SEG];         // ... and entry index inside the segment
+    __shared__ float4 pixrec[32][8];              // per PIXEL PAIR: coords, bg term, 11 upstream grads, carries
     SegCtx c;
-    if (!seg_setup(cam, ranges, seg_off, c)) return;
+    const int w = (int)(blockIdx.x & 3u);
+    if (!seg_setup_at(cam, ranges, seg_off, blockIdx.x >> 2, w, c)) return;
     const int needed = (int)seg_needed[c.tile];
     if (c.sl >= needed) return;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x;
+    const int pixslot = w * 64 + lane;            // this pixel's slot in the [segment][256] buffers
 
-    // ---- entry j of the segment: id; per-strip lists of the relevant entries (masks from the forward)
-    const unsigned long long* masks = segmask + (size_t)c.seg * 16;
+    // ---- the entries relevant to this strip (masks from the forward), compacted in list order
+    const unsigned long long* masks = segmask + (size_t)c.seg * 16 + w * 4;
+    const unsigned long long m0 = uniform64(masks[0]), m1 = uniform64(masks[1]), m2 = uniform64(masks[2]),
+                             m3 = uniform64(masks[3]);
+    const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+    const int nrel = n0 + n1 + n2 + n3;
+    if (nrel == 0) return;
     {
-        const bool have = (int)threadIdx.x < c.count;
-        ids[threadIdx.x] = have ? point_list[c.first + threadIdx.x] : 0xFFFFFFFFu;
-        for (int v = threadIdx.x; v < SEG * NACC; v += 256) gsum[v] = 0.0f;
         const unsigned long long lt = (1ull << lane) - 1ull;
+        const unsigned long long mm[4] = {m0, m1, m2, m3};
+        const int before[4] = {0, n0, n0 + n1, n0 + n1 + n2};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            int before = 0;
-            for (int q = 0; q < w; ++q) before += __popcll(masks[s * 4 + q]);
-            const unsigned long long mine = masks[s * 4 + w];
-            if ((mine >> lane) & 1ull) ridx[s][before + __popcll(mine & lt)] = (unsigned short)threadIdx.x;
+        for (int q = 0; q < 4; ++q) {
+            if ((mm[q] >> lane) & 1ull) {
+                const int pos = before[q] + __popcll(mm[q] & lt);
+                rel_j[pos] = (unsigned short)(q * 64 + lane);
+                rel_gid[pos] = point_list[c.first + q * 64 + lane];
+            }
         }
     }
     __syncthreads();
-    const int nrel = __popcll(masks[w * 4]) + __popcll(masks[w * 4 + 1]) + __popcll(masks[w * 4 + 2]) +
-                     __popcll(masks[w * 4 + 3]);
 
     // ---- pixel state, lane = pixel of this wave's 16x4 strip
     const size_t N = (size_t)cam.H * cam.W;
@@ -224,10 +233,10 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     // everything behind the segment
     float v_Tcar = v_Tf;
     if (c.sl + 1 < needed) {
-        const float Tn = Tbuf[(size_t)(c.seg + 1) * SEG + threadIdx.x];
+        const float Tn = Tbuf[(size_t)(c.seg + 1) * SEG + pixslot];
         if (!(Tn < 0.0f)) v_Tcar = Tn;   // pixel still alive at the next segment
     }
-    float v_Scar = Ubuf[(size_t)c.seg * SEG + threadIdx.x];
+    float v_Scar = Ubuf[(size_t)c.seg * SEG + pixslot];
     const int seg_lo = c.sl * SEG;       // first list entry (tile-relative) of this segment
     // Per-pixel record in LDS, interleaved by PIXEL PAIR (a = even pixel, b = odd pixel of the strip): the
     // pixel loop reads it back as wave-uniform broadcasts (LDS pipe, not 16 v_readlane on the VALU pipe) and
@@ -235,13 +244,13 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     //   0 {px_a px_b py_a py_b}  1 {bg_a bg_b g0_a g0_b}  2 {g1 g2}  3 {g3 g4}  4 {g5 g6}  5 {g7 g8}
     //   6 {g9 g10}  7 {Tcar_a Tcar_b Scar_a Scar_b} -- the two carries, updated in place by lane 63.
     {
-        float* rec2 = reinterpret_cast<float*>(&pixrec[w][lane >> 1][0]) + (lane & 1);
+        float* rec2 = reinterpret_cast<float*>(&pixrec[lane >> 1][0]) + (lane & 1);
         rec2[0] = v_pxf; rec2[2] = v_pyf; rec2[4] = v_bgterm;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) rec2[6 + 2 * k] = pg.g[k];
         rec2[28] = v_Tcar; rec2[30] = v_Scar;
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
 
     int mx = v_nc;
 #pragma unroll
@@ -253,14 +262,14 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
         // ---- lane l owns the strip's relevant entry number ch*64 + (63-l): back-to-front over lanes
         const int r = ch * 64 + (63 - lane);
         const bool has = r < nrel;
-        const int ej = has ? (int)ridx[w][r] : 0;      // entry index inside the segment
+        const int ej = has ? (int)rel_j[r] : 0;        // entry index inside the segment
         const int e = seg_lo + ej;                      // tile-relative list index
         float sx = 0.f, sy = 0.f, cA = 0.f, cB = 0.f, cC = 0.f, op = 0.f, thr = 1.0f;
         float at[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) at[k] = 0.0f;
         if (has) {
-            const float4* src = reinterpret_cast<const float4*>(rec + ids[ej]);
+            const float4* src = reinterpret_cast<const float4*>(rec + rel_gid[r]);
             const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4];
             sx = q0.x; sy = q0.y; cA = q0.z; cB = q0.w; cC = q1.x; op = q1.y; thr = q1.z;
             at[0] = q2.x; at[1] = q2.y; at[2] = q2.z; at[3] = q1.w;
@@ -273,13 +282,13 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
         for (int k = 0; k < NACC; ++k) acc[k] = f2_splat(0.0f);
         // nearest list index held by this chunk (its first relevant entry): pixels whose last
         // contributor lies in front of it have nothing to do here
-        const int chunk_lo = seg_lo + (int)ridx[w][ch * 64];
+        const int chunk_lo = seg_lo + (int)rel_j[ch * 64];
 
         if (chunk_lo < wave_maxc) {
             for (int pp = 0; pp < 32; ++pp) {
                 const int nc0 = __builtin_amdgcn_readlane(v_nc, 2 * pp), nc1 = __builtin_amdgcn_readlane(v_nc, 2 * pp + 1);
                 if (max(nc0, nc1) <= chunk_lo) continue;  // neither pixel has a contributor in this chunk (wave-uniform)
-                const float4 r0 = pixrec[w][pp][0];
+                const float4 r0 = pixrec[pp][0];
                 const f2 pxf = {r0.x, r0.y}, pyf = {r0.z, r0.w};
                 f2 dx, dy;
                 const f2 power = splat_power_x2(sx, sy, cA, cB, cC, pxf, pyf, dx, dy);
@@ -294,8 +303,8 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                 const f2 a_eff = {contrib0 ? alpha.x : 0.0f, contrib1 ? alpha.y : 0.0f};
                 G.x = contrib0 ? G.x : 0.0f;              // (exp of a positive exponent may be inf: keep it out of 0*inf)
                 G.y = contrib1 ? G.y : 0.0f;
-                const float4 r1 = pixrec[w][pp][1], r2 = pixrec[w][pp][2], r3 = pixrec[w][pp][3], r4 = pixrec[w][pp][4],
-                             r5 = pixrec[w][pp][5], r6 = pixrec[w][pp][6], r7 = pixrec[w][pp][7];
+                const float4 r1 = pixrec[pp][1], r2 = pixrec[pp][2], r3 = pixrec[pp][3], r4 = pixrec[pp][4],
+                             r5 = pixrec[pp][5], r6 = pixrec[pp][6], r7 = pixrec[pp][7];
                 const f2 bgterm = {r1.x, r1.y}, Tc = {r7.x, r7.y}, Sc = {r7.z, r7.w};
                 const f2 g[NCH] = {{r1.z, r1.w}, {r2.x, r2.y}, {r2.z, r2.w}, {r3.x, r3.y}, {r3.z, r3.w}, {r4.x, r4.y},
                                    {r4.z, r4.w}, {r5.x, r5.y}, {r5.z, r5.w}, {r6.x, r6.y}, {r6.z, r6.w}};
@@ -320,7 +329,7 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                 // carries for the next (nearer) chunk: values at the chunk's first entry = lane 63
                 if (lane == 63) {
                     const f2 Sn = Sc + psum;
-                    pixrec[w][pp][7] = make_float4(Tl.x, Tl.y, Sn.x, Sn.y);
+                    pixrec[pp][7] = make_float4(Tl.x, Tl.y, Sn.x, Sn.y);
                 }
                 if (contrib0 || contrib1) {
                     const f2 inv_om = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
@@ -339,25 +348,24 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                     acc[16] = f2_fma(dLdG, -gdy * f2_splat(cC) - gdx * f2_splat(cB), acc[16]);
                 }
             }
-            // the strips of a tile share entries: combine them in LDS (ds_add_f32)
+            // ---- per-entry sums of the chunk -> LDS (entry-major) -> one coalesced set of global atomics per entry
             if (has) {
 #pragma unroll
-                for (int k = 0; k < NACC; ++k) {
-                    const float a = acc[k].x + acc[k].y;
-                    if (a != 0.0f) atomicAdd(&gsum[ej * NACC + k], a);
-                }
+                for (int k = 0; k < NACC; ++k) stage[lane * NACC + k] = acc[k].x + acc[k].y;
             }
+            __syncthreads();
+            for (int v = lane; v < 64 * NACC; v += 64) {
+                const int l = v / NACC, k = v - l * NACC;
+                const int rr = ch * 64 + (63 - l);
+                if (rr >= nrel) continue;
+                const float sum = stage[v];
+                if (sum == 0.0f) continue;
+                const uint32_t gid = rel_gid[rr];
+                if (k < 15) atomicAdd(&gacc[(size_t)gid * 16 + k], sum);
+                else atomicAdd(&gmean2D[(size_t)gid * 3 + (k - 15)], sum * (k == 15 ? 0.5f * (float)cam.W : 0.5f * (float)cam.H));
+            }
+            __syncthreads();
         }
-    }
-    // ---- one coalesced set of global atomics per (tile, entry)
-    __syncthreads();
-    for (int v = threadIdx.x; v < SEG * NACC; v += 256) {
-        const int l = v / NACC, k = v - l * NACC;
-        const uint32_t gid = ids[l];
-        const float sum = gsum[v];
-        if (gid == 0xFFFFFFFFu || sum == 0.0f) continue;
-        if (k < 15) atomicAdd(&gacc[(size_t)gid * 16 + k], sum);
-        else atomicAdd(&gmean2D[(size_t)gid * 3 + (k - 15)], sum * (k == 15 ? 0.5f * (float)cam.W : 0.5f * (float)cam.H));
     }
 }
 
@@ -382,7 +390,7 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
     hipLaunchKernelGGL(k_seg_suffix, dim3(ntiles), dim3(256), 0, s, seg_off, seg_needed, Ubuf);
     VR_KERNEL_CHECK("seg_suffix", s, debug);
     prof_begin(VR_STAGE_K_SEG_BWD, s);
-    hipLaunchKernelGGL(k_seg_bwd, dim3(nseg), dim3(256), 0, s, cam, ranges, seg_off, seg_needed, point_list, rec, Tbuf,
+    hipLaunchKernelGGL(k_seg_bwd, dim3(nseg * 4), dim3(64), 0, s, cam, ranges, seg_off, seg_needed, point_list, rec, Tbuf,
                        (const float*)Ubuf, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, dL_dalpha,
                        gacc, gmean2D, segmask);
     prof_end(VR_STAGE_K_SEG_BWD, s);

@@ -25,15 +25,24 @@ struct SegCtx {
     size_t pix;
 };
 
+// (b, w): segment id and strip handled by the calling wave; lane = threadIdx.x & 63
+__device__ __forceinline__ bool seg_setup_at(const Camera& cam, const int2* __restrict__ ranges,
+                                             const uint32_t* __restrict__ seg_off, uint32_t b, int w, SegCtx& c);
+
 __device__ __forceinline__ bool seg_setup(const Camera& cam, const int2* __restrict__ ranges,
                                           const uint32_t* __restrict__ seg_off, SegCtx& c)
+{
+    return seg_setup_at(cam, ranges, seg_off, blockIdx.x, threadIdx.x >> 6, c);
+}
+
+__device__ __forceinline__ bool seg_setup_at(const Camera& cam, const int2* __restrict__ ranges,
+                                             const uint32_t* __restrict__ seg_off, uint32_t b, int w, SegCtx& c)
 {
     const int ntiles = cam.gx * cam.gy;
     // Identity block -> segment map on purpose: the dispatcher deals consecutive blocks round-robin to
     // the 8 XCDs, which spreads the (contiguous) segments of the heavy vanishing-point tiles over the
     // whole chip.  Giving each XCD a contiguous run of segments for L2 locality was measured 1.4-2x
     // SLOWER (one XCD ends up with all the long tiles).
-    const uint32_t b = blockIdx.x;
     const uint32_t t = seg_off[seg_tile_offset(ntiles) + b];
     if (t == 0xFFFFFFFFu) return false;
     c.seg = b;
@@ -44,7 +53,7 @@ __device__ __forceinline__ bool seg_setup(const Camera& cam, const int2* __restr
     c.first = r.x + c.sl * SEG;
     c.count = min(SEG, r.y - c.first);
     const int tx = c.tile % cam.gx, ty = c.tile / cam.gx;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     c.px = tx * TILE + (lane & 15);
     c.py = ty * TILE + w * 4 + (lane >> 4);
     c.x0 = (float)(tx * TILE);

@@ -183,6 +183,24 @@ __device__ __forceinline__ uint32_t strips_relevant_exact(float sx, float sy, fl
     return bits;
 }
 
+// the same test for ONE strip (rows ys .. ys+3): identical arithmetic, so the bit equals bit s of the function above
+__device__ __forceinline__ bool strip_relevant_exact(float sx, float sy, float A, float B, float C, float thr, float x0,
+                                                     float ys)
+{
+    const float k = -2.0f * thr;
+    if (!(k > 0.0f)) return false;
+    const float lim = k * 1.001f + 0.001f;
+    const float inv_A = __builtin_amdgcn_rcpf(A), inv_C = __builtin_amdgcn_rcpf(C);
+    const float xl = x0 - sx, xh = x0 + 15.0f - sx;
+    const float yl = ys - sy, yh = yl + 3.0f;
+    bool rel = xl <= 0.0f && xh >= 0.0f && yl <= 0.0f && yh >= 0.0f;
+    float q = quad_edge_min(A, inv_A, B, C, yl, xl, xh);
+    q = fminf(q, quad_edge_min(A, inv_A, B, C, yh, xl, xh));
+    q = fminf(q, quad_edge_min(C, inv_C, B, A, xl, yl, yh));
+    q = fminf(q, quad_edge_min(C, inv_C, B, A, xh, yl, yh));
+    return rel || q <= lim;
+}
+
 // Gaussian exponent at a pixel; identical expression in forward and backward.
 __device__ __forceinline__ float splat_power(float sx, float sy, float A, float B, float C, float pxf, float pyf,
                                              float& dx, float& dy)

@@ -16,15 +16,23 @@
 namespace vr {
 
 constexpr int SH_ROW_MAX = 48;  // floats per Gaussian staged through LDS (M <= 16 coefficients x 3)
+// LDS row stride: 52 floats = 13 x 16 bytes.  Lanes read their own row, so with the natural 48-float stride
+// eight consecutive lanes fell on two 16-byte bank groups (8-way conflicts on every access, 16-way for scalar
+// accesses: SQ_WAIT_INST_LDS was 28 % of the backward kernel's wave cycles); 13 is odd, so eight consecutive
+// lanes now cover all eight groups, and rows are moved as whole float4s.
+constexpr int SH_LDS_STRIDE = 52;
 
 // colour_c = sum_k basis[k] * sh[k][c]   (fixed fma order: part of the numerics contract)
 __device__ __forceinline__ void sh_dot(const float* bas, int K, const float* sh, float* acc)
 {
     float a0 = bas[0] * sh[0], a1 = bas[0] * sh[1], a2 = bas[0] * sh[2];
-    for (int k = 1; k < K; ++k) {
-        a0 = fmaf(bas[k], sh[3 * k + 0], a0);
-        a1 = fmaf(bas[k], sh[3 * k + 1], a1);
-        a2 = fmaf(bas[k], sh[3 * k + 2], a2);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {       // constant trip count + guard: `sh` may be a register array
+        if (k < K) {
+            a0 = fmaf(bas[k], sh[3 * k + 0], a0);
+            a1 = fmaf(bas[k], sh[3 * k + 1], a1);
+            a2 = fmaf(bas[k], sh[3 * k + 2], a2);
+        }
     }
     acc[0] = a0; acc[1] = a1; acc[2] = a2;
 }
@@ -36,7 +44,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
              const float* __restrict__ cov3D_precomp, Splat* __restrict__ rec, int* __restrict__ radii,
              uint2* __restrict__ rect, uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clampb)
 {
-    __shared__ __attribute__((aligned(16))) float sh_lds[4][64 * SH_ROW_MAX];
+    __shared__ __attribute__((aligned(16))) float sh_lds[4][64 * SH_LDS_STRIDE];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool in_range = i < P;
@@ -122,14 +130,31 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
             const float4* src4 = reinterpret_cast<const float4*>(src);
             // all (up to 12) loads of the lane in flight before the first LDS store
             float4 tmp[SH_ROW_MAX / 4];
+            const int row4 = row >> 2;
 #pragma unroll
             for (int j = 0; j < SH_ROW_MAX / 4; ++j)
                 if (lane + 64 * j < nvec) tmp[j] = nt_load4(&src4[lane + 64 * j]);  // streamed once
 #pragma unroll
-            for (int j = 0; j < SH_ROW_MAX / 4; ++j)
-                if (lane + 64 * j < nvec) dst4[lane + 64 * j] = tmp[j];
+            for (int j = 0; j < SH_ROW_MAX / 4; ++j) {
+                const int v = lane + 64 * j;
+                if (v < nvec) {
+                    const int r = row4 == 12 ? v / 12 : v / row4;
+                    dst4[r * (SH_LDS_STRIDE / 4) + (v - r * row4)] = tmp[j];
+                }
+            }
             __builtin_amdgcn_wave_barrier();
-            if (vis) sh_dot(bas, K, sh_lds[w] + lane * row, acc);
+            if (vis) {
+                float srow[SH_ROW_MAX];
+                const float4* my4 = dst4 + lane * (SH_LDS_STRIDE / 4);
+#pragma unroll
+                for (int j = 0; j < SH_ROW_MAX / 4; ++j) {
+                    if (j < row4) {
+                        const float4 t = my4[j];
+                        srow[4 * j] = t.x; srow[4 * j + 1] = t.y; srow[4 * j + 2] = t.z; srow[4 * j + 3] = t.w;
+                    }
+                }
+                sh_dot(bas, K, srow, acc);
+            }
         } else if (vis) {
             sh_dot(bas, K, shs + (size_t)i * row, acc);        // unusual M / alignment: direct row reads
         }

@@ -36,6 +36,7 @@ __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z
 }
 
 constexpr int SH_ROW_MAX = 48;  // floats per Gaussian staged through LDS (M <= 16 coefficients x 3)
+constexpr int SH_LDS_STRIDE = 52;  // padded LDS row stride (13 x 16 bytes: conflict-free per-lane float4 rows, see preprocess.hip)
 
 // One Gaussian's SH backward: gsh[k][c] = basis[k] * dL/drgb_c (zero where the colour was clamped) and
 // the gradient through the view direction into the mean.  `sh` and `gsh` may alias (in-place in LDS).
@@ -54,17 +55,21 @@ __device__ __forceinline__ void sh_backward_row(const Camera& cam, float px3, fl
     const float gc1 = (clampbits & 2u) ? 0.f : g1;
     const float gc2 = (clampbits & 4u) ? 0.f : g2;
     float ddir[3] = {0.f, 0.f, 0.f};
-    for (int k = 0; k < K; ++k) {
-        const float s0 = sh[3 * k], s1 = sh[3 * k + 1], s2 = sh[3 * k + 2];
-        gsh[3 * k + 0] = bas[k] * gc0;
-        gsh[3 * k + 1] = bas[k] * gc1;
-        gsh[3 * k + 2] = bas[k] * gc2;
-        const float sg = s0 * gc0 + s1 * gc1 + s2 * gc2;
-        ddir[0] += bx[k] * sg;
-        ddir[1] += by[k] * sg;
-        ddir[2] += bz[k] * sg;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {       // constant trip count + guards: `sh` / `gsh` may be a register array
+        if (k < K) {
+            const float s0 = sh[3 * k], s1 = sh[3 * k + 1], s2 = sh[3 * k + 2];
+            gsh[3 * k + 0] = bas[k] * gc0;
+            gsh[3 * k + 1] = bas[k] * gc1;
+            gsh[3 * k + 2] = bas[k] * gc2;
+            const float sg = s0 * gc0 + s1 * gc1 + s2 * gc2;
+            ddir[0] += bx[k] * sg;
+            ddir[1] += by[k] * sg;
+            ddir[2] += bz[k] * sg;
+        } else if (k < cam.M) {
+            gsh[3 * k] = 0.f; gsh[3 * k + 1] = 0.f; gsh[3 * k + 2] = 0.f;
+        }
     }
-    for (int k = K; k < cam.M; ++k) { gsh[3 * k] = 0.f; gsh[3 * k + 1] = 0.f; gsh[3 * k + 2] = 0.f; }
     const float dot = dir[0] * ddir[0] + dir[1] * ddir[1] + dir[2] * ddir[2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) dmean[k] += (ddir[k] - dir[k] * dot) * il;
@@ -79,7 +84,7 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
                  float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
                  float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D)
 {
-    __shared__ __attribute__((aligned(16))) float sh_lds[4][64 * SH_ROW_MAX];
+    __shared__ __attribute__((aligned(16))) float sh_lds[4][64 * SH_LDS_STRIDE];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool in_range = i < P;
@@ -98,6 +103,7 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
         const size_t wave_first = (size_t)(blockIdx.x * blockDim.x + w * 64);
         const int rows_here = max(0, min(64, P - (int)wave_first));
         const int nvec = rows_here * row / 4;
+        const int row4 = row >> 2;
         float4* lds4 = reinterpret_cast<float4*>(sh_lds[w]);
         const bool any = __ballot(vis) != 0ull;
         if (any) {
@@ -107,24 +113,47 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
             for (int j = 0; j < SH_ROW_MAX / 4; ++j)
                 if (lane + 64 * j < nvec) tmp[j] = nt_load4(&src4[lane + 64 * j]);  // streamed once
 #pragma unroll
-            for (int j = 0; j < SH_ROW_MAX / 4; ++j)
-                if (lane + 64 * j < nvec) lds4[lane + 64 * j] = tmp[j];
+            for (int j = 0; j < SH_ROW_MAX / 4; ++j) {
+                const int v = lane + 64 * j;
+                if (v < nvec) {
+                    const int r = row4 == 12 ? v / 12 : v / row4;
+                    lds4[r * (SH_LDS_STRIDE / 4) + (v - r * row4)] = tmp[j];
+                }
+            }
             __builtin_amdgcn_wave_barrier();
-            float* myrow = sh_lds[w] + lane * row;
+            float4* my4 = lds4 + lane * (SH_LDS_STRIDE / 4);
             if (vis) {
                 const float4 a1 = reinterpret_cast<const float4*>(gacc + (size_t)i * 16)[1];
                 const float px3 = means3D[3 * (size_t)i], py3 = means3D[3 * (size_t)i + 1], pz3 = means3D[3 * (size_t)i + 2];
-                sh_backward_row(cam, px3, py3, pz3, (uint32_t)clampb[i], a1.x, a1.y, a1.z, myrow, myrow, dmean);
+                float srow[SH_ROW_MAX];          // the lane's row: whole float4s in, whole float4s out
+#pragma unroll
+                for (int j = 0; j < SH_ROW_MAX / 4; ++j) {
+                    if (j < row4) {
+                        const float4 t = my4[j];
+                        srow[4 * j] = t.x; srow[4 * j + 1] = t.y; srow[4 * j + 2] = t.z; srow[4 * j + 3] = t.w;
+                    }
+                }
+                sh_backward_row(cam, px3, py3, pz3, (uint32_t)clampb[i], a1.x, a1.y, a1.z, srow, srow, dmean);
+#pragma unroll
+                for (int j = 0; j < SH_ROW_MAX / 4; ++j)
+                    if (j < row4) my4[j] = make_float4(srow[4 * j], srow[4 * j + 1], srow[4 * j + 2], srow[4 * j + 3]);
             } else if (lane < rows_here) {
-                for (int k = 0; k < row; ++k) myrow[k] = 0.0f;
+                for (int j = 0; j < row4; ++j) my4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             __builtin_amdgcn_wave_barrier();
         }
         float4* dst4 = reinterpret_cast<float4*>(dL_dshs + wave_first * row);
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < SH_ROW_MAX / 4; ++j)
-            if (lane + 64 * j < nvec) nt_store4(any ? lds4[lane + 64 * j] : zero4, &dst4[lane + 64 * j]);
+        for (int j = 0; j < SH_ROW_MAX / 4; ++j) {
+            const int v = lane + 64 * j;
+            if (v < nvec) {
+                const int r = row4 == 12 ? v / 12 : v / row4;
+                float4 val = zero4;
+                if (any) val = lds4[r * (SH_LDS_STRIDE / 4) + (v - r * row4)];
+                nt_store4(val, &dst4[v]);
+            }
+        }
     } else if (shs && vis) {
         // unusual coefficient count / alignment: direct row access, dL_dshs pre-zeroed by the caller
         const float4 a1 = reinterpret_cast<const float4*>(gacc + (size_t)i * 16)[1];

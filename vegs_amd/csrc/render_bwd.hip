@@ -171,7 +171,7 @@ k_seg_suffix(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ 
     }
 }
 
-// ---- C': gradients of one (tile, segment, 16x4 strip).  ONE WAVE PER WORKGROUP: the four strips of a segment have
+// ---- C': gradients of one (tile, segment, 8x8 region = "strip").  ONE WAVE PER WORKGROUP: the four strips of a segment have
 // different numbers of relevant entries and live pixels; as four waves of one workgroup the fast ones idled at
 // the final barrier while still holding their occupancy slot (SQ_WAIT_ANY was 48 % of the wave cycles).  As
 // independent 64-thread workgroups they are scheduled -- and leave -- individually.  An entry is relevant to
@@ -219,7 +219,7 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     }
     __syncthreads();
 
-    // ---- pixel state, lane = pixel of this wave's 16x4 strip
+    // ---- pixel state, lane = pixel of this wave's 8x8 region
     const size_t N = (size_t)cam.H * cam.W;
     const float v_pxf = (float)c.px, v_pyf = (float)c.py;
     PixGrad pg;

@@ -20,7 +20,7 @@
 //   D  k_seg_combine per tile: add the segment-local sums in order, write the images
 // The arithmetic (local product / local sums per segment, added in order) is the one the spec
 // fixes (oracle: or_render_fwd), so the images stay bit-identical to the sequential oracle.
-// One 256-thread workgroup = one 16x16 tile = 4 wave64, lane = pixel (16x4 strip per wave); splat
+// One 256-thread workgroup = one 16x16 tile = 4 wave64, lane = pixel (one 8x8 region = "strip" per wave); splat
 // records are gathered with dwordx4 loads into LDS and read back as wave-uniform broadcasts.
 #include "vr_host.h"
 #include "vr_segment.h"
@@ -130,7 +130,7 @@ k_seg_scan(Camera cam, const uint32_t* __restrict__ seg_off, const float* __rest
     const int tile = blockIdx.x;
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int px = tx * TILE + (lane & 15), py = ty * TILE + w * 4 + (lane >> 4);
+    const int px = tx * TILE + region_x(w, lane), py = ty * TILE + region_y(w, lane);
     bool alive = px < cam.W && py < cam.H;
     const uint32_t s0 = seg_off[tile], s1 = seg_off[tile + 1];
     float Tb = 1.0f;
@@ -173,7 +173,7 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
             const Splat* __restrict__ rec, const float* __restrict__ Tbuf, float* __restrict__ part,
             const unsigned long long* __restrict__ segmask)
 {
-    // ONE WAVE (16x4 strip) PER WORKGROUP, like k_seg_bwd: the four strips of a segment see very different numbers
+    // ONE WAVE (8x8 region = "strip") PER WORKGROUP, like k_seg_bwd: the four strips of a segment see very different numbers
     // of relevant entries and live pixels; as independent 64-thread workgroups they are scheduled and retire
     // individually (0.229 -> 0.205 ms).  The strip's relevant entries are staged 64 at a time.  (k_seg_alpha stays a
     // 256-thread workgroup: its relevance test is shared by the four strips, per-strip workgroups repeat it 4x.)
@@ -277,7 +277,7 @@ k_seg_combine(Camera cam, const uint32_t* __restrict__ seg_off, const uint32_t* 
     const int tile = xcd_tile(blockIdx.x, cam.gx * cam.gy);
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int px = tx * TILE + (lane & 15), py = ty * TILE + w * 4 + (lane >> 4);
+    const int px = tx * TILE + region_x(w, lane), py = ty * TILE + region_y(w, lane);
     if (!(px < cam.W && py < cam.H)) return;
     const uint32_t s0 = seg_off[tile];
     const uint32_t needed = seg_needed[tile];

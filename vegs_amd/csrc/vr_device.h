@@ -145,7 +145,7 @@ __device__ __forceinline__ void tile_rect(float px, float py, int rad, int gx, i
 __device__ __forceinline__ float splat_thr(float opacity) { return -__logf(255.0f * opacity) - 0.01f; }
 
 // Strip relevance.  The reference's tile rectangle comes from the 3-sigma radius of the LARGER axis, so
-// most tile-list entries never reach alpha >= 1/255 inside a given 16x4 pixel strip (VEGS discs are
+// most tile-list entries never reach alpha >= 1/255 inside a given 8x8 pixel region (VEGS discs are
 // thin ellipses).  Does the footprint ellipse  A dx^2 + 2B dx dy + C dy^2 <= k,  k = -2 thr, intersect
 // the strip's rectangle of pixel centres?  Minimum of the convex quadratic over the rectangle: 0 if the
 // centre is inside, otherwise on one of the four edges (1-D clamped minimum).  Conservative by
@@ -158,7 +158,14 @@ __device__ __forceinline__ float quad_edge_min(float a, float inv_a, float b, fl
     const float t = fminf(hi, fmaxf(lo, -b * fixed * inv_a));
     return fmaf(fmaf(a, t, 2.0f * b * fixed), t, c * fixed * fixed);
 }
-// relevance of one splat for the four 16x4 strips of a tile (bit s of the result = strip s)
+// Pixel regions of a 16x16 tile: wave w of a segment workgroup owns region w, lane l its pixel
+// (REGION_W x REGION_H pixels, REGION_W * REGION_H = 64).
+constexpr int REGION_W = 8, REGION_H = 8;
+constexpr int REGIONS_X = TILE / REGION_W;   // regions per tile row
+__device__ __forceinline__ int region_x(int w, int lane) { return (w % REGIONS_X) * REGION_W + (lane % REGION_W); }
+__device__ __forceinline__ int region_y(int w, int lane) { return (w / REGIONS_X) * REGION_H + (lane / REGION_W); }
+
+// relevance of one splat for the four regions of a tile (bit s of the result = region s)
 __device__ __forceinline__ uint32_t strips_relevant_exact(float sx, float sy, float A, float B, float C, float thr,
                                                           float x0, float y0)
 {
@@ -166,13 +173,12 @@ __device__ __forceinline__ uint32_t strips_relevant_exact(float sx, float sy, fl
     if (!(k > 0.0f)) return 0u;
     const float lim = k * 1.001f + 0.001f;
     const float inv_A = __builtin_amdgcn_rcpf(A), inv_C = __builtin_amdgcn_rcpf(C);
-    const float xl = x0 - sx, xh = x0 + 15.0f - sx;
-    const bool x_in = xl <= 0.0f && xh >= 0.0f;
     uint32_t bits = 0;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const float yl = y0 + 4.0f * (float)s - sy, yh = yl + 3.0f;
-        bool rel = x_in && yl <= 0.0f && yh >= 0.0f;
+        const float xl = x0 + (float)((s % REGIONS_X) * REGION_W) - sx, xh = xl + (float)(REGION_W - 1);
+        const float yl = y0 + (float)((s / REGIONS_X) * REGION_H) - sy, yh = yl + (float)(REGION_H - 1);
+        bool rel = xl <= 0.0f && xh >= 0.0f && yl <= 0.0f && yh >= 0.0f;
         float q = quad_edge_min(A, inv_A, B, C, yl, xl, xh);
         q = fminf(q, quad_edge_min(A, inv_A, B, C, yh, xl, xh));
         q = fminf(q, quad_edge_min(C, inv_C, B, A, xl, yl, yh));
@@ -181,24 +187,6 @@ __device__ __forceinline__ uint32_t strips_relevant_exact(float sx, float sy, fl
         bits |= rel ? (1u << s) : 0u;
     }
     return bits;
-}
-
-// the same test for ONE strip (rows ys .. ys+3): identical arithmetic, so the bit equals bit s of the function above
-__device__ __forceinline__ bool strip_relevant_exact(float sx, float sy, float A, float B, float C, float thr, float x0,
-                                                     float ys)
-{
-    const float k = -2.0f * thr;
-    if (!(k > 0.0f)) return false;
-    const float lim = k * 1.001f + 0.001f;
-    const float inv_A = __builtin_amdgcn_rcpf(A), inv_C = __builtin_amdgcn_rcpf(C);
-    const float xl = x0 - sx, xh = x0 + 15.0f - sx;
-    const float yl = ys - sy, yh = yl + 3.0f;
-    bool rel = xl <= 0.0f && xh >= 0.0f && yl <= 0.0f && yh >= 0.0f;
-    float q = quad_edge_min(A, inv_A, B, C, yl, xl, xh);
-    q = fminf(q, quad_edge_min(A, inv_A, B, C, yh, xl, xh));
-    q = fminf(q, quad_edge_min(C, inv_C, B, A, xl, yl, yh));
-    q = fminf(q, quad_edge_min(C, inv_C, B, A, xh, yl, yh));
-    return rel || q <= lim;
 }
 
 // Gaussian exponent at a pixel; identical expression in forward and backward.

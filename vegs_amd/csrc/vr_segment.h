@@ -1,6 +1,6 @@
 // vr_segment.h -- device helpers shared by the segmented compositing kernels (render_fwd.hip,
 // render_bwd.hip).  Unit of work: (tile, segment of SEG = 256 consecutive tile-list entries);
-// workgroup = 256 threads = 4 wave64; wave w owns the 16x4 pixel strip w of the tile, lane = pixel.
+// workgroup = 256 threads = 4 wave64; wave w owns the 8x8 pixel region w of the tile (a "strip" in the comments; see REGION_W/REGION_H), lane = pixel.
 #pragma once
 #include "vr_device.h"
 
@@ -54,8 +54,8 @@ __device__ __forceinline__ bool seg_setup_at(const Camera& cam, const int2* __re
     c.count = min(SEG, r.y - c.first);
     const int tx = c.tile % cam.gx, ty = c.tile / cam.gx;
     const int lane = threadIdx.x & 63;
-    c.px = tx * TILE + (lane & 15);
-    c.py = ty * TILE + w * 4 + (lane >> 4);
+    c.px = tx * TILE + region_x(w, lane);
+    c.py = ty * TILE + region_y(w, lane);
     c.x0 = (float)(tx * TILE);
     c.y0 = (float)(ty * TILE);
     c.inside = c.px < cam.W && c.py < cam.H;
@@ -64,7 +64,7 @@ __device__ __forceinline__ bool seg_setup_at(const Camera& cam, const int2* __re
 }
 
 // Relevance masks of the segment's entries: mask[strip*4 + part] bit j set <=> entry part*64+j can reach
-// alpha >= 1/255 somewhere in that 16x4 strip (conservative ellipse-vs-rectangle test).  Built once per
+// alpha >= 1/255 somewhere in that region (conservative ellipse-vs-rectangle test).  Built once per
 // segment by k_seg_alpha (thread j tests entry j; q0 = x y A B, q1 = C opacity thr depth), kept in the
 // binning buffer (16 x u64 per segment) and reused by the blend and backward kernels.
 __device__ __forceinline__ void seg_build_masks(const SegCtx& c, bool have, float4 q0, float4 q1,

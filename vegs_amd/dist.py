@@ -41,36 +41,63 @@ def view_for_rank(step, rank, world, n_views):
     return (step * world + rank) % n_views
 
 
-def allreduce_grads(tensors, world=None, group=None, flat_bucket_bytes=64 << 20):
+_AVG_OK = {}
+
+
+def _avg_supported(group, device):
+    """ReduceOp.AVG exists on RCCL/NCCL only; probed once per (backend, group) with a one-element collective
+    (every rank takes the same branch, so the probe cannot desynchronise the ranks)."""
+    backend = dist.get_backend(group)
+    key = (backend, id(group))
+    if key not in _AVG_OK:
+        ok = False
+        if backend == "nccl":
+            try:
+                probe = torch.ones(1, device=device)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=group)
+                ok = abs(float(probe.item()) - 1.0) < 1e-6
+            except (RuntimeError, ValueError):
+                ok = False
+        _AVG_OK[key] = ok
+    return _AVG_OK[key]
+
+
+def allreduce_grads(tensors, world=None, group=None, flat_bucket_bytes=1 << 20):
     """In-place mean over ranks of `tensor.grad` for every tensor in `tensors` (same shapes on all
-    ranks).  Large gradients are reduced in place, one collective each (they are already contiguous
-    [P,k] blocks written by the rasterizer's backward); small ones are packed into one flat bucket so
-    the launch count stays low.  Returns the list of async work handles already waited for."""
+    ranks).  Gradients of at least `flat_bucket_bytes` are reduced in place, one collective each, with no
+    staging copies (they are already contiguous [P,k] blocks written by the rasterizer's backward; at
+    2 M Gaussians that is all five: 8 ... 384 MB); smaller ones are packed into one flat bucket so the launch
+    count stays low.  On RCCL/NCCL the 1/world scaling rides in the collective (ReduceOp.AVG) instead of
+    a separate pass over the 236 bytes per Gaussian; backends without AVG (gloo) sum and scale."""
     if world is None:
         world = dist.get_world_size(group) if dist.is_initialized() else 1
     grads = [t.grad for t in tensors if t.grad is not None]
     if world <= 1 or not grads:
         return
-    big = [g for g in grads if g.numel() * g.element_size() >= flat_bucket_bytes]
-    small = [g for g in grads if g.numel() * g.element_size() < flat_bucket_bytes]
+    avg = _avg_supported(group, grads[0].device)
+    op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+    big = [g for g in grads if g.numel() * g.element_size() >= flat_bucket_bytes and g.is_contiguous()]
+    small = [g for g in grads if not (g.numel() * g.element_size() >= flat_bucket_bytes and g.is_contiguous())]
     works = []
     for g in big:
-        works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        works.append(dist.all_reduce(g, op=op, group=group, async_op=True))
     flat = None
     if small:
         flat = torch.cat([g.reshape(-1) for g in small])
-        works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        works.append(dist.all_reduce(flat, op=op, group=group, async_op=True))
     for w in works:
         w.wait()
     inv = 1.0 / world
-    for g in big:
-        g.mul_(inv)
+    if not avg:
+        for g in big:
+            g.mul_(inv)
     if flat is not None:
+        if not avg:
+            flat.mul_(inv)
         off = 0
         for g in small:
             n = g.numel()
             g.copy_(flat[off:off + n].view_as(g))
-            g.mul_(inv)
             off += n
 
 

@@ -213,8 +213,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "alg_bytes_per_launch": round(bytes_k), "avg_launch_ms": round(ms_k, 4),
-                     "stage_ms": {"render_fwd": round(stage["render_fwd"][0] / max(stage["render_fwd"][1], 1), 4),
-                                  "render_bwd": round(stage["render_bwd"][0] / max(stage["render_bwd"][1], 1), 4)},
+                     "stage_ms": {k: round(stage[k][0] / max(stage[k][1], 1), 4) for k in ("render_fwd", "render_bwd")
+                                  if stage[k][1] > 0},
                      "whole_view_alg_bytes": round(b_alg),
                      "whole_view_frac": round(b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
     }

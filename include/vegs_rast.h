@@ -164,7 +164,7 @@ int vr_count_fragments(const VrSaved* saved, int32_t image_height, int32_t image
                        int64_t* fragments);
 
 /* ---- stage timing (HIP events recorded on `stream` around the kernels of each stage).
- * level 0 = off (default), 1 = only the render stages (+ the k_seg_bwd kernel), 2 = every stage.
+ * level 0 = off (default), 1 = only the k_seg_bwd kernel (the roofline kernel), 2 = every stage.
  * vr_profile_collect synchronises the recorded events, ADDS the elapsed milliseconds and launch
  * counts of each stage to ms[VR_STAGE_COUNT] / count[VR_STAGE_COUNT], and clears the record. */
 typedef enum VrStage {

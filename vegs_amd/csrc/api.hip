@@ -15,7 +15,8 @@ namespace vr {
 
 static thread_local char g_err[512] = "";
 static thread_local VrCounters g_counters = {0, 0, 0, 0, 0};
-static thread_local uint32_t* g_pinned = nullptr;  // 2 x uint32 host-pinned mailbox for (V, R)
+static thread_local uint32_t* g_pinned = nullptr;  // host-pinned mailbox for (V, R, min key, max key)
+static thread_local hipEvent_t g_mail_event = nullptr;
 
 void set_error(const char* fmt, ...)
 {
@@ -38,7 +39,7 @@ static bool prof_on(int stage)
 {
     int lvl = g_prof_level.load(std::memory_order_relaxed);
     if (lvl >= 2) return true;
-    return lvl == 1 && (stage == VR_STAGE_RENDER_FWD || stage == VR_STAGE_RENDER_BWD || stage == VR_STAGE_K_SEG_BWD);
+    return lvl == 1 && stage == VR_STAGE_K_SEG_BWD;   // level 1: only the roofline kernel (every event pair costs a ~5 us bubble)
 }
 static hipEvent_t prof_event()
 {
@@ -231,12 +232,18 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
         prof_end(VR_STAGE_PREPROCESS, s);
         if (rc) return rc;
         prof_begin(VR_STAGE_COMPACT, s);
-        rc = launch_compact_visible(P, rect, depth_key, scan_scr, vis_key, vis_id, totals_dev, s, debug);
+        rc = launch_compact_reduce(P, rect, depth_key, scan_scr, totals_dev, s, debug);
+        if (rc) return rc;
+        // the one host<->device round trip of the forward pass: sizes of the data-dependent lists.  The copy is
+        // queued BEFORE the compaction's apply kernel and the host waits on an event right after the copy, so the
+        // round trip (and the host's launch of what follows) overlaps with that kernel instead of idling the GPU.
+        VR_HIP(hipMemcpyAsync(g_pinned, totals_dev, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        if (!g_mail_event) VR_HIP(hipEventCreateWithFlags(&g_mail_event, hipEventDisableTiming));
+        VR_HIP(hipEventRecord(g_mail_event, s));
+        rc = launch_compact_apply(P, rect, depth_key, scan_scr, vis_key, vis_id, s, debug);
         prof_end(VR_STAGE_COMPACT, s);
         if (rc) return rc;
-        // the one host<->device round trip of the forward pass: sizes of the data-dependent lists
-        VR_HIP(hipMemcpyAsync(g_pinned, totals_dev, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        VR_HIP(hipStreamSynchronize(s));
+        VR_HIP(hipEventSynchronize(g_mail_event));
         V = g_pinned[0];
         R = g_pinned[1];
         if (V > 0) {

@@ -199,6 +199,37 @@ k_scan_apply(Src src, Sink sink, long n, const uint32_t* __restrict__ bsum, cons
     }
 }
 
+// Grand totals of a reduce pass on their own (one workgroup): lets the host read them back while the apply
+// kernel is still running.  totals = {sum, secondary sum, min key, max key}.
+__global__ void __launch_bounds__(256)
+k_scan_totals(const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ bsum2, int nb, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t lds4[4];
+    __shared__ uint32_t mm[8];
+    uint32_t t0 = 0, t1 = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+    for (int j = threadIdx.x; j < nb; j += 256) {
+        t0 += bsum[j];
+        t1 += bsum2[j];
+        kmin = min(kmin, bsum2[nb + j]);
+        kmax = max(kmax, bsum2[2 * nb + j]);
+    }
+    t0 = block_sum(t0, lds4);
+    t1 = block_sum(t1, lds4);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { mm[threadIdx.x >> 6] = kmin; mm[4 + (threadIdx.x >> 6)] = kmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        totals[0] = t0;
+        totals[1] = t1;
+        totals[2] = min(min(mm[0], mm[1]), min(mm[2], mm[3]));
+        totals[3] = max(max(mm[4], mm[5]), max(mm[6], mm[7]));
+    }
+}
+
 template <class Src, class Sink>
 static int run_scan(Src src, Sink sink, long n, uint32_t* bsum, uint32_t* bsum2, uint32_t* totals, hipStream_t s,
                     bool debug, const char* what)
@@ -221,15 +252,34 @@ size_t binning_stage1_scratch_bytes(int P)
     return align_up(4 * nb * sizeof(uint32_t), 256);
 }
 
-int launch_compact_visible(int P, const uint2* rect, const uint32_t* depth_key, void* scratch,
-                           uint32_t* vis_key, uint32_t* vis_id, uint32_t* totals_dev, hipStream_t s, bool debug)
+// Two halves, so that the caller can start reading the totals {V, R, min key, max key} back to the host between
+// them: the device->host round trip then overlaps with the apply kernel instead of idling the GPU.
+int launch_compact_reduce(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,
+                          hipStream_t s, bool debug)
+{
+    int nb = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
+    uint32_t* bsum = (uint32_t*)scratch;
+    uint32_t* bsum2 = bsum + nb;
+    SrcFlagTiles src{rect, depth_key};
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_reduce<SrcFlagTiles>), dim3(nb), dim3(256), 0, s, src, (long)P, bsum, bsum2);
+    VR_KERNEL_CHECK("compact_reduce", s, debug);
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(256), 0, s, (const uint32_t*)bsum, (const uint32_t*)bsum2, nb, totals_dev);
+    VR_KERNEL_CHECK("compact_totals", s, debug);
+    return 0;
+}
+
+int launch_compact_apply(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, uint32_t* vis_key,
+                         uint32_t* vis_id, hipStream_t s, bool debug)
 {
     int nb = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
     uint32_t* bsum = (uint32_t*)scratch;
     uint32_t* bsum2 = bsum + nb;
     SrcFlagTiles src{rect, depth_key};
     SinkCompact sink{depth_key, vis_key, vis_id};
-    return run_scan(src, sink, P, bsum, bsum2, totals_dev, s, debug, "compact_visible");
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<SrcFlagTiles, SinkCompact>), dim3(nb), dim3(256), 0, s, src, sink,
+                       (long)P, (const uint32_t*)bsum, (const uint32_t*)bsum2, nb, (uint32_t*)nullptr);
+    VR_KERNEL_CHECK("compact_apply", s, debug);
+    return 0;
 }
 
 // ---------------------------------------------------------------- radix sort pass (stable LSD)

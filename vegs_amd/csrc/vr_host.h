@@ -56,8 +56,10 @@ struct BinningPlan {
 };
 // stage 1 (P-sized): compaction of visible Gaussians in id order + totals.  totals_dev[0]=V, [1]=R.
 size_t binning_stage1_scratch_bytes(int P);
-int launch_compact_visible(int P, const uint2* rect, const uint32_t* depth_key, void* scratch,
-                           uint32_t* vis_key, uint32_t* vis_id, uint32_t* totals_dev, hipStream_t s, bool debug);
+int launch_compact_reduce(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,
+                          hipStream_t s, bool debug);
+int launch_compact_apply(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, uint32_t* vis_key,
+                         uint32_t* vis_id, hipStream_t s, bool debug);
 // stage 2 (V- and R-sized): depth sort, emission, tile sort, ranges.
 size_t binning_stage2_scratch_bytes(int V, long R, int ntiles);
 int launch_binning(const Camera& cam, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,

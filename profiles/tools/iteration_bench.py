@@ -17,6 +17,7 @@ from vegs_amd import harness, losses, optim, scenes
 ap = argparse.ArgumentParser()
 ap.add_argument("--gaussians", type=int, default=2_000_000)
 ap.add_argument("--iters", type=int, default=32)
+ap.add_argument("--boxes", type=int, default=0, help="dynamic box instances of 8196 Gaussians each (BASELINE config C5)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 H, W = 376, 1376
@@ -44,10 +45,25 @@ def model():
     return p, [{"params": [p[k]], "lr": lrs[k], "name": k} for k in p]
 
 
-def render(p, v):
+BOX = []
+if args.boxes:
+    brng = np.random.default_rng(5)
+    for i in range(args.boxes):
+        b, _ = scenes.scene_random(P=8196, sh_degree=3, seed=100 + i, extent=1.0, scale=0.05)
+        B = np.eye(4, dtype=np.float32)
+        ang = brng.uniform(0, 6.28)
+        B[:3, :3] = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32) * 1.5
+        B[:3, 3] = [10.0 + 12.0 * i, brng.uniform(-3, 3), -0.8]
+        BOX.append(({k: torch.tensor(v, device=dev, requires_grad=True) for k, v in b.items()},
+                    torch.tensor(B, device=dev, requires_grad=True)))
+
+
+def render(p, v, fused):
     t = {"means3D": p["xyz"], "shs": torch.cat((p["f_dc"], p["f_rest"]), dim=1), "opacities": torch.sigmoid(p["opacity"]),
          "scales": torch.exp(p["scaling"]), "rotations": F.normalize(p["rotation"])}          # gaussian_model.py:100-120
-    return harness.render(cams[v], t, deg, bg, cam_t=cam_ts[v])
+    if not BOX:
+        return harness.render(cams[v], t, deg, bg, cam_t=cam_ts[v])
+    return harness.render_all(cams[v], t, [b for b, _ in BOX], [w for _, w in BOX], deg, bg, cam_t=cam_ts[v], fused=fused)
 
 
 def aten_loss(pkg, gt, normal):
@@ -73,12 +89,12 @@ def fused_loss(pkg, gt, normal):
 def run(fused):
     p, groups = model()
     opt = (optim.Adam if fused else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
-    P = p["xyz"].shape[0]
+    P = p["xyz"].shape[0] + 8196 * len(BOX)     # statistics over the concatenated op inputs
     accum, denom, maxr = (torch.zeros(P, 1, device=dev), torch.zeros(P, 1, device=dev), torch.zeros(P, device=dev))
 
     def it(i):
         v = i % len(cams)
-        pkg = render(p, v)
+        pkg = render(p, v, fused)
         # NaN guard for pixels no Gaussian covers (the reference's loss would be NaN there): same in both variants
         q = pkg["render_cov_quat"]
         pkg["render_cov_quat"] = torch.where((q.detach() * q.detach()).sum(0, keepdim=True) > 0, q, torch.ones_like(q))
@@ -108,7 +124,7 @@ def run(fused):
 
 a_ms, a_loss = run(False)
 b_ms, b_loss = run(True)
-print(json.dumps({"gaussians": args.gaussians, "frame": [H, W], "iters": args.iters,
+print(json.dumps({"gaussians": args.gaussians, "boxes": args.boxes, "frame": [H, W], "iters": args.iters,
                   "A_rasterizer_only_ms": round(a_ms, 3), "B_all_fused_ms": round(b_ms, 3),
                   "A_iter_per_s": round(1e3 / a_ms, 1), "B_iter_per_s": round(1e3 / b_ms, 1),
                   "loss_A": a_loss, "loss_B": b_loss}))

@@ -156,7 +156,7 @@ k_seg_suffix(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ 
     const int tile = blockIdx.x;
     const uint32_t s0 = seg_off[tile];
     const int needed = (int)seg_needed[tile];
-    constexpr int CU = 8;
+    constexpr int CU = 24;
     float run = 0.0f;
     for (int s = needed - 1; s >= 0; s -= CU) {
         float v[CU];

@@ -136,7 +136,7 @@ k_seg_scan(Camera cam, const uint32_t* __restrict__ seg_off, const float* __rest
     float Tb = 1.0f;
     // Each wave walks the segment chain of its own 64 pixels without block barriers; the P values of
     // UNROLL segments are fetched together so the chain is not bound by one memory latency per segment.
-    constexpr int UNROLL = 8;
+    constexpr int UNROLL = 24;
     uint32_t mine = 0;  // segments this wave needs (some pixel alive at the segment start)
     bool wave_alive = __ballot(alive) != 0ull;
     for (uint32_t s = s0; s < s1 && wave_alive; s += UNROLL) {

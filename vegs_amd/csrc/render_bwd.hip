@@ -8,22 +8,22 @@
 //                   behind = sum_{j behind s} w_j u_j
 // and dL/dalpha fans out to opacity, conic and the 2D mean.
 //
-// MI355X design.  (1) SEGMENTED like the forward: the unit of work is (tile, 256-entry segment), so
-// the 10^5-entry vanishing-point tiles spread over the whole chip.  The two compositing carries are
-// made available per segment: the transmittance at the segment end comes from the forward's boundary
-// buffer (Tbuf, kept in the binning buffer), and the "behind" sum comes from a cheap pixel-parallel
-// pass (k_seg_wu: U = sum of w*u per segment) followed by a per-tile suffix sum (k_seg_suffix).
-// (2) SPLAT-parallel inside a segment with wave64 DPP scans (not the pixel-parallel +
-// per-fragment-atomic scheme of CUDA rasterizers): the reduction target of the backward pass is the
-// splat, so the splat owns the lane.  A wave holds 64 consecutive list entries in registers (record +
-// 17 gradient accumulators) and walks its 64 pixels, whose quantities are wave-uniform
-// (v_readlane -> SGPR).  The two recurrences become wave scans in DPP (row_shr / row_bcast):
+// MI355X design.  (1) SEGMENTED like the forward: the unit of work is (tile, 256-entry segment, 8x8 pixel region),
+// so the 10^5-entry vanishing-point tiles spread over the whole chip.  The two compositing carries are made
+// available per segment: the transmittance at the segment end comes from the forward's boundary buffer (Tbuf,
+// kept in the binning buffer), and the "behind" sum comes from a cheap pixel-parallel pass (k_seg_u: U = sum of
+// w*u per segment, straight from the forward's segment-local channel sums) followed by a per-tile suffix sum
+// (k_seg_suffix).
+// (2) SPLAT-parallel inside a segment with wave64 DPP scans (not the pixel-parallel + per-fragment-atomic scheme
+// of CUDA rasterizers): the reduction target of the backward pass is the splat, so the splat owns the lane.  A
+// wave (= one 64-thread workgroup) holds 64 entries relevant to its region in registers (record + 17 gradient
+// accumulators) and walks the region's pixels two at a time; the pixel quantities are wave-uniform (LDS
+// broadcasts).  The two recurrences become wave scans in DPP (row_shr / row_bcast):
 //   T in front of splat s = T_after_chunk / prod_{j>=s}(1-alpha_j)   (inclusive scan-product)
 //   behind(s)             = carry + sum_{j>s} w_j u_j                (inclusive scan-sum)
 // Lanes hold a chunk back-to-front (lane l <-> entry 63-l) so both are PREFIX scans over lanes.
-// Per-splat gradients stay in registers until the chunk is finished; the four waves (pixel strips)
-// of the tile are reduced through LDS and one coalesced set of global atomics per (tile, splat) is
-// issued -- 256x fewer atomics than one per fragment.
+// Per-splat gradients stay in registers until the chunk is finished, are transposed through LDS and leave as one
+// coalesced set of global atomics per (region, splat) -- ~250x fewer atomics than one per fragment.
 #include "../../include/vegs_rast.h"
 #include "vr_host.h"
 #include "vr_segment.h"
@@ -32,43 +32,11 @@ namespace vr {
 
 constexpr int NACC = 17;  // conic(3) opacity(1) attr(11) mean2D(2)
 
-__device__ __forceinline__ float readlane_f(float v, int l)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
-
 // wave64 inclusive prefix scans in DPP: row_shr 1,2,4,8 inside each 16-lane row, then row_bcast 15 / 31.
 // VOP2-DPP semantics do the masking for free: a lane whose DPP source is out of range (or whose row is
-// masked off) is simply not written, i.e. keeps its value -- one instruction per scan step.  The
-// "s_nop 1" are the two wait states a DPP read needs after the VALU write of the same VGPR.
-__device__ __forceinline__ float wave_prefix_mul(float v)
-{
-    asm volatile(
-        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(v));
-    return v;
-}
-__device__ __forceinline__ float wave_prefix_add(float v)
-{
-    asm volatile(
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(v));
-    return v;
-}
-
-// two independent scans interleaved: the other chain's instruction fills one of the two DPP wait states
+// masked off) is simply not written, i.e. keeps its value -- one instruction per scan step.  A DPP read needs
+// two wait states after the VALU write of the same VGPR; two independent scans are interleaved, so the other
+// chain's instruction fills one of them.
 #define VR_DPP2(op, ctl)                                                        \
     op " %0, %0, %0 " ctl "\n\t" op " %1, %1, %1 " ctl "\n\ts_nop 0\n\t"
 __device__ __forceinline__ void wave_prefix_mul_x2(float& a, float& b)

@@ -90,29 +90,10 @@ __device__ __forceinline__ float vr_exp_unclamped(float x)
 }
 
 // ---- packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process two floats per lane per issue):
-// two-wide versions of the compositing arithmetic, component-wise identical to the scalar functions
+// two-wide helpers for the compositing arithmetic of the backward pass
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 f2_splat(float v) { f2 r = {v, v}; return r; }
 __device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 vr_exp_x2(f2 x)
-{
-    const f2 t = x * f2_splat(1.44269504088896341f);
-    const f2 n = {rintf(t.x), rintf(t.y)};
-    f2 r = f2_fma(n, f2_splat(-0.693145751953125f), x);
-    r = f2_fma(n, f2_splat(-1.42860682030941723212e-6f), r);
-    f2 p = f2_splat(1.0f / 720.0f);
-    p = f2_fma(p, r, f2_splat(1.0f / 120.0f));
-    p = f2_fma(p, r, f2_splat(1.0f / 24.0f));
-    p = f2_fma(p, r, f2_splat(1.0f / 6.0f));
-    p = f2_fma(p, r, f2_splat(0.5f));
-    p = f2_fma(p, r, f2_splat(1.0f));
-    p = f2_fma(p, r, f2_splat(1.0f));
-    f2 v = {ldexpf(p.x, (int)n.x), ldexpf(p.y, (int)n.y)};
-    v.x = x.x < -87.0f ? 0.0f : v.x;
-    v.y = x.y < -87.0f ? 0.0f : v.y;
-    return v;
-}
-
 __device__ __forceinline__ void xform43(const float* __restrict__ m, float px, float py, float pz, float& ox,
                                         float& oy, float& oz)
 {

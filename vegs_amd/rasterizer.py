@@ -77,7 +77,7 @@ def _cpu_args_copy(args):
     return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
 
 
-# largest number of tile-list entries seen per device: handed to the library as a capacity hint so that
+# largest number of tile-list entries seen per (device, image size, model size): handed to the library as a capacity hint so that
 # it can request its R-sized buffers before the forward's single host synchronisation.  A running
 # maximum (not the last value) keeps every request the same size from step to step, so PyTorch's
 # caching allocator serves them from its pool instead of going back to hipMalloc.
@@ -126,7 +126,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                   alpha.data_ptr(), _capi.ptr(radii))
             arena = _capi.Arena(device)
             saved = _capi.VrSaved()
-            hint = _LAST_R.get(device.index, 0)
+            hint_key = (device.index, H, W, P >> 16)
+            hint = _LAST_R.get(hint_key, 0)
             saved.binning_capacity = int(hint * 1.125) + 65536 if hint > 0 else 0
             stream = torch.cuda.current_stream(device).cuda_stream
             cpu_args = _cpu_args_copy((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)) \
@@ -146,7 +147,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = int(saved.num_rendered)
         ctx.num_visible = int(saved.num_visible)
         ctx.binning_capacity = int(saved.binning_capacity)
-        _LAST_R[device.index] = max(_LAST_R.get(device.index, 0), ctx.num_rendered)
+        _LAST_R[hint_key] = max(_LAST_R.get(hint_key, 0), ctx.num_rendered)
         ctx.buffers = (arena.kept[_capi.VR_BUF_GEOM], arena.kept[_capi.VR_BUF_BINNING], arena.kept[_capi.VR_BUF_IMAGE])
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
         ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VR_ABI_VERSION 2
+#define VR_ABI_VERSION 3
 
 typedef enum VrStatus {
     VR_OK = 0,
@@ -72,14 +72,19 @@ typedef struct VrSettings {
  * shs / colors_precomp and exactly one of (scales, rotations) / cov3D_precomp is non-NULL. */
 typedef struct VrInputs {
     int32_t P;                   /* number of Gaussians */
-    int32_t M;                   /* SH coefficients stored per Gaussian (shs.shape[1]); 0 if shs == NULL */
+    int32_t M;                   /* SH coefficients stored per Gaussian IN TOTAL (shs.shape[1], or 1 + shs_rest.shape[1]
+                                    with split storage); 0 if shs == NULL */
     const float* means3D;        /* [P,3] */
-    const float* shs;            /* [P,M,3] or NULL */
+    const float* shs;            /* [P,M,3] or NULL; with split storage: [P,1,3], the DC coefficient */
     const float* colors_precomp; /* [P,3] or NULL */
     const float* opacities;      /* [P,1] */
     const float* scales;         /* [P,3] or NULL */
     const float* rotations;      /* [P,4] (w,x,y,z) or NULL */
     const float* cov3D_precomp;  /* [P,6] or NULL */
+    const float* shs_rest;       /* optional, split SH storage: [P,M-1,3], the remaining coefficients.  The reference's
+                                    model keeps _features_dc / _features_rest apart and concatenates them on every
+                                    call (get_features, scene/gaussian_model.py:112-116); passing the two tensors as
+                                    they are saves that 2 x 384 MB copy per view at 2 M Gaussians.  NULL = shs is whole. */
 } VrInputs;
 
 typedef struct VrOutputs {
@@ -120,12 +125,13 @@ typedef struct VrOutGrads {
 typedef struct VrInGrads {
     float* dL_dmeans3D;        /* [P,3] */
     float* dL_dmeans2D;        /* [P,3] */
-    float* dL_dshs;            /* [P,M,3] or NULL */
+    float* dL_dshs;            /* [P,M,3] or NULL; with split storage [P,1,3] */
     float* dL_dcolors_precomp; /* [P,3] or NULL */
     float* dL_dopacities;      /* [P,1] */
     float* dL_dscales;         /* [P,3] or NULL */
     float* dL_drotations;      /* [P,4] or NULL */
     float* dL_dcov3D_precomp;  /* [P,6] or NULL */
+    float* dL_dshs_rest;       /* [P,M-1,3], required when VrInputs.shs_rest is given */
 } VrInGrads;
 
 /* Work counters of the most recent vr_forward on this thread (roofline accounting). */

@@ -59,9 +59,12 @@ if args.boxes:
 
 
 def render(p, v, fused):
-    t = {"means3D": p["xyz"], "shs": torch.cat((p["f_dc"], p["f_rest"]), dim=1), "opacities": torch.sigmoid(p["opacity"]),
+    t = {"means3D": p["xyz"], "shs": None if (fused and not BOX) else torch.cat((p["f_dc"], p["f_rest"]), dim=1),
+         "opacities": torch.sigmoid(p["opacity"]),
          "scales": torch.exp(p["scaling"]), "rotations": F.normalize(p["rotation"])}          # gaussian_model.py:100-120
     if not BOX:
+        if fused:   # the model's two SH tensors as they are: no torch.cat, no slicing copies in the backward
+            t["shs"] = (p["f_dc"], p["f_rest"])
         return harness.render(cams[v], t, deg, bg, cam_t=cam_ts[v])
     return harness.render_all(cams[v], t, [b for b, _ in BOX], [w for _, w in BOX], deg, bg, cam_t=cam_ts[v], fused=fused)
 

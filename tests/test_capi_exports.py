@@ -35,11 +35,11 @@ def test_struct_layouts_match_header_sizes():
     from vegs_amd import _capi
     p = ctypes.sizeof(ctypes.c_void_p)
     assert ctypes.sizeof(_capi.VrSettings) == 8 * 4 + 4 * p
-    assert ctypes.sizeof(_capi.VrInputs) == 2 * 4 + 7 * p
+    assert ctypes.sizeof(_capi.VrInputs) == 2 * 4 + 8 * p
     assert ctypes.sizeof(_capi.VrOutputs) == 6 * p
     assert ctypes.sizeof(_capi.VrSaved) == 3 * p + 3 * 8
     assert ctypes.sizeof(_capi.VrOutGrads) == 5 * p
-    assert ctypes.sizeof(_capi.VrInGrads) == 8 * p
+    assert ctypes.sizeof(_capi.VrInGrads) == 9 * p
     assert ctypes.sizeof(_capi.VrCounters) == 5 * 8
 
 

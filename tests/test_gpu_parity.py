@@ -296,3 +296,46 @@ def test_many_tiles_large_image(dev):
     inputs = dict(means3D=sc["means3D"], shs=sc["shs"], colors_precomp=None, opacities=sc["opacities"],
                   scales=sc["scales"], rotations=sc["rotations"], cov3D_precomp=None)
     _check_against_oracle(inputs, scenes.camera_c1(2048, 1200), [0, 0, 0], deg, 1.0, dev, grad_rtol=5e-4)
+
+
+@pytest.mark.parametrize("P,M,deg", [(3000, 16, 3), (1000, 16, 1), (777, 4, 1), (130, 9, 2), (64, 2, 0)])
+def test_split_sh_storage_equals_concatenated(P, M, deg, dev):
+    """Extension of the op's `shs` argument: the pair (features_dc [P,1,3], features_rest [P,M-1,3]) as the
+    reference's model stores them (scene/gaussian_model.py:112-116 concatenates on every call).  Images must be
+    bit-identical to the concatenated call, gradients equal to the slices of its dL_dshs."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from vegs_amd import scenes
+    sc, _ = scenes.scene_random(P=P, sh_degree=3, seed=P, scale=0.05)
+    cam = scenes.camera_c1(120, 72)
+    st = _settings(cam, [0.1, 0.2, 0.3], deg, 1.0, dev)
+    rng = np.random.default_rng(P)
+    gouts = [torch.tensor(rng.normal(size=s).astype(np.float32), device=dev) for s in [(3, 72, 120), (4, 72, 120), (3, 72, 120)]]
+    shs = np.ascontiguousarray(sc["shs"][:, :M])
+
+    def run(split):
+        t = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in sc.items() if k != "shs"}
+        if split:
+            dc = torch.tensor(shs[:, :1].copy(), device=dev, requires_grad=True)
+            rest = torch.tensor(shs[:, 1:].copy(), device=dev, requires_grad=True)
+            sh_arg, leaves = (dc, rest), (dc, rest)
+        else:
+            full = torch.tensor(shs, device=dev, requires_grad=True)
+            sh_arg, leaves = full, (full,)
+        m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
+        res = GaussianRasterizer(raster_settings=st)(means3D=t["means3D"], means2D=m2d, shs=sh_arg, opacities=t["opacities"],
+                                                    scales=t["scales"], rotations=t["rotations"])
+        torch.autograd.backward([res[0], res[2], res[3]], gouts)
+        return res, t, leaves, m2d
+
+    ra, ta, (full,), m2a = run(False)
+    rb, tb, (dc, rest), m2b = run(True)
+    for a, b in zip(ra, rb):
+        assert torch.equal(a, b)
+    assert dc.grad.shape == (P, 1, 3) and rest.grad.shape == (P, M - 1, 3)
+    fg = full.grad.cpu().numpy()
+    assert rel_err(dc.grad.cpu().numpy(), fg[:, :1]) < 1e-5 and rel_err(rest.grad.cpu().numpy(), fg[:, 1:]) < 1e-5
+    for k in ("means3D", "opacities", "scales", "rotations"):
+        assert rel_err(tb[k].grad.cpu().numpy(), ta[k].grad.cpu().numpy()) < 1e-4, k
+    # culled Gaussians: exact zero rows in both gradient tensors
+    culled = (rb[5] == 0).cpu().numpy()
+    assert not dc.grad.cpu().numpy()[culled].any() and not rest.grad.cpu().numpy()[culled].any()

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libvegsrast.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH = 0, 1, 2, 3
 
@@ -35,7 +35,7 @@ class VrSettings(C.Structure):
 class VrInputs(C.Structure):
     _fields_ = [("P", C.c_int32), ("M", C.c_int32), ("means3D", C.c_void_p), ("shs", C.c_void_p),
                 ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
-                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p)]
+                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("shs_rest", C.c_void_p)]
 
 
 class VrOutputs(C.Structure):
@@ -56,7 +56,7 @@ class VrOutGrads(C.Structure):
 class VrInGrads(C.Structure):
     _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
                 ("dL_dcolors_precomp", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
-                ("dL_drotations", C.c_void_p), ("dL_dcov3D_precomp", C.c_void_p)]
+                ("dL_drotations", C.c_void_p), ("dL_dcov3D_precomp", C.c_void_p), ("dL_dshs_rest", C.c_void_p)]
 
 
 class VrAdamTensor(C.Structure):

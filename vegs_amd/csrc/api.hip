@@ -125,6 +125,10 @@ static int check_inputs(const VrSettings* st, const VrInputs* in)
             if (in->M < K)
                 return fail(VR_ERR_INVALID_ARGUMENT, "shs holds %d coefficients but sh_degree %d needs %d", in->M,
                             st->sh_degree, K);
+            if (in->shs_rest && (in->M < 2 || in->M > 16))
+                return fail(VR_ERR_INVALID_ARGUMENT, "split SH storage needs 2..16 coefficients in total (got %d)", in->M);
+        } else if (in->shs_rest) {
+            return fail(VR_ERR_INVALID_ARGUMENT, "shs_rest given without shs (the DC coefficients)");
         }
     }
     return 0;
@@ -226,7 +230,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     }
     if (P > 0) {
         prof_begin(VR_STAGE_PREPROCESS, s);
-        rc = launch_preprocess(cam, P, in->means3D, in->shs, in->colors_precomp, in->opacities, in->scales,
+        rc = launch_preprocess(cam, P, in->means3D, in->shs, in->shs_rest, in->colors_precomp, in->opacities, in->scales,
                                in->rotations, in->cov3D_precomp, rec, out->radii, rect, depth_key,
                                (uint8_t*)geom + align_up(p1 * sizeof(Splat), 256), s, debug);
         prof_end(VR_STAGE_PREPROCESS, s);
@@ -325,8 +329,12 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
     prof_begin(VR_STAGE_BWD_ZERO, s);
     VR_HIP(hipMemsetAsync(gacc, 0, (size_t)P * 16 * sizeof(float), s));
     VR_HIP(hipMemsetAsync(gin->dL_dmeans2D, 0, (size_t)P * 3 * sizeof(float), s));
-    if (gin->dL_dshs && !preprocess_bwd_writes_all_sh(in->M, in->shs, gin->dL_dshs))
+    if (in->shs_rest) {   // split SH storage: the kernel writes every row of both gradient arrays
+        if (!gin->dL_dshs || !gin->dL_dshs_rest)
+            return fail(VR_ERR_INVALID_ARGUMENT, "split SH storage needs both dL_dshs and dL_dshs_rest");
+    } else if (gin->dL_dshs && !preprocess_bwd_writes_all_sh(in->M, in->shs, gin->dL_dshs)) {
         VR_HIP(hipMemsetAsync(gin->dL_dshs, 0, (size_t)P * in->M * 3 * sizeof(float), s));
+    }
     prof_end(VR_STAGE_BWD_ZERO, s);
     if (saved->num_rendered > 0) {
         void* scr = alloc(user, VR_BUF_SCRATCH, render_bwd_scratch_bytes((long)Rcap, (int)T) + 256);
@@ -344,9 +352,9 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
         if (rc) return rc;
     }
     ProfScope ps2(VR_STAGE_PREPROCESS_BWD, s);
-    rc = launch_preprocess_bwd(cam, P, in->means3D, in->shs, in->colors_precomp, in->scales, in->rotations,
+    rc = launch_preprocess_bwd(cam, P, in->means3D, in->shs, in->shs_rest, in->colors_precomp, in->scales, in->rotations,
                                in->cov3D_precomp, radii,
-                               (const uint8_t*)saved->geom + align_up((size_t)P * sizeof(Splat), 256), gacc, gin->dL_dmeans2D, gin->dL_dmeans3D, gin->dL_dshs,
+                               (const uint8_t*)saved->geom + align_up((size_t)P * sizeof(Splat), 256), gacc, gin->dL_dmeans2D, gin->dL_dmeans3D, gin->dL_dshs, gin->dL_dshs_rest,
                                gin->dL_dcolors_precomp, gin->dL_dopacities, gin->dL_dscales, gin->dL_drotations,
                                gin->dL_dcov3D_precomp, s, debug);
     return rc;

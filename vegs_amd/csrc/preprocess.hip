@@ -39,7 +39,7 @@ __device__ __forceinline__ void sh_dot(const float* bas, int K, const float* sh,
 
 __global__ void __launch_bounds__(256)
 k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
-             const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+             const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
              const float* __restrict__ scales, const float* __restrict__ rotations,
              const float* __restrict__ cov3D_precomp, Splat* __restrict__ rec, int* __restrict__ radii,
              uint2* __restrict__ rect, uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clampb)
@@ -122,7 +122,25 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
             dx = dx / len; dy = dy / len; dz = dz / len;
             sh_basis(cam.deg, dx, dy, dz, bas);
         }
-        if (staged) {
+        if (shs_rest) {
+            // split storage (the model's own two tensors, no torch.cat): shs = [P,1,3] DC rows, shs_rest = [P,M-1,3].
+            // The wave's 64 rest rows are one contiguous block: copied linearly into LDS, where the row stride is
+            // the memory's own (45 floats at M = 16: odd, so the per-lane row reads are bank-conflict free).
+            const int rowr = row - 3;
+            const int rows_here = min(64, P - (int)wave_first);
+            wave_copy_to_lds<SH_ROW_MAX / 4>(shs_rest + wave_first * rowr, sh_lds[w], rows_here * rowr, lane);
+            __builtin_amdgcn_wave_barrier();
+            if (vis) {
+                float srow[SH_ROW_MAX];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) srow[c] = shs[3 * (size_t)i + c];
+                const float* my = sh_lds[w] + lane * rowr;
+#pragma unroll
+                for (int k = 0; k < SH_ROW_MAX - 3; ++k)
+                    if (k < rowr) srow[3 + k] = my[k];
+                sh_dot(bas, K, srow, acc);
+            }
+        } else if (staged) {
             const float* src = shs + wave_first * row;
             const int rows_here = min(64, P - (int)wave_first);
             const int nvec = rows_here * row / 4;               // float4s to move
@@ -198,14 +216,15 @@ k_mark_visible(const float* __restrict__ xyz, int P, const float* __restrict__ v
     present[i] = t2 > NEAR_Z ? 1 : 0;
 }
 
-int launch_preprocess(const Camera& cam, int P, const float* means3D, const float* shs, const float* colors_precomp,
+int launch_preprocess(const Camera& cam, int P, const float* means3D, const float* shs, const float* shs_rest,
+                      const float* colors_precomp,
                       const float* opacities, const float* scales, const float* rotations,
                       const float* cov3D_precomp, Splat* rec, int* radii, uint2* rect,
                       uint32_t* depth_key, uint8_t* clampb, hipStream_t s, bool debug)
 {
     if (P == 0) return 0;
-    hipLaunchKernelGGL(k_preprocess, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, means3D, shs, colors_precomp,
-                       opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, clampb);
+    hipLaunchKernelGGL(k_preprocess, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, means3D, shs, shs_rest,
+                       colors_precomp, opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, clampb);
     VR_KERNEL_CHECK("preprocess", s, debug);
     return 0;
 }

@@ -77,6 +77,7 @@ __device__ __forceinline__ void sh_backward_row(const Camera& cam, float px3, fl
 
 __global__ void __launch_bounds__(256)
 k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ means3D, const float* __restrict__ shs,
+                 const float* __restrict__ shs_rest, float* __restrict__ dL_dshs_rest,
                  const float* __restrict__ colors_precomp, const float* __restrict__ scales,
                  const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
                  const int* __restrict__ radii, const uint8_t* __restrict__ clampb, const float* __restrict__ gacc,
@@ -98,7 +99,46 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
     // staged through LDS with coalesced dwordx4 loads, every lane turns its row into its dL/dsh row in
     // place, and the 64 rows are stored back coalesced (zeros for culled Gaussians: the kernel writes
     // every row of dL_dshs itself, no separate memset).
-    if (shs && sh_staged) {
+    if (shs && shs_rest) {
+        // split storage: shs / dL_dshs = [P,1,3] DC rows (read and written by their own lane: 12 contiguous bytes per
+        // lane), shs_rest / dL_dshs_rest = [P,M-1,3]: the wave's 64 rest rows are one contiguous block, copied
+        // linearly into LDS (row stride = the memory's own, 45 floats at M = 16: odd, conflict-free row access),
+        // turned into gradient rows in place and copied back linearly.  Every row of both gradients is written.
+        const int rowr = cam.M * 3 - 3;
+        const size_t wave_first = (size_t)(blockIdx.x * blockDim.x + w * 64);
+        const int rows_here = max(0, min(64, P - (int)wave_first));
+        const bool any = __ballot(vis) != 0ull;
+        float dc[3] = {0.f, 0.f, 0.f};
+        if (any) {
+            wave_copy_to_lds<SH_ROW_MAX / 4>(shs_rest + wave_first * rowr, sh_lds[w], rows_here * rowr, lane);
+            __builtin_amdgcn_wave_barrier();
+            float* my = sh_lds[w] + lane * rowr;
+            if (vis) {
+                const float4 a1 = reinterpret_cast<const float4*>(gacc + (size_t)i * 16)[1];
+                const float px3 = means3D[3 * (size_t)i], py3 = means3D[3 * (size_t)i + 1], pz3 = means3D[3 * (size_t)i + 2];
+                float srow[SH_ROW_MAX];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) srow[c] = shs[3 * (size_t)i + c];
+#pragma unroll
+                for (int k = 0; k < SH_ROW_MAX - 3; ++k)
+                    if (k < rowr) srow[3 + k] = my[k];
+                sh_backward_row(cam, px3, py3, pz3, (uint32_t)clampb[i], a1.x, a1.y, a1.z, srow, srow, dmean);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dc[c] = srow[c];
+#pragma unroll
+                for (int k = 0; k < SH_ROW_MAX - 3; ++k)
+                    if (k < rowr) my[k] = srow[3 + k];
+            } else if (lane < rows_here) {
+                for (int k = 0; k < rowr; ++k) my[k] = 0.0f;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (in_range) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dL_dshs[3 * (size_t)i + c] = dc[c];
+        }
+        wave_copy_from_lds<SH_ROW_MAX / 4>(dL_dshs_rest + wave_first * rowr, sh_lds[w], rows_here * rowr, lane, !any);
+    } else if (shs && sh_staged) {
         const int row = cam.M * 3;
         const size_t wave_first = (size_t)(blockIdx.x * blockDim.x + w * 64);
         const int rows_here = max(0, min(64, P - (int)wave_first));
@@ -309,17 +349,18 @@ bool preprocess_bwd_writes_all_sh(int M, const float* shs, const float* dL_dshs)
            (reinterpret_cast<size_t>(dL_dshs) & 15) == 0;
 }
 
-int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const float* shs,
+int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const float* shs, const float* shs_rest,
                           const float* colors_precomp, const float* scales, const float* rotations,
                           const float* cov3D_precomp, const int* radii, const uint8_t* clampb, const float* gacc,
-                          const float* gmean2D, float* dL_dmeans3D, float* dL_dshs, float* dL_dcolors,
+                          const float* gmean2D, float* dL_dmeans3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dcolors,
                           float* dL_dopacities, float* dL_dscales, float* dL_drots, float* dL_dcov3D,
                           hipStream_t s, bool debug)
 {
     if (P == 0) return 0;
     const int sh_staged = preprocess_bwd_writes_all_sh(cam.M, shs, dL_dshs) ? 1 : 0;
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, sh_staged, means3D, shs, colors_precomp,
-                       scales, rotations, cov3D_precomp, radii, clampb, gacc, gmean2D, dL_dmeans3D, dL_dshs, dL_dcolors,
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, sh_staged, means3D, shs, shs_rest,
+                       dL_dshs_rest, colors_precomp, scales, rotations, cov3D_precomp, radii, clampb, gacc, gmean2D, dL_dmeans3D,
+                       dL_dshs, dL_dcolors,
                        dL_dopacities, dL_dscales, dL_drots, dL_dcov3D);
     VR_KERNEL_CHECK("preprocess_bwd", s, debug);
     return 0;

@@ -89,6 +89,50 @@ __device__ __forceinline__ float vr_exp_unclamped(float x)
     return ldexpf(p, (int)n);
 }
 
+// ---- wave-cooperative linear copies between a contiguous global block and LDS (n floats, one wave).  16-byte
+// vector path when the global address is aligned (all of a lane's loads in flight before the first store), plus a
+// scalar tail; scalar path otherwise.  Used for the split SH storage, whose LDS row stride is the memory's own.
+template <int MAXV>
+__device__ __forceinline__ void wave_copy_to_lds(const float* __restrict__ src, float* __restrict__ lds, int n, int lane)
+{
+    if ((reinterpret_cast<size_t>(src) & 15) == 0) {
+        const int nv = n >> 2;
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(lds);
+        float4 tmp[MAXV];
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j)
+            if (lane + 64 * j < nv) tmp[j] = nt_load4(&s4[lane + 64 * j]);
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j)
+            if (lane + 64 * j < nv) d4[lane + 64 * j] = tmp[j];
+        if (lane < (n & 3)) lds[(nv << 2) + lane] = src[(nv << 2) + lane];
+    } else {
+        for (int e = lane; e < n; e += 64) lds[e] = src[e];
+    }
+}
+template <int MAXV>
+__device__ __forceinline__ void wave_copy_from_lds(float* __restrict__ dst, const float* __restrict__ lds, int n, int lane,
+                                                   bool zeros)
+{
+    if ((reinterpret_cast<size_t>(dst) & 15) == 0) {
+        const int nv = n >> 2;
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        const float4* s4 = reinterpret_cast<const float4*>(lds);
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            if (lane + 64 * j < nv) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!zeros) v = s4[lane + 64 * j];
+                nt_store4(v, &d4[lane + 64 * j]);
+            }
+        }
+        if (lane < (n & 3)) dst[(nv << 2) + lane] = zeros ? 0.0f : lds[(nv << 2) + lane];
+    } else {
+        for (int e = lane; e < n; e += 64) dst[e] = zeros ? 0.0f : lds[e];
+    }
+}
+
 // ---- packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process two floats per lane per issue):
 // two-wide helpers for the compositing arithmetic of the backward pass
 typedef float f2 __attribute__((ext_vector_type(2)));

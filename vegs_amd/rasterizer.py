@@ -66,11 +66,11 @@ def _settings_struct(rs, device, keep):
                             int(bool(rs.debug)), bg.data_ptr(), view.data_ptr(), proj.data_ptr(), campos.data_ptr())
 
 
-def _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp):
+def _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, sh_rest=None):
     P = means3D.shape[0]
-    M = sh.shape[1] if sh is not None else 0
+    M = (sh.shape[1] if sh is not None else 0) + (sh_rest.shape[1] if sh_rest is not None else 0)
     return _capi.VrInputs(P, M, _capi.ptr(means3D), _capi.ptr(sh), _capi.ptr(colors_precomp), _capi.ptr(opacities),
-                          _capi.ptr(scales), _capi.ptr(rotations), _capi.ptr(cov3Ds_precomp))
+                          _capi.ptr(scales), _capi.ptr(rotations), _capi.ptr(cov3Ds_precomp), _capi.ptr(sh_rest))
 
 
 def _cpu_args_copy(args):
@@ -87,7 +87,7 @@ _LAST_R = {}
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
+                raster_settings, sh_rest=None):
         lib = _capi.load()
         rs = raster_settings
         if means3D.dim() != 2 or means3D.shape[1] != 3:
@@ -103,6 +103,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         scales = _prep(scales, "scales", device)
         rotations = _prep(rotations, "rotations", device)
         cov3Ds_precomp = _prep(cov3Ds_precomp, "cov3D_precomp", device)
+        sh_rest = _prep(sh_rest, "shs[1] (features_rest)", device)
+        if sh_rest is not None:
+            # split SH storage: shs = (features_dc [P,1,3], features_rest [P,M-1,3]) as the model keeps them
+            if sh is None or sh.dim() != 3 or sh.shape[1] != 1 or sh_rest.dim() != 3 or sh_rest.shape[0] != P \
+                    or sh_rest.shape[2] != 3:
+                raise ValueError("split shs must be (features_dc [P,1,3], features_rest [P,M-1,3])")
         for t, name, shape in ((sh, "shs", (P, None, 3)), (colors_precomp, "colors_precomp", (P, 3)),
                                (opacities, "opacities", None), (scales, "scales", (P, 3)),
                                (rotations, "rotations", (P, 4)), (cov3Ds_precomp, "cov3D_precomp", (P, 6))):
@@ -117,7 +123,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         keep = []
         with torch.cuda.device(device):
             st = _settings_struct(rs, device, keep)
-            inp = _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+            inp = _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, sh_rest)
             # one [12,H,W] block: colour(3) depth(1) quat(4) scale(3) alpha(1) -- sliced into the 5 outputs
             img = torch.empty((12, H, W), dtype=torch.float32, device=device)
             color, depth, cov_quat, cov_scale, alpha = img[0:3], img[3:4], img[4:8], img[8:11], img[11:12]
@@ -150,7 +156,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         _LAST_R[hint_key] = max(_LAST_R.get(hint_key, 0), ctx.num_rendered)
         ctx.buffers = (arena.kept[_capi.VR_BUF_GEOM], arena.kept[_capi.VR_BUF_BINNING], arena.kept[_capi.VR_BUF_IMAGE])
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
-        ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii)
+        ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, sh_rest)
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)   # unused outputs arrive as None -> NULL, no zero tensors
         return color, depth, cov_quat, cov_scale, alpha, radii
@@ -159,7 +165,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, g_color, g_depth, g_quat, g_scale, g_alpha, _g_radii):
         lib = _capi.load()
         rs = ctx.raster_settings
-        means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii = ctx.saved_tensors
+        means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, sh_rest = ctx.saved_tensors
         geom, binning, image = ctx.buffers
         device = means3D.device
         P = means3D.shape[0]
@@ -170,11 +176,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         g_color, g_depth, g_quat, g_scale, g_alpha = g(g_color), g(g_depth), g(g_quat), g(g_scale), g(g_alpha)
         with torch.cuda.device(device):
             st = _settings_struct(rs, device, keep)
-            inp = _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+            inp = _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, sh_rest)
             d_means3D = torch.empty_like(means3D)
             d_means2D = torch.empty((P, 3), dtype=torch.float32, device=device)
             d_opac = torch.empty_like(opacities) if opacities is not None else None
             d_sh = torch.empty_like(sh) if sh is not None else None
+            d_sh_rest = torch.empty_like(sh_rest) if sh_rest is not None else None
             d_col = torch.empty_like(colors_precomp) if colors_precomp is not None else None
             d_scales = torch.empty_like(scales) if scales is not None else None
             d_rot = torch.empty_like(rotations) if rotations is not None else None
@@ -182,7 +189,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             gout = _capi.VrOutGrads(_capi.ptr(g_color), _capi.ptr(g_depth), _capi.ptr(g_quat), _capi.ptr(g_scale),
                                     _capi.ptr(g_alpha))
             gin = _capi.VrInGrads(_capi.ptr(d_means3D), _capi.ptr(d_means2D), _capi.ptr(d_sh), _capi.ptr(d_col),
-                                  _capi.ptr(d_opac), _capi.ptr(d_scales), _capi.ptr(d_rot), _capi.ptr(d_cov))
+                                  _capi.ptr(d_opac), _capi.ptr(d_scales), _capi.ptr(d_rot), _capi.ptr(d_cov),
+                                  _capi.ptr(d_sh_rest))
             saved = _capi.VrSaved(geom.data_ptr(), binning.data_ptr(), image.data_ptr(), ctx.num_rendered,
                                   ctx.num_visible, ctx.binning_capacity)
             arena = _capi.Arena(device)
@@ -202,13 +210,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                     raise arena.error
                 _capi.check(rc)
         # input order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings
-        return d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None
+        return d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, d_sh_rest
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
+                        raster_settings, sh_rest=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, sh_rest)
 
 
 class GaussianRasterizer(nn.Module):
@@ -243,6 +251,16 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("exactly one of (scales, rotations) and cov3D_precomp must be given")
+        # Extension: shs may be the PAIR (features_dc [P,1,3], features_rest [P,M-1,3]) the reference's model stores
+        # (scene/gaussian_model.py:112-116 concatenates them on every call); the kernels then read the two tensors
+        # in place and return their gradients separately -- no torch.cat, no slicing copies.
+        sh_rest = None
+        if isinstance(shs, (tuple, list)):
+            if len(shs) != 2:
+                raise Exception("split shs must be the pair (features_dc, features_rest)")
+            shs, sh_rest = shs
+            if sh_rest is not None and sh_rest.shape[1] == 0:
+                sh_rest = None
         empty = torch.Tensor([])
         shs = empty if shs is None else shs
         colors_precomp = empty if colors_precomp is None else colors_precomp
@@ -250,4 +268,4 @@ class GaussianRasterizer(nn.Module):
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, rs)
+                                   cov3D_precomp, rs, sh_rest)

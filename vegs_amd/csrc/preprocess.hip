@@ -128,12 +128,14 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
             // the memory's own (45 floats at M = 16: odd, so the per-lane row reads are bank-conflict free).
             const int rowr = row - 3;
             const int rows_here = min(64, P - (int)wave_first);
+            float srow[SH_ROW_MAX];
+            if (vis) {      // DC row first: its loads are in flight together with the staging loads below
+#pragma unroll
+                for (int c = 0; c < 3; ++c) srow[c] = shs[3 * (size_t)i + c];
+            }
             wave_copy_to_lds<SH_ROW_MAX / 4>(shs_rest + wave_first * rowr, sh_lds[w], rows_here * rowr, lane);
             __builtin_amdgcn_wave_barrier();
             if (vis) {
-                float srow[SH_ROW_MAX];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) srow[c] = shs[3 * (size_t)i + c];
                 const float* my = sh_lds[w] + lane * rowr;
 #pragma unroll
                 for (int k = 0; k < SH_ROW_MAX - 3; ++k)

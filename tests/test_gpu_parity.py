@@ -339,3 +339,29 @@ def test_split_sh_storage_equals_concatenated(P, M, deg, dev):
     # culled Gaussians: exact zero rows in both gradient tensors
     culled = (rb[5] == 0).cpu().numpy()
     assert not dc.grad.cpu().numpy()[culled].any() and not rest.grad.cpu().numpy()[culled].any()
+
+
+def test_non_finite_inputs_do_not_crash_or_poison_the_frame(dev):
+    """NaN / Inf / absurd values in 1 % of the Gaussians: the call returns, the list sizes stay sane and the other
+    Gaussians still render (such splats are culled or clamped, as NaN comparisons fail)."""
+    from vegs_amd import harness, scenes
+    sc, deg = scenes.scene_random(P=5000, sh_degree=1, seed=1, scale=0.05)
+    cam = scenes.camera_c1(160, 96)
+    base = None
+    for key, val in [(None, None), ("scales", float("nan")), ("scales", float("inf")), ("scales", 1e20), ("means3D", float("nan")),
+                     ("means3D", float("inf")), ("rotations", float("nan")), ("rotations", 0.0), ("opacities", float("nan")),
+                     ("opacities", -1.0), ("opacities", 50.0)]:
+        t = {k: torch.tensor(v.copy(), device=dev) for k, v in sc.items()}
+        if key is not None:
+            t[key][:50] = val
+        t = {k: v.requires_grad_(True) for k, v in t.items()}
+        pkg = harness.render(cam, t, deg, torch.zeros(3, device=dev))
+        (pkg["render"].nan_to_num().sum() + pkg["render_cov_scale"].nan_to_num().sum()).backward()
+        torch.cuda.synchronize()
+        fn = pkg["render"].grad_fn
+        if base is None:
+            base = fn.num_rendered
+        assert 0.9 * base <= fn.num_rendered <= 1.1 * base, (key, val, fn.num_rendered)
+        assert int(pkg["radii"].max()) < 10_000 and int(pkg["radii"].min()) >= 0
+        if key in ("scales", "means3D") or val in (0.0, -1.0):
+            assert torch.isfinite(pkg["render"]).all(), (key, val)

@@ -197,7 +197,9 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
 
     // ---- buffers that survive until backward
     const size_t p1 = (size_t)(P > 0 ? P : 1);
-    void* geom = alloc(user, VR_BUF_GEOM, align_up(p1 * sizeof(Splat), 256) + align_up(p1, 256));   // records | clamp bits
+    // records | clamp bits | d colour / d direction (9 floats per Gaussian, written for visible ones in the SH modes)
+    const size_t geom_clamp = align_up(p1 * sizeof(Splat), 256), geom_shd = geom_clamp + align_up(p1, 256);
+    void* geom = alloc(user, VR_BUF_GEOM, geom_shd + align_up(p1 * 9 * sizeof(float), 256));
     const ImageLayout IL = image_layout(N);
     void* image = alloc(user, VR_BUF_IMAGE, IL.total);
     // ---- transient, P-sized
@@ -232,7 +234,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
         prof_begin(VR_STAGE_PREPROCESS, s);
         rc = launch_preprocess(cam, P, in->means3D, in->shs, in->shs_rest, in->colors_precomp, in->opacities, in->scales,
                                in->rotations, in->cov3D_precomp, rec, out->radii, rect, depth_key,
-                               (uint8_t*)geom + align_up(p1 * sizeof(Splat), 256), s, debug);
+                               (uint8_t*)geom + geom_clamp, (float*)((char*)geom + geom_shd), s, debug);
         prof_end(VR_STAGE_PREPROCESS, s);
         if (rc) return rc;
         prof_begin(VR_STAGE_COMPACT, s);
@@ -354,7 +356,9 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
     ProfScope ps2(VR_STAGE_PREPROCESS_BWD, s);
     rc = launch_preprocess_bwd(cam, P, in->means3D, in->shs, in->shs_rest, in->colors_precomp, in->scales, in->rotations,
                                in->cov3D_precomp, radii,
-                               (const uint8_t*)saved->geom + align_up((size_t)P * sizeof(Splat), 256), gacc, gin->dL_dmeans2D, gin->dL_dmeans3D, gin->dL_dshs, gin->dL_dshs_rest,
+                               (const uint8_t*)saved->geom + align_up((size_t)P * sizeof(Splat), 256),
+                               (const float*)((const char*)saved->geom + align_up((size_t)P * sizeof(Splat), 256) + align_up((size_t)P, 256)),
+                               gacc, gin->dL_dmeans2D, gin->dL_dmeans3D, gin->dL_dshs, gin->dL_dshs_rest,
                                gin->dL_dcolors_precomp, gin->dL_dopacities, gin->dL_dscales, gin->dL_drotations,
                                gin->dL_dcov3D_precomp, s, debug);
     return rc;

@@ -42,7 +42,8 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
              const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
              const float* __restrict__ scales, const float* __restrict__ rotations,
              const float* __restrict__ cov3D_precomp, Splat* __restrict__ rec, int* __restrict__ radii,
-             uint2* __restrict__ rect, uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clampb)
+             uint2* __restrict__ rect, uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clampb,
+             float* __restrict__ shd)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4][64 * SH_LDS_STRIDE];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,13 +115,15 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
         const bool staged = row <= SH_ROW_MAX && (row & 3) == 0 && (reinterpret_cast<size_t>(shs) & 15) == 0;
         const size_t wave_first = (size_t)(blockIdx.x * blockDim.x + w * 64);
         float acc[3] = {0.f, 0.f, 0.f};
-        float bas[16];
+        float bas[16], bx[16], by[16], bz[16];
+        float D[9];            // d colour / d direction, kept for the backward (see sh_ddir9)
         const int K = (cam.deg + 1) * (cam.deg + 1);
         if (vis) {
             float dx = px3 - cam.campos[0], dy = py3 - cam.campos[1], dz = pz3 - cam.campos[2];
             const float len = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
             dx = dx / len; dy = dy / len; dz = dz / len;
             sh_basis(cam.deg, dx, dy, dz, bas);
+            sh_basis_grad(cam.deg, dx, dy, dz, bx, by, bz);
         }
         if (shs_rest) {
             // split storage (the model's own two tensors, no torch.cat): shs = [P,1,3] DC rows, shs_rest = [P,M-1,3].
@@ -141,6 +144,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
                 for (int k = 0; k < SH_ROW_MAX - 3; ++k)
                     if (k < rowr) srow[3 + k] = my[k];
                 sh_dot(bas, K, srow, acc);
+                sh_ddir9(bx, by, bz, K, srow, D);
             }
         } else if (staged) {
             const float* src = shs + wave_first * row;
@@ -174,9 +178,20 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
                     }
                 }
                 sh_dot(bas, K, srow, acc);
+                sh_ddir9(bx, by, bz, K, srow, D);
             }
         } else if (vis) {
             sh_dot(bas, K, shs + (size_t)i * row, acc);        // unusual M / alignment: direct row reads
+            sh_ddir9(bx, by, bz, K, shs + (size_t)i * row, D);
+        }
+        {   // the wave's 64 D rows are one contiguous 2304-byte block: through LDS (row stride 9, odd), out as float4s
+            const int rows_here = min(64, P - (int)wave_first);
+            __builtin_amdgcn_wave_barrier();          // the SH rows in sh_lds[w] are no longer needed
+            float* myd = sh_lds[w] + lane * 9;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) myd[q] = vis ? D[q] : 0.0f;
+            __builtin_amdgcn_wave_barrier();
+            wave_copy_from_lds<3>(shd + wave_first * 9, sh_lds[w], rows_here * 9, lane, false);
         }
         if (vis) {
             acc[0] += 0.5f; acc[1] += 0.5f; acc[2] += 0.5f;
@@ -222,11 +237,11 @@ int launch_preprocess(const Camera& cam, int P, const float* means3D, const floa
                       const float* colors_precomp,
                       const float* opacities, const float* scales, const float* rotations,
                       const float* cov3D_precomp, Splat* rec, int* radii, uint2* rect,
-                      uint32_t* depth_key, uint8_t* clampb, hipStream_t s, bool debug)
+                      uint32_t* depth_key, uint8_t* clampb, float* shd, hipStream_t s, bool debug)
 {
     if (P == 0) return 0;
     hipLaunchKernelGGL(k_preprocess, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, means3D, shs, shs_rest,
-                       colors_precomp, opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, clampb);
+                       colors_precomp, opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, clampb, shd);
     VR_KERNEL_CHECK("preprocess", s, debug);
     return 0;
 }

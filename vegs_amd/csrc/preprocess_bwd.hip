@@ -12,64 +12,38 @@
 
 namespace vr {
 
-__device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float* bx, float* by, float* bz)
-{
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { bx[k] = 0.f; by[k] = 0.f; bz[k] = 0.f; }
-    if (deg < 1) return;
-    by[1] = -SH_C1; bz[2] = SH_C1; bx[3] = -SH_C1;
-    if (deg < 2) return;
-    float xx = x * x, yy = y * y, zz = z * z;
-    bx[4] = SH_C2[0] * y; by[4] = SH_C2[0] * x;
-    by[5] = SH_C2[1] * z; bz[5] = SH_C2[1] * y;
-    bx[6] = SH_C2[2] * -2.0f * x; by[6] = SH_C2[2] * -2.0f * y; bz[6] = SH_C2[2] * 4.0f * z;
-    bx[7] = SH_C2[3] * z; bz[7] = SH_C2[3] * x;
-    bx[8] = SH_C2[4] * 2.0f * x; by[8] = SH_C2[4] * -2.0f * y;
-    if (deg < 3) return;
-    bx[9] = SH_C3[0] * 6.0f * x * y; by[9] = SH_C3[0] * (3.0f * xx - 3.0f * yy);
-    bx[10] = SH_C3[1] * y * z; by[10] = SH_C3[1] * x * z; bz[10] = SH_C3[1] * x * y;
-    bx[11] = SH_C3[2] * -2.0f * x * y; by[11] = SH_C3[2] * (4.0f * zz - xx - 3.0f * yy); bz[11] = SH_C3[2] * 8.0f * y * z;
-    bx[12] = SH_C3[3] * -6.0f * x * z; by[12] = SH_C3[3] * -6.0f * y * z; bz[12] = SH_C3[3] * (6.0f * zz - 3.0f * xx - 3.0f * yy);
-    bx[13] = SH_C3[4] * (4.0f * zz - 3.0f * xx - yy); by[13] = SH_C3[4] * -2.0f * x * y; bz[13] = SH_C3[4] * 8.0f * x * z;
-    bx[14] = SH_C3[5] * 2.0f * x * z; by[14] = SH_C3[5] * -2.0f * y * z; bz[14] = SH_C3[5] * (xx - yy);
-    bx[15] = SH_C3[6] * (3.0f * xx - 3.0f * yy); by[15] = SH_C3[6] * -6.0f * x * y;
-}
-
 constexpr int SH_ROW_MAX = 48;  // floats per Gaussian staged through LDS (M <= 16 coefficients x 3)
 constexpr int SH_LDS_STRIDE = 52;  // padded LDS row stride (13 x 16 bytes: conflict-free per-lane float4 rows, see preprocess.hip)
 
-// One Gaussian's SH backward: gsh[k][c] = basis[k] * dL/drgb_c (zero where the colour was clamped) and
-// the gradient through the view direction into the mean.  `sh` and `gsh` may alias (in-place in LDS).
+// One Gaussian's SH backward from the forward's cached d colour / d direction (D, see sh_ddir9):
+// gsh[k][c] = basis[k] * dL/drgb_c (zero where the colour was clamped) and the gradient through the view
+// direction into the mean.  The SH coefficients themselves are not needed any more.
 __device__ __forceinline__ void sh_backward_row(const Camera& cam, float px3, float py3, float pz3, uint32_t clampbits,
-                                                float g0, float g1, float g2, const float* sh, float* gsh, float* dmean)
+                                                float g0, float g1, float g2, const float* D, float* gsh, float* dmean)
 {
     const float d0 = px3 - cam.campos[0], d1 = py3 - cam.campos[1], d2v = pz3 - cam.campos[2];
     const float len = sqrtf(d0 * d0 + d1 * d1 + d2v * d2v);
     const float il = 1.0f / len;
     const float dir[3] = {d0 * il, d1 * il, d2v * il};
-    float bas[16], bx[16], by[16], bz[16];
+    float bas[16];
     sh_basis(cam.deg, dir[0], dir[1], dir[2], bas);
-    sh_basis_grad(cam.deg, dir[0], dir[1], dir[2], bx, by, bz);
     const int K = (cam.deg + 1) * (cam.deg + 1);
     const float gc0 = (clampbits & 1u) ? 0.f : g0;
     const float gc1 = (clampbits & 2u) ? 0.f : g1;
     const float gc2 = (clampbits & 4u) ? 0.f : g2;
-    float ddir[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {       // constant trip count + guards: `sh` / `gsh` may be a register array
+    for (int k = 0; k < 16; ++k) {       // constant trip count + guards: `gsh` may be a register array
         if (k < K) {
-            const float s0 = sh[3 * k], s1 = sh[3 * k + 1], s2 = sh[3 * k + 2];
             gsh[3 * k + 0] = bas[k] * gc0;
             gsh[3 * k + 1] = bas[k] * gc1;
             gsh[3 * k + 2] = bas[k] * gc2;
-            const float sg = s0 * gc0 + s1 * gc1 + s2 * gc2;
-            ddir[0] += bx[k] * sg;
-            ddir[1] += by[k] * sg;
-            ddir[2] += bz[k] * sg;
         } else if (k < cam.M) {
             gsh[3 * k] = 0.f; gsh[3 * k + 1] = 0.f; gsh[3 * k + 2] = 0.f;
         }
     }
+    float ddir[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) ddir[a] = fmaf(gc2, D[6 + a], fmaf(gc1, D[3 + a], gc0 * D[a]));
     const float dot = dir[0] * ddir[0] + dir[1] * ddir[1] + dir[2] * ddir[2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) dmean[k] += (ddir[k] - dir[k] * dot) * il;
@@ -80,7 +54,8 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
                  const float* __restrict__ shs_rest, float* __restrict__ dL_dshs_rest,
                  const float* __restrict__ colors_precomp, const float* __restrict__ scales,
                  const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
-                 const int* __restrict__ radii, const uint8_t* __restrict__ clampb, const float* __restrict__ gacc,
+                 const int* __restrict__ radii, const uint8_t* __restrict__ clampb, const float* __restrict__ shd,
+                 const float* __restrict__ gacc,
                  const float* __restrict__ gmean2D, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dshs,
                  float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
                  float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D)
@@ -100,29 +75,24 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
     // place, and the 64 rows are stored back coalesced (zeros for culled Gaussians: the kernel writes
     // every row of dL_dshs itself, no separate memset).
     if (shs && shs_rest) {
-        // split storage: shs / dL_dshs = [P,1,3] DC rows (read and written by their own lane: 12 contiguous bytes per
-        // lane), shs_rest / dL_dshs_rest = [P,M-1,3]: the wave's 64 rest rows are one contiguous block, copied
-        // linearly into LDS (row stride = the memory's own, 45 floats at M = 16: odd, conflict-free row access),
-        // turned into gradient rows in place and copied back linearly.  Every row of both gradients is written.
+        // split storage: dL_dshs = [P,1,3] DC rows (written by their own lane: 12 contiguous bytes per lane),
+        // dL_dshs_rest = [P,M-1,3]: every lane builds its gradient row in LDS (row stride = the memory's own, 45
+        // floats at M = 16: odd, conflict-free) and the wave's 64 rows, one contiguous block, are copied out
+        // linearly.  Every row of both gradients is written.
         const int rowr = cam.M * 3 - 3;
         const size_t wave_first = (size_t)(blockIdx.x * blockDim.x + w * 64);
         const int rows_here = max(0, min(64, P - (int)wave_first));
         const bool any = __ballot(vis) != 0ull;
         float dc[3] = {0.f, 0.f, 0.f};
         if (any) {
-            wave_copy_to_lds<SH_ROW_MAX / 4>(shs_rest + wave_first * rowr, sh_lds[w], rows_here * rowr, lane);
-            __builtin_amdgcn_wave_barrier();
             float* my = sh_lds[w] + lane * rowr;
             if (vis) {
                 const float4 a1 = reinterpret_cast<const float4*>(gacc + (size_t)i * 16)[1];
                 const float px3 = means3D[3 * (size_t)i], py3 = means3D[3 * (size_t)i + 1], pz3 = means3D[3 * (size_t)i + 2];
-                float srow[SH_ROW_MAX];
+                float D[9], srow[SH_ROW_MAX];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) srow[c] = shs[3 * (size_t)i + c];
-#pragma unroll
-                for (int k = 0; k < SH_ROW_MAX - 3; ++k)
-                    if (k < rowr) srow[3 + k] = my[k];
-                sh_backward_row(cam, px3, py3, pz3, (uint32_t)clampb[i], a1.x, a1.y, a1.z, srow, srow, dmean);
+                for (int q = 0; q < 9; ++q) D[q] = shd[9 * (size_t)i + q];
+                sh_backward_row(cam, px3, py3, pz3, (uint32_t)clampb[i], a1.x, a1.y, a1.z, D, srow, dmean);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) dc[c] = srow[c];
 #pragma unroll
@@ -147,33 +117,14 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
         float4* lds4 = reinterpret_cast<float4*>(sh_lds[w]);
         const bool any = __ballot(vis) != 0ull;
         if (any) {
-            const float4* src4 = reinterpret_cast<const float4*>(shs + wave_first * row);
-            float4 tmp[SH_ROW_MAX / 4];   // all (up to 12) loads of the lane in flight before the first LDS store
-#pragma unroll
-            for (int j = 0; j < SH_ROW_MAX / 4; ++j)
-                if (lane + 64 * j < nvec) tmp[j] = nt_load4(&src4[lane + 64 * j]);  // streamed once
-#pragma unroll
-            for (int j = 0; j < SH_ROW_MAX / 4; ++j) {
-                const int v = lane + 64 * j;
-                if (v < nvec) {
-                    const int r = row4 == 12 ? v / 12 : v / row4;
-                    lds4[r * (SH_LDS_STRIDE / 4) + (v - r * row4)] = tmp[j];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
             float4* my4 = lds4 + lane * (SH_LDS_STRIDE / 4);
             if (vis) {
                 const float4 a1 = reinterpret_cast<const float4*>(gacc + (size_t)i * 16)[1];
                 const float px3 = means3D[3 * (size_t)i], py3 = means3D[3 * (size_t)i + 1], pz3 = means3D[3 * (size_t)i + 2];
-                float srow[SH_ROW_MAX];          // the lane's row: whole float4s in, whole float4s out
+                float D[9], srow[SH_ROW_MAX];    // the lane's gradient row, written to LDS as whole float4s
 #pragma unroll
-                for (int j = 0; j < SH_ROW_MAX / 4; ++j) {
-                    if (j < row4) {
-                        const float4 t = my4[j];
-                        srow[4 * j] = t.x; srow[4 * j + 1] = t.y; srow[4 * j + 2] = t.z; srow[4 * j + 3] = t.w;
-                    }
-                }
-                sh_backward_row(cam, px3, py3, pz3, (uint32_t)clampb[i], a1.x, a1.y, a1.z, srow, srow, dmean);
+                for (int q = 0; q < 9; ++q) D[q] = shd[9 * (size_t)i + q];
+                sh_backward_row(cam, px3, py3, pz3, (uint32_t)clampb[i], a1.x, a1.y, a1.z, D, srow, dmean);
 #pragma unroll
                 for (int j = 0; j < SH_ROW_MAX / 4; ++j)
                     if (j < row4) my4[j] = make_float4(srow[4 * j], srow[4 * j + 1], srow[4 * j + 2], srow[4 * j + 3]);
@@ -198,8 +149,10 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
         // unusual coefficient count / alignment: direct row access, dL_dshs pre-zeroed by the caller
         const float4 a1 = reinterpret_cast<const float4*>(gacc + (size_t)i * 16)[1];
         const float px3 = means3D[3 * (size_t)i], py3 = means3D[3 * (size_t)i + 1], pz3 = means3D[3 * (size_t)i + 2];
-        sh_backward_row(cam, px3, py3, pz3, (uint32_t)clampb[i], a1.x, a1.y, a1.z, shs + (size_t)i * cam.M * 3,
-                        dL_dshs + (size_t)i * cam.M * 3, dmean);
+        float D[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) D[q] = shd[9 * (size_t)i + q];
+        sh_backward_row(cam, px3, py3, pz3, (uint32_t)clampb[i], a1.x, a1.y, a1.z, D, dL_dshs + (size_t)i * cam.M * 3, dmean);
     }
 
     if (vis) {
@@ -351,7 +304,7 @@ bool preprocess_bwd_writes_all_sh(int M, const float* shs, const float* dL_dshs)
 
 int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const float* shs, const float* shs_rest,
                           const float* colors_precomp, const float* scales, const float* rotations,
-                          const float* cov3D_precomp, const int* radii, const uint8_t* clampb, const float* gacc,
+                          const float* cov3D_precomp, const int* radii, const uint8_t* clampb, const float* shd, const float* gacc,
                           const float* gmean2D, float* dL_dmeans3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dcolors,
                           float* dL_dopacities, float* dL_dscales, float* dL_drots, float* dL_dcov3D,
                           hipStream_t s, bool debug)
@@ -359,7 +312,7 @@ int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const 
     if (P == 0) return 0;
     const int sh_staged = preprocess_bwd_writes_all_sh(cam.M, shs, dL_dshs) ? 1 : 0;
     hipLaunchKernelGGL(k_preprocess_bwd, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, sh_staged, means3D, shs, shs_rest,
-                       dL_dshs_rest, colors_precomp, scales, rotations, cov3D_precomp, radii, clampb, gacc, gmean2D, dL_dmeans3D,
+                       dL_dshs_rest, colors_precomp, scales, rotations, cov3D_precomp, radii, clampb, shd, gacc, gmean2D, dL_dmeans3D,
                        dL_dshs, dL_dcolors,
                        dL_dopacities, dL_dscales, dL_drots, dL_dcov3D);
     VR_KERNEL_CHECK("preprocess_bwd", s, debug);

@@ -266,6 +266,51 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     b[15] = SH_C3[6] * x * (xx - 3.0f * yy);
 }
 
+__device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float* bx, float* by, float* bz)
+{
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { bx[k] = 0.f; by[k] = 0.f; bz[k] = 0.f; }
+    if (deg < 1) return;
+    by[1] = -SH_C1; bz[2] = SH_C1; bx[3] = -SH_C1;
+    if (deg < 2) return;
+    float xx = x * x, yy = y * y, zz = z * z;
+    bx[4] = SH_C2[0] * y; by[4] = SH_C2[0] * x;
+    by[5] = SH_C2[1] * z; bz[5] = SH_C2[1] * y;
+    bx[6] = SH_C2[2] * -2.0f * x; by[6] = SH_C2[2] * -2.0f * y; bz[6] = SH_C2[2] * 4.0f * z;
+    bx[7] = SH_C2[3] * z; bz[7] = SH_C2[3] * x;
+    bx[8] = SH_C2[4] * 2.0f * x; by[8] = SH_C2[4] * -2.0f * y;
+    if (deg < 3) return;
+    bx[9] = SH_C3[0] * 6.0f * x * y; by[9] = SH_C3[0] * (3.0f * xx - 3.0f * yy);
+    bx[10] = SH_C3[1] * y * z; by[10] = SH_C3[1] * x * z; bz[10] = SH_C3[1] * x * y;
+    bx[11] = SH_C3[2] * -2.0f * x * y; by[11] = SH_C3[2] * (4.0f * zz - xx - 3.0f * yy); bz[11] = SH_C3[2] * 8.0f * y * z;
+    bx[12] = SH_C3[3] * -6.0f * x * z; by[12] = SH_C3[3] * -6.0f * y * z; bz[12] = SH_C3[3] * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+    bx[13] = SH_C3[4] * (4.0f * zz - 3.0f * xx - yy); by[13] = SH_C3[4] * -2.0f * x * y; bz[13] = SH_C3[4] * 8.0f * x * z;
+    bx[14] = SH_C3[5] * 2.0f * x * z; by[14] = SH_C3[5] * -2.0f * y * z; bz[14] = SH_C3[5] * (xx - yy);
+    bx[15] = SH_C3[6] * (3.0f * xx - 3.0f * yy); by[15] = SH_C3[6] * -6.0f * x * y;
+}
+
+// D[3*c + a] = d colour_c / d direction_a = sum_k grad_a basis_k(dir) * sh[k][c]  (before normalisation of the
+// direction and before the clamp).  Computed in the FORWARD, next to the colour itself, and kept (9 floats per
+// visible Gaussian): the backward then needs neither the 192-byte SH row nor the basis gradients again.
+__device__ __forceinline__ void sh_ddir9(const float* bx, const float* by, const float* bz, int K, const float* sh, float* D)
+{
+#pragma unroll
+    for (int q = 0; q < 9; ++q) D[q] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (k < K) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float sv = sh[3 * k + c];
+                D[3 * c + 0] = fmaf(bx[k], sv, D[3 * c + 0]);
+                D[3 * c + 1] = fmaf(by[k], sv, D[3 * c + 1]);
+                D[3 * c + 2] = fmaf(bz[k], sv, D[3 * c + 2]);
+            }
+        }
+    }
+}
+
+
 // Rotation matrix of a (not re-normalised) quaternion (w,x,y,z), row-major.
 __device__ __forceinline__ void quat_to_R(float r, float x, float y, float z, float* R)
 {

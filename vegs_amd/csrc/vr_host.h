@@ -47,7 +47,7 @@ int launch_preprocess(const Camera& cam, int P, const float* means3D, const floa
                       const float* colors_precomp,
                       const float* opacities, const float* scales, const float* rotations,
                       const float* cov3D_precomp, Splat* rec, int* radii, uint2* rect,
-                      uint32_t* depth_key, uint8_t* clampb, hipStream_t s, bool debug);
+                      uint32_t* depth_key, uint8_t* clampb, float* shd, hipStream_t s, bool debug);
 int launch_mark_visible(const float* xyz, int P, const float* view, uint8_t* present, hipStream_t s);
 
 // ---- binning.hip
@@ -111,7 +111,7 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
 bool preprocess_bwd_writes_all_sh(int M, const float* shs, const float* dL_dshs);
 int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const float* shs, const float* shs_rest,
                           const float* colors_precomp, const float* scales, const float* rotations,
-                          const float* cov3D_precomp, const int* radii, const uint8_t* clampb, const float* gacc,
+                          const float* cov3D_precomp, const int* radii, const uint8_t* clampb, const float* shd, const float* gacc,
                           const float* gmean2D, float* dL_dmeans3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dcolors,
                           float* dL_dopacities, float* dL_dscales, float* dL_drots, float* dL_dcov3D,
                           hipStream_t s, bool debug);

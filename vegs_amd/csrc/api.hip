@@ -144,7 +144,7 @@ static ImageLayout image_layout(size_t N)
     L.total = L.n_contrib + align_up(N * 4, 256);
     return L;
 }
-// binning buffer: tile ranges | segment table (seg_off[T+1], seg_tile[S]) | point list | boundary transmittances per (segment, pixel) |
+// binning buffer: tile ranges | segment table (seg_off[T+1], seg_info[S] int4) | point list | boundary transmittances per (segment, pixel) |
 // segment-local channel sums per (segment, channel, pixel) -- the backward derives its w*u sums from them
 struct BinLayout { size_t ranges, seg_off, seg_needed, point_list, tbuf, part, segmask, total; };
 static BinLayout bin_layout(size_t T, size_t R)
@@ -152,7 +152,7 @@ static BinLayout bin_layout(size_t T, size_t R)
     BinLayout L;
     L.ranges = 0;
     L.seg_off = align_up(T * 8, 256);
-    L.seg_needed = L.seg_off + align_up(((size_t)seg_tile_offset((int)T) + seg_capacity((long)R, (int)T)) * 4, 256);
+    L.seg_needed = L.seg_off + align_up(((size_t)seg_tile_offset((int)T) + 4 * seg_capacity((long)R, (int)T)) * 4, 256);
     L.point_list = L.seg_needed + align_up(T * 4, 256);
     L.tbuf = L.point_list + align_up((R > 0 ? R : 1) * 4, 256);
     L.part = L.tbuf + align_up(seg_capacity((long)R, (int)T) * 256 * sizeof(float), 256);

@@ -103,7 +103,7 @@ k_seg_u(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict_
 {
     SegCtx c;
     if (!seg_setup(cam, ranges, seg_off, c)) return;
-    if ((uint32_t)c.sl >= seg_needed[c.tile]) return;
+    if (c.flag == 0u) return;
     const size_t N = (size_t)cam.H * cam.W;
     PixGrad pg;
     load_pixgrad(c.inside, c.pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, nullptr, pg);
@@ -160,8 +160,7 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     SegCtx c;
     const int w = (int)(blockIdx.x & 3u);
     if (!seg_setup_at(cam, ranges, seg_off, blockIdx.x >> 2, w, c)) return;
-    const int needed = (int)seg_needed[c.tile];
-    if (c.sl >= needed) return;
+    if (c.flag == 0u) return;
     const int lane = threadIdx.x;
     const int pixslot = w * 64 + lane;            // this pixel's slot in the [segment][256] buffers
 
@@ -200,7 +199,7 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     // carries at the END of this segment: transmittance behind its last entry, and the w*u sum of
     // everything behind the segment
     float v_Tcar = v_Tf;
-    if (c.sl + 1 < needed) {
+    if (c.flag == 2u) {
         const float Tn = Tbuf[(size_t)(c.seg + 1) * SEG + pixslot];
         if (!(Tn < 0.0f)) v_Tcar = Tn;   // pixel still alive at the next segment
     }

@@ -60,20 +60,23 @@ k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict_
     if (threadIdx.x == 0) seg_off[ntiles] = carry_s;
 }
 
-// seg_tile[s] = largest t with seg_off[t] <= s  (one thread per segment of the launch grid)
+// segment table entries (vr_segment.h): one thread per segment of the launch grid
 __global__ void __launch_bounds__(256)
-k_seg_tiles(int ntiles, uint32_t* __restrict__ seg_off, uint32_t cap)
+k_seg_tiles(int ntiles, const int2* __restrict__ ranges, uint32_t* __restrict__ seg_off, uint32_t cap)
 {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= cap) return;
-    uint32_t* __restrict__ seg_tile = seg_off + seg_tile_offset(ntiles);
-    if (b >= seg_off[ntiles]) { seg_tile[b] = 0xFFFFFFFFu; return; }
-    int lo = 0, hi = ntiles;
+    int4* __restrict__ seg_info = reinterpret_cast<int4*>(seg_off + seg_tile_offset(ntiles));
+    if (b >= seg_off[ntiles]) { seg_info[b] = make_int4(-1, 0, 0, 0); return; }
+    int lo = 0, hi = ntiles;       // largest t with seg_off[t] <= b
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (seg_off[mid] <= b) lo = mid; else hi = mid - 1;
     }
-    seg_tile[b] = (uint32_t)lo;
+    const int sl = (int)(b - seg_off[lo]);
+    const int2 r = ranges[lo];
+    const int first = r.x + sl * SEG;
+    seg_info[b] = make_int4(lo, first, min(SEG, r.y - first), sl);
 }
 
 // ---- A: per (tile, segment, pixel) product of (1 - alpha)
@@ -123,7 +126,7 @@ k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
 // ---- B: per tile, boundary transmittances.  Tbuf[seg][pix] = Tb at the segment start, or -1 when
 // the pixel is finished before that segment; seg_needed[tile] = number of segments any pixel needs.
 __global__ void __launch_bounds__(256)
-k_seg_scan(Camera cam, const uint32_t* __restrict__ seg_off, const float* __restrict__ Pbuf,
+k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, const float* __restrict__ Pbuf,
            float* __restrict__ Tbuf, uint32_t* __restrict__ seg_needed)
 {
     __shared__ uint32_t wneed[4];
@@ -161,6 +164,12 @@ k_seg_scan(Camera cam, const uint32_t* __restrict__ seg_off, const float* __rest
     const uint32_t needed = max(max(wneed[0], wneed[1]), max(wneed[2], wneed[3]));
     for (uint32_t s = s0 + mine; s < s0 + needed; ++s) Tbuf[(size_t)s * SEG + threadIdx.x] = -1.0f;
     if (threadIdx.x == 0) seg_needed[tile] = needed;
+    // per-segment flag for the segment kernels (vr_segment.h): 0 not needed / 1 needed, last / 2 needed, next too
+    int4* seg_info = reinterpret_cast<int4*>(seg_off + seg_tile_offset(cam.gx * cam.gy));
+    for (uint32_t k = threadIdx.x; k < s1 - s0; k += 256) {
+        const uint32_t flag = k >= needed ? 0u : (k + 1 < needed ? 2u : 1u);
+        seg_info[s0 + k].w = (int)(k | (flag << 30));
+    }
 }
 
 // ---- C: blend one segment from its boundary transmittance into segment-local sums.
@@ -182,7 +191,7 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     SegCtx c;
     const int w = (int)(blockIdx.x & 3u);
     if (!seg_setup_at(cam, ranges, seg_off, blockIdx.x >> 2, w, c)) return;
-    if ((uint32_t)c.sl >= seg_needed[c.tile]) return;
+    if (c.flag == 0u) return;
     const int lane = threadIdx.x;
     const int pixslot = w * 64 + lane;
     const float Tb = Tbuf[(size_t)c.seg * SEG + pixslot];
@@ -354,14 +363,14 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     const size_t nseg = seg_capacity(R, ntiles);
     float* Pbuf = (float*)scratch;
     hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(256), 0, s, ranges, ntiles, seg_off);
-    hipLaunchKernelGGL(k_seg_tiles, dim3(cdiv((long)nseg, 256)), dim3(256), 0, s, ntiles, seg_off, (uint32_t)nseg);
+    hipLaunchKernelGGL(k_seg_tiles, dim3(cdiv((long)nseg, 256)), dim3(256), 0, s, ntiles, ranges, seg_off, (uint32_t)nseg);
     VR_KERNEL_CHECK("seg_offsets", s, debug);
     if (R > 0) {
         hipLaunchKernelGGL(k_seg_alpha, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
                            point_list, rec, Pbuf, segmask);
         VR_KERNEL_CHECK("seg_alpha", s, debug);
     }
-    hipLaunchKernelGGL(k_seg_scan, dim3(ntiles), dim3(256), 0, s, cam, (const uint32_t*)seg_off, (const float*)Pbuf,
+    hipLaunchKernelGGL(k_seg_scan, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (const float*)Pbuf,
                        Tbuf, seg_needed);
     VR_KERNEL_CHECK("seg_scan", s, debug);
     if (R > 0) {

@@ -9,16 +9,21 @@ namespace vr {
 constexpr int SEG = 256;
 
 // The segment table lives in one array: seg_off[0..T] (first global segment id of every tile, seg_off[T] =
-// number of segments) followed, at element seg_tile_offset(T), by seg_tile[s] = tile of segment s
-// (0xFFFFFFFF for the unused tail of the launch grid).  A workgroup finds its work with two dependent
-// loads instead of a 12-step binary search over seg_off.
+// number of segments) followed, at element seg_tile_offset(T), by one int4 per segment of the launch grid:
+//   { tile (-1 beyond the last segment), first list entry, entries, sl | flag << 30 }
+// sl = index of the segment inside its tile; flag (written by k_seg_scan): 0 = no pixel needs the segment,
+// 1 = needed and the last needed one of its tile, 2 = needed and so is the next.  A workgroup finds ALL of its
+// work description with ONE 16-byte load indexed by its block id: workgroups are short-lived, so the number of
+// dependent memory round trips before the first useful instruction sets their lifetime, and with it (Little) how
+// many of them it takes to keep the SIMDs busy.  (Before: binary search over seg_off -> seg_off[tile] ->
+// ranges[tile] -> seg_needed[tile].)
 __host__ __device__ inline int seg_tile_offset(int ntiles) { return (ntiles + 1 + 63) & ~63; }
 
 struct SegCtx {
     uint32_t seg;      // global segment id handled by this workgroup
     int tile, sl;      // tile id, segment index inside the tile
     int first, count;  // first list entry of the segment (absolute index into point_list), entries
-    int nlist;         // entries in the whole tile list
+    uint32_t flag;     // 0 not needed / 1 needed, last of its tile / 2 needed and the next one too (after k_seg_scan)
     int px, py;        // this lane's pixel
     float x0, y0;      // tile origin (pixel coordinates of its first column / row)
     bool inside;
@@ -43,15 +48,14 @@ __device__ __forceinline__ bool seg_setup_at(const Camera& cam, const int2* __re
     // the 8 XCDs, which spreads the (contiguous) segments of the heavy vanishing-point tiles over the
     // whole chip.  Giving each XCD a contiguous run of segments for L2 locality was measured 1.4-2x
     // SLOWER (one XCD ends up with all the long tiles).
-    const uint32_t t = seg_off[seg_tile_offset(ntiles) + b];
-    if (t == 0xFFFFFFFFu) return false;
+    const int4 si = reinterpret_cast<const int4*>(seg_off + seg_tile_offset(ntiles))[b];
+    if (si.x < 0) return false;
     c.seg = b;
-    c.tile = (int)t;
-    c.sl = (int)(b - seg_off[c.tile]);
-    const int2 r = ranges[c.tile];
-    c.nlist = r.y - r.x;
-    c.first = r.x + c.sl * SEG;
-    c.count = min(SEG, r.y - c.first);
+    c.tile = si.x;
+    c.first = si.y;
+    c.count = si.z;
+    c.sl = si.w & 0x3FFFFFFF;
+    c.flag = (uint32_t)si.w >> 30;
     const int tx = c.tile % cam.gx, ty = c.tile / cam.gx;
     const int lane = threadIdx.x & 63;
     c.px = tx * TILE + region_x(w, lane);

@@ -68,10 +68,10 @@ def test_product_path_has_no_cpu_fallback():
 
 def test_product_never_imports_the_oracle():
     """oracle/ is test infrastructure: nothing under vegs_amd/ or diff_gaussian_rasterization/ may use it."""
-    for pkg in ("vegs_amd", "diff_gaussian_rasterization"):
+    for pkg in ("vegs_amd", "diff_gaussian_rasterization", "simple_knn", "tools", "include"):
         for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
             for f in files:
-                if f.endswith((".py", ".hip", ".h")):
+                if f.endswith((".py", ".hip", ".h", ".c")):
                     txt = open(os.path.join(dirpath, f)).read()
                     assert "import oracle" not in txt and "from oracle" not in txt and "vr_oracle" not in txt, f
 

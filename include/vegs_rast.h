@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VR_ABI_VERSION 3
+#define VR_ABI_VERSION 4
 
 typedef enum VrStatus {
     VR_OK = 0,
@@ -66,7 +66,37 @@ typedef struct VrSettings {
     const float* viewmatrix; /* device [16], row-major 4x4, row-vector convention (scene/cameras.py:76) */
     const float* projmatrix; /* device [16], full_proj_transform (scene/cameras.py:87) */
     const float* campos;     /* device [3] */
+    uint32_t flags;          /* OR of VrFlags; 0 = the documented defaults (ABI v4) */
 } VrSettings;
+
+/* VrSettings.flags.
+ *
+ * Bits 0-7: the FORK ASSUMPTIONS as switches.  The rasterizer VEGS pins (emjay73/diff_gaussian_rasterization_with_depth,
+ * reference .gitmodules:7-9) is not vendored, so what exactly it blends into its extra outputs is inferred from the
+ * call sites only (assumptions A-1..A-6 and the open questions of A.8).  Each open question
+ * that would change training behaviour is a flag here, implemented in the kernels, the CPU oracle and the float64
+ * autograd restatement alike; 0 selects the assumption SURVEY.md states.  A maintainer who can read the fork flips
+ * the bit instead of rewriting a kernel.
+ * Bit 8: execution mode of the backward pass (no effect on the forward). */
+typedef enum VrFlags {
+    /* A-3 / A.8(1): cov_scale blends scale_modifier * scales (the row the covariance is built from) instead of the
+     * raw `scales` input row.  Identical in training, where the modifier is 1.0 (gaussian_renderer/__init__.py:263). */
+    VR_FLAG_SCALE_MODIFIED = 1u << 0,
+    /* A-1 / A.8(3): depth = sum(w z) / sum(w) with sum(w) = alpha = 1 - T_final (0 where nothing contributes)
+     * instead of the un-normalised sum(w z). */
+    VR_FLAG_DEPTH_NORMALIZED = 1u << 1,
+    /* A.5 / A.8(2): the extra channels (depth, cov_quat, cov_scale) send gradients to their per-Gaussian attributes
+     * only; nothing flows from them through alpha (opacity, conic, 2D mean).  Default: they flow through both. */
+    VR_FLAG_EXTRA_NO_ALPHA_GRAD = 1u << 2,
+    /* A-5 / A.8(4): cov_quat += T_final * (1,0,0,0) -- an identity "background" rotation, so that a pixel nothing
+     * covers holds (1,0,0,0) instead of exact zeros (the reference's quaternion_to_matrix divides by |q|^2,
+     * utils/graphics_utils.py:217, and returns NaN for zeros). */
+    VR_FLAG_FILL_EMPTY = 1u << 3,
+    /* Backward without floating-point atomics: every (tile-list entry, 8x8 pixel region) writes its partial sums to
+     * its own slot and a second kernel adds the slots of each Gaussian in list order.  Gradients are then
+     * bit-reproducible from run to run (and independent of scheduling); costs 272 bytes per list entry of scratch. */
+    VR_FLAG_DETERMINISTIC = 1u << 8
+} VrFlags;
 
 /* The op's tensor arguments (reference gaussian_renderer/__init__.py:86-94). Exactly one of
  * shs / colors_precomp and exactly one of (scales, rotations) / cov3D_precomp is non-NULL. */
@@ -168,6 +198,12 @@ void vr_get_counters(VrCounters* out);
  * forward whose state is `saved`; blocks the host. */
 int vr_count_fragments(const VrSaved* saved, int32_t image_height, int32_t image_width, void* stream,
                        int64_t* fragments);
+
+/* B = number of (pixel, splat) pairs actually BLENDED by the forward whose state is `saved` (alpha >= 1/255 and
+ * in front of the pixel's stop), as opposed to the pairs merely traversed (vr_count_fragments); blocks the host.
+ * Needs the forward's inputs only through `saved`; a slow one-thread-per-pixel walk, for benchmarks' bookkeeping. */
+int vr_count_blended(const VrSaved* saved, int32_t image_height, int32_t image_width, void* stream,
+                     int64_t* blended);
 
 /* ---- stage timing (HIP events recorded on `stream` around the kernels of each stage).
  * level 0 = off (default), 1 = only the k_seg_bwd kernel (the roofline kernel), 2 = every stage.

@@ -30,6 +30,7 @@ class OrCam(C.Structure):
         ("campos", C.c_float * 3),
         ("sh_degree", C.c_int),
         ("M", C.c_int),
+        ("flags", C.c_uint),
     ]
 
 
@@ -62,8 +63,10 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def make_cam(H, W, tanfovx, tanfovy, bg, scale_modifier, viewmatrix, projmatrix, campos, sh_degree, M):
+def make_cam(H, W, tanfovx, tanfovy, bg, scale_modifier, viewmatrix, projmatrix, campos, sh_degree, M, flags=0):
+    """flags: VrFlags bits 0-3 of include/vegs_rast.h (the fork assumptions of SURVEY.md A.8 as switches)."""
     cam = OrCam()
+    cam.flags = int(flags) & 0xF
     cam.H, cam.W = int(H), int(W)
     cam.tanfovx, cam.tanfovy = float(tanfovx), float(tanfovy)
     cam.bg[:] = [float(x) for x in np.asarray(bg, dtype=np.float32).reshape(3)]
@@ -74,6 +77,14 @@ def make_cam(H, W, tanfovx, tanfovy, bg, scale_modifier, viewmatrix, projmatrix,
     cam.sh_degree = int(sh_degree)
     cam.M = int(M)
     return cam
+
+
+def cov3d(scales, scale_modifier, rotations):
+    """[n,6] upper-triangular covariance R diag(mod*s)^2 R^T exactly as or_preprocess computes it."""
+    scales, rotations = _f32(scales), _f32(rotations)
+    out = np.zeros((scales.shape[0], 6), np.float32)
+    lib().or_cov3d(scales.shape[0], _p(scales), C.c_float(scale_modifier), _p(rotations), _p(out))
+    return out
 
 
 def mark_visible(cam, means3D):
@@ -119,7 +130,7 @@ def forward(cam, means3D, shs, colors_precomp, opacities, scales, rotations, cov
     L.or_render_fwd(C.byref(cam), _p(ranges), _p(point_list), _p(st["xy"]), _p(st["conic_op"]), _p(st["rgb"]),
                     _p(st["depth"]), _p(rotations), _p(scales), _p(out["color"]), _p(out["depth"]),
                     _p(out["cov_quat"]), _p(out["cov_scale"]), _p(out["alpha"]), _p(final_T), _p(n_contrib))
-    st.update(R=R, keys=keys[:R], point_list=point_list[:R], ranges=ranges, final_T=final_T, n_contrib=n_contrib,
+    st.update(out_depth=out["depth"].copy(), R=R, keys=keys[:R], point_list=point_list[:R], ranges=ranges, final_T=final_T, n_contrib=n_contrib,
               inputs=dict(means3D=means3D, shs=shs, colors_precomp=colors_precomp, opacities=opacities,
                           scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp))
     return out, st
@@ -139,7 +150,7 @@ def backward(cam, st, dL_dcolor=None, dL_ddepth=None, dL_dquat=None, dL_dscale=N
     pl = st["point_list"] if st["R"] > 0 else np.zeros(1, np.uint32)
     L.or_render_bwd(C.byref(cam), P, _p(st["ranges"]), _p(pl), _p(st["xy"]), _p(st["conic_op"]), _p(st["rgb"]),
                     _p(st["depth"]), _p(inp["rotations"]), _p(inp["scales"]), _p(st["final_T"]), _p(st["n_contrib"]),
-                    _p(dL_dcolor), _p(dL_ddepth), _p(dL_dquat), _p(dL_dscale), _p(dL_dalpha),
+                    _p(st["out_depth"]), _p(dL_dcolor), _p(dL_ddepth), _p(dL_dquat), _p(dL_dscale), _p(dL_dalpha),
                     _p(g_mean2D), _p(g_conic), _p(g_opacity), _p(g_attr))
     M = cam.M
     has_sh = inp["shs"] is not None

@@ -51,12 +51,15 @@ def build_cov3d(scales, mod, q):
 
 def rasterize(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, *,
               H, W, tanfovx, tanfovy, bg, scale_modifier, viewmatrix, projmatrix, campos, sh_degree,
-              means2D=None):
+              means2D=None, flags=0):
     """Returns (color[3,H,W], depth[1,H,W], cov_quat[4,H,W], cov_scale[3,H,W], alpha[1,H,W], radii[P]).
 
     If `means2D` ([P,3], requires_grad) is given it is added (as zeros) to the NDC position so
     that its gradient is d loss / d NDC -- the quantity the op deposits on `viewspace_points`.
+    `flags`: VrFlags bits 0-3 of include/vegs_rast.h (1 scale x modifier, 2 normalised depth, 4 extra channels give
+    no gradient through alpha, 8 identity fill of cov_quat) -- the open questions of SURVEY.md A.8 as switches.
     """
+    f_scale, f_dnorm, f_noalpha, f_fill = bool(flags & 1), bool(flags & 2), bool(flags & 4), bool(flags & 8)
     dt = means3D.dtype
     P = means3D.shape[0]
     V, PM = viewmatrix.to(dt), projmatrix.to(dt)
@@ -117,6 +120,8 @@ def rasterize(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_
     depth = t[:, 2]
     quat = rotations if rotations is not None else torch.zeros(P, 4, dtype=dt)
     scl = scales if scales is not None else torch.zeros(P, 3, dtype=dt)
+    if f_scale:
+        scl = scl * scale_modifier
     attrs = torch.cat([rgb, depth[:, None], quat, scl], 1)  # [P,11]
 
     out = torch.zeros(11, H, W, dtype=dt)
@@ -151,10 +156,19 @@ def rasterize(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_
             dead = torch.cumsum(stop.to(torch.int32), 0) > 0
             wgt = torch.where(dead, torch.zeros_like(a_eff), a_eff * T_excl)   # [n, npix]
             acc = attrs[sel].t() @ wgt                                          # [11, npix]
+            if f_noalpha:   # extra channels: gradient to the attributes only (weights are constants for them)
+                acc = torch.cat([acc[:3], attrs[sel][:, 3:].t() @ wgt.detach()], 0)
             # final T = product of (1-alpha) over applied splats
             om_applied = torch.where(dead, torch.ones_like(om), om)
             Tf = torch.prod(om_applied, 0)
             out[:, ys[0]:ys[-1] + 1, xs[0]:xs[-1] + 1] = acc.reshape(11, len(ys), len(xs))
             Tfin[ys[0]:ys[-1] + 1, xs[0]:xs[-1] + 1] = Tf.reshape(len(ys), len(xs))
     color = out[0:3] + Tfin[None] * bgv[:, None, None]
-    return color, out[3:4], out[4:8], out[8:11], (1 - Tfin)[None], radii
+    Tx = Tfin.detach() if f_noalpha else Tfin      # transmittance as seen by the extra channels
+    depth_img, quat_img = out[3:4], out[4:8]
+    if f_dnorm:
+        A = 1 - Tx
+        depth_img = torch.where(A > 0, depth_img / torch.where(A > 0, A, torch.ones_like(A)), torch.zeros_like(depth_img))
+    if f_fill:
+        quat_img = torch.cat([quat_img[0:1] + Tx[None], quat_img[1:]], 0)
+    return color, depth_img, quat_img, out[8:11], (1 - Tfin)[None], radii

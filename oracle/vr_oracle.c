@@ -46,7 +46,13 @@ typedef struct {
     float campos[3];
     int sh_degree;
     int M; /* SH coefficients stored per Gaussian (16 for max degree 3) */
+    unsigned flags; /* VrFlags of include/vegs_rast.h, bits 0-3: the fork assumptions of SURVEY.md A.8 as switches */
 } OrCam;
+
+#define FLAG_SCALE_MODIFIED 1u      /* cov_scale blends scale_modifier * scales                    (A-3 variant) */
+#define FLAG_DEPTH_NORMALIZED 2u    /* depth = sum(w z) / (1 - T_final), 0 where nothing contributes (A-1 variant) */
+#define FLAG_EXTRA_NO_ALPHA_GRAD 4u /* depth/quat/scale: gradients reach the attributes only, not alpha (A.5 variant) */
+#define FLAG_FILL_EMPTY 8u          /* cov_quat += T_final * (1,0,0,0)                              (A-5 variant) */
 
 /* ------------------------------------------------------------------ math */
 
@@ -157,6 +163,13 @@ static inline void cov3d_from_scale_rot(const float* s, float mod, const float* 
     c6[3] = fmaf(L[5], L[5], fmaf(L[4], L[4], L[3] * L[3]));
     c6[4] = fmaf(L[5], L[8], fmaf(L[4], L[7], L[3] * L[6]));
     c6[5] = fmaf(L[8], L[8], fmaf(L[7], L[7], L[6] * L[6]));
+}
+
+/* exported for the cov3D pin (tests/golden/ref_cov3d.npz, generated by the reference's own
+ * build_scaling_rotation / strip_symmetric, utils/general_utils.py:83-129) */
+void or_cov3d(int n, const float* scales, float mod, const float* rotations, float* cov6)
+{
+    for (int i = 0; i < n; ++i) cov3d_from_scale_rot(scales + 3 * i, mod, rotations + 4 * i, cov6 + 6 * i);
 }
 
 /* EWA projection: rows m0,m1 of M2 = J * Wview (2x3) and the 2D covariance (a,b,c), A.2 */
@@ -341,14 +354,15 @@ static inline float splat_power(const float* xy, const float* con, float pxf, fl
     return fmaf(-0.5f, q, -((con[1] * *dx) * *dy));
 }
 
-static inline void splat_attrs(int id, const float* rgb, const float* depth, const float* rotations,
+static inline void splat_attrs(const OrCam* cam, int id, const float* rgb, const float* depth, const float* rotations,
                                const float* scales, float* a)
 {
+    const float sm = (cam->flags & FLAG_SCALE_MODIFIED) ? cam->scale_modifier : 1.0f;
     a[0] = rgb[3 * id]; a[1] = rgb[3 * id + 1]; a[2] = rgb[3 * id + 2];
     a[3] = depth[id];
     if (rotations) { for (int k = 0; k < 4; ++k) a[4 + k] = rotations[4 * id + k]; }
     else { for (int k = 0; k < 4; ++k) a[4 + k] = 0.f; }      /* A-6 */
-    if (scales) { for (int k = 0; k < 3; ++k) a[8 + k] = scales[3 * id + k]; }
+    if (scales) { for (int k = 0; k < 3; ++k) a[8 + k] = scales[3 * id + k] * sm; }
     else { for (int k = 0; k < 3; ++k) a[8 + k] = 0.f; }
 }
 
@@ -398,7 +412,7 @@ void or_render_fwd(const OrCam* cam, const int* ranges, const uint32_t* point_li
                         float pn = p * (1.0f - alpha);
                         if (Tb * pn < T_EPS) { done = 1; break; }
                         float w = alpha * (Tb * p), a[NCH];
-                        splat_attrs(id, rgb, depth, rotations, scales, a);
+                        splat_attrs(cam, id, rgb, depth, rotations, scales, a);
                         for (int k = 0; k < NCH; ++k) Cs[k] = fmaf(a[k], w, Cs[k]);
                         p = pn;
                         last = (uint32_t)(j - s + 1);
@@ -411,7 +425,13 @@ void or_render_fwd(const OrCam* cam, const int* ranges, const uint32_t* point_li
                 final_T[pix] = T;
                 n_contrib[pix] = last;
                 for (int c = 0; c < 3; ++c) out_color[c * N + pix] = fmaf(T, cam->bg[c], C[c]);
-                out_depth[pix] = C[3];
+                float depth_out = C[3];
+                if (cam->flags & FLAG_DEPTH_NORMALIZED) {
+                    float A = 1.0f - T;
+                    depth_out = A > 0.0f ? C[3] / A : 0.0f;
+                }
+                out_depth[pix] = depth_out;
+                if (cam->flags & FLAG_FILL_EMPTY) C[4] += T;
                 for (int k = 0; k < 4; ++k) out_quat[k * N + pix] = C[4 + k];
                 for (int k = 0; k < 3; ++k) out_scale[k * N + pix] = C[8 + k];
                 out_alpha[pix] = 1.0f - T;
@@ -426,11 +446,14 @@ void or_render_fwd(const OrCam* cam, const int* ranges, const uint32_t* point_li
 void or_render_bwd(const OrCam* cam, int P, const int* ranges, const uint32_t* point_list,
                    const float* xy, const float* conic_op, const float* rgb, const float* depth,
                    const float* rotations, const float* scales,
-                   const float* final_T, const uint32_t* n_contrib,
+                   const float* final_T, const uint32_t* n_contrib, const float* out_depth,
                    const float* dL_dcolor, const float* dL_ddepth, const float* dL_dquat,
                    const float* dL_dscale, const float* dL_dalpha,
                    double* g_mean2D, double* g_conic, double* g_opacity, double* g_attr)
 {
+    /* out_depth: the forward's depth image (only read with FLAG_DEPTH_NORMALIZED) */
+    const int no_extra = (cam->flags & FLAG_EXTRA_NO_ALPHA_GRAD) != 0;
+    const int nu = no_extra ? 3 : NCH; /* channels whose gradient also flows through alpha */
     int H = cam->H, W = cam->W;
     int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     size_t N = (size_t)H * W;
@@ -456,7 +479,17 @@ void or_render_bwd(const OrCam* cam, int P, const int* ranges, const uint32_t* p
                 float galpha = dL_dalpha ? dL_dalpha[pix] : 0.f;
                 float Tf = final_T[pix];
                 float T = Tf;
-                float bgdot = fmaf(cam->bg[2], g[2], fmaf(cam->bg[1], g[1], cam->bg[0] * g[0])) - galpha;
+                if ((cam->flags & FLAG_DEPTH_NORMALIZED) && dL_ddepth) {
+                    /* depth = D / A, A = 1 - T_final: dL/dD = g/A and (through alpha) dL/dA -= g D / A^2 */
+                    float A = 1.0f - Tf;
+                    float inv = A > 0.0f ? 1.0f / A : 0.0f;
+                    float D = out_depth[pix] * A;
+                    float g3 = g[3];
+                    g[3] = g3 * inv;
+                    if (!no_extra) galpha -= (g3 * D) * (inv * inv);
+                }
+                float fill = ((cam->flags & FLAG_FILL_EMPTY) && !no_extra) ? g[4] : 0.0f;
+                float bgdot = (fmaf(cam->bg[2], g[2], fmaf(cam->bg[1], g[1], cam->bg[0] * g[0])) + fill) - galpha;
                 float behind = 0.f; /* sum_{j>s} w_j u_j */
                 for (int j = s + (int)n_contrib[pix] - 1; j >= s; --j) {
                     int id = (int)point_list[j];
@@ -470,10 +503,10 @@ void or_render_bwd(const OrCam* cam, int P, const int* ranges, const uint32_t* p
                     float oma = 1.0f - alpha;
                     T = T / oma;
                     float w = alpha * T, a[NCH];
-                    splat_attrs(id, rgb, depth, rotations, scales, a);
+                    splat_attrs(cam, id, rgb, depth, rotations, scales, a);
                     float u = 0.f;
                     for (int k = 0; k < NCH; ++k) {
-                        u = fmaf(a[k], g[k], u);
+                        if (k < nu) u = fmaf(a[k], g[k], u);
 #pragma omp atomic
                         g_attr[(size_t)NCH * id + k] += (double)(w * g[k]);
                     }
@@ -641,7 +674,7 @@ void or_preprocess_bwd(const OrCam* cam, int P, const float* means3D, const floa
             for (int k = 0; k < 3; ++k) {
                 float acc = 0.f;
                 for (int ii = 0; ii < 3; ++ii) { acc += dLm[3 * ii + k] * R[3 * ii + k]; D[3 * ii + k] = dLm[3 * ii + k] * sp[k]; }
-                dL_dscales[3 * i + k] = mod * acc + ga[8 + k];
+                dL_dscales[3 * i + k] = mod * acc + ((cam->flags & FLAG_SCALE_MODIFIED) ? mod : 1.0f) * ga[8 + k];
             }
             float gr = 2.f * (z * (D[3] - D[1]) + y * (D[2] - D[6]) + x * (D[7] - D[5]));
             float gxq = 2.f * (y * (D[1] + D[3]) + z * (D[2] + D[6]) + r * (D[7] - D[5])) - 4.f * x * (D[4] + D[8]);

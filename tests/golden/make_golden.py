@@ -12,6 +12,9 @@ nothing of it is copied -- only inputs and outputs are stored):
   * utils/loss_utils.py:18-22 l1_loss, :39-79 ssim (values + gradients)  -> ref_photometric.npz
   * utils/graphics_utils.py:49-53 decompose_T_to_RS, :140-201 matrix_to_quaternion, :204-248
     quaternion_to_matrix composed as gaussian_renderer/__init__.py:122-153 does -> ref_instances.npz
+  * utils/general_utils.py:83-129 build_scaling_rotation / strip_symmetric composed as
+    scene/gaussian_model.py:32-36 build_covariance_from_scaling_rotation does (their hard-coded device='cuda'
+    is redirected to the CPU for the duration of the call)                         -> ref_cov3d.npz
 Part B runs the independent float64 autograd restatement oracle/torch_ref.py on tiny
 seeded scenes (vegs_amd/scenes.py) and stores inputs, forward images and input gradients
 -> raster_case*.npz.  These pin vr_oracle.c and, on the GPU box, the HIP kernels.
@@ -152,6 +155,38 @@ def part_a():
                      f"grad_rot_{b}": rot.grad.numpy(), f"grad_box2world_{b}": box2world.grad.numpy()})
     np.savez_compressed(os.path.join(HERE, "ref_instances.npz"), **blob)
 
+    # cov3D: the in-repo definition the rasterizer's scale/rotation path must reproduce (scene/gaussian_model.py:32-36
+    # = strip_symmetric(L L^T), L = build_scaling_rotation(modifier * scaling, rotation), utils/general_utils.py:83-129).
+    # Those helpers allocate with device='cuda'; there is no GPU in the build container, so torch.zeros is wrapped to
+    # ignore the device while they run -- the arithmetic is the reference's own.
+    import types
+    if "torchvision" not in sys.modules:          # general_utils imports torchvision for an image helper only; absent here
+        tv, tvt = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+        tvt.functional = types.ModuleType("torchvision.transforms.functional")
+        tv.transforms = tvt
+        sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt,
+                            "torchvision.transforms.functional": tvt.functional})
+    import utils.general_utils as gen
+    real_zeros = torch.zeros
+
+    def zeros_cpu(*a, **k):
+        k.pop("device", None)
+        return real_zeros(*a, **k)
+    n = 200
+    s = np.exp(rng.normal(np.log(0.05), 1.0, (n, 3))).astype(np.float32)
+    s[:20, 0] = 1e-5                                                  # VEGS discs (utils/norminit_utils.py:217-219)
+    q = rng.normal(size=(n, 4))
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    blob = {"scales": s, "rotations": q}
+    torch.zeros = zeros_cpu
+    try:
+        for mod in (1.0, 0.37):
+            L = gen.build_scaling_rotation(mod * torch.tensor(s), torch.tensor(q))
+            blob[f"cov6_mod{mod}"] = gen.strip_symmetric(L @ L.transpose(1, 2)).numpy()
+    finally:
+        torch.zeros = real_zeros
+    np.savez_compressed(os.path.join(HERE, "ref_cov3d.npz"), **blob)
+
 
 CASES = {
     # name: (scene kwargs, camera (W,H), sh_degree, bg, mode)
@@ -159,6 +194,13 @@ CASES = {
     "case_precomp": dict(P=250, seed=12, scale=0.04, W=48, H=48, deg=0, bg=(0.0, 0.0, 0.0), mode="precomp", mod=1.0),
     "case_cull_deg1": dict(P=400, seed=13, scale=0.08, W=80, H=40, deg=1, bg=(1.0, 1.0, 1.0), mode="sh_sr", mod=1.3,
                            extent=2.5, opaque=True),
+    # the fork assumptions as switches (include/vegs_rast.h VrFlags): one case per flag + all together
+    "case_flag_scale": dict(P=260, seed=21, scale=0.05, W=64, H=48, deg=2, bg=(0.1, 0.2, 0.3), mode="sh_sr", mod=1.4, flags=1),
+    "case_flag_depthnorm": dict(P=260, seed=22, scale=0.05, W=64, H=48, deg=1, bg=(0.3, 0.1, 0.0), mode="sh_sr", mod=1.0, flags=2),
+    "case_flag_noalpha": dict(P=260, seed=23, scale=0.05, W=64, H=48, deg=1, bg=(0.0, 0.2, 0.1), mode="sh_sr", mod=1.0, flags=4),
+    "case_flag_fill": dict(P=150, seed=24, scale=0.04, W=64, H=48, deg=0, bg=(0.2, 0.2, 0.2), mode="sh_sr", mod=1.0, flags=8),
+    "case_flag_all": dict(P=260, seed=25, scale=0.05, W=64, H=48, deg=3, bg=(0.5, 0.4, 0.3), mode="sh_sr", mod=0.8, flags=15),
+    "case_flag_dnorm_fill": dict(P=200, seed=26, scale=0.05, W=48, H=48, deg=1, bg=(0.0, 0.0, 0.0), mode="sh_sr", mod=1.2, flags=10),
 }
 
 
@@ -174,9 +216,11 @@ def build_case(c):
     return sc, deg, cam
 
 
-def part_b():
+def part_b(only_new=False):
     from oracle import torch_ref
     for name, c in CASES.items():
+        if only_new and os.path.exists(os.path.join(HERE, f"raster_{name}.npz")):
+            continue
         sc, deg, cam = build_case(c)
         P = c["P"]
         T = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in sc.items()}
@@ -198,7 +242,7 @@ def part_b():
             extra = {"in_colors_precomp": col, "in_cov3D_precomp": cov6}
         else:
             res = torch_ref.rasterize(T["means3D"], T["shs"], None, T["opacities"], T["scales"], T["rotations"], None,
-                                      means2D=m2d, **kw)
+                                      means2D=m2d, flags=c.get("flags", 0), **kw)
         rng = np.random.default_rng(c["seed"] + 7)
         names = ["color", "depth", "cov_quat", "cov_scale", "alpha"]
         gouts = [rng.normal(size=tuple(r.shape)).astype(np.float32) for r in res[:5]]
@@ -208,7 +252,7 @@ def part_b():
                 "bg": np.array(c["bg"], np.float32), "scale_modifier": np.float32(c["mod"]),
                 "tanfov": np.array([cam.tanfovx, cam.tanfovy], np.float64),
                 "viewmatrix": cam.world_view_transform, "projmatrix": cam.full_proj_transform,
-                "campos": cam.camera_center, "radii": res[5].numpy()}
+                "campos": cam.camera_center, "radii": res[5].numpy(), "flags": np.int64(c.get("flags", 0))}
         for k, v in sc.items():
             blob["in_" + k] = v
         for k, v in extra.items():
@@ -231,5 +275,8 @@ def part_b():
 
 
 if __name__ == "__main__":
-    part_a()
-    part_b()
+    # --new: keep the committed fixtures (their random draws are part of the pins) and only add missing ones
+    new = "--new" in sys.argv
+    if not new or not os.path.exists(os.path.join(HERE, "ref_cov3d.npz")):
+        part_a()
+    part_b(only_new=new)

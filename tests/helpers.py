@@ -12,6 +12,15 @@ def load_case(name):
     return {k: z[k] for k in z.files}
 
 
+FLAG_CASES = ["case_flag_scale", "case_flag_depthnorm", "case_flag_noalpha", "case_flag_fill", "case_flag_all",
+              "case_flag_dnorm_fill"]
+
+
+def case_flags(c):
+    """VrFlags (include/vegs_rast.h) the golden case was rendered with (0 for the cases of round 1)."""
+    return int(c["flags"]) if "flags" in c else 0
+
+
 def case_inputs(c):
     """The 7 tensor kwargs of the op (numpy), in the reference's naming."""
     pre = "in_colors_precomp" in c
@@ -30,20 +39,60 @@ def oracle_cam_from_case(c):
     from oracle import oracle as orc
     P, W, H, deg = (int(v) for v in c["meta"])
     return orc.make_cam(H, W, c["tanfov"][0], c["tanfov"][1], c["bg"], float(c["scale_modifier"]),
-                        c["viewmatrix"], c["projmatrix"], c["campos"], deg, 16)
+                        c["viewmatrix"], c["projmatrix"], c["campos"], deg, 16, flags=case_flags(c))
 
 
-def oracle_cam(cam, bg, sh_degree, scale_modifier=1.0, M=16):
+def oracle_cam(cam, bg, sh_degree, scale_modifier=1.0, M=16, flags=0):
     from oracle import oracle as orc
     return orc.make_cam(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy, bg, scale_modifier,
-                        cam.world_view_transform, cam.full_proj_transform, cam.camera_center, sh_degree, M)
+                        cam.world_view_transform, cam.full_proj_transform, cam.camera_center, sh_degree, M, flags=flags)
 
 
 def rel_err(a, b):
-    """max |a-b| / max(|b|, tiny): gradient comparison metric (tensor-level relative error)."""
+    """max |a-b| / max(|b|, tiny): tensor-level relative error.  Kept for quantities that have no per-Gaussian
+    rows (images, optimizer state); GRADIENTS are compared with assert_grad_close below."""
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def grad_mismatch(got, want, rtol=1e-3, floor=1e-6):
+    """Per-row (= per-Gaussian) gradient comparison.  Row i passes when every element satisfies
+        |got - want| <= rtol * max|want[i]| + floor * max|want|
+    i.e. the error is measured against the size of THAT Gaussian's gradient (a Gaussian whose gradient is 1e-4 of
+    the tensor maximum cannot hide a 100 % error under a tensor-level norm), with a floor tied to the tensor
+    maximum for rows that are pure cancellation noise (fp32 sums of terms ~1e-6 * max).  Returns (failing row
+    indices, per-row error in units of the allowance)."""
+    g = np.asarray(got, np.float64)
+    w = np.asarray(want, np.float64)
+    assert g.shape == w.shape, (g.shape, w.shape)
+    if g.size == 0:
+        return np.zeros(0, np.int64), np.zeros(0)
+    g2 = g.reshape(g.shape[0], -1) if g.ndim > 1 else g.reshape(-1, 1)
+    w2 = w.reshape(g2.shape)
+    rowmax = np.abs(w2).max(axis=1)
+    allow = rtol * rowmax + floor * max(np.abs(w2).max(), 1e-30)
+    err = np.abs(g2 - w2).max(axis=1)
+    bad = ~np.isfinite(g2).all(axis=1) | (err > allow)
+    return np.nonzero(bad)[0], err / allow
+
+
+def assert_grad_close(name, got, want, rtol=1e-3, floor=1e-6, outliers=1e-4):
+    """Assert the per-row criterion of grad_mismatch for all but a fraction `outliers` of the rows (fp32 atomics
+    are order-dependent: a handful of rows dominated by cancellation may exceed the allowance) -- and never by
+    more than 100x.  The offenders are printed so that a systematic error is visible in the log."""
+    bad, ratio = grad_mismatch(got, want, rtol, floor)
+    n = max(int(np.asarray(want).shape[0]) if np.asarray(want).ndim else 1, 1)
+    if len(bad):
+        w = np.asarray(want).reshape(n, -1)
+        g = np.asarray(got).reshape(n, -1)
+        worst = bad[np.argsort(-ratio[bad])][:8]
+        print(f"[grad] {name}: {len(bad)} / {n} rows outside rtol={rtol} floor={floor}; worst rows:")
+        for i in worst:
+            print(f"    row {i}: err/allow {ratio[i]:.2f}  got {g[i][:4]}  want {w[i][:4]}")
+    assert len(bad) <= outliers * n, f"{name}: {len(bad)} of {n} rows fail the per-row gradient check"
+    if len(bad):
+        assert np.isfinite(ratio[bad]).all() and ratio[bad].max() < 100.0, f"{name}: outlier row off by {ratio[bad].max():.1f}x the allowance"
 
 
 def normal_guidance_loss(cov_quat, cov_scale, normal, R_cam2world):

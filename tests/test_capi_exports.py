@@ -34,7 +34,7 @@ def test_struct_layouts_match_header_sizes():
     """ctypes mirrors of the ABI structs: pointer-sized fields and 4-byte scalars, no surprises."""
     from vegs_amd import _capi
     p = ctypes.sizeof(ctypes.c_void_p)
-    assert ctypes.sizeof(_capi.VrSettings) == 8 * 4 + 4 * p
+    assert ctypes.sizeof(_capi.VrSettings) == 8 * 4 + 4 * p + 8          # + uint32 flags, padded to pointer alignment
     assert ctypes.sizeof(_capi.VrInputs) == 2 * 4 + 8 * p
     assert ctypes.sizeof(_capi.VrOutputs) == 6 * p
     assert ctypes.sizeof(_capi.VrSaved) == 3 * p + 3 * 8

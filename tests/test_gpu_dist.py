@@ -42,3 +42,114 @@ def test_gradient_exchange_on_rccl_single_rank():
     script = SCRIPT % ROOT
     r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout + r.stderr
+
+
+# ---- two ranks through the real operator.  RCCL refuses two ranks on one device, so the ranks of this test talk over
+# gloo (VEGS_DIST_BACKEND=gloo, vegs_amd/dist.py) while each of them renders on the GPU: the HIP path, the per-rank view
+# assignment and the exchange arithmetic are the production ones; only the transport differs from the 8-GPU job.
+WORKER = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+from vegs_amd import dist as vdist, harness, scenes
+rank, world, local = vdist.init_from_env()
+assert world == 2 and torch.distributed.get_backend() == "gloo"
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+sc, deg = scenes.scene_street(P=60000, length=80.0, sh_degree=3, seed=12)
+cams = [scenes.kitti_camera(5.0, 0.3, 688, 188), scenes.kitti_camera(5.0, -0.3, 688, 188)]     # a stereo pair
+T = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in sc.items()}
+params = [T[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+g = np.load(%(gpath)r)
+v = vdist.view_for_rank(0, rank, world, len(cams))
+assert v == rank
+pkg = harness.render(cams[v], T, deg, torch.zeros(3, device=dev))
+torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]],
+                        [torch.tensor(g["gc%%d" %% v], device=dev), torch.tensor(g["gq%%d" %% v], device=dev), torch.tensor(g["gs%%d" %% v], device=dev)])
+vdist.allreduce_grads(params, world)
+gsum, den, mr = vdist.allreduce_densification_stats(pkg["viewspace_points"].grad, pkg["visibility_filter"], pkg["radii"])
+np.savez(os.path.join(%(out)r, "rank%%d.npz" %% rank), gsum=gsum.cpu().numpy(), den=den.cpu().numpy(), mr=mr.cpu().numpy(),
+         **{"grad_" + k: T[k].grad.cpu().numpy() for k in T})
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+print("RANK_OK", rank)
+"""
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_equal_mean_of_two_views(tmp_path):
+    """2 ranks x 1 view each, all-reduced  ==  1 process averaging the two views' gradients (loss = mean over the
+    views), through the real HIP operator; plus the densification statistics of the view batch."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import assert_grad_close
+    from vegs_amd import harness, scenes
+    H, W = 188, 688
+    rng = np.random.default_rng(4)
+    gd = {}
+    for v in range(2):
+        gd[f"gc{v}"] = rng.normal(size=(3, H, W)).astype(np.float32)
+        gd[f"gq{v}"] = rng.normal(size=(4, H, W)).astype(np.float32)
+        gd[f"gs{v}"] = rng.normal(size=(3, H, W)).astype(np.float32)
+    gpath = str(tmp_path / "gouts.npz")
+    np.savez(gpath, **gd)
+    script = WORKER % dict(root=ROOT, gpath=gpath, out=str(tmp_path))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), VEGS_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs) and all("RANK_OK" in o for o in outs), "\n".join(outs)
+
+    # ---- one process, both views, mean of the gradients
+    dev = torch.device("cuda:0")
+    sc, deg = scenes.scene_street(P=60000, length=80.0, sh_degree=3, seed=12)
+    cams = [scenes.kitti_camera(5.0, 0.3, W, H), scenes.kitti_camera(5.0, -0.3, W, H)]
+    T = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in sc.items()}
+    gsum = torch.zeros(60000, 1, device=dev)
+    den = torch.zeros(60000, 1, device=dev)
+    mr = torch.zeros(60000, dtype=torch.int32, device=dev)
+    for v, cam in enumerate(cams):
+        pkg = harness.render(cam, T, deg, torch.zeros(3, device=dev))
+        torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]],
+                                [torch.tensor(gd[f"gc{v}"], device=dev), torch.tensor(gd[f"gq{v}"], device=dev),
+                                 torch.tensor(gd[f"gs{v}"], device=dev)])
+        vis = pkg["visibility_filter"]
+        gsum += torch.norm(pkg["viewspace_points"].grad[:, :2], dim=-1, keepdim=True) * vis[:, None]
+        den += vis[:, None].float()
+        mr = torch.maximum(mr, pkg["radii"])
+    want = {k: (T[k].grad / 2).cpu().numpy() for k in T}
+    R = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    for k in T:
+        assert np.array_equal(R[0]["grad_" + k], R[1]["grad_" + k]), k          # identical on every rank
+        assert_grad_close("2-rank " + k, R[0]["grad_" + k], want[k], rtol=1e-3, floor=2e-6)
+    assert np.array_equal(R[0]["den"], den.cpu().numpy()) and np.array_equal(R[0]["mr"], mr.cpu().numpy())
+    assert_grad_close("2-rank grad-norm sum", R[0]["gsum"], gsum.cpu().numpy(), rtol=1e-3, floor=2e-6)
+    assert (R[0]["den"] == 2).sum() > 1000                                         # the stereo views overlap
+
+
+def test_bench_two_ranks_gloo_transport(tmp_path):
+    """bench.py --gpus 2 under torch.distributed.run (the driver's launch line), both ranks on the one GPU of this
+    box with the gloo transport: the N > 1 code path of the benchmark runs end to end and reports n_gpus 2."""
+    import json
+    env = dict(os.environ, VEGS_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--gaussians", "200000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
+    assert res["config"]["gaussians"] == 200000 and "roofline" in res

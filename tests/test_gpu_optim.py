@@ -125,3 +125,26 @@ def test_densification_stats_match_the_reference_expressions():
     assert np.abs(d["accum"].cpu().numpy() - t["accum"].numpy()).max() < 1e-6
     with pytest.raises(ValueError):
         add_densification_stats(d["grad"], d["radii"].long(), d["accum"], d["denom"], d["maxr"])
+
+
+def test_fused_adam_many_tensors_with_an_empty_one():
+    """More tensors than one launch carries (8) with an EMPTY one among the first batch: every tensor must be updated
+    exactly once per step (the batching once advanced by 8 although the empty tensor had taken no slot, and
+    repeated a tensor)."""
+    from vegs_amd.optim import Adam
+    rng = np.random.default_rng(5)
+    sizes = [5, 0, 7, 300, 1, 64, 33, 2, 1025, 17, 4, 9]          # 12 tensors, the second one empty
+    ref = [torch.nn.Parameter(torch.tensor(rng.normal(size=(n, 3)).astype(np.float32))) for n in sizes]
+    our = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref]
+    ref_opt = torch.optim.Adam([{"params": [p], "lr": 1e-2 * (i + 1)} for i, p in enumerate(ref)], lr=0.0, eps=1e-15)
+    our_opt = Adam([{"params": [p], "lr": 1e-2 * (i + 1)} for i, p in enumerate(our)], lr=0.0, eps=1e-15)
+    for step in range(4):
+        for p, q in zip(ref, our):
+            g = rng.normal(size=tuple(p.shape)).astype(np.float32)
+            p.grad, q.grad = torch.tensor(g), torch.tensor(g, device=DEV)
+        ref_opt.step(); our_opt.step()
+    for i, (p, q) in enumerate(zip(ref, our)):
+        assert q.shape == p.shape
+        if p.numel():
+            assert rel_err(q.detach().cpu().numpy(), p.detach().numpy()) < 2e-6, i
+            assert float(our_opt.state[q]["step"]) == 4.0

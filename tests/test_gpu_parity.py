@@ -11,11 +11,13 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import OUT_NAMES, case_inputs, load_case, normal_guidance_loss, oracle_cam, oracle_cam_from_case, rel_err
+from helpers import (FLAG_CASES, OUT_NAMES, assert_grad_close, case_flags, case_inputs, load_case, normal_guidance_loss,
+                     oracle_cam, oracle_cam_from_case, rel_err)
 
 pytestmark = pytest.mark.gpu
 
-GRAD_RTOL = 2e-4   # tensor-level relative error, gradients (HIP fp32 atomics vs oracle double sums)
+GRAD_RTOL = 1e-3   # PER-ROW relative tolerance of the gradients (helpers.assert_grad_close: HIP fp32 atomics vs
+                   # the oracle's double sums; floor 1e-6 of the tensor maximum, <= 0.01 % outlier rows)
 
 
 @pytest.fixture(scope="module")
@@ -44,16 +46,19 @@ def _settings(c_or_cam, bg, deg, mod, dev, debug=False):
                                          torch.tensor(cam.camera_center, device=dev), False, debug)
 
 
-def _run_hip(settings, inputs, dev, gouts=None):
-    """inputs: dict of numpy (op kwargs).  Returns (outputs dict np, grads dict np or None, ctx info)."""
+def _run_hip(settings, inputs, dev, gouts=None, flags=0):
+    """inputs: dict of numpy (op kwargs).  Returns (outputs dict np, grads dict np or None, ctx info).
+    flags: VrFlags (include/vegs_rast.h) in force for this forward and its backward."""
     from diff_gaussian_rasterization import GaussianRasterizer
+    from vegs_amd import rasterizer
     T = {k: (None if v is None else torch.tensor(v, device=dev, requires_grad=True)) for k, v in inputs.items()}
     P = inputs["means3D"].shape[0]
     m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
     rast = GaussianRasterizer(raster_settings=settings)
-    res = rast(means3D=T["means3D"], means2D=m2d, shs=T["shs"], colors_precomp=T["colors_precomp"],
-               opacities=T["opacities"], scales=T["scales"], rotations=T["rotations"],
-               cov3D_precomp=T["cov3D_precomp"])
+    with rasterizer.flags(flags):
+        res = rast(means3D=T["means3D"], means2D=m2d, shs=T["shs"], colors_precomp=T["colors_precomp"],
+                   opacities=T["opacities"], scales=T["scales"], rotations=T["rotations"],
+                   cov3D_precomp=T["cov3D_precomp"])
     out = {n: r.detach().cpu().numpy() for n, r in zip(OUT_NAMES, res[:5])}
     out["radii"] = res[5].cpu().numpy()
     grads = None
@@ -81,15 +86,16 @@ def _export_binning(res, H, W, dev):
     return pl[:R].cpu().numpy().astype(np.uint32), rg.cpu().numpy()
 
 
-def _check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=0, grad_rtol=GRAD_RTOL, gmask=(1, 1, 1, 1, 1), M=16):
+def _check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=0, grad_rtol=GRAD_RTOL, gmask=(1, 1, 1, 1, 1), M=16,
+                          flags=0):
     from oracle import oracle as orc
-    oc = oracle_cam(cam, bg, deg, mod, M)
+    oc = oracle_cam(cam, bg, deg, mod, M, flags=flags)
     o_out, st = orc.forward(oc, **inputs)
     rng = np.random.default_rng(seed)
     H, W = cam.image_height, cam.image_width
     shapes = [(3, H, W), (1, H, W), (4, H, W), (3, H, W), (1, H, W)]
     gouts = [rng.normal(size=s).astype(np.float32) if m else None for s, m in zip(shapes, gmask)]
-    h_out, h_grads, res = _run_hip(_settings(cam, bg, deg, mod, dev), inputs, dev, gouts)
+    h_out, h_grads, res = _run_hip(_settings(cam, bg, deg, mod, dev), inputs, dev, gouts, flags=flags)
     # integers: bit exact
     assert np.array_equal(h_out["radii"], o_out["radii"])
     pl, rg = _export_binning(res, H, W, dev)
@@ -105,32 +111,106 @@ def _check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=0, grad_rtol=GRAD
             assert o_grads[k] is None, k
             continue
         assert g.shape == o_grads[k].shape, k
-        assert rel_err(g, o_grads[k]) < grad_rtol, (k, rel_err(g, o_grads[k]))
+        assert_grad_close(k, g, o_grads[k], rtol=grad_rtol)
     return h_out, h_grads, o_out, st
 
 
-@pytest.mark.parametrize("name", ["case_sh3", "case_precomp", "case_cull_deg1"])
+@pytest.mark.parametrize("name", ["case_sh3", "case_precomp", "case_cull_deg1"] + FLAG_CASES)
 def test_golden_fixture(name, dev):
-    """HIP vs the committed float64 golden vectors (tests/golden/raster_*.npz)."""
+    """HIP vs the committed float64 golden vectors (tests/golden/raster_*.npz), incl. one case per fork switch
+    (include/vegs_rast.h VrFlags) rendered by the float64 autograd restatement with the same switch."""
     c = load_case(name)
     gouts = [c["gout_" + n] for n in OUT_NAMES]
-    out, grads, _ = _run_hip(_settings(c, None, None, None, dev), case_inputs(c), dev, gouts)
+    out, grads, _ = _run_hip(_settings(c, None, None, None, dev), case_inputs(c), dev, gouts, flags=case_flags(c))
     assert np.array_equal(out["radii"], c["radii"])
     for n in OUT_NAMES:
         scale = max(1.0, np.abs(c["out_" + n]).max())
         assert np.abs(out[n] - c["out_" + n]).max() < 1e-5 * scale, n
     for k in [k[5:] for k in c if k.startswith("grad_")]:
-        assert rel_err(grads[k], c["grad_" + k]) < 3e-4, (k, rel_err(grads[k], c["grad_" + k]))
+        assert_grad_close(k, grads[k], c["grad_" + k], rtol=1e-3)
     assert np.all(grads["means2D"][:, 2] == 0)
 
 
-@pytest.mark.parametrize("name", ["case_sh3", "case_precomp", "case_cull_deg1"])
+@pytest.mark.parametrize("name", ["case_sh3", "case_precomp", "case_cull_deg1"] + FLAG_CASES)
 def test_golden_inputs_vs_oracle_bit_exact(name, dev):
     from vegs_amd import scenes
     c = load_case(name)
     P, W, H, deg = (int(v) for v in c["meta"])
     cam = scenes.camera_c1(W, H)
-    _check_against_oracle(case_inputs(c), cam, c["bg"], deg, float(c["scale_modifier"]), dev)
+    _check_against_oracle(case_inputs(c), cam, c["bg"], deg, float(c["scale_modifier"]), dev, flags=case_flags(c))
+
+
+@pytest.mark.parametrize("flags", [1, 2, 4, 8, 6, 15])
+def test_fork_switches_on_a_street_scene(flags, dev):
+    """The A.8 switches on a KITTI-shaped scene with sky pixels (exact zeros / identity fill), scale modifier != 1
+    and all five upstream gradients: images bit-exact and gradients per-row against the oracle run with the same
+    switches."""
+    from vegs_amd import scenes
+    sc, deg = scenes.scene_street(P=15000, length=50.0, sh_degree=2, seed=30 + flags)
+    inputs = dict(means3D=sc["means3D"], shs=sc["shs"], colors_precomp=None, opacities=sc["opacities"],
+                  scales=sc["scales"], rotations=sc["rotations"], cov3D_precomp=None)
+    cam = scenes.kitti_camera(0.0, 0.0, 688, 188)
+    h_out, *_ = _check_against_oracle(inputs, cam, [0.1, 0.0, 0.2], deg, 1.25, dev, flags=flags, seed=flags)
+    empty = h_out["alpha"][0] == 0
+    assert empty.any()
+    if flags & 8:
+        assert np.all(h_out["cov_quat"][0][empty] == 1.0) and np.all(h_out["cov_quat"][1:, empty] == 0.0)
+    else:
+        assert np.all(h_out["cov_quat"][:, empty] == 0.0)
+    assert np.all(h_out["depth"][0][empty] == 0.0) and np.isfinite(h_out["depth"]).all()
+
+
+def test_cov3d_path_matches_reference_covariances(dev):
+    """scales + rotations through the kernels' own cov3D  ==  the same Gaussians with cov3D_precomp taken from the
+    reference's build_scaling_rotation / strip_symmetric (tests/golden/ref_cov3d.npz, utils/general_utils.py:83-129)."""
+    import os
+    from helpers import GOLDEN
+    from vegs_amd import scenes
+    z = np.load(os.path.join(GOLDEN, "ref_cov3d.npz"))
+    n = z["scales"].shape[0]
+    rng = np.random.default_rng(8)
+    means = rng.uniform(-0.6, 0.6, (n, 3)).astype(np.float32)
+    col = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    op = rng.uniform(0.2, 0.9, (n, 1)).astype(np.float32)
+    cam = scenes.camera_c1(96, 96)
+    for mod in (1.0, 0.37):
+        a, _, _ = _run_hip(_settings(cam, [0, 0, 0], 0, mod, dev),
+                           dict(means3D=means, shs=None, colors_precomp=col, opacities=op, scales=z["scales"],
+                                rotations=z["rotations"], cov3D_precomp=None), dev)
+        b, _, _ = _run_hip(_settings(cam, [0, 0, 0], 0, mod, dev),
+                           dict(means3D=means, shs=None, colors_precomp=col, opacities=op, scales=None, rotations=None,
+                                cov3D_precomp=z[f"cov6_mod{mod}"]), dev)
+        assert np.array_equal(a["radii"], b["radii"]) and (a["radii"] > 0).sum() > 100
+        for k in ("color", "depth", "alpha"):
+            assert np.abs(a[k] - b[k]).max() < 2e-5, (mod, k, np.abs(a[k] - b[k]).max())
+
+
+def test_deterministic_backward_is_bit_reproducible(dev):
+    """VR_FLAG_DETERMINISTIC: no floating-point atomics in the backward -> gradients identical bit for bit from run to
+    run, and (per-(entry, region) partials added in list order) closer to the oracle's double sums than the
+    atomic mode's order-dependent fp32 sums."""
+    from oracle import oracle as orc
+    from vegs_amd import rasterizer, scenes
+    sc, deg = scenes.scene_street(P=40000, length=60.0, sh_degree=3, seed=17)
+    inputs = dict(means3D=sc["means3D"], shs=sc["shs"], colors_precomp=None, opacities=sc["opacities"],
+                  scales=sc["scales"], rotations=sc["rotations"], cov3D_precomp=None)
+    cam = scenes.kitti_camera(0.0, 0.3, 1376, 376)
+    H, W = 376, 1376
+    rng = np.random.default_rng(2)
+    gouts = [rng.normal(size=s).astype(np.float32) for s in [(3, H, W), (1, H, W), (4, H, W), (3, H, W), (1, H, W)]]
+    st = _settings(cam, [0, 0, 0], deg, 1.0, dev)
+    runs = [_run_hip(st, inputs, dev, gouts, flags=rasterizer.FLAG_DETERMINISTIC)[1] for _ in range(3)]
+    for k, g in runs[0].items():
+        if g is None:
+            continue
+        assert np.array_equal(g, runs[1][k]) and np.array_equal(g, runs[2][k]), k
+    atomic = _run_hip(st, inputs, dev, gouts)[1]
+    oc = oracle_cam(cam, [0, 0, 0], deg)
+    o_out, ost = orc.forward(oc, **inputs)
+    og = orc.backward(oc, ost, *gouts)
+    for k in ("means3D", "shs", "opacities", "scales", "rotations", "means2D"):
+        assert_grad_close("det " + k, runs[0][k], og[k], rtol=2e-4, floor=2e-7, outliers=1e-4)
+        assert_grad_close("atomic vs det " + k, atomic[k], runs[0][k], rtol=1e-3, floor=1e-6)
 
 
 def test_c1_random_10k(dev):
@@ -150,7 +230,7 @@ def test_street_small_ragged_image(W, H, dev):
     inputs = dict(means3D=sc["means3D"], shs=sc["shs"], colors_precomp=None, opacities=sc["opacities"],
                   scales=sc["scales"], rotations=sc["rotations"], cov3D_precomp=None)
     cam = scenes.kitti_camera(0.0, 0.0, W, H)
-    h_out, *_ = _check_against_oracle(inputs, cam, [0.0, 0.0, 0.0], deg, 1.0, dev, grad_rtol=5e-4)
+    h_out, *_ = _check_against_oracle(inputs, cam, [0.0, 0.0, 0.0], deg, 1.0, dev)
     assert (h_out["radii"] > 0).sum() > 1000
 
 
@@ -181,8 +261,8 @@ def test_training_shaped_gradients_normal_guidance(dev):
     o_out, st = orc.forward(oc, sc["means3D"], sc["shs"], None, sc["opacities"], sc["scales"], sc["rotations"], None)
     og = orc.backward(oc, st, gc.cpu().numpy(), None, gq.cpu().numpy(), gs.cpu().numpy(), None)
     for k in ("means3D", "shs", "opacities", "scales", "rotations"):
-        assert rel_err(T[k].grad.cpu().numpy(), og[k]) < 5e-4, (k, rel_err(T[k].grad.cpu().numpy(), og[k]))
-    assert rel_err(vsp.grad.cpu().numpy(), og["means2D"]) < 5e-4
+        assert_grad_close(k, T[k].grad.cpu().numpy(), og[k])
+    assert_grad_close("means2D", vsp.grad.cpu().numpy(), og["means2D"])
     vis = pkg["visibility_filter"].cpu().numpy()
     assert np.array_equal(vis, o_out["radii"] > 0)
 
@@ -284,7 +364,7 @@ def test_sh_storage_widths(M, deg, dev):
     og = orc.backward(oc, st, *gouts)
     for k in ("means3D", "shs", "opacities", "scales", "rotations"):
         assert h_grads[k].shape == og[k].shape
-        assert rel_err(h_grads[k], og[k]) < GRAD_RTOL, (k, rel_err(h_grads[k], og[k]))
+        assert_grad_close(k, h_grads[k], og[k], rtol=GRAD_RTOL)
     K = (deg + 1) ** 2
     assert np.all(h_grads["shs"][:, K:, :] == 0)       # inactive coefficients receive exact zeros
 
@@ -295,7 +375,7 @@ def test_many_tiles_large_image(dev):
     sc, deg = scenes.scene_random(P=4000, sh_degree=1, seed=77, extent=1.2, scale=0.03)
     inputs = dict(means3D=sc["means3D"], shs=sc["shs"], colors_precomp=None, opacities=sc["opacities"],
                   scales=sc["scales"], rotations=sc["rotations"], cov3D_precomp=None)
-    _check_against_oracle(inputs, scenes.camera_c1(2048, 1200), [0, 0, 0], deg, 1.0, dev, grad_rtol=5e-4)
+    _check_against_oracle(inputs, scenes.camera_c1(2048, 1200), [0, 0, 0], deg, 1.0, dev)
 
 
 @pytest.mark.parametrize("P,M,deg", [(3000, 16, 3), (1000, 16, 1), (777, 4, 1), (130, 9, 2), (64, 2, 0)])

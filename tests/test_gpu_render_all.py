@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import oracle_cam, rel_err
+from helpers import assert_grad_close, oracle_cam, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -67,9 +67,9 @@ def test_render_all_gradients_reach_box_parameters():
     torch.autograd.backward([kw[k] for k in keys], [torch.tensor(og[k], dtype=torch.float64) for k in keys])
 
     for k in keys:
-        assert rel_err(static[k].grad.cpu().numpy(), c_static[k].grad.numpy()) < 5e-4, k
+        assert_grad_close(k, static[k].grad.cpu().numpy(), c_static[k].grad.numpy())
         for b, cb in zip(boxes, c_boxes):
-            assert rel_err(b[k].grad.cpu().numpy(), cb[k].grad.numpy()) < 5e-4, ("box", k)
+            assert_grad_close("box " + k, b[k].grad.cpu().numpy(), cb[k].grad.numpy())
     for bp, cbp in zip(bparams, c_bparams):           # the BoxModel-like deltas: angle, log-scale, translation
         for p, cp in zip(bp, cbp):
             assert p.grad is not None and torch.isfinite(p.grad).all()

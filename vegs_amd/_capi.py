@@ -11,13 +11,16 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libvegsrast.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
+
+# VrSettings.flags (include/vegs_rast.h, VrFlags)
+FLAG_SCALE_MODIFIED, FLAG_DEPTH_NORMALIZED, FLAG_EXTRA_NO_ALPHA_GRAD, FLAG_FILL_EMPTY, FLAG_DETERMINISTIC = 1, 2, 4, 8, 256
 
 VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH = 0, 1, 2, 3
 
 # every symbol include/vegs_rast.h declares
 EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_mark_visible", "vr_get_counters",
-           "vr_count_fragments", "vr_debug_export_binning", "vr_profile_level", "vr_profile_collect",
+           "vr_count_fragments", "vr_count_blended", "vr_debug_export_binning", "vr_profile_level", "vr_profile_collect",
            "vr_knn3_mean_dist2", "vr_photometric_forward", "vr_photometric_backward",
            "vr_normal_guidance_forward", "vr_normal_guidance_backward", "vr_adam_step", "vr_densify_stats",
            "vr_instances_forward", "vr_instances_backward"]
@@ -29,7 +32,7 @@ class VrSettings(C.Structure):
     _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float),
                 ("tanfovy", C.c_float), ("scale_modifier", C.c_float), ("sh_degree", C.c_int32),
                 ("prefiltered", C.c_int32), ("debug", C.c_int32), ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
-                ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
+                ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("flags", C.c_uint32)]
 
 
 class VrInputs(C.Structure):
@@ -110,6 +113,8 @@ def load():
     lib.vr_get_counters.argtypes = [C.POINTER(VrCounters)]
     lib.vr_count_fragments.restype = C.c_int
     lib.vr_count_fragments.argtypes = [C.POINTER(VrSaved), C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]
+    lib.vr_count_blended.restype = C.c_int
+    lib.vr_count_blended.argtypes = [C.POINTER(VrSaved), C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]
     lib.vr_debug_export_binning.restype = C.c_int
     lib.vr_debug_export_binning.argtypes = [C.POINTER(VrSaved), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_void_p]
@@ -219,6 +224,15 @@ def saved_of(grad_fn):
     geom, binning, image = grad_fn.buffers
     return VrSaved(geom.data_ptr(), binning.data_ptr(), image.data_ptr(), grad_fn.num_rendered, grad_fn.num_visible,
                    grad_fn.binning_capacity)
+
+
+def count_blended(grad_fn, H, W, device):
+    """B = (pixel, splat) pairs actually blended by the forward behind `grad_fn` (alpha >= 1/255, before the stop)."""
+    saved = saved_of(grad_fn)
+    out = C.c_int64(0)
+    with torch.cuda.device(device):
+        check(load().vr_count_blended(C.byref(saved), H, W, torch.cuda.current_stream(device).cuda_stream, C.byref(out)))
+    return out.value
 
 
 def count_fragments(grad_fn, H, W, device):

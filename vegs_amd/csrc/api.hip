@@ -13,10 +13,20 @@
 
 namespace vr {
 
+static_assert(FLAG_SCALE_MODIFIED == VR_FLAG_SCALE_MODIFIED && FLAG_DEPTH_NORMALIZED == VR_FLAG_DEPTH_NORMALIZED &&
+              FLAG_EXTRA_NO_ALPHA_GRAD == VR_FLAG_EXTRA_NO_ALPHA_GRAD && FLAG_FILL_EMPTY == VR_FLAG_FILL_EMPTY &&
+              FLAG_DETERMINISTIC == VR_FLAG_DETERMINISTIC, "device-side flag constants must match include/vegs_rast.h");
+constexpr uint32_t KNOWN_FLAGS = FLAG_SCALE_MODIFIED | FLAG_DEPTH_NORMALIZED | FLAG_EXTRA_NO_ALPHA_GRAD | FLAG_FILL_EMPTY |
+                                 FLAG_DETERMINISTIC;
+
 static thread_local char g_err[512] = "";
 static thread_local VrCounters g_counters = {0, 0, 0, 0, 0};
-static thread_local uint32_t* g_pinned = nullptr;  // host-pinned mailbox for (V, R, min key, max key)
-static thread_local hipEvent_t g_mail_event = nullptr;
+// host-pinned mailbox for (V, R, min key, max key) and the event that says the copy has landed: one pair per
+// (host thread, device) -- an event belongs to the device it was created on, so a thread that renders on a second
+// GPU must not reuse the first one's
+constexpr int MAX_DEVICES = 64;
+struct Mailbox { uint32_t* pinned; hipEvent_t event; };
+static thread_local Mailbox g_mail[MAX_DEVICES] = {};
 
 void set_error(const char* fmt, ...)
 {
@@ -97,6 +107,9 @@ static int make_camera(const VrSettings* st, int M, Camera* cam)
     cam->tanfovy = st->tanfovy;
     cam->fx = (float)cam->W / (2.0f * st->tanfovx);
     cam->fy = (float)cam->H / (2.0f * st->tanfovy);
+    if (st->flags & ~KNOWN_FLAGS)
+        return fail(VR_ERR_INVALID_ARGUMENT, "unknown bits in settings.flags (0x%x)", st->flags & ~KNOWN_FLAGS);
+    cam->flags = st->flags;
     cam->mod = st->scale_modifier;
     cam->deg = st->sh_degree;
     cam->M = M;
@@ -134,14 +147,17 @@ static int check_inputs(const VrSettings* st, const VrInputs* in)
     return 0;
 }
 
-struct ImageLayout { size_t counters, final_T, n_contrib, total; };
+// per-pixel state kept for the backward: final transmittance, contributor count and (written only with
+// VR_FLAG_DEPTH_NORMALIZED) the un-normalised depth sum
+struct ImageLayout { size_t counters, final_T, n_contrib, dsum, total; };
 static ImageLayout image_layout(size_t N)
 {
     ImageLayout L;
     L.counters = 0;
     L.final_T = 256;
     L.n_contrib = L.final_T + align_up(N * 4, 256);
-    L.total = L.n_contrib + align_up(N * 4, 256);
+    L.dsum = L.n_contrib + align_up(N * 4, 256);
+    L.total = L.dsum + align_up(N * 4, 256);
     return L;
 }
 // binning buffer: tile ranges | segment table (seg_off[T+1], seg_info[S] int4) | point list | boundary transmittances per (segment, pixel) |
@@ -193,7 +209,13 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     const int P = in->P;
     const size_t N = (size_t)cam.H * cam.W, T = (size_t)cam.gx * cam.gy;
 
-    if (!g_pinned) VR_HIP(hipHostMalloc((void**)&g_pinned, 256, hipHostMallocDefault));
+    int dev_id = 0;
+    VR_HIP(hipGetDevice(&dev_id));
+    if (dev_id < 0 || dev_id >= MAX_DEVICES) return fail(VR_ERR_NO_DEVICE, "device ordinal %d out of range", dev_id);
+    Mailbox& mail = g_mail[dev_id];
+    if (!mail.pinned) VR_HIP(hipHostMalloc((void**)&mail.pinned, 256, hipHostMallocDefault));
+    if (!mail.event) VR_HIP(hipEventCreateWithFlags(&mail.event, hipEventDisableTiming));
+    uint32_t* const g_pinned = mail.pinned;
 
     // ---- buffers that survive until backward
     const size_t p1 = (size_t)(P > 0 ? P : 1);
@@ -244,12 +266,11 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
         // queued BEFORE the compaction's apply kernel and the host waits on an event right after the copy, so the
         // round trip (and the host's launch of what follows) overlaps with that kernel instead of idling the GPU.
         VR_HIP(hipMemcpyAsync(g_pinned, totals_dev, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        if (!g_mail_event) VR_HIP(hipEventCreateWithFlags(&g_mail_event, hipEventDisableTiming));
-        VR_HIP(hipEventRecord(g_mail_event, s));
+        VR_HIP(hipEventRecord(mail.event, s));
         rc = launch_compact_apply(P, rect, depth_key, scan_scr, vis_key, vis_id, s, debug);
         prof_end(VR_STAGE_COMPACT, s);
         if (rc) return rc;
-        VR_HIP(hipEventSynchronize(g_mail_event));
+        VR_HIP(hipEventSynchronize(mail.event));
         V = g_pinned[0];
         R = g_pinned[1];
         if (V > 0) {
@@ -276,8 +297,8 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
                            (uint32_t*)((char*)binning + BL.seg_needed), (float*)((char*)binning + BL.tbuf),
                            (float*)((char*)binning + BL.part),
                            (unsigned long long*)((char*)binning + BL.segmask), scr3,
-                           out->color, out->depth, out->cov_quat, out->cov_scale, out->alpha, final_T, n_contrib, s,
-                           debug);
+                           out->color, out->depth, out->cov_quat, out->cov_scale, out->alpha, final_T, n_contrib,
+                           (float*)((char*)image + IL.dsum), s, debug);
     prof_end(VR_STAGE_RENDER_FWD, s);
     if (rc) return rc;
 
@@ -341,6 +362,11 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
     if (saved->num_rendered > 0) {
         void* scr = alloc(user, VR_BUF_SCRATCH, render_bwd_scratch_bytes((long)Rcap, (int)T) + 256);
         if (!scr) return fail(VR_ERR_ALLOC, "allocator returned NULL");
+        void* det_scr = nullptr;
+        if (cam.flags & FLAG_DETERMINISTIC) {
+            det_scr = alloc(user, VR_BUF_SCRATCH, render_bwd_det_bytes((long)saved->num_rendered, P));
+            if (!det_scr) return fail(VR_ERR_ALLOC, "allocator returned NULL");
+        }
         ProfScope ps(VR_STAGE_RENDER_BWD, s);
         rc = launch_render_bwd(cam, (long)saved->num_rendered, ranges, point_list, rec,
                                (const uint32_t*)((const char*)saved->binning + BL.seg_off),
@@ -350,7 +376,8 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
                                (const unsigned long long*)((const char*)saved->binning + BL.segmask), scr, final_T,
                                n_contrib,
                                gout->dL_dcolor, gout->dL_ddepth, gout->dL_dcov_quat, gout->dL_dcov_scale,
-                               gout->dL_dalpha, gacc, gin->dL_dmeans2D, s, debug);
+                               gout->dL_dalpha, gacc, gin->dL_dmeans2D,
+                               (const float*)((const char*)saved->image + IL.dsum), det_scr, P, s, debug);
         if (rc) return rc;
     }
     ProfScope ps2(VR_STAGE_PREPROCESS_BWD, s);
@@ -465,6 +492,33 @@ int vr_count_fragments(const VrSaved* saved, int32_t H, int32_t W, void* stream,
     VR_HIP(hipMemcpyAsync(&host, ctr, sizeof host, hipMemcpyDeviceToHost, s));
     VR_HIP(hipStreamSynchronize(s));
     *fragments = (int64_t)host;
+    return VR_OK;
+}
+
+int vr_count_blended(const VrSaved* saved, int32_t H, int32_t W, void* stream, int64_t* blended)
+{
+    g_err[0] = 0;
+    if (!saved || !saved->image || !saved->geom || !saved->binning || !blended || H <= 0 || W <= 0)
+        return fail(VR_ERR_INVALID_ARGUMENT, "count_blended: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    Camera cam = {};
+    cam.H = H; cam.W = W;
+    cam.gx = (W + TILE - 1) / TILE;
+    cam.gy = (H + TILE - 1) / TILE;
+    const size_t N = (size_t)H * W, T = (size_t)cam.gx * cam.gy;
+    const ImageLayout IL = image_layout(N);
+    const BinLayout BL = bin_layout(T, saved->binning_capacity > 0 ? (size_t)saved->binning_capacity : (size_t)saved->num_rendered);
+    unsigned long long* ctr = (unsigned long long*)((char*)saved->image + IL.counters) + 1;
+    *blended = 0;
+    if (saved->num_rendered == 0) return VR_OK;
+    int rc = launch_count_blended(cam, (const int2*)((const char*)saved->binning + BL.ranges),
+                                  (const uint32_t*)((const char*)saved->binning + BL.point_list), (const Splat*)saved->geom,
+                                  (const uint32_t*)((const char*)saved->image + IL.n_contrib), ctr, s);
+    if (rc) return rc;
+    unsigned long long host = 0;
+    VR_HIP(hipMemcpyAsync(&host, ctr, sizeof host, hipMemcpyDeviceToHost, s));
+    VR_HIP(hipStreamSynchronize(s));
+    *blended = (int64_t)host;
     return VR_OK;
 }
 

@@ -106,7 +106,9 @@ extern "C" int vr_adam_step(const VrAdamTensor* tensors, int32_t count, double b
         if (t.n < 0 || t.step < 1 || (t.n > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq)))
             { set_error("adam: tensor with NULL array, negative size or step < 1"); return VR_ERR_INVALID_ARGUMENT; }
     }
-    for (int first = 0; first < count; first += ADAM_MAX_T) {
+    // `first` advances by the entries CONSUMED (empty tensors are skipped without taking a slot), not by
+    // ADAM_MAX_T: otherwise a batch that skipped an empty tensor would be followed by one that repeats its tail
+    for (int first = 0, next = 0; first < count; first = next) {
         AdamArgs a;
         a.count = 0;
         a.one_minus_b1 = (float)(1.0 - beta1);
@@ -114,8 +116,8 @@ extern "C" int vr_adam_step(const VrAdamTensor* tensors, int32_t count, double b
         a.one_minus_b2 = (float)(1.0 - beta2);
         a.eps = (float)eps;
         int blocks = 0;
-        for (int i = first; i < count && a.count < ADAM_MAX_T; ++i) {
-            const VrAdamTensor& t = tensors[i];
+        for (next = first; next < count && a.count < ADAM_MAX_T; ++next) {
+            const VrAdamTensor& t = tensors[next];
             if (t.n == 0) continue;
             AdamSeg& s = a.seg[a.count++];
             s.p = t.param; s.g = t.grad; s.m = t.exp_avg; s.v = t.exp_avg_sq; s.n = (long)t.n;

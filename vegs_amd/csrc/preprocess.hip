@@ -206,8 +206,10 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
         s.x = px; s.y = py; s.conA = conA; s.conB = conB;
         s.conC = conC; s.opacity = opac; s.thr = splat_thr(opac); s.depth = t2;
         s.r = rgb[0]; s.g = rgb[1]; s.b = rgb[2]; s.qw = q[0];
-        s.qx = q[1]; s.qy = q[2]; s.qz = q[3]; s.s0 = sc[0];
-        s.s1 = sc[1]; s.s2 = sc[2]; s.clamped = clampbits; s.pad0 = 0;
+        // blended scale row: the raw input row (A-3) or, with VR_FLAG_SCALE_MODIFIED, the row the covariance is built from
+        const float sm = (cam.flags & FLAG_SCALE_MODIFIED) ? cam.mod : 1.0f;
+        s.qx = q[1]; s.qy = q[2]; s.qz = q[3]; s.s0 = sc[0] * sm;
+        s.s1 = sc[1] * sm; s.s2 = sc[2] * sm; s.clamped = clampbits; s.pad0 = 0;
         float4* dst = reinterpret_cast<float4*>(rec + i);
         const float4* src = reinterpret_cast<const float4*>(&s);
 #pragma unroll

@@ -251,6 +251,7 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
                                  0.5f * gS[2], 0.5f * gS[4], gS[5]};
             const float sp[3] = {cam.mod * sc[0], cam.mod * sc[1], cam.mod * sc[2]};
             float D[9];
+            const float sm = (cam.flags & FLAG_SCALE_MODIFIED) ? cam.mod : 1.0f;   // blended row = sm * scales
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 float accs = 0.f;
@@ -263,7 +264,7 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
                     accs += dLm * R[3 * ii + k];
                     D[3 * ii + k] = dLm * sp[k];
                 }
-                dsc[k] = cam.mod * accs + ga[8 + k];
+                dsc[k] = cam.mod * accs + sm * ga[8 + k];
             }
             const float r = q[0], x = q[1], y = q[2], z = q[3];
             drot[0] = 2.f * (z * (D[3] - D[1]) + y * (D[2] - D[6]) + x * (D[7] - D[5])) + ga[4];

@@ -69,9 +69,13 @@ struct PixGrad {
     float g[NCH];
     float galpha;
 };
+// With VR_FLAG_DEPTH_NORMALIZED the depth image is D / A (D = sum w z, A = 1 - T_final): the kernels keep
+// working on the un-normalised sums, so the incoming gradient is carried back through the quotient here:
+// dL/dD = g / A and (unless the extra channels are cut off from alpha) dL/dA -= g D / A^2.
 __device__ __forceinline__ void load_pixgrad(bool inside, size_t pix, size_t N, const float* dL_dcolor,
                                              const float* dL_ddepth, const float* dL_dquat, const float* dL_dscale,
-                                             const float* dL_dalpha, PixGrad& o)
+                                             const float* dL_dalpha, uint32_t flags, const float* final_T,
+                                             const float* dsum, PixGrad& o)
 {
 #pragma unroll
     for (int k = 0; k < NCH; ++k) o.g[k] = 0.0f;
@@ -88,7 +92,16 @@ __device__ __forceinline__ void load_pixgrad(bool inside, size_t pix, size_t N, 
         for (int k = 0; k < 3; ++k) o.g[8 + k] = dL_dscale[k * N + pix];
     }
     if (dL_dalpha) o.galpha = dL_dalpha[pix];
+    if ((flags & FLAG_DEPTH_NORMALIZED) && dL_ddepth) {
+        const float A = 1.0f - final_T[pix];
+        const float inv = A > 0.0f ? 1.0f / A : 0.0f;
+        const float g3 = o.g[3];
+        o.g[3] = g3 * inv;
+        if (!(flags & FLAG_EXTRA_NO_ALPHA_GRAD)) o.galpha -= (g3 * dsum[pix]) * (inv * inv);
+    }
 }
+// channels whose upstream gradient also flows through alpha (u = <attr, g> over these): all 11, or colour only
+__device__ __forceinline__ int alpha_grad_channels(uint32_t flags) { return (flags & FLAG_EXTRA_NO_ALPHA_GRAD) ? 3 : NCH; }
 
 // ---- A': U[seg][pix] = sum over the segment's applied entries of w*u = <dL/dout(pix), segment-local
 // channel sums> -- the sums the forward already produced (`part`), so no second pass over the splats.
@@ -99,20 +112,22 @@ k_seg_u(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict_
         const uint32_t* __restrict__ seg_needed, const float* __restrict__ part,
         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
         const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dquat, const float* __restrict__ dL_dscale,
-        float* __restrict__ Ubuf)
+        const float* __restrict__ final_T, const float* __restrict__ dsum, float* __restrict__ Ubuf)
 {
     SegCtx c;
     if (!seg_setup(cam, ranges, seg_off, c)) return;
     if (c.flag == 0u) return;
     const size_t N = (size_t)cam.H * cam.W;
     PixGrad pg;
-    load_pixgrad(c.inside, c.pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, nullptr, pg);
+    load_pixgrad(c.inside, c.pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, nullptr, cam.flags, final_T, dsum, pg);
+    const int nu = alpha_grad_channels(cam.flags);
     const int nc = c.inside ? (int)n_contrib[c.pix] : 0;
     float U = 0.0f;
     if (c.sl * SEG < nc) {   // the pixel applied entries of this segment (otherwise `part` is not defined for it)
         const float* src = part + (size_t)c.seg * (NPART_B * SEG) + threadIdx.x;
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) U = fmaf(src[k * SEG], pg.g[k], U);
+        for (int k = 0; k < NCH; ++k)
+            if (k < nu) U = fmaf(src[k * SEG], pg.g[k], U);
     }
     Ubuf[(size_t)c.seg * SEG + threadIdx.x] = U;
 }
@@ -151,7 +166,8 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
           const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
           const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dquat,
           const float* __restrict__ dL_dscale, const float* __restrict__ dL_dalpha, float* __restrict__ gacc,
-          float* __restrict__ gmean2D, const unsigned long long* __restrict__ segmask)
+          float* __restrict__ gmean2D, const unsigned long long* __restrict__ segmask, const float* __restrict__ dsum,
+          float* __restrict__ gpart)
 {
     __shared__ float stage[64 * NACC];            // one chunk's per-entry sums, entry-major, for the coalesced flush
     __shared__ uint32_t rel_gid[SEG];             // the strip's relevant entries, ascending: Gaussian id ...
@@ -190,12 +206,16 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     const size_t N = (size_t)cam.H * cam.W;
     const float v_pxf = (float)c.px, v_pyf = (float)c.py;
     PixGrad pg;
-    load_pixgrad(c.inside, c.pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, dL_dalpha, pg);
+    load_pixgrad(c.inside, c.pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, dL_dalpha, cam.flags, final_T, dsum, pg);
     float v_Tf = 1.0f;
     int v_nc = 0;
     if (c.inside) { v_Tf = final_T[c.pix]; v_nc = (int)n_contrib[c.pix]; }
+    // "background" terms weighted by the final transmittance: bg colour, alpha = 1 - T and, with VR_FLAG_FILL_EMPTY,
+    // the identity rotation added to cov_quat (an extra channel: cut off together with the others)
+    const bool no_extra = (cam.flags & FLAG_EXTRA_NO_ALPHA_GRAD) != 0u;
+    const float v_fill = ((cam.flags & FLAG_FILL_EMPTY) && !no_extra) ? pg.g[4] : 0.0f;
     const float v_bgterm =
-        v_Tf * (fmaf(cam.bg[2], pg.g[2], fmaf(cam.bg[1], pg.g[1], cam.bg[0] * pg.g[0])) - pg.galpha);
+        v_Tf * ((fmaf(cam.bg[2], pg.g[2], fmaf(cam.bg[1], pg.g[1], cam.bg[0] * pg.g[0])) + v_fill) - pg.galpha);
     // carries at the END of this segment: transmittance behind its last entry, and the w*u sum of
     // everything behind the segment
     float v_Tcar = v_Tf;
@@ -282,12 +302,17 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                 const f2 wgt = a_eff * Tl;
                 // <attr, g> in two independent chains (a dependent v_pk_fma_f32 costs an extra wait state)
                 f2 u0 = f2_splat(at[0]) * g[0], u1 = f2_splat(at[1]) * g[1];
+                f2 u;
+                if (!no_extra) {
 #pragma unroll
-                for (int k = 2; k + 1 < NCH; k += 2) {
-                    u0 = f2_fma(f2_splat(at[k]), g[k], u0);
-                    u1 = f2_fma(f2_splat(at[k + 1]), g[k + 1], u1);
+                    for (int k = 2; k + 1 < NCH; k += 2) {
+                        u0 = f2_fma(f2_splat(at[k]), g[k], u0);
+                        u1 = f2_fma(f2_splat(at[k + 1]), g[k + 1], u1);
+                    }
+                    u = f2_fma(f2_splat(at[NCH - 1]), g[NCH - 1], u0) + u1;
+                } else {
+                    u = f2_fma(f2_splat(at[2]), g[2], u0) + u1;     // colour channels only (wave-uniform branch)
                 }
-                const f2 u = f2_fma(f2_splat(at[NCH - 1]), g[NCH - 1], u0) + u1;
                 const f2 wu = wgt * u;
                 float sa = wu.x, sb = wu.y;
                 wave_prefix_add_x2(sa, sb);                               // sum over entries >= mine
@@ -327,13 +352,60 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                 if (rr >= nrel) continue;
                 const float sum = stage[v];
                 if (sum == 0.0f) continue;
+                const float val = k < 15 ? sum : sum * (k == 15 ? 0.5f * (float)cam.W : 0.5f * (float)cam.H);
+                if (gpart) {   // deterministic mode: this (list entry, region)'s own slot, summed later in list order
+                    gpart[((size_t)(c.first + (int)rel_j[rr]) * 4 + w) * NACC + k] = val;
+                    continue;
+                }
                 const uint32_t gid = rel_gid[rr];
-                if (k < 15) atomicAdd(&gacc[(size_t)gid * 16 + k], sum);
-                else atomicAdd(&gmean2D[(size_t)gid * 3 + (k - 15)], sum * (k == 15 ? 0.5f * (float)cam.W : 0.5f * (float)cam.H));
+                if (k < 15) atomicAdd(&gacc[(size_t)gid * 16 + k], val);
+                else atomicAdd(&gmean2D[(size_t)gid * 3 + (k - 15)], val);
             }
             __syncthreads();
         }
     }
+}
+
+// ---- deterministic mode (VR_FLAG_DETERMINISTIC): k_seg_bwd wrote one slot of NACC sums per (list entry, region);
+// the list entries of every Gaussian are found by a stable sort of (Gaussian id, list index) pairs and their
+// slots are added in list order, regions 0..3, by ONE thread per Gaussian -- a fixed order, so the per-Gaussian sums
+// are bit-reproducible.  A test/debug mode: 272 bytes per list entry of scratch and a sort on top of the normal pass.
+__global__ void __launch_bounds__(256)
+k_det_pairs(const uint32_t* __restrict__ point_list, long R, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j < R) { keys[j] = point_list[j]; vals[j] = (uint32_t)j; }
+}
+
+__global__ void __launch_bounds__(256)
+k_det_reduce(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, long R, const float* __restrict__ gpart,
+             float* __restrict__ gacc, float* __restrict__ gmean2D)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R) return;
+    const uint32_t gid = keys[i];
+    if (i > 0 && keys[i - 1] == gid) return;          // not the first list entry of its Gaussian
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+    for (long t = i; t < R && keys[t] == gid; ++t) {
+        const float* src = gpart + (size_t)vals[t] * 4 * NACC;
+        for (int q = 0; q < 4 * NACC; q += NACC) {
+#pragma unroll
+            for (int k = 0; k < NACC; ++k) acc[k] += src[q + k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 15; ++k) gacc[(size_t)gid * 16 + k] = acc[k];
+    gmean2D[(size_t)gid * 3 + 0] = acc[15];
+    gmean2D[(size_t)gid * 3 + 1] = acc[16];
+}
+
+size_t render_bwd_det_bytes(long R, int P)
+{
+    (void)P;
+    const size_t r = (size_t)(R > 0 ? R : 1);
+    return align_up(r * 4 * NACC * sizeof(float), 256) + 4 * align_up(r * 4, 256) + sort_pairs_scratch_bytes(R) + 256;
 }
 
 size_t render_bwd_scratch_bytes(long R, int ntiles)
@@ -345,23 +417,44 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
                       const uint32_t* seg_off, const uint32_t* seg_needed, const float* Tbuf, const float* part,
                       const unsigned long long* segmask, void* scratch, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                       const float* dL_ddepth, const float* dL_dquat, const float* dL_dscale,
-                      const float* dL_dalpha, float* gacc, float* gmean2D, hipStream_t s, bool debug)
+                      const float* dL_dalpha, float* gacc, float* gmean2D, const float* dsum, void* det_scratch, int P,
+                      hipStream_t s, bool debug)
 {
     const int ntiles = cam.gx * cam.gy;
     if (ntiles == 0 || R == 0) return 0;
     const unsigned nseg = (unsigned)seg_capacity(R, ntiles);
     float* Ubuf = (float*)scratch;
+    float* gpart = nullptr;
+    if (det_scratch) {
+        gpart = (float*)det_scratch;
+        VR_HIP(hipMemsetAsync(gpart, 0, (size_t)R * 4 * NACC * sizeof(float), s));
+    }
     hipLaunchKernelGGL(k_seg_u, dim3(nseg), dim3(256), 0, s, cam, ranges, seg_off, seg_needed, part, n_contrib,
-                       dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, Ubuf);
+                       dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, final_T, dsum, Ubuf);
     VR_KERNEL_CHECK("seg_u", s, debug);
     hipLaunchKernelGGL(k_seg_suffix, dim3(ntiles), dim3(256), 0, s, seg_off, seg_needed, Ubuf);
     VR_KERNEL_CHECK("seg_suffix", s, debug);
     prof_begin(VR_STAGE_K_SEG_BWD, s);
     hipLaunchKernelGGL(k_seg_bwd, dim3(nseg * 4), dim3(64), 0, s, cam, ranges, seg_off, seg_needed, point_list, rec, Tbuf,
                        (const float*)Ubuf, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, dL_dalpha,
-                       gacc, gmean2D, segmask);
+                       gacc, gmean2D, segmask, dsum, gpart);
     prof_end(VR_STAGE_K_SEG_BWD, s);
     VR_KERNEL_CHECK("seg_bwd", s, debug);
+    if (gpart) {
+        const size_t r4 = align_up((size_t)R * 4, 256);
+        char* base = (char*)det_scratch + align_up((size_t)R * 4 * NACC * sizeof(float), 256);
+        uint32_t *k0 = (uint32_t*)base, *v0 = (uint32_t*)(base + r4), *k1 = (uint32_t*)(base + 2 * r4),
+                 *v1 = (uint32_t*)(base + 3 * r4);
+        void* sort_scr = base + 4 * r4;
+        hipLaunchKernelGGL(k_det_pairs, dim3(cdiv(R, 256)), dim3(256), 0, s, point_list, R, k0, v0);
+        int bits = 1, where = 0;
+        while ((1L << bits) < (long)P) ++bits;
+        int rc = launch_sort_pairs(k0, v0, k1, v1, R, 0u, bits, sort_scr, s, debug, &where);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_det_reduce, dim3(cdiv(R, 256)), dim3(256), 0, s, (const uint32_t*)(where ? k1 : k0),
+                           (const uint32_t*)(where ? v1 : v0), R, (const float*)gpart, gacc, gmean2D);
+        VR_KERNEL_CHECK("det_reduce", s, debug);
+    }
     return 0;
 }
 

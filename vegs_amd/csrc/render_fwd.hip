@@ -281,7 +281,8 @@ __global__ void __launch_bounds__(256)
 k_seg_combine(Camera cam, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_needed,
               const float* __restrict__ Tbuf, const float* __restrict__ part, float* __restrict__ out_color,
               float* __restrict__ out_depth, float* __restrict__ out_quat, float* __restrict__ out_scale,
-              float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
+              float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+              float* __restrict__ dsum)
 {
     const int tile = xcd_tile(blockIdx.x, cam.gx * cam.gy);
     const int tx = tile % cam.gx, ty = tile / cam.gx;
@@ -328,7 +329,15 @@ k_seg_combine(Camera cam, const uint32_t* __restrict__ seg_off, const uint32_t* 
     out_color[pix] = fmaf(T, cam.bg[0], C[0]);
     out_color[N + pix] = fmaf(T, cam.bg[1], C[1]);
     out_color[2 * N + pix] = fmaf(T, cam.bg[2], C[2]);
-    out_depth[pix] = C[3];
+    // fork switches (include/vegs_rast.h VrFlags): normalised depth, identity fill of the rotation image
+    float depth_out = C[3];
+    if (cam.flags & FLAG_DEPTH_NORMALIZED) {
+        const float A = 1.0f - T;
+        dsum[pix] = C[3];                       // the backward needs the un-normalised sum
+        depth_out = A > 0.0f ? C[3] / A : 0.0f;
+    }
+    out_depth[pix] = depth_out;
+    if (cam.flags & FLAG_FILL_EMPTY) C[4] += T;
 #pragma unroll
     for (int k = 0; k < 4; ++k) out_quat[k * N + pix] = C[4 + k];
 #pragma unroll
@@ -346,6 +355,46 @@ k_count_fragments(const uint32_t* __restrict__ n_contrib, long N, unsigned long 
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
 
+// blended (pixel, splat) pairs: every valid entry in front of the pixel's last contributor was applied
+__global__ void __launch_bounds__(256)
+k_count_blended(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                const Splat* __restrict__ rec, const uint32_t* __restrict__ n_contrib, unsigned long long* __restrict__ out)
+{
+    const int tile = blockIdx.x;
+    const int tx = tile % cam.gx, ty = tile / cam.gx;
+    const int px = tx * TILE + (int)(threadIdx.x % TILE), py = ty * TILE + (int)(threadIdx.x / TILE);
+    unsigned long long cnt = 0;
+    if (px < cam.W && py < cam.H) {
+        const int start = ranges[tile].x;
+        const int nc = (int)n_contrib[(size_t)py * cam.W + px];
+        const float pxf = (float)px, pyf = (float)py;
+        for (int j = 0; j < nc; ++j) {
+            const float4* src = reinterpret_cast<const float4*>(rec + point_list[start + j]);
+            const float4 a = src[0], b = src[1];
+            float dx, dy;
+            const float power = splat_power(a.x, a.y, a.z, a.w, b.x, pxf, pyf, dx, dy);
+            if (power > 0.0f) continue;
+            const float alpha = fminf(ALPHA_MAX, b.y * vr_exp(power));
+            if (!(alpha < ALPHA_MIN)) ++cnt;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(out, cnt);
+}
+
+int launch_count_blended(const Camera& cam, const int2* ranges, const uint32_t* point_list, const Splat* rec,
+                         const uint32_t* n_contrib, unsigned long long* out_dev, hipStream_t s)
+{
+    VR_HIP(hipMemsetAsync(out_dev, 0, sizeof(unsigned long long), s));
+    const int ntiles = cam.gx * cam.gy;
+    if (ntiles > 0) {
+        hipLaunchKernelGGL(k_count_blended, dim3(ntiles), dim3(256), 0, s, cam, ranges, point_list, rec, n_contrib, out_dev);
+        VR_KERNEL_CHECK("count_blended", s, false);
+    }
+    return 0;
+}
+
 size_t render_fwd_scratch_bytes(long R, int ntiles)
 {
     const size_t nseg = seg_capacity(R, ntiles);
@@ -356,7 +405,7 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
                       uint32_t* seg_off, uint32_t* seg_needed, float* Tbuf, float* part, unsigned long long* segmask,
                       void* scratch, float* out_color,
                       float* out_depth, float* out_quat, float* out_scale, float* out_alpha, float* final_T,
-                      uint32_t* n_contrib, hipStream_t s, bool debug)
+                      uint32_t* n_contrib, float* dsum, hipStream_t s, bool debug)
 {
     const int ntiles = cam.gx * cam.gy;
     if (ntiles == 0) return 0;
@@ -381,7 +430,7 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     }
     hipLaunchKernelGGL(k_seg_combine, dim3(ntiles), dim3(256), 0, s, cam, (const uint32_t*)seg_off,
                        (const uint32_t*)seg_needed, (const float*)Tbuf, (const float*)part, out_color, out_depth,
-                       out_quat, out_scale, out_alpha, final_T, n_contrib);
+                       out_quat, out_scale, out_alpha, final_T, n_contrib, dsum);
     VR_KERNEL_CHECK("seg_combine", s, debug);
     return 0;
 }

@@ -30,11 +30,19 @@ struct __attribute__((aligned(16))) Splat {
 };
 static_assert(sizeof(Splat) == 80, "Splat must be 80 bytes");
 
+// VrSettings.flags (include/vegs_rast.h, VrFlags; api.hip asserts that the values agree)
+constexpr uint32_t FLAG_SCALE_MODIFIED = 1u << 0;       // cov_scale blends scale_modifier * scales
+constexpr uint32_t FLAG_DEPTH_NORMALIZED = 1u << 1;     // depth = sum(w z) / (1 - T_final)
+constexpr uint32_t FLAG_EXTRA_NO_ALPHA_GRAD = 1u << 2;  // depth/quat/scale channels: no gradient through alpha
+constexpr uint32_t FLAG_FILL_EMPTY = 1u << 3;           // cov_quat += T_final * (1,0,0,0)
+constexpr uint32_t FLAG_DETERMINISTIC = 1u << 8;        // backward without atomics
+
 struct Camera {
     int H, W, gx, gy;
     float tanfovx, tanfovy, fx, fy;
     float mod;
     int deg, M;
+    uint32_t flags;
     const float* view;
     const float* proj;
     const float* campos;
@@ -196,6 +204,10 @@ __device__ __forceinline__ uint32_t strips_relevant_exact(float sx, float sy, fl
 {
     const float k = -2.0f * thr;
     if (!(k > 0.0f)) return 0u;
+    // The edge minimisation assumes a positive-definite conic.  det = a*c - b*b of a huge, thin splat can cancel to
+    // <= 0 in fp32 (and an invalid cov3D_precomp can be indefinite outright); then "closest point on the edge" is a
+    // maximum, not a minimum.  Such splats are simply relevant everywhere: the exact per-pixel rule decides.
+    if (!(A > 0.0f) || !(C > 0.0f) || !(A * C - B * B > 0.0f)) return 0xFu;
     const float lim = k * 1.001f + 0.001f;
     const float inv_A = __builtin_amdgcn_rcpf(A), inv_C = __builtin_amdgcn_rcpf(C);
     uint32_t bits = 0;

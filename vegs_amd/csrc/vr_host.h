@@ -96,7 +96,7 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
                       uint32_t* seg_off, uint32_t* seg_needed, float* Tbuf, float* part, unsigned long long* segmask,
                       void* scratch, float* out_color,
                       float* out_depth, float* out_quat, float* out_scale, float* out_alpha, float* final_T,
-                      uint32_t* n_contrib, hipStream_t s, bool debug);
+                      uint32_t* n_contrib, float* dsum, hipStream_t s, bool debug);
 int launch_count_fragments(const uint32_t* n_contrib, long N, unsigned long long* out_dev, hipStream_t s);
 
 // gacc: [P][16] floats = conic dA,dB,dC | opacity | attr[11] | pad ; gmean2D: [P][3] (x,y used)
@@ -105,7 +105,13 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
                       const uint32_t* seg_off, const uint32_t* seg_needed, const float* Tbuf, const float* part,
                       const unsigned long long* segmask, void* scratch, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                       const float* dL_ddepth, const float* dL_dquat, const float* dL_dscale,
-                      const float* dL_dalpha, float* gacc, float* gmean2D, hipStream_t s, bool debug);
+                      const float* dL_dalpha, float* gacc, float* gmean2D, const float* dsum, void* det_scratch, int P,
+                      hipStream_t s, bool debug);
+// scratch of the deterministic backward mode (VR_FLAG_DETERMINISTIC): per-(entry, region) slots + the id sort
+size_t render_bwd_det_bytes(long R, int P);
+// B = blended (pixel, splat) pairs of a finished forward (one thread per pixel walks its list; bookkeeping only)
+int launch_count_blended(const Camera& cam, const int2* ranges, const uint32_t* point_list, const Splat* rec,
+                         const uint32_t* n_contrib, unsigned long long* out_dev, hipStream_t s);
 
 // ---- preprocess_bwd.hip
 bool preprocess_bwd_writes_all_sh(int M, const float* shs, const float* dL_dshs);

@@ -62,6 +62,18 @@ def _avg_supported(group, device):
     return _AVG_OK[key]
 
 
+def _all_reduce(t, op, group=None, async_op=False):
+    """dist.all_reduce that also serves GPU tensors on a backend without device support (gloo: the hook that lets the
+    N > 1 path run with several ranks on ONE GPU, which RCCL refuses) by staging through the host.  Returns a work
+    handle or None."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+        return None
+    return dist.all_reduce(t, op=op, group=group, async_op=async_op)
+
+
 def allreduce_grads(tensors, world=None, group=None, flat_bucket_bytes=1 << 20):
     """In-place mean over ranks of `tensor.grad` for every tensor in `tensors` (same shapes on all
     ranks).  Gradients of at least `flat_bucket_bytes` are reduced in place, one collective each, with no
@@ -80,13 +92,14 @@ def allreduce_grads(tensors, world=None, group=None, flat_bucket_bytes=1 << 20):
     small = [g for g in grads if not (g.numel() * g.element_size() >= flat_bucket_bytes and g.is_contiguous())]
     works = []
     for g in big:
-        works.append(dist.all_reduce(g, op=op, group=group, async_op=True))
+        works.append(_all_reduce(g, op, group, async_op=True))
     flat = None
     if small:
         flat = torch.cat([g.reshape(-1) for g in small])
-        works.append(dist.all_reduce(flat, op=op, group=group, async_op=True))
+        works.append(_all_reduce(flat, op, group, async_op=True))
     for w in works:
-        w.wait()
+        if w is not None:
+            w.wait()
     inv = 1.0 / world
     if not avg:
         for g in big:
@@ -111,6 +124,6 @@ def allreduce_densification_stats(viewspace_grad, visibility, radii, group=None)
     stats = torch.cat([torch.norm(viewspace_grad[:, :2], dim=-1, keepdim=True) * vis, vis], dim=1)
     mr = radii.clone()
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(mr, op=dist.ReduceOp.MAX, group=group)
+        _all_reduce(stats, dist.ReduceOp.SUM, group)
+        _all_reduce(mr, dist.ReduceOp.MAX, group)
     return stats[:, 0:1], stats[:, 1:2], mr

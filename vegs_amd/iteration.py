@@ -1,0 +1,144 @@
+"""Device-side counterpart of ONE VEGS training iteration, for tests and benchmarks (not a trainer).
+
+What the reference does per iteration, in its own words (none of that Python is shipped or imported here):
+  train.py:143-150   render_all(viewpoint_cam, gaussians, boxmodels, ...)       -> harness.render / render_all
+  train.py:152-168   Ll1, ssim, loss_normal_guidance                            -> photometric + normal guidance
+  train.py:196       loss.backward()
+  train.py:299-301   max_radii2D / add_densification_stats                      -> densification statistics
+  train.py:319-320   optimizer.step(); zero_grad(set_to_none=True)              -> Adam over the six named groups
+with the model's activations of scene/gaussian_model.py:100-120 (sigmoid opacity, exp scaling, normalised rotation,
+cat(features_dc, features_rest)) and its optimizer groups (:159-168).
+
+Two variants of the same step are built from the same pieces so that tests can compare them:
+  fused=False  the reference's composition: op-by-op prepare_rasterization/merge_kwargs, ATen loss code as
+               utils/loss_utils.py:18-79 and loss/normal_guidance.py:3-22 write it, torch.optim.Adam
+  fused=True   rows N1/N2/N4 of DESIGN.md section 10: vegs_amd.instances, vegs_amd.losses, vegs_amd.optim
+Both go through the same rasterizer (there is only one).
+"""
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import harness, scenes
+
+LRS = {"xyz": 1.6e-6, "f_dc": 2.5e-4, "f_rest": 2.5e-4 / 20, "opacity": 5e-3, "scaling": 5e-4, "rotation": 1e-4}
+LAMBDA_DSSIM = 0.2          # arguments/__init__.py (lambda_dssim)
+LAMBDA_NORMAL = 1e-3
+
+
+def make_model(sc, device):
+    """Raw parameters + optimizer groups as scene/gaussian_model.py:145-168 builds them from a scene dict."""
+    t = {k: torch.as_tensor(v, device=device) for k, v in sc.items()}
+    p = {"xyz": t["means3D"].clone(), "f_dc": t["shs"][:, :1].contiguous(), "f_rest": t["shs"][:, 1:].contiguous(),
+         "opacity": torch.logit(t["opacities"].clamp(1e-4, 1 - 1e-4)), "scaling": torch.log(t["scales"]),
+         "rotation": t["rotations"].clone()}
+    p = {k: torch.nn.Parameter(v.requires_grad_(True)) for k, v in p.items()}
+    return p, [{"params": [p[k]], "lr": LRS[k], "name": k} for k in p]
+
+
+def make_boxes(n, device, points=8196, seed=5, spacing=12.0):
+    """n dynamic box instances of `points` Gaussians (scene/gaussian_model.py:462) with a random similarity box2world."""
+    out = []
+    brng = np.random.default_rng(seed)
+    for i in range(n):
+        b, _ = scenes.scene_random(P=points, sh_degree=3, seed=100 + i, extent=1.0, scale=0.05)
+        B = np.eye(4, dtype=np.float32)
+        ang = brng.uniform(0, 6.28)
+        B[:3, :3] = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32) * 1.5
+        B[:3, 3] = [10.0 + spacing * i, brng.uniform(-3, 3), -0.8]
+        out.append(({k: torch.tensor(v, device=device, requires_grad=True) for k, v in b.items()},
+                    torch.tensor(B, device=device, requires_grad=True)))
+    return out
+
+
+def ssim_window(device):
+    g1 = torch.tensor([np.exp(-(i - 5) ** 2 / 4.5) for i in range(11)], dtype=torch.float32)
+    g1 = g1 / g1.sum()
+    return (g1[:, None] @ g1[None, :]).expand(3, 1, 11, 11).contiguous().to(device)
+
+
+def render_model(p, boxes, cam, cam_t, deg, bg, fused):
+    t = {"means3D": p["xyz"], "opacities": torch.sigmoid(p["opacity"]), "scales": torch.exp(p["scaling"]),
+         "rotations": F.normalize(p["rotation"])}
+    if not boxes:
+        # fused: the model's two SH tensors as they are (no torch.cat, no slicing copies in the backward)
+        t["shs"] = (p["f_dc"], p["f_rest"]) if fused else torch.cat((p["f_dc"], p["f_rest"]), dim=1)
+        return harness.render(cam, t, deg, bg, cam_t=cam_t)
+    t["shs"] = torch.cat((p["f_dc"], p["f_rest"]), dim=1)
+    return harness.render_all(cam, t, [b for b, _ in boxes], [w for _, w in boxes], deg, bg, cam_t=cam_t, fused=fused)
+
+
+def aten_loss(pkg, gt, normal, win, R_c2w):
+    """The reference's loss block op by op (utils/loss_utils.py:18-79 l1 + ssim, loss/normal_guidance.py:3-22)."""
+    x, q, s = pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]
+    l1 = (x - gt).abs().mean()
+    mu1, mu2 = F.conv2d(x, win, padding=5, groups=3), F.conv2d(gt, win, padding=5, groups=3)
+    s1 = F.conv2d(x * x, win, padding=5, groups=3) - mu1 * mu1
+    s2 = F.conv2d(gt * gt, win, padding=5, groups=3) - mu2 * mu2
+    s12 = F.conv2d(x * gt, win, padding=5, groups=3) - mu1 * mu2
+    ss = (((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))).mean()
+    Rm = harness.quaternion_to_matrix(q.permute(1, 2, 0).reshape(-1, 4))
+    Rw = torch.as_tensor(R_c2w, dtype=torch.float32, device=x.device)
+    nw = (Rw @ normal.reshape(3, -1)).t()[:, :, None].repeat(1, 1, 3)
+    ng = 0.8 * (Rm * nw).sum(-2).abs().mean() + 0.2 * (Rm.detach() * s.permute(1, 2, 0).reshape(-1, 1, 3) * nw).sum(-2).abs().mean()
+    return (1.0 - LAMBDA_DSSIM) * l1 + LAMBDA_DSSIM * (1 - ss) + LAMBDA_NORMAL * ng
+
+
+def fused_loss(pkg, gt, normal, R_c2w):
+    from . import losses
+    loss, _ = losses.photometric_loss(pkg["render"], gt, LAMBDA_DSSIM)
+    cam = types.SimpleNamespace(original_normal=normal, R=R_c2w)
+    return loss + LAMBDA_NORMAL * losses.loss_normal_guidance(cam, pkg["render_cov_quat"], pkg["render_cov_scale"])
+
+
+class Trainer:
+    """State of one variant: parameters, optimizer, densification statistics."""
+
+    def __init__(self, sc, device, n_boxes=0, fused=True, box_points=8196):
+        from . import optim
+        self.device, self.fused = device, fused
+        self.p, groups = make_model(sc, device)
+        self.boxes = make_boxes(n_boxes, device, box_points) if n_boxes else []
+        self.opt = (optim.Adam if fused else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
+        P = self.p["xyz"].shape[0] + sum(b["means3D"].shape[0] for b, _ in self.boxes)   # statistics over the op inputs
+        self.accum = torch.zeros(P, 1, device=device)
+        self.denom = torch.zeros(P, 1, device=device)
+        self.max_radii = torch.zeros(P, device=device)
+        self.win = ssim_window(device)
+
+    def forward_loss(self, cam, cam_t, deg, bg, gt, normal):
+        pkg = render_model(self.p, self.boxes, cam, cam_t, deg, bg, self.fused)
+        # NaN guard for pixels no Gaussian covers (A-5: exact zeros; the reference's 2/|q|^2 is NaN there) -- same in
+        # both variants
+        q = pkg["render_cov_quat"]
+        pkg["render_cov_quat_raw"] = q
+        pkg["render_cov_quat"] = torch.where((q.detach() * q.detach()).sum(0, keepdim=True) > 0, q, torch.ones_like(q))
+        if self.fused:
+            loss = fused_loss(pkg, gt, normal, cam.R)
+        else:
+            loss = aten_loss(pkg, gt, normal, self.win, cam.R)
+        return loss, pkg
+
+    def step(self, cam, cam_t, deg, bg, gt, normal, keep_grads=False):
+        from . import optim
+        loss, pkg = self.forward_loss(cam, cam_t, deg, bg, gt, normal)
+        loss.backward()
+        with torch.no_grad():
+            vis, radii, vsp = pkg["visibility_filter"], pkg["radii"], pkg["viewspace_points"]
+            if self.fused:
+                optim.add_densification_stats(vsp.grad, radii, self.accum, self.denom, self.max_radii)
+            else:
+                self.max_radii[vis] = torch.max(self.max_radii[vis], radii[vis].float())             # train.py:299
+                self.accum[vis] += torch.norm(vsp.grad[vis, :2], dim=-1, keepdim=True)                # gaussian_model.py:411-413
+                self.denom[vis] += 1
+        grads = {k: v.grad.detach().clone() for k, v in self.p.items()} if keep_grads else None
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        if not keep_grads:
+            for b, w in self.boxes:                  # box tensors are not optimizer parameters here
+                w.grad = None
+                for t in b.values():
+                    t.grad = None
+        return loss.detach(), pkg, grads

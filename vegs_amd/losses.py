@@ -81,16 +81,20 @@ class _PhotometricSums(torch.autograd.Function):
         return grad, None
 
 
-_last = {"key": None, "sums": None}
+_last = {"key": None, "sums": None, "img": None, "gt": None}
 
 
 def _sums(image, gt):
-    """(l1 mean, ssim mean) of the pair, sharing one kernel launch between train.py's two calls."""
-    key = (id(image), image._version, id(gt), gt._version, image.data_ptr(), gt.data_ptr(), torch.is_grad_enabled())
-    if _last["key"] == key and _last["img"]() is image:
-        return _last["sums"]
+    """(l1 mean, ssim mean) of the pair, sharing one kernel launch between train.py's two calls
+    (l1_loss(image, gt) then ssim(image, gt), train.py:162-164).  Both tensors are held by weak reference and
+    compared by identity AND version: `id()` / `data_ptr()` alone can be reused by a freed temporary."""
+    key = (image._version, gt._version, image.data_ptr(), gt.data_ptr(), torch.is_grad_enabled())
+    if _last["key"] == key and _last["img"] is not None and _last["img"]() is image and _last["gt"]() is gt:
+        sums = _last["sums"]
+        _last.update(key=None, sums=None, img=None, gt=None)   # second call of the pair: drop the graph reference
+        return sums
     sums = _PhotometricSums.apply(image, gt)
-    _last.update(key=key, sums=sums, img=weakref.ref(image))
+    _last.update(key=key, sums=sums, img=weakref.ref(image), gt=weakref.ref(gt))
     return sums
 
 

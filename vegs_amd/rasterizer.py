@@ -12,7 +12,9 @@ Same names, arguments and return values as the reference's call sites use:
 All computation happens in libvegsrast.so (hand-written HIP, gfx950) through the C ABI of
 include/vegs_rast.h; there is no PyTorch/CPU fallback.
 """
+import contextlib
 import ctypes as C
+import os
 from typing import NamedTuple
 
 import torch
@@ -36,6 +38,38 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+# ---- switches for the assumptions about the un-vendored fork (include/vegs_rast.h VrFlags) and the
+# deterministic backward mode.  GaussianRasterizationSettings keeps the reference's 12 fields, so the flags live
+# beside it: process-wide default from the environment (VEGS_RAST_FLAGS=<int>), changed with set_flags() or, for a
+# block of code, `with flags(...)`.  A forward captures the flags in force; its backward uses the same ones.
+FLAG_SCALE_MODIFIED = _capi.FLAG_SCALE_MODIFIED            # cov_scale blends scale_modifier * scales
+FLAG_DEPTH_NORMALIZED = _capi.FLAG_DEPTH_NORMALIZED        # depth = sum(w z) / alpha
+FLAG_EXTRA_NO_ALPHA_GRAD = _capi.FLAG_EXTRA_NO_ALPHA_GRAD  # depth/quat/scale: gradients to the attributes only
+FLAG_FILL_EMPTY = _capi.FLAG_FILL_EMPTY                    # cov_quat += T_final * (1,0,0,0)
+FLAG_DETERMINISTIC = _capi.FLAG_DETERMINISTIC              # backward without atomics (bit-reproducible gradients)
+_flags = int(os.environ.get("VEGS_RAST_FLAGS", "0"), 0)
+
+
+def set_flags(value):
+    """Set the process-wide VrFlags; returns the previous value."""
+    global _flags
+    old, _flags = _flags, int(value)
+    return old
+
+
+def get_flags():
+    return _flags
+
+
+@contextlib.contextmanager
+def flags(value):
+    old = set_flags(value)
+    try:
+        yield
+    finally:
+        set_flags(old)
+
+
 def _dev_f32(t, device):
     return t.to(device=device, dtype=torch.float32).contiguous()
 
@@ -53,7 +87,7 @@ def _prep(t, name, device, cols=None):
     return t.contiguous()
 
 
-def _settings_struct(rs, device, keep):
+def _settings_struct(rs, device, keep, flag_bits=0):
     bg = _dev_f32(rs.bg, device)
     view = _dev_f32(rs.viewmatrix, device)
     proj = _dev_f32(rs.projmatrix, device)
@@ -63,7 +97,8 @@ def _settings_struct(rs, device, keep):
     keep.extend([bg, view, proj, campos])
     return _capi.VrSettings(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
                             float(rs.scale_modifier), int(rs.sh_degree), int(bool(rs.prefiltered)),
-                            int(bool(rs.debug)), bg.data_ptr(), view.data_ptr(), proj.data_ptr(), campos.data_ptr())
+                            int(bool(rs.debug)), bg.data_ptr(), view.data_ptr(), proj.data_ptr(), campos.data_ptr(),
+                            int(flag_bits))
 
 
 def _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, sh_rest=None):
@@ -121,8 +156,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {shape}")
         H, W = int(rs.image_height), int(rs.image_width)
         keep = []
+        flag_bits = _flags
         with torch.cuda.device(device):
-            st = _settings_struct(rs, device, keep)
+            st = _settings_struct(rs, device, keep, flag_bits)
             inp = _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, sh_rest)
             # one [12,H,W] block: colour(3) depth(1) quat(4) scale(3) alpha(1) -- sliced into the 5 outputs
             img = torch.empty((12, H, W), dtype=torch.float32, device=device)
@@ -150,6 +186,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     raise arena.error
                 _capi.check(rc)
         ctx.raster_settings = rs
+        ctx.flag_bits = flag_bits
         ctx.num_rendered = int(saved.num_rendered)
         ctx.num_visible = int(saved.num_visible)
         ctx.binning_capacity = int(saved.binning_capacity)
@@ -175,7 +212,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             return None if t is None else _dev_f32(t, device)
         g_color, g_depth, g_quat, g_scale, g_alpha = g(g_color), g(g_depth), g(g_quat), g(g_scale), g(g_alpha)
         with torch.cuda.device(device):
-            st = _settings_struct(rs, device, keep)
+            st = _settings_struct(rs, device, keep, ctx.flag_bits)
             inp = _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, sh_rest)
             d_means3D = torch.empty_like(means3D)
             d_means2D = torch.empty((P, 3), dtype=torch.float32, device=device)

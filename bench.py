@@ -87,6 +87,123 @@ def cpu_baseline(sc, deg, cams, gouts, views):
     return dt, frags, os.cpu_count()
 
 
+def prepare(sc, deg, cams, device, rng, count=True):
+    """Scene tensors + per-view upstream gradients and work counters (one untimed pass over every view)."""
+    T = {k: torch.tensor(v, device=device, requires_grad=True) for k, v in sc.items()}
+    bg = torch.zeros(3, device=device)
+    cam_ts = [harness.cam_tensors(c, device) for c in cams]
+    gouts, counters = [], []
+    from vegs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    for v, cam in enumerate(cams):
+        H, W = cam.image_height, cam.image_width
+        pkg = harness.render(cam, T, deg, bg, cam_t=cam_ts[v])
+        gouts.append(upstream_grads(pkg, cam, rng, device))
+        c = _capi.counters()
+        if count:
+            c["F"] = _capi.count_fragments(pkg["render"].grad_fn, H, W, device)
+            c["B"] = _capi.count_blended(pkg["render"].grad_fn, H, W, device)
+            rs = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, bg, 1.0, cam_ts[v]["viewmatrix"],
+                                               cam_ts[v]["projmatrix"], deg, cam_ts[v]["campos"], False, False)
+            c["Pz"] = int(GaussianRasterizer(rs).markVisible(T["means3D"]).sum().item())
+        counters.append(c)
+        del pkg
+    torch.cuda.synchronize()
+    return dict(T=T, params=[T[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")], bg=bg, cams=cams,
+                cam_ts=cam_ts, gouts=gouts, counters=counters, deg=deg)
+
+
+def make_step(wl, rank, world, vps):
+    T, cams, cam_ts, gouts, params, deg, bg = (wl[k] for k in ("T", "cams", "cam_ts", "gouts", "params", "deg", "bg"))
+    n_views = len(cams)
+
+    def step(i):
+        done = []
+        for k in range(vps):
+            v = vdist.view_for_rank(i * vps + k, rank, world, n_views)
+            pkg = harness.render(cams[v], T, deg, bg, cam_t=cam_ts[v])
+            gc, gq, gs = gouts[v]
+            torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], [gc, gq, gs])
+            done.append(v)
+        if world > 1:
+            vdist.allreduce_grads(params, world)
+        for p in params:
+            p.grad = None
+        return done
+    return step
+
+
+def timed(step, warmup, steps, world):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides.  Returns (seconds, views)."""
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    views_done = []
+    for i in range(warmup, warmup + steps):
+        views_done.extend(step(i))
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, views_done
+
+
+def stage_profile(step, steps):
+    """Per-stage milliseconds per view (HIP events around every stage: level 2), measured OUTSIDE the timed region
+    because every event pair costs a few microseconds of bubble."""
+    _capi.profile_level(2)
+    _capi.profile_collect()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    st = _capi.profile_collect()
+    _capi.profile_level(0)
+    return {k: round(v[0] / max(v[1], 1), 4) for k, v in st.items() if v[1] > 0}
+
+
+def variant(name, sc, deg, cams, device, steps, warmup):
+    """A few steps of another scene/camera configuration, reported next to the headline (N = 1 only)."""
+    wl = prepare(sc, deg, cams, device, np.random.default_rng(77))
+    step = make_step(wl, 0, 1, 1)
+    dt, done = timed(step, warmup, steps, 1)
+    cn = wl["counters"]
+    mean = {k: float(np.mean([cn[v][k] for v in done])) for k in ("V", "R", "F", "B")}
+    return {"workload": name, "views_per_s": round(steps / dt, 2), "ms_per_view": round(dt / steps * 1e3, 4),
+            "mfragments_per_s": round(sum(cn[v]["F"] for v in done) / dt / 1e6, 1),
+            "blended_mfragments_per_s": round(sum(cn[v]["B"] for v in done) / dt / 1e6, 1),
+            "mean_counters": {k: round(v, 1) for k, v in mean.items()}}
+
+
+def cpu_plan(cores):
+    """the CPU restatement on C1 (10 k random Gaussians, 256x256, SH 0) and on a down-scaled C2
+    (50 k street Gaussians, 1376x376, SH 3), forward + backward, median of 5 after one warm-up."""
+    from oracle import oracle as orc
+    out = {}
+    sc1, d1 = scenes.scene_random(P=10000, sh_degree=0, seed=0)
+    sc2, d2 = scenes.scene_street(P=50000, length=120.0, sh_degree=3, seed=1)
+    for tag, sc, deg, cam in (("c1_10k_256x256_sh0", sc1, d1, scenes.camera_c1(256, 256)),
+                              ("c2_50k_1376x376_sh3", sc2, d2, scenes.kitti_camera(0.0, 0.3, 1376, 376))):
+        H, W = cam.image_height, cam.image_width
+        oc = orc.make_cam(H, W, cam.tanfovx, cam.tanfovy, [0, 0, 0], 1.0, cam.world_view_transform,
+                          cam.full_proj_transform, cam.camera_center, deg, 16)
+        rng = np.random.default_rng(3)
+        g = [rng.normal(size=(k, H, W)).astype(np.float32) for k in (3, 4, 3)]
+        ts, frags = [], 0
+        for it in range(6):
+            t0 = time.perf_counter()
+            o, st = orc.forward(oc, sc["means3D"], sc["shs"], None, sc["opacities"], sc["scales"], sc["rotations"], None)
+            orc.backward(oc, st, g[0], None, g[1], g[2], None)
+            if it:
+                ts.append(time.perf_counter() - t0)
+            frags = int(st["n_contrib"].sum())
+        med = float(np.median(ts))
+        out[tag] = {"views_per_s": round(1.0 / med, 3), "mfragments_per_s": round(frags / med / 1e6, 2), "runs": 5}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,6 +214,7 @@ def main():
     ap.add_argument("--width", type=int, default=1376)
     ap.add_argument("--height", type=int, default=376)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra 1408x376 / dense-scene measurements")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage time breakdown to stderr")
     ap.add_argument("--views-per-step", type=int, default=1,
                     help="views each rank renders per step; their gradients accumulate locally and are exchanged once")
@@ -112,84 +230,45 @@ def main():
     _capi.load()
 
     sc, deg, cams, P = build_workload(args)
-    T = {k: torch.tensor(v, device=device, requires_grad=True) for k, v in sc.items()}
-    params = [T["means3D"], T["shs"], T["opacities"], T["scales"], T["rotations"]]
-    bg = torch.zeros(3, device=device)
-    cam_ts = [harness.cam_tensors(c, device) for c in cams]
-    n_views = len(cams)
     H, W = args.height, args.width
     N = H * W
     K = (deg + 1) ** 2
-
-    # ---- untimed setup pass over every view: upstream gradients + work counters (P_z, V, R, F)
-    rng = np.random.default_rng(1234)
-    gouts, counters = [], []
-    from vegs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
-    for v, cam in enumerate(cams):
-        pkg = harness.render(cam, T, deg, bg, cam_t=cam_ts[v])
-        gouts.append(upstream_grads(pkg, cam, rng, device))
-        c = _capi.counters()
-        c["F"] = _capi.count_fragments(pkg["render"].grad_fn, H, W, device)
-        rs = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, bg, 1.0, cam_ts[v]["viewmatrix"],
-                                           cam_ts[v]["projmatrix"], deg, cam_ts[v]["campos"], False, False)
-        c["Pz"] = int(GaussianRasterizer(rs).markVisible(T["means3D"]).sum().item())
-        counters.append(c)
-        del pkg
-    torch.cuda.synchronize()
-
+    n_views = len(cams)
+    wl = prepare(sc, deg, cams, device, np.random.default_rng(1234))
+    counters, gouts = wl["counters"], wl["gouts"]
     vps = max(1, args.views_per_step)
-
-    def step(i):
-        done = []
-        for k in range(vps):
-            v = vdist.view_for_rank(i * vps + k, rank, world, n_views)
-            pkg = harness.render(cams[v], T, deg, bg, cam_t=cam_ts[v])
-            gc, gq, gs = gouts[v]
-            torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], [gc, gq, gs])
-            done.append(v)
-        if world > 1:
-            vdist.allreduce_grads(params, world)
-        for p in params:
-            p.grad = None
-        return done
+    step = make_step(wl, rank, world, vps)
 
     for i in range(args.warmup):
         step(i)
-    _capi.profile_level(2 if args.stages else 1)
+    _capi.profile_level(1)          # level 1: HIP events around the roofline kernel only, inside the timed region
     _capi.profile_collect()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
     mallocs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     reserved0 = torch.cuda.memory_reserved(device)
-    t0 = time.perf_counter()
-    views_done = []
-    for i in range(args.warmup, args.warmup + args.steps):
-        views_done.extend(step(i))
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed, views_done = timed(step, 0, args.steps, world)
     stage = _capi.profile_collect()
     _capi.profile_level(0)
+    mallocs1 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
 
     frag_local = float(sum(counters[v]["F"] for v in views_done))
+    blend_local = float(sum(counters[v]["B"] for v in views_done))
     if world > 1:
-        t = torch.tensor([elapsed, frag_local], dtype=torch.float64, device=device)
+        # host tensors with gloo (the single-GPU test transport), device tensors with RCCL
+        red_dev = device if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed, frag_local, blend_local], dtype=torch.float64, device=red_dev)
         tmax = t.clone()
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
-        elapsed, frag_total = float(tmax[0]), float(t[1])
+        elapsed, frag_total, blend_total = float(tmax[0]), float(t[1]), float(t[2])
     else:
-        frag_total = frag_local
+        frag_total, blend_total = frag_local, blend_local
 
     if rank != 0:
         return
+    stage_ms = stage_profile(step, 8) if world == 1 else {}
     views = args.steps * world * vps
     value = views / elapsed
-    mean = {k: float(np.mean([counters[v][k] for v in views_done])) for k in ("Pz", "V", "R", "F")}
+    mean = {k: float(np.mean([counters[v][k] for v in views_done])) for k in ("Pz", "V", "R", "F", "B")}
     # algorithmic bytes per view, SURVEY.md section 8(d)
     b_alg = 32 * P + 28 * mean["Pz"] + (294 + 24 * K) * mean["V"] + 188 * mean["R"] + 112 * N + (56 + 12 * K) * P
     # dominant kernel: k_seg_bwd (gradients of one (tile, segment)), timed with HIP events recorded by the
@@ -211,7 +290,10 @@ def main():
         "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        # F = sum of n_contrib = list entries TRAVERSED by the forward blend loop (BASELINE.md's fragment definition);
+        # B = (pixel, splat) pairs actually BLENDED (alpha >= 1/255 before the stop) -- an order of magnitude fewer
         "mfragments_per_s": round(frag_total / elapsed / 1e6, 2),
+        "blended_mfragments_per_s": round(blend_total / elapsed / 1e6, 2),
         "config": {"workload": f"{args.workload}: {P} street Gaussians (VEGS disc init), SH deg {deg}, {W}x{H} "
                                f"KITTI-360 intrinsics, {n_views} views cycled, 12 output channels + colour/quat/scale grads",
                    "gaussians": P, "width": W, "height": H, "views_per_step_per_gpu": vps,
@@ -220,25 +302,36 @@ def main():
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "alg_bytes_per_launch": round(bytes_k), "avg_launch_ms": round(ms_k, 4),
-                     "stage_ms": {k: round(stage[k][0] / max(stage[k][1], 1), 4) for k in ("render_fwd", "render_bwd")
-                                  if stage[k][1] > 0},
+                     "stage_ms": stage_ms,
                      "whole_view_alg_bytes": round(b_alg),
                      "whole_view_frac": round(b_alg / (elapsed / (args.steps * vps)) / 1e9 / HBM_PEAK_GBS, 5)},
     }
     if args.stages:
-        print("hipMalloc calls inside the timed region:",
-              torch.cuda.memory_stats(device).get("num_device_alloc", 0) - mallocs0, "reserved MB before/after:",
+        print("hipMalloc calls inside the timed region:", mallocs1 - mallocs0, "reserved MB before/after:",
               reserved0 >> 20, torch.cuda.memory_reserved(device) >> 20, file=sys.stderr)
-        print("stage breakdown (ms per step; k_seg_bwd is part of render_bwd):",
-              {k: round(v[0] / args.steps, 4) for k, v in stage.items()},
-              file=sys.stderr)
+        print("stage breakdown (ms per view; k_seg_bwd is part of render_bwd):", stage_ms, file=sys.stderr)
+    if world == 1 and not args.no_variants:
+        del wl, step
+        torch.cuda.empty_cache()
+        cams_w = []
+        for s_ in range(4):
+            for y in (0.3, -0.3):
+                cams_w.append(scenes.kitti_camera(10.0 * s_, y, 1408, 376))
+        dense = dict(sc)
+        dense["scales"] = (sc["scales"] * 3.0).astype(np.float32)
+        res["variants"] = [
+            variant("same scene at 1408x376 (the resolution the reference's comments use)", sc, deg, cams_w, device, 16, 4),
+            variant("dense: same scene with every disc 3x larger (R ~ an order of magnitude up), 1376x376", dense, deg,
+                    cams[:8], device, 8, 2),
+        ]
     if world == 1 and not args.no_cpu_baseline:
         cpu_views = [0, 5, 10, 15]
         dt, frags, cores = cpu_baseline(sc, deg, cams, gouts, cpu_views)
         res["cpu_baseline"] = {"value": round(len(cpu_views) / dt, 5), "unit": "views/s", "cores": cores, "kind": "port",
                                "sample": f"{len(cpu_views)} views (0,5,10,15) of the same workload, oracle fwd+bwd on all "
                                          f"host cores, {dt:.1f} s",
-                               "mfragments_per_s": round(frags / dt / 1e6, 2)}
+                               "mfragments_per_s": round(frags / dt / 1e6, 2),
+                               "baseline_md_plan": cpu_plan(cores)}
     print(json.dumps(res))
 
 

@@ -91,7 +91,7 @@ def test_oracle_backward_matches_golden(name):
     for k in keys:
         assert g[k] is not None, k
         assert g[k].shape == c["grad_" + k].shape, k
-        assert_grad_close(k, g[k], c["grad_" + k], rtol=2e-4, floor=1e-6, outliers=0.0)
+        assert_grad_close(k, g[k], c["grad_" + k], rtol=2e-4, floor=1e-6, outliers=0.0, near=0.0)
     assert np.all(g["means2D"][:, 2] == 0)
 
 

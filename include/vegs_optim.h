@@ -37,6 +37,32 @@ int vr_adam_step(const VrAdamTensor* tensors, int32_t count, double beta1, doubl
 int vr_densify_stats(const float* means2D_grad, const int32_t* radii, int32_t P, float* xyz_gradient_accum,
                      float* denom, float* max_radii2D, void* stream);
 
+/* ---- factored SH gradients (VrInGrads.dL_dcolors_sh of vegs_rast.h).
+ * Dense gradient from the factors of n_views views (what a view-sharded job all-gathers: 3 floats per Gaussian and
+ * view instead of all-reducing 48):
+ *   dL_dshs[i][k][c] = scale * sum_v basis_k(normalize(means3D[i] - campos[v])) * factors[v][i][c]   k < (deg+1)^2,
+ * zeros for the inactive coefficients.  campos [n_views,3], factors [n_views,P,3], all on the device.  Output either
+ * whole (dL_dshs [P,M,3], dL_dshs_rest NULL) or split as the model stores it (dL_dshs [P,1,3] + dL_dshs_rest [P,M-1,3]). */
+int vr_sh_grad_from_factors(const float* means3D, int32_t P, const float* campos, const float* factors, int32_t n_views,
+                            int32_t sh_degree, int32_t M, float scale, float* dL_dshs, float* dL_dshs_rest, void* stream);
+
+/* One SH tensor of the optimizer (same meaning as VrAdamTensor, the gradient being implicit). */
+typedef struct VrShAdamTensor {
+    float* param;
+    float* exp_avg;
+    float* exp_avg_sq;
+    double lr;
+    int64_t step;
+} VrShAdamTensor;
+
+/* Adam step of the SH tensors straight from the factors: the gradient of vr_sh_grad_from_factors is built per Gaussian
+ * in registers and consumed at once -- the [P,M,3] gradient (384 MB at 2 M Gaussians) is never written or read.
+ * `dc` = f_dc [P,1,3] and `rest` = f_rest [P,M-1,3] (scene/gaussian_model.py:159-166), or dc = the whole [P,M,3] tensor
+ * and rest = NULL.  Arithmetic = vr_adam_step's. */
+int vr_sh_adam_step(const float* means3D, int32_t P, const float* campos, const float* factors, int32_t n_views,
+                    int32_t sh_degree, int32_t M, float scale, const VrShAdamTensor* dc, const VrShAdamTensor* rest,
+                    double beta1, double beta2, double eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

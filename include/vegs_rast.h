@@ -162,6 +162,13 @@ typedef struct VrInGrads {
     float* dL_drotations;      /* [P,4] or NULL */
     float* dL_dcov3D_precomp;  /* [P,6] or NULL */
     float* dL_dshs_rest;       /* [P,M-1,3], required when VrInputs.shs_rest is given */
+    float* dL_dcolors_sh;      /* optional (SH mode, ABI v4): FACTORED SH gradient.  dL/dshs of one view is a rank-1
+                                  product per Gaussian, dL_dshs[i][k][c] = basis_k(dir_i) * g[i][c] with g = dL/d(colour)
+                                  zeroed where the colour was clamped.  When this [P,3] array is given the library
+                                  writes g into it (zeros for culled Gaussians) and does NOT write dL_dshs /
+                                  dL_dshs_rest (they may be NULL): 12 instead of 192 bytes per Gaussian leave the
+                                  kernel, and a multi-GPU job exchanges 3 instead of 48 floats per Gaussian and view
+                                  (vegs_optim.h: vr_sh_grad_from_factors / vr_sh_adam_step rebuild or consume it). */
 } VrInGrads;
 
 /* Work counters of the most recent vr_forward on this thread (roofline accounting). */

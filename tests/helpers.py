@@ -77,11 +77,11 @@ def grad_mismatch(got, want, rtol=1e-3, floor=1e-6):
     return np.nonzero(bad)[0], err / allow
 
 
-def assert_grad_close(name, got, want, rtol=1e-3, floor=1e-6, outliers=1e-4, near=1e-3):
+def assert_grad_close(name, got, want, rtol=1e-3, floor=1e-6, outliers=1e-4, near=1e-3, cap=100.0):
     """Assert the per-row criterion of grad_mismatch.  fp32 atomics are order-dependent and the preprocess backward
     amplifies the noise of rows that are pure cancellation (1e-5-thin discs), so a few rows may leave the allowance:
     at most a fraction `near` of the rows by up to 3x, at most a fraction `outliers` (0.01 %) by more than that, and
-    none by 100x.  The offenders are printed so that a systematic error is visible in the log."""
+    none by `cap` (100x).  The offenders are printed so that a systematic error is visible in the log."""
     bad, ratio = grad_mismatch(got, want, rtol, floor)
     n = max(int(np.asarray(want).shape[0]) if np.asarray(want).ndim else 1, 1)
     if len(bad):
@@ -95,7 +95,7 @@ def assert_grad_close(name, got, want, rtol=1e-3, floor=1e-6, outliers=1e-4, nea
         far = int((ratio[bad] > 3.0).sum())
         assert far <= outliers * n, f"{name}: {far} of {n} rows are off by more than 3x the per-row allowance"
         assert len(bad) <= near * n, f"{name}: {len(bad)} of {n} rows fail the per-row gradient check"
-        assert ratio[bad].max() < 100.0, f"{name}: outlier row off by {ratio[bad].max():.1f}x the allowance"
+        assert ratio[bad].max() < cap, f"{name}: outlier row off by {ratio[bad].max():.1f}x the allowance"
 
 
 def normal_guidance_loss(cov_quat, cov_scale, normal, R_cam2world):

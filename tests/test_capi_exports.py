@@ -39,7 +39,7 @@ def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(_capi.VrOutputs) == 6 * p
     assert ctypes.sizeof(_capi.VrSaved) == 3 * p + 3 * 8
     assert ctypes.sizeof(_capi.VrOutGrads) == 5 * p
-    assert ctypes.sizeof(_capi.VrInGrads) == 9 * p
+    assert ctypes.sizeof(_capi.VrInGrads) == 10 * p
     assert ctypes.sizeof(_capi.VrCounters) == 5 * 8
 
 

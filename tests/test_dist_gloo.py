@@ -36,8 +36,17 @@ def _worker(rank, world, port, outdir):
     vis = torch.rand(P, generator=g) > 0.5
     radii = torch.randint(0, 50, (P,), generator=g, dtype=torch.int32)
     gsum, den, mr = vdist.allreduce_densification_stats(vg, vis, radii)
+    # factored SH exchange: 11 floats all-reduced, the 3-float factor and the camera centre all-gathered
+    others = [torch.zeros(s, requires_grad=True) for s in [(P, 3), (P, 1), (P, 3), (P, 4)]]
+    olocal = [torch.randn(p.shape, generator=g) for p in others]
+    for p, l in zip(others, olocal):
+        p.grad = l.clone()
+    factor = torch.randn(P, 3, generator=g)
+    campos = torch.randn(3, generator=g)
+    F, Cc = vdist.exchange_factored(others, factor, campos, world)
     torch.save(dict(grads=[p.grad for p in params], local=local, gsum=gsum, den=den, mr=mr, vg=vg, vis=vis,
-                    radii=radii, view=[vdist.view_for_rank(s, rank, world, 16) for s in range(4)]),
+                    radii=radii, view=[vdist.view_for_rank(s, rank, world, 16) for s in range(4)],
+                    others=[p.grad for p in others], olocal=olocal, factor=factor, campos=campos, F=F, C=Cc),
                os.path.join(outdir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -58,6 +67,13 @@ def test_view_sharded_gradient_exchange_gloo(tmp_path):
         assert torch.allclose(R[r]["gsum"], want_g, atol=1e-6)
         assert torch.equal(R[r]["den"], want_d)
         assert torch.equal(R[r]["mr"], want_m)
+    # factored exchange: every rank ends up with all factors / camera centres in rank order, the rest averaged
+    for r in range(world):
+        assert R[r]["F"].shape == (world, 1000, 3) and R[r]["C"].shape == (world, 3)
+        for q in range(world):
+            assert torch.equal(R[r]["F"][q], R[q]["factor"]) and torch.equal(R[r]["C"][q], R[q]["campos"])
+        for k in range(4):
+            assert torch.allclose(R[r]["others"][k], (R[0]["olocal"][k] + R[1]["olocal"][k]) / world, atol=1e-6)
     # consecutive views go to consecutive ranks, every view visited once per cycle
     assert R[0]["view"] == [0, 2, 4, 6] and R[1]["view"] == [1, 3, 5, 7]
 

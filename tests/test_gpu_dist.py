@@ -67,8 +67,27 @@ torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_
                         [torch.tensor(g["gc%%d" %% v], device=dev), torch.tensor(g["gq%%d" %% v], device=dev), torch.tensor(g["gs%%d" %% v], device=dev)])
 vdist.allreduce_grads(params, world)
 gsum, den, mr = vdist.allreduce_densification_stats(pkg["viewspace_points"].grad, pkg["visibility_filter"], pkg["radii"])
+dense = {"grad_" + k: T[k].grad.cpu().numpy() for k in T}
+# ---- the same iteration with the FACTORED SH exchange: 3 floats per Gaussian and view all-gathered instead of 48 all-reduced
+from vegs_amd import optim
+from vegs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+for t in T.values():
+    t.grad = None
+ct = harness.cam_tensors(cams[v], dev)
+rs = GaussianRasterizationSettings(188, 688, cams[v].tanfovx, cams[v].tanfovy, torch.zeros(3, device=dev), 1.0,
+                                   ct["viewmatrix"], ct["projmatrix"], deg, ct["campos"], False, False)
+sink = torch.zeros(60000, 3, device=dev, requires_grad=True)
+out = GaussianRasterizer(rs)(means3D=T["means3D"], means2D=torch.zeros(60000, 3, device=dev, requires_grad=True),
+                             opacities=T["opacities"], shs=T["shs"], scales=T["scales"], rotations=T["rotations"],
+                             sh_color_grad=sink)
+torch.autograd.backward([out[0], out[2], out[3]],
+                        [torch.tensor(g["gc%%d" %% v], device=dev), torch.tensor(g["gq%%d" %% v], device=dev), torch.tensor(g["gs%%d" %% v], device=dev)])
+assert T["shs"].grad is None
+F, C = vdist.exchange_factored([T[k] for k in ("means3D", "opacities", "scales", "rotations")], sink.grad, ct["campos"], world)
+assert F.shape == (2, 60000, 3) and torch.equal(F[rank], sink.grad)
+fact_shs = optim.sh_grad_from_factors(T["means3D"].detach(), C, F, deg, 16, 1.0 / world)
 np.savez(os.path.join(%(out)r, "rank%%d.npz" %% rank), gsum=gsum.cpu().numpy(), den=den.cpu().numpy(), mr=mr.cpu().numpy(),
-         **{"grad_" + k: T[k].grad.cpu().numpy() for k in T})
+         fact_shs=fact_shs.cpu().numpy(), fact_means3D=T["means3D"].grad.cpu().numpy(), **dense)
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()
 print("RANK_OK", rank)
@@ -134,6 +153,11 @@ def test_two_ranks_equal_mean_of_two_views(tmp_path):
     for k in T:
         assert np.array_equal(R[0]["grad_" + k], R[1]["grad_" + k]), k          # identical on every rank
         assert_grad_close("2-rank " + k, R[0]["grad_" + k], want[k], rtol=1e-3, floor=2e-6)
+    # factored SH exchange: rebuilt from the all-gathered 3-float factors == the dense all-reduced gradient
+    assert np.array_equal(R[0]["fact_shs"], R[1]["fact_shs"])
+    assert_grad_close("2-rank factored shs", R[0]["fact_shs"], want["shs"], rtol=1e-3, floor=2e-6)
+    assert_grad_close("2-rank factored vs dense exchange", R[0]["fact_shs"], R[0]["grad_shs"], rtol=1e-3, floor=2e-6)
+    assert_grad_close("2-rank factored means3D", R[0]["fact_means3D"], want["means3D"], rtol=1e-3, floor=2e-6)
     assert np.array_equal(R[0]["den"], den.cpu().numpy()) and np.array_equal(R[0]["mr"], mr.cpu().numpy())
     assert_grad_close("2-rank grad-norm sum", R[0]["gsum"], gsum.cpu().numpy(), rtol=1e-3, floor=2e-6)
     assert (R[0]["den"] == 2).sum() > 1000                                         # the stereo views overlap

@@ -23,6 +23,7 @@ EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_m
            "vr_count_fragments", "vr_count_blended", "vr_debug_export_binning", "vr_profile_level", "vr_profile_collect",
            "vr_knn3_mean_dist2", "vr_photometric_forward", "vr_photometric_backward",
            "vr_normal_guidance_forward", "vr_normal_guidance_backward", "vr_adam_step", "vr_densify_stats",
+           "vr_sh_grad_from_factors", "vr_sh_adam_step",
            "vr_instances_forward", "vr_instances_backward"]
 STAGES = ["preprocess", "compact", "depth_sort", "emit", "tile_sort", "ranges", "render_fwd", "bwd_zero",
           "render_bwd", "preprocess_bwd", "k_seg_bwd"]
@@ -59,12 +60,18 @@ class VrOutGrads(C.Structure):
 class VrInGrads(C.Structure):
     _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
                 ("dL_dcolors_precomp", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
-                ("dL_drotations", C.c_void_p), ("dL_dcov3D_precomp", C.c_void_p), ("dL_dshs_rest", C.c_void_p)]
+                ("dL_drotations", C.c_void_p), ("dL_dcov3D_precomp", C.c_void_p), ("dL_dshs_rest", C.c_void_p),
+                ("dL_dcolors_sh", C.c_void_p)]
 
 
 class VrAdamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("n", C.c_int64), ("lr", C.c_double), ("step", C.c_int64)]
+
+
+class VrShAdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("lr", C.c_double),
+                ("step", C.c_int64)]
 
 
 class VrInstance(C.Structure):
@@ -133,6 +140,11 @@ def load():
     lib.vr_adam_step.argtypes = [C.POINTER(VrAdamTensor), i32, C.c_double, C.c_double, C.c_double, vp]
     lib.vr_densify_stats.restype = C.c_int
     lib.vr_densify_stats.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    lib.vr_sh_grad_from_factors.restype = C.c_int
+    lib.vr_sh_grad_from_factors.argtypes = [vp, i32, vp, vp, i32, i32, i32, C.c_float, vp, vp, vp]
+    lib.vr_sh_adam_step.restype = C.c_int
+    lib.vr_sh_adam_step.argtypes = [vp, i32, vp, vp, i32, i32, i32, C.c_float, C.POINTER(VrShAdamTensor),
+                                    C.POINTER(VrShAdamTensor), C.c_double, C.c_double, C.c_double, vp]
     lib.vr_instances_forward.restype = C.c_int
     lib.vr_instances_forward.argtypes = [C.POINTER(VrInstance), i32, vp, vp, vp, vp]
     lib.vr_instances_backward.restype = C.c_int

@@ -332,7 +332,8 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
         return fail(VR_ERR_INVALID_ARGUMENT, "radii and the saved forward buffers are required");
     if (!gin->dL_dmeans3D || !gin->dL_dmeans2D || !gin->dL_dopacities)
         return fail(VR_ERR_INVALID_ARGUMENT, "dL_dmeans3D, dL_dmeans2D and dL_dopacities are required");
-    if ((in->shs && !gin->dL_dshs) || (in->colors_precomp && !gin->dL_dcolors_precomp) ||
+    const bool sh_factored = in->shs && gin->dL_dcolors_sh;     // factored SH gradient: dL_dshs is not written
+    if ((in->shs && !gin->dL_dshs && !sh_factored) || (in->colors_precomp && !gin->dL_dcolors_precomp) ||
         (in->scales && (!gin->dL_dscales || !gin->dL_drotations)) || (in->cov3D_precomp && !gin->dL_dcov3D_precomp))
         return fail(VR_ERR_INVALID_ARGUMENT, "a gradient array is missing for a provided input");
     hipStream_t s = (hipStream_t)stream;
@@ -352,7 +353,9 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
     prof_begin(VR_STAGE_BWD_ZERO, s);
     VR_HIP(hipMemsetAsync(gacc, 0, (size_t)P * 16 * sizeof(float), s));
     VR_HIP(hipMemsetAsync(gin->dL_dmeans2D, 0, (size_t)P * 3 * sizeof(float), s));
-    if (in->shs_rest) {   // split SH storage: the kernel writes every row of both gradient arrays
+    if (sh_factored) {
+        // nothing to clear: the kernel writes every row of the [P,3] factor array
+    } else if (in->shs_rest) {   // split SH storage: the kernel writes every row of both gradient arrays
         if (!gin->dL_dshs || !gin->dL_dshs_rest)
             return fail(VR_ERR_INVALID_ARGUMENT, "split SH storage needs both dL_dshs and dL_dshs_rest");
     } else if (gin->dL_dshs && !preprocess_bwd_writes_all_sh(in->M, in->shs, gin->dL_dshs)) {
@@ -387,7 +390,7 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
                                (const float*)((const char*)saved->geom + align_up((size_t)P * sizeof(Splat), 256) + align_up((size_t)P, 256)),
                                gacc, gin->dL_dmeans2D, gin->dL_dmeans3D, gin->dL_dshs, gin->dL_dshs_rest,
                                gin->dL_dcolors_precomp, gin->dL_dopacities, gin->dL_dscales, gin->dL_drotations,
-                               gin->dL_dcov3D_precomp, s, debug);
+                               gin->dL_dcov3D_precomp, sh_factored ? gin->dL_dcolors_sh : nullptr, s, debug);
     return rc;
 }
 

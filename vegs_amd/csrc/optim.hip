@@ -94,9 +94,170 @@ k_densify_stats(const float* __restrict__ g2d, const int32_t* __restrict__ radii
     max_radii[i] = fmaxf(max_radii[i], (float)r);
 }
 
+// ---- factored SH gradients (VrInGrads.dL_dcolors_sh).  One lane per Gaussian rebuilds its dense row
+//   g[k][c] = scale * sum_v basis_k(dir(means[i], campos[v])) * factors[v][i][c]
+// in registers (n_views x (direction + 16-term basis + 3K fma)), parks it in LDS, and the wave then walks the 64 rows --
+// contiguous in memory -- linearly: either storing them (vr_sh_grad_from_factors) or applying Adam to param / exp_avg /
+// exp_avg_sq in place (vr_sh_adam_step), so the 192-byte gradient row never exists in HBM.  Rows of the whole
+// [P,M,3] tensor are parked at stride 3M + 1 (odd for even M: bank-conflict free); with split storage the rest rows use
+// stride 3(M-1) + 1 and the DC row is handled by its own lane.
+constexpr int SHF_ROW_MAX = 48;
+struct ShAdamSeg {
+    float* p; float* m; float* v;          // Adam mode
+    float* out;                            // store mode
+    float step_size, inv_bc2_sqrt;
+};
+struct ShFactorArgs {
+    const float* means3D; const float* campos; const float* factors;
+    int P, n_views, deg, M;
+    float scale;
+    ShAdamSeg dc, rest;                    // rest.p / rest.out == nullptr: `dc` is the whole [P,M,3] tensor
+    float one_minus_b1, b2, one_minus_b2, eps;
+};
+
+template <bool ADAM>
+__device__ __forceinline__ void sh_consume(const ShFactorArgs& a, const ShAdamSeg& s, size_t e, float g)
+{
+    if (ADAM) {
+        float p = s.p[e], m = s.m[e], v = s.v[e];
+        m = m + (g - m) * a.one_minus_b1;
+        v = v * a.b2 + (a.one_minus_b2 * g) * g;
+        const float denom = sqrtf(v) * s.inv_bc2_sqrt + a.eps;
+        p = p - s.step_size * (m / denom);
+        s.p[e] = p; s.m[e] = m; s.v[e] = v;
+    } else {
+        s.out[e] = g;
+    }
+}
+
+template <bool ADAM>
+__global__ void __launch_bounds__(256) k_sh_factors(ShFactorArgs a)
+{
+    __shared__ float rows[4][64 * (SHF_ROW_MAX + 1)];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wave_first = (blockIdx.x * 4 + w) * 64;
+    if (wave_first >= a.P) return;
+    const int i = wave_first + lane;
+    const int rows_here = min(64, a.P - wave_first);
+    const bool split = ADAM ? a.rest.p != nullptr : a.rest.out != nullptr;
+    const int K = (a.deg + 1) * (a.deg + 1);
+    float g[SHF_ROW_MAX];
+#pragma unroll
+    for (int q = 0; q < SHF_ROW_MAX; ++q) g[q] = 0.0f;
+    if (i < a.P) {
+        const float px = a.means3D[3 * (size_t)i], py = a.means3D[3 * (size_t)i + 1], pz = a.means3D[3 * (size_t)i + 2];
+        for (int v = 0; v < a.n_views; ++v) {
+            const float* f = a.factors + ((size_t)v * a.P + i) * 3;
+            const float f0 = f[0], f1 = f[1], f2v = f[2];
+            if (f0 == 0.0f && f1 == 0.0f && f2v == 0.0f) continue;      // not visible in this view (or fully clamped)
+            const float d0 = px - a.campos[3 * v], d1 = py - a.campos[3 * v + 1], d2 = pz - a.campos[3 * v + 2];
+            const float il = 1.0f / sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+            float bas[16];
+            sh_basis(a.deg, d0 * il, d1 * il, d2 * il, bas);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k < K) {
+                    g[3 * k + 0] = fmaf(bas[k], f0, g[3 * k + 0]);
+                    g[3 * k + 1] = fmaf(bas[k], f1, g[3 * k + 1]);
+                    g[3 * k + 2] = fmaf(bas[k], f2v, g[3 * k + 2]);
+                }
+            }
+        }
+    }
+    const int row = 3 * a.M;
+    if (split) {
+        if (i < a.P) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sh_consume<ADAM>(a, a.dc, 3 * (size_t)i + c, a.scale * g[c]);
+        }
+        const int rowr = row - 3, stride = rowr + 1;
+        float* my = rows[w] + lane * stride;
+#pragma unroll
+        for (int q = 0; q < SHF_ROW_MAX - 3; ++q)
+            if (q < rowr) my[q] = a.scale * g[3 + q];
+        __builtin_amdgcn_wave_barrier();
+        const size_t base = (size_t)wave_first * rowr;
+        for (int e = lane; e < rows_here * rowr; e += 64) {
+            const int r = e / rowr;
+            sh_consume<ADAM>(a, a.rest, base + e, rows[w][r * stride + (e - r * rowr)]);
+        }
+    } else {
+        const int stride = row + 1;
+        float* my = rows[w] + lane * stride;
+#pragma unroll
+        for (int q = 0; q < SHF_ROW_MAX; ++q)
+            if (q < row) my[q] = a.scale * g[q];
+        __builtin_amdgcn_wave_barrier();
+        const size_t base = (size_t)wave_first * row;
+        for (int e = lane; e < rows_here * row; e += 64) {
+            const int r = e / row;
+            sh_consume<ADAM>(a, a.dc, base + e, rows[w][r * stride + (e - r * row)]);
+        }
+    }
+}
+
+static int sh_factor_args(ShFactorArgs& a, const float* means3D, int32_t P, const float* campos, const float* factors,
+                          int32_t n_views, int32_t sh_degree, int32_t M, float scale)
+{
+    if (P < 0 || n_views < 1 || sh_degree < 0 || sh_degree > 3 || M < (sh_degree + 1) * (sh_degree + 1) || M > 16)
+        { set_error("sh factors: need P >= 0, n_views >= 1, sh_degree 0..3 and (sh_degree+1)^2 <= M <= 16"); return VR_ERR_INVALID_ARGUMENT; }
+    if (P > 0 && (!means3D || !campos || !factors)) { set_error("sh factors: means3D, campos and factors are required"); return VR_ERR_INVALID_ARGUMENT; }
+    a.means3D = means3D; a.campos = campos; a.factors = factors;
+    a.P = P; a.n_views = n_views; a.deg = sh_degree; a.M = M; a.scale = scale;
+    a.dc = ShAdamSeg{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f};
+    a.rest = a.dc;
+    a.one_minus_b1 = a.b2 = a.one_minus_b2 = a.eps = 0.f;
+    return VR_OK;
+}
+
 }  // namespace vr
 
 using namespace vr;
+
+extern "C" int vr_sh_grad_from_factors(const float* means3D, int32_t P, const float* campos, const float* factors,
+                                       int32_t n_views, int32_t sh_degree, int32_t M, float scale, float* dL_dshs,
+                                       float* dL_dshs_rest, void* stream)
+{
+    ShFactorArgs a;
+    int rc = sh_factor_args(a, means3D, P, campos, factors, n_views, sh_degree, M, scale);
+    if (rc) return rc;
+    if (P == 0) return VR_OK;
+    if (!dL_dshs || (dL_dshs_rest && M < 2)) { set_error("sh factors: dL_dshs is required (and M >= 2 for split storage)"); return VR_ERR_INVALID_ARGUMENT; }
+    a.dc.out = dL_dshs;
+    a.rest.out = dL_dshs_rest;
+    hipLaunchKernelGGL(k_sh_factors<false>, dim3(cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    if (hipGetLastError() != hipSuccess) { set_error("sh factors: kernel launch failed"); return VR_ERR_HIP; }
+    return VR_OK;
+}
+
+extern "C" int vr_sh_adam_step(const float* means3D, int32_t P, const float* campos, const float* factors, int32_t n_views,
+                               int32_t sh_degree, int32_t M, float scale, const VrShAdamTensor* dc, const VrShAdamTensor* rest,
+                               double beta1, double beta2, double eps, void* stream)
+{
+    ShFactorArgs a;
+    int rc = sh_factor_args(a, means3D, P, campos, factors, n_views, sh_degree, M, scale);
+    if (rc) return rc;
+    if (P == 0) return VR_OK;
+    if (!dc || !dc->param || !dc->exp_avg || !dc->exp_avg_sq || dc->step < 1 ||
+        (rest && (!rest->param || !rest->exp_avg || !rest->exp_avg_sq || rest->step < 1 || M < 2)))
+        { set_error("sh adam: tensor with NULL array or step < 1"); return VR_ERR_INVALID_ARGUMENT; }
+    auto fill = [&](ShAdamSeg& s, const VrShAdamTensor& t) {
+        s.p = t.param; s.m = t.exp_avg; s.v = t.exp_avg_sq; s.out = nullptr;
+        const double bc1 = 1.0 - pow(beta1, (double)t.step), bc2 = 1.0 - pow(beta2, (double)t.step);
+        s.step_size = (float)(t.lr / bc1);
+        s.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    };
+    fill(a.dc, *dc);
+    if (rest) fill(a.rest, *rest);
+    a.one_minus_b1 = (float)(1.0 - beta1);
+    a.b2 = (float)beta2;
+    a.one_minus_b2 = (float)(1.0 - beta2);
+    a.eps = (float)eps;
+    hipLaunchKernelGGL(k_sh_factors<true>, dim3(cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    if (hipGetLastError() != hipSuccess) { set_error("sh adam: kernel launch failed"); return VR_ERR_HIP; }
+    return VR_OK;
+}
+
 
 extern "C" int vr_adam_step(const VrAdamTensor* tensors, int32_t count, double beta1, double beta2, double eps, void* stream)
 {

@@ -49,6 +49,27 @@ __device__ __forceinline__ void sh_backward_row(const Camera& cam, float px3, fl
     for (int k = 0; k < 3; ++k) dmean[k] += (ddir[k] - dir[k] * dot) * il;
 }
 
+// Factored variant (VrInGrads.dL_dcolors_sh): only the clamp-masked dL/d(colour) leaves the kernel -- dL/dshs is the
+// rank-1 product basis(dir) x that vector and is rebuilt (or consumed by the optimizer) elsewhere -- plus, as always,
+// the gradient through the view direction into the mean.
+__device__ __forceinline__ void sh_backward_factor(const Camera& cam, float px3, float py3, float pz3, uint32_t clampbits,
+                                                   float g0, float g1, float g2, const float* D, float* gc, float* dmean)
+{
+    const float d0 = px3 - cam.campos[0], d1 = py3 - cam.campos[1], d2v = pz3 - cam.campos[2];
+    const float len = sqrtf(d0 * d0 + d1 * d1 + d2v * d2v);
+    const float il = 1.0f / len;
+    const float dir[3] = {d0 * il, d1 * il, d2v * il};
+    gc[0] = (clampbits & 1u) ? 0.f : g0;
+    gc[1] = (clampbits & 2u) ? 0.f : g1;
+    gc[2] = (clampbits & 4u) ? 0.f : g2;
+    float ddir[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) ddir[a] = fmaf(gc[2], D[6 + a], fmaf(gc[1], D[3 + a], gc[0] * D[a]));
+    const float dot = dir[0] * ddir[0] + dir[1] * ddir[1] + dir[2] * ddir[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dmean[k] += (ddir[k] - dir[k] * dot) * il;
+}
+
 __global__ void __launch_bounds__(256)
 k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ means3D, const float* __restrict__ shs,
                  const float* __restrict__ shs_rest, float* __restrict__ dL_dshs_rest,
@@ -58,7 +79,7 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
                  const float* __restrict__ gacc,
                  const float* __restrict__ gmean2D, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dshs,
                  float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
-                 float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D)
+                 float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dcolors_sh)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4][64 * SH_LDS_STRIDE];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,7 +95,21 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
     // staged through LDS with coalesced dwordx4 loads, every lane turns its row into its dL/dsh row in
     // place, and the 64 rows are stored back coalesced (zeros for culled Gaussians: the kernel writes
     // every row of dL_dshs itself, no separate memset).
-    if (shs && shs_rest) {
+    if (shs && dL_dcolors_sh) {
+        float gc[3] = {0.f, 0.f, 0.f};
+        if (vis) {
+            const float4 a1 = reinterpret_cast<const float4*>(gacc + (size_t)i * 16)[1];
+            const float px3 = means3D[3 * (size_t)i], py3 = means3D[3 * (size_t)i + 1], pz3 = means3D[3 * (size_t)i + 2];
+            float D[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) D[q] = shd[9 * (size_t)i + q];
+            sh_backward_factor(cam, px3, py3, pz3, (uint32_t)clampb[i], a1.x, a1.y, a1.z, D, gc, dmean);
+        }
+        if (in_range) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dL_dcolors_sh[3 * (size_t)i + c] = gc[c];
+        }
+    } else if (shs && shs_rest) {
         // split storage: dL_dshs = [P,1,3] DC rows (written by their own lane: 12 contiguous bytes per lane),
         // dL_dshs_rest = [P,M-1,3]: every lane builds its gradient row in LDS (row stride = the memory's own, 45
         // floats at M = 16: odd, conflict-free) and the wave's 64 rows, one contiguous block, are copied out
@@ -308,14 +343,14 @@ int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const 
                           const float* cov3D_precomp, const int* radii, const uint8_t* clampb, const float* shd, const float* gacc,
                           const float* gmean2D, float* dL_dmeans3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dcolors,
                           float* dL_dopacities, float* dL_dscales, float* dL_drots, float* dL_dcov3D,
-                          hipStream_t s, bool debug)
+                          float* dL_dcolors_sh, hipStream_t s, bool debug)
 {
     if (P == 0) return 0;
     const int sh_staged = preprocess_bwd_writes_all_sh(cam.M, shs, dL_dshs) ? 1 : 0;
     hipLaunchKernelGGL(k_preprocess_bwd, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, sh_staged, means3D, shs, shs_rest,
                        dL_dshs_rest, colors_precomp, scales, rotations, cov3D_precomp, radii, clampb, shd, gacc, gmean2D, dL_dmeans3D,
                        dL_dshs, dL_dcolors,
-                       dL_dopacities, dL_dscales, dL_drots, dL_dcov3D);
+                       dL_dopacities, dL_dscales, dL_drots, dL_dcov3D, dL_dcolors_sh);
     VR_KERNEL_CHECK("preprocess_bwd", s, debug);
     return 0;
 }

@@ -87,3 +87,86 @@ def add_densification_stats(viewspace_point_grad, radii, xyz_gradient_accum, den
                                   _capi.ptr(denom), _capi.ptr(max_radii2D),
                                   torch.cuda.current_stream(radii.device).cuda_stream)
     _capi.check(rc)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Factored SH gradients.  The rasterizer can return, instead of dL/dshs [P,M,3], its rank-1 factor: the clamp-masked
+# dL/d(colour) [P,3] of the view (GaussianRasterizer(..., sh_color_grad=sink)); dL/dshs[i,k,c] = basis_k(dir_i) *
+# factor[i,c].  A view-sharded job all-gathers those 3 floats per Gaussian and view (vegs_amd.dist.exchange_factored)
+# and every rank rebuilds -- or, better, consumes -- the sum over views locally.
+
+def _check_factor_inputs(means3D, campos, factors):
+    if not (means3D.is_cuda and campos.is_cuda and factors.is_cuda):
+        raise ValueError("means3D, campos and factors must be GPU tensors (there is no CPU path)")
+    P = means3D.shape[0]
+    if means3D.dtype != torch.float32 or tuple(means3D.shape) != (P, 3):
+        raise ValueError("means3D must be float32 [P,3]")
+    if campos.dtype != torch.float32 or campos.dim() != 2 or campos.shape[1] != 3:
+        raise ValueError("campos must be float32 [n_views,3]")
+    n = campos.shape[0]
+    if factors.dtype != torch.float32 or tuple(factors.shape) != (n, P, 3):
+        raise ValueError(f"factors must be float32 [{n},{P},3] (got {tuple(factors.shape)})")
+    return P, n, means3D.contiguous(), campos.contiguous(), factors.contiguous()
+
+
+def sh_grad_from_factors(means3D, campos, factors, sh_degree, M, scale=1.0, split=False):
+    """Dense dL/dshs from the factors of `n_views` views: scale * sum_v basis(dir(means3D, campos[v])) x factors[v].
+    Returns [P,M,3], or (dc [P,1,3], rest [P,M-1,3]) with split=True (the model's own storage)."""
+    P, n, means3D, campos, factors = _check_factor_inputs(means3D, campos, factors)
+    dev = means3D.device
+    if split:
+        out = torch.empty((P, 1, 3), dtype=torch.float32, device=dev)
+        rest = torch.empty((P, M - 1, 3), dtype=torch.float32, device=dev)
+    else:
+        out, rest = torch.empty((P, M, 3), dtype=torch.float32, device=dev), None
+    with torch.cuda.device(dev):
+        rc = _capi.load().vr_sh_grad_from_factors(_capi.ptr(means3D), P, _capi.ptr(campos), _capi.ptr(factors), n,
+                                                  int(sh_degree), int(M), float(scale), _capi.ptr(out), _capi.ptr(rest),
+                                                  torch.cuda.current_stream(dev).cuda_stream)
+    _capi.check(rc)
+    return (out, rest) if split else out
+
+
+def _sh_state(opt, p):
+    for group in opt.param_groups:
+        for q in group["params"]:
+            if q is p:
+                st = opt.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                return group, st
+    raise ValueError("parameter is not in the optimizer")
+
+
+@torch.no_grad()
+def adam_step_sh_factored(opt, features_dc, features_rest, means3D, campos, factors, sh_degree, scale=1.0):
+    """One Adam step of the SH parameters (features_dc [P,1,3] + features_rest [P,M-1,3], or the whole [P,M,3] tensor with
+    features_rest=None) of optimizer `opt` (vegs_amd.optim.Adam or torch.optim.Adam: same state layout) straight from
+    the factors -- the dense gradient is built per Gaussian in registers and never written.  Equivalent to setting
+    .grad = sh_grad_from_factors(...) on the two parameters and stepping only them."""
+    P, n, means3D, campos, factors = _check_factor_inputs(means3D, campos, factors)
+    M = features_dc.shape[1] + (features_rest.shape[1] if features_rest is not None else 0)
+    items, betas, eps = [], None, None
+    for p in (features_dc, features_rest):
+        if p is None:
+            items.append(None)
+            continue
+        if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+            raise ValueError("SH parameters must be contiguous float32 GPU tensors")
+        group, st = _sh_state(opt, p)
+        if betas is None:
+            betas, eps = tuple(group["betas"]), float(group["eps"])
+        elif betas != tuple(group["betas"]) or eps != float(group["eps"]):
+            raise ValueError("features_dc and features_rest must share betas and eps")
+        items.append(_capi.VrShAdamTensor(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                          float(group["lr"]), int(st["step"].item())))
+    dev = means3D.device
+    with torch.cuda.device(dev):
+        rc = _capi.load().vr_sh_adam_step(_capi.ptr(means3D), P, _capi.ptr(campos), _capi.ptr(factors), n, int(sh_degree),
+                                          int(M), float(scale), C.byref(items[0]),
+                                          C.byref(items[1]) if items[1] is not None else None, betas[0], betas[1], eps,
+                                          torch.cuda.current_stream(dev).cuda_stream)
+    _capi.check(rc)

@@ -122,7 +122,7 @@ _LAST_R = {}
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, sh_rest=None):
+                raster_settings, sh_rest=None, sh_color_grad=None):
         lib = _capi.load()
         rs = raster_settings
         if means3D.dim() != 2 or means3D.shape[1] != 3:
@@ -193,6 +193,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         _LAST_R[hint_key] = max(_LAST_R.get(hint_key, 0), ctx.num_rendered)
         ctx.buffers = (arena.kept[_capi.VR_BUF_GEOM], arena.kept[_capi.VR_BUF_BINNING], arena.kept[_capi.VR_BUF_IMAGE])
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
+        if sh_color_grad is not None and (sh is None or tuple(sh_color_grad.shape) != (P, 3)):
+            raise ValueError("sh_color_grad needs shs and must be a [P,3] tensor")
+        ctx.sh_factored = sh_color_grad is not None
         ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, sh_rest)
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)   # unused outputs arrive as None -> NULL, no zero tensors
@@ -217,8 +220,12 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_means3D = torch.empty_like(means3D)
             d_means2D = torch.empty((P, 3), dtype=torch.float32, device=device)
             d_opac = torch.empty_like(opacities) if opacities is not None else None
-            d_sh = torch.empty_like(sh) if sh is not None else None
-            d_sh_rest = torch.empty_like(sh_rest) if sh_rest is not None else None
+            # factored SH gradient: only the clamp-masked dL/d(colour) [P,3] is produced (it lands on the caller's
+            # `sh_color_grad` tensor); shs / features_rest receive no gradient from this op
+            factored = ctx.sh_factored
+            d_sink = torch.empty((P, 3), dtype=torch.float32, device=device) if factored else None
+            d_sh = torch.empty_like(sh) if sh is not None and not factored else None
+            d_sh_rest = torch.empty_like(sh_rest) if sh_rest is not None and not factored else None
             d_col = torch.empty_like(colors_precomp) if colors_precomp is not None else None
             d_scales = torch.empty_like(scales) if scales is not None else None
             d_rot = torch.empty_like(rotations) if rotations is not None else None
@@ -227,7 +234,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                     _capi.ptr(g_alpha))
             gin = _capi.VrInGrads(_capi.ptr(d_means3D), _capi.ptr(d_means2D), _capi.ptr(d_sh), _capi.ptr(d_col),
                                   _capi.ptr(d_opac), _capi.ptr(d_scales), _capi.ptr(d_rot), _capi.ptr(d_cov),
-                                  _capi.ptr(d_sh_rest))
+                                  _capi.ptr(d_sh_rest), _capi.ptr(d_sink))
             saved = _capi.VrSaved(geom.data_ptr(), binning.data_ptr(), image.data_ptr(), ctx.num_rendered,
                                   ctx.num_visible, ctx.binning_capacity)
             arena = _capi.Arena(device)
@@ -247,13 +254,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                     raise arena.error
                 _capi.check(rc)
         # input order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings
-        return d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, d_sh_rest
+        return d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, d_sh_rest, d_sink
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, sh_rest=None):
+                        raster_settings, sh_rest=None, sh_color_grad=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, sh_rest)
+                                     cov3Ds_precomp, raster_settings, sh_rest, sh_color_grad)
 
 
 class GaussianRasterizer(nn.Module):
@@ -281,7 +288,12 @@ class GaussianRasterizer(nn.Module):
             return present.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, sh_color_grad=None):
+        """The reference's eight keyword arguments (gaussian_renderer/__init__.py:86-94), plus one extension:
+        `sh_color_grad`, a [P,3] zeros tensor with requires_grad.  When given, the backward deposits on it the
+        clamp-masked dL/d(colour) -- the 3-float factor of the rank-1 SH gradient dL/dshs[i,k,c] = basis_k(dir_i) *
+        factor[i,c] -- and `shs` itself receives NO gradient (vegs_amd.optim.sh_grad_from_factors / Adam.step_sh_factored
+        rebuild or consume it; vegs_amd.dist exchanges 3 instead of 48 floats per Gaussian and view)."""
         rs = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception("exactly one of shs and colors_precomp must be given")
@@ -305,4 +317,4 @@ class GaussianRasterizer(nn.Module):
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, rs, sh_rest)
+                                   cov3D_precomp, rs, sh_rest, sh_color_grad)

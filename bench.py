@@ -112,7 +112,7 @@ def prepare(sc, deg, cams, device, rng, count=True):
                 cam_ts=cam_ts, gouts=gouts, counters=counters, deg=deg)
 
 
-def make_step(wl, rank, world, vps):
+def make_step(wl, rank, world, vps, factored=False):
     T, cams, cam_ts, gouts, params, deg, bg = (wl[k] for k in ("T", "cams", "cam_ts", "gouts", "params", "deg", "bg"))
     n_views = len(cams)
 
@@ -120,7 +120,8 @@ def make_step(wl, rank, world, vps):
         done = []
         for k in range(vps):
             v = vdist.view_for_rank(i * vps + k, rank, world, n_views)
-            pkg = harness.render(cams[v], T, deg, bg, cam_t=cam_ts[v])
+            sink = torch.zeros_like(T["means3D"], requires_grad=True) if factored else None
+            pkg = harness.render(cams[v], T, deg, bg, cam_t=cam_ts[v], sh_color_grad=sink)
             gc, gq, gs = gouts[v]
             torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], [gc, gq, gs])
             done.append(v)
@@ -164,10 +165,10 @@ def stage_profile(step, steps):
     return {k: round(v[0] / max(v[1], 1), 4) for k, v in st.items() if v[1] > 0}
 
 
-def variant(name, sc, deg, cams, device, steps, warmup):
+def variant(name, sc, deg, cams, device, steps, warmup, factored=False):
     """A few steps of another scene/camera configuration, reported next to the headline (N = 1 only)."""
     wl = prepare(sc, deg, cams, device, np.random.default_rng(77))
-    step = make_step(wl, 0, 1, 1)
+    step = make_step(wl, 0, 1, 1, factored)
     dt, done = timed(step, warmup, steps, 1)
     cn = wl["counters"]
     mean = {k: float(np.mean([cn[v][k] for v in done])) for k in ("V", "R", "F", "B")}
@@ -323,6 +324,8 @@ def main():
             variant("same scene at 1408x376 (the resolution the reference's comments use)", sc, deg, cams_w, device, 16, 4),
             variant("dense: same scene with every disc 3x larger (R ~ an order of magnitude up), 1376x376", dense, deg,
                     cams[:8], device, 8, 2),
+            variant("headline scene, SH gradient returned as its 3-float factor (sh_color_grad) instead of [P,16,3]", sc,
+                    deg, cams[:8], device, 16, 4, factored=True),
         ]
     if world == 1 and not args.no_cpu_baseline:
         cpu_views = [0, 5, 10, 15]

@@ -50,3 +50,30 @@ def test_fitting_a_small_scene_reduces_the_loss():
     assert np.isfinite(losses).all()
     assert last < 0.5 * first, (first, last)
     assert (denom > 0).sum() > 1000 and torch.isfinite(grad_accum).all() and grad_accum.sum() > 0
+
+
+def test_iteration_with_factored_sh_equals_dense_iteration():
+    """vegs_amd.iteration.Trainer: the fused step with the FACTORED SH gradient (op -> 3-float factor -> Adam) tracks
+    the fused step with the dense gradient over a few iterations."""
+    from vegs_amd import harness, iteration, scenes
+    dev = torch.device("cuda:0")
+    sc, deg = scenes.scene_street(P=50000, length=80.0, sh_degree=3, seed=21)
+    cams = [scenes.kitti_camera(2.0 * i, 0.3, 688, 188) for i in range(3)]
+    rng = np.random.default_rng(0)
+    gt = torch.tensor(rng.uniform(0, 1, (3, 188, 688)).astype(np.float32), device=dev)
+    normal = torch.tensor(rng.normal(size=(3, 188, 688)).astype(np.float32), device=dev)
+    bg = torch.zeros(3, device=dev)
+    out = []
+    for factored in (False, True):
+        tr = iteration.Trainer(sc, dev, fused=True, factored_sh=factored)
+        losses = []
+        for it in range(6):
+            cam = cams[it % 3]
+            losses.append(float(tr.step(cam, harness.cam_tensors(cam, dev), deg, bg, gt, normal)[0]))
+        out.append((losses, {k: v.detach().cpu().numpy() for k, v in tr.p.items()}))
+    (la, pa), (lb, pb) = out
+    assert np.allclose(la, lb, rtol=2e-5)
+    for k in pa:
+        # Adam's first steps move by ~lr * sign(g): differences come from noise-level gradients changing sign
+        tol = 1e-4 * np.abs(pa[k]).max()
+        assert float((np.abs(pa[k] - pb[k]) > tol).mean()) < 5e-3, k

@@ -18,7 +18,7 @@ def cam_tensors(cam, device):
 
 
 def render(cam, tensors, sh_degree, bg_color, scaling_modifier=1.0, debug=False, colors_precomp=None,
-           cov3D_precomp=None, cam_t=None):
+           cov3D_precomp=None, cam_t=None, sh_color_grad=None):
     """tensors: dict with means3D, opacities, shs, scales, rotations (torch, on the GPU)."""
     means3D = tensors["means3D"]
     device = means3D.device
@@ -38,7 +38,8 @@ def render(cam, tensors, sh_degree, bg_color, scaling_modifier=1.0, debug=False,
     rotations = None if cov3D_precomp is not None else tensors["rotations"]
     rendered_image, depth_image, cov_quat, cov_scale, alpha, radii = rasterizer(
         means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp,
-        opacities=tensors["opacities"], scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+        opacities=tensors["opacities"], scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp,
+        **({} if sh_color_grad is None else {"sh_color_grad": sh_color_grad}))
     return {"render": rendered_image, "render_depth": depth_image, "render_cov_quat": cov_quat,
             "render_cov_scale": cov_scale, "alpha": alpha, "viewspace_points": screenspace_points,
             "visibility_filter": radii > 0, "radii": radii}

@@ -59,13 +59,13 @@ def ssim_window(device):
     return (g1[:, None] @ g1[None, :]).expand(3, 1, 11, 11).contiguous().to(device)
 
 
-def render_model(p, boxes, cam, cam_t, deg, bg, fused):
+def render_model(p, boxes, cam, cam_t, deg, bg, fused, sh_sink=None):
     t = {"means3D": p["xyz"], "opacities": torch.sigmoid(p["opacity"]), "scales": torch.exp(p["scaling"]),
          "rotations": F.normalize(p["rotation"])}
     if not boxes:
         # fused: the model's two SH tensors as they are (no torch.cat, no slicing copies in the backward)
         t["shs"] = (p["f_dc"], p["f_rest"]) if fused else torch.cat((p["f_dc"], p["f_rest"]), dim=1)
-        return harness.render(cam, t, deg, bg, cam_t=cam_t)
+        return harness.render(cam, t, deg, bg, cam_t=cam_t, sh_color_grad=sh_sink)
     t["shs"] = torch.cat((p["f_dc"], p["f_rest"]), dim=1)
     return harness.render_all(cam, t, [b for b, _ in boxes], [w for _, w in boxes], deg, bg, cam_t=cam_t, fused=fused)
 
@@ -96,9 +96,12 @@ def fused_loss(pkg, gt, normal, R_c2w):
 class Trainer:
     """State of one variant: parameters, optimizer, densification statistics."""
 
-    def __init__(self, sc, device, n_boxes=0, fused=True, box_points=8196):
+    def __init__(self, sc, device, n_boxes=0, fused=True, box_points=8196, factored_sh=False):
+        """factored_sh (fused variant without box instances): the op returns the 3-float factor of the SH gradient
+        and Adam consumes it directly (optim.adam_step_sh_factored) -- the dense [P,16,3] gradient is never written."""
         from . import optim
         self.device, self.fused = device, fused
+        self.factored_sh = bool(factored_sh and fused and not n_boxes)
         self.p, groups = make_model(sc, device)
         self.boxes = make_boxes(n_boxes, device, box_points) if n_boxes else []
         self.opt = (optim.Adam if fused else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
@@ -109,7 +112,11 @@ class Trainer:
         self.win = ssim_window(device)
 
     def forward_loss(self, cam, cam_t, deg, bg, gt, normal):
-        pkg = render_model(self.p, self.boxes, cam, cam_t, deg, bg, self.fused)
+        sink = None
+        if self.factored_sh and torch.is_grad_enabled():
+            sink = torch.zeros_like(self.p["xyz"], requires_grad=True)
+        pkg = render_model(self.p, self.boxes, cam, cam_t, deg, bg, self.fused, sh_sink=sink)
+        pkg["sh_sink"] = sink
         # NaN guard for pixels no Gaussian covers (A-5: exact zeros; the reference's 2/|q|^2 is NaN there) -- same in
         # both variants
         q = pkg["render_cov_quat"]
@@ -133,7 +140,11 @@ class Trainer:
                 self.max_radii[vis] = torch.max(self.max_radii[vis], radii[vis].float())             # train.py:299
                 self.accum[vis] += torch.norm(vsp.grad[vis, :2], dim=-1, keepdim=True)                # gaussian_model.py:411-413
                 self.denom[vis] += 1
-        grads = {k: v.grad.detach().clone() for k, v in self.p.items()} if keep_grads else None
+        grads = {k: v.grad.detach().clone() for k, v in self.p.items() if v.grad is not None} if keep_grads else None
+        if pkg.get("sh_sink") is not None:
+            ct = cam_t if cam_t is not None else harness.cam_tensors(cam, self.device)
+            optim.adam_step_sh_factored(self.opt, self.p["f_dc"], self.p["f_rest"], self.p["xyz"].detach(),
+                                        ct["campos"].reshape(1, 3), pkg["sh_sink"].grad[None], deg, 1.0)
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
         if not keep_grads:

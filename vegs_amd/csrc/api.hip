@@ -238,6 +238,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     uint32_t* vis_id = (uint32_t*)((char*)scr + 4 * arr);
     void* scan_scr = (char*)scr + 5 * arr;
     uint32_t* totals_dev = (uint32_t*)((char*)scr + 5 * arr + s1);
+    bool ranges_zeroed = false;
 
     uint32_t V = 0, R = 0, key_min = 0;
     int key_bits = 0;
@@ -267,7 +268,11 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
         // round trip (and the host's launch of what follows) overlaps with that kernel instead of idling the GPU.
         VR_HIP(hipMemcpyAsync(g_pinned, totals_dev, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         VR_HIP(hipEventRecord(mail.event, s));
-        rc = launch_compact_apply(P, rect, depth_key, scan_scr, vis_key, vis_id, s, debug);
+        // the apply kernel also clears the tile ranges (when the binning buffer already exists): no fill launch
+        uint32_t* rz = binning ? (uint32_t*)((char*)binning + bin_layout(T, Rcap).ranges) : nullptr;
+        ranges_zeroed = rz != nullptr;
+        rc = launch_compact_apply(P, rect, depth_key, scan_scr, vis_key, vis_id, rz, rz ? (long)(2 * T) : 0L, nullptr,
+                                  0L, s, debug);
         prof_end(VR_STAGE_COMPACT, s);
         if (rc) return rc;
         VR_HIP(hipEventSynchronize(mail.event));
@@ -281,6 +286,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     }
     if (Rcap == 0 || R > Rcap) {   // no hint, or the hint was too small: size for the actual R
         Rcap = R;
+        ranges_zeroed = false;     // a fresh binning buffer
         binning = alloc(user, VR_BUF_BINNING, bin_layout(T, Rcap).total);
         scr2 = alloc(user, VR_BUF_SCRATCH, binning_stage2_scratch_bytes(P, (long)Rcap, (int)T));
         scr3 = alloc(user, VR_BUF_SCRATCH, render_fwd_scratch_bytes((long)Rcap, (int)T) + 256);
@@ -289,8 +295,8 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     const BinLayout BL = bin_layout(T, Rcap);
     int2* ranges = (int2*)((char*)binning + BL.ranges);
     uint32_t* point_list = (uint32_t*)((char*)binning + BL.point_list);
-    rc = launch_binning(cam, (int)V, (long)R, key_min, key_bits, vis_key, vis_id, rect, scr2, point_list, ranges, s,
-                        debug);
+    rc = launch_binning(cam, P, (int)V, (long)R, key_min, key_bits, vis_key, vis_id, rect, scr2, point_list, ranges,
+                        ranges_zeroed, s, debug);
     if (rc) return rc;
     prof_begin(VR_STAGE_RENDER_FWD, s);
     rc = launch_render_fwd(cam, (long)R, ranges, point_list, rec, (uint32_t*)((char*)binning + BL.seg_off),

@@ -147,9 +147,13 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* lds4)
 template <class Src, class Sink>
 __global__ void __launch_bounds__(256)
 k_scan_apply(Src src, Sink sink, long n, const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ bsum2,
-             int nb, uint32_t* __restrict__ totals)
+             int nb, uint32_t* __restrict__ totals, uint32_t* __restrict__ zero_a = nullptr, long zero_na = 0,
+             uint32_t* __restrict__ zero_b = nullptr, long zero_nb = 0)
 {
     __shared__ uint32_t lds4[4];
+    // side duty (saves two fill launches): clear small arrays that LATER kernels of the same stream accumulate into
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_na; i += (long)gridDim.x * 256) zero_a[i] = 0u;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_nb; i += (long)gridDim.x * 256) zero_b[i] = 0u;
     uint32_t acc = 0;
     for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) acc += bsum[j];
     const uint32_t prefix = block_sum(acc, lds4);
@@ -269,7 +273,8 @@ int launch_compact_reduce(int P, const uint2* rect, const uint32_t* depth_key, v
 }
 
 int launch_compact_apply(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, uint32_t* vis_key,
-                         uint32_t* vis_id, hipStream_t s, bool debug)
+                         uint32_t* vis_id, uint32_t* zero_a, long zero_na, uint32_t* zero_b, long zero_nb, hipStream_t s,
+                         bool debug)
 {
     int nb = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
     uint32_t* bsum = (uint32_t*)scratch;
@@ -277,7 +282,8 @@ int launch_compact_apply(int P, const uint2* rect, const uint32_t* depth_key, vo
     SrcFlagTiles src{rect, depth_key};
     SinkCompact sink{depth_key, vis_key, vis_id};
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<SrcFlagTiles, SinkCompact>), dim3(nb), dim3(256), 0, s, src, sink,
-                       (long)P, (const uint32_t*)bsum, (const uint32_t*)bsum2, nb, (uint32_t*)nullptr);
+                       (long)P, (const uint32_t*)bsum, (const uint32_t*)bsum2, nb, (uint32_t*)nullptr, zero_a, zero_na,
+                       zero_b, zero_nb);
     VR_KERNEL_CHECK("compact_apply", s, debug);
     return 0;
 }
@@ -341,11 +347,16 @@ k_radix_hist(const uint32_t* __restrict__ keys, long n, uint32_t kmin, int shift
     for (int d = threadIdx.x; d < SIZE; d += 256) hist[(size_t)d * nblk + blockIdx.x] = h[d];
 }
 
-template <int BITS>
+// GATHER (last pass of the depth sort): the value is a Gaussian id; its packed tile rectangle is gathered into sorted
+// order on the way out (the only gather of the binning stage, formerly its own kernel).  (Tried and rejected:
+// accumulating the block sums of the following scans with global atomics here and in the histogram kernel, to save
+// the scans' reduce launches -- a few hundred hot words serialise at ~12 ns per atomic: 9 -> 358 us.)
+template <int BITS, bool GATHER>
 __global__ void __launch_bounds__(256)
 k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, long n, uint32_t kmin, int shift,
-                const uint32_t* __restrict__ hist_scanned, int nblk)
+                const uint32_t* __restrict__ hist_scanned, int nblk, const uint2* __restrict__ rect,
+                uint2* __restrict__ rect_sorted)
 {
     constexpr int SIZE = 1 << BITS;
     __shared__ uint32_t cnt[4][SIZE];
@@ -431,25 +442,33 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
         const uint32_t k = skey[j];
         const uint32_t d = digit_of<BITS>(k, kmin, shift);
         const uint32_t dst = gl[d] + ((uint32_t)j - loc[d]);
+        const uint32_t v = sval[j];
         keys_out[dst] = k;
-        vals_out[dst] = sval[j];
+        vals_out[dst] = v;
+        if (GATHER) rect_sorted[dst] = rect[v];
     }
 }
 
+// One pass = histogram -> scan (reduce + apply) -> scatter.
+struct RadixGather { const uint2* rect; uint2* rect_sorted; };
 template <int BITS>
 static int radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, long n, uint32_t kmin,
-                      int shift, uint32_t* hist, uint32_t* bsum, hipStream_t s, bool debug)
+                      int shift, uint32_t* hist, uint32_t* bsum, const RadixGather* gather, hipStream_t s, bool debug)
 {
     int nblk = cdiv(n, RADIX_BLOCK);
+    long hn = (long)(1 << BITS) * nblk;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<BITS>), dim3(nblk), dim3(256), 0, s, kin, n, kmin, shift, hist,
                        nblk);
     VR_KERNEL_CHECK("radix_hist", s, debug);
-    long hn = (long)(1 << BITS) * nblk;
     int rc = run_scan(SrcPlain{hist}, SinkStore{hist}, hn, bsum, (uint32_t*)nullptr, (uint32_t*)nullptr, s, debug,
                       "radix_scan");
     if (rc) return rc;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<BITS>), dim3(nblk), dim3(256), 0, s, kin, vin, kout, vout, n,
-                       kmin, shift, (const uint32_t*)hist, nblk);
+    if (gather)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<BITS, true>), dim3(nblk), dim3(256), 0, s, kin, vin, kout, vout,
+                           n, kmin, shift, (const uint32_t*)hist, nblk, gather->rect, gather->rect_sorted);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<BITS, false>), dim3(nblk), dim3(256), 0, s, kin, vin, kout, vout,
+                           n, kmin, shift, (const uint32_t*)hist, nblk, (const uint2*)nullptr, (uint2*)nullptr);
     VR_KERNEL_CHECK("radix_scatter", s, debug);
     return 0;
 }
@@ -468,8 +487,12 @@ static int radix_digit(int nbits)
 // Stable LSD sort of (key, val) pairs on the low `nbits` bits of (key - kmin).  Ping-pongs between
 // (k0,v0) and (k1,v1); returns in *res which pair holds the result (0 or 1).  Digit width is chosen
 // per call: few wide passes for many bits, narrow digits (cheaper ballot ranking) for few bits.
+// number of scan block sums one pass over n elements needs (any digit width: 512 digits is the maximum)
+static inline size_t radix_bsum_words(long n) { return (size_t)cdiv((long)cdiv(n, RADIX_BLOCK) * 512, SCAN_BLOCK) + 1; }
+
+// `bsum`: radix_bsum_words(n) words of scratch.  `gather`: rectangle gather on the LAST pass (depth sort).
 static int radix_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long n, uint32_t kmin, int nbits,
-                      uint32_t* hist, uint32_t* bsum, hipStream_t s, bool debug, int* res)
+                      uint32_t* hist, uint32_t* bsum, const RadixGather* gather, hipStream_t s, bool debug, int* res)
 {
     const int digit = radix_digit(nbits);
     const int passes = nbits <= 0 ? 0 : cdiv(nbits, digit);
@@ -477,9 +500,10 @@ static int radix_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, lo
     int where = 0;
     for (int pass = 0; pass < passes; ++pass) {
         int rc;
-        if (digit == 6) rc = radix_pass<6>(ka, va, kb, vb, n, kmin, pass * digit, hist, bsum, s, debug);
-        else if (digit == 9) rc = radix_pass<9>(ka, va, kb, vb, n, kmin, pass * digit, hist, bsum, s, debug);
-        else rc = radix_pass<8>(ka, va, kb, vb, n, kmin, pass * digit, hist, bsum, s, debug);
+        const RadixGather* g = pass == passes - 1 ? gather : nullptr;
+        if (digit == 6) rc = radix_pass<6>(ka, va, kb, vb, n, kmin, pass * digit, hist, bsum, g, s, debug);
+        else if (digit == 9) rc = radix_pass<9>(ka, va, kb, vb, n, kmin, pass * digit, hist, bsum, g, s, debug);
+        else rc = radix_pass<8>(ka, va, kb, vb, n, kmin, pass * digit, hist, bsum, g, s, debug);
         if (rc) return rc;
         uint32_t* t = ka; ka = kb; kb = t;
         t = va; va = vb; vb = t;
@@ -497,8 +521,7 @@ int radix_sort_passes(int nbits)
 size_t sort_pairs_scratch_bytes(long n)
 {
     const size_t nblk = (size_t)cdiv(n > 0 ? n : 1, RADIX_BLOCK);
-    const size_t scan_n = nblk * 512 > (size_t)n ? nblk * 512 : (size_t)n;
-    return align_up(nblk * 512 * 4, 256) + align_up((size_t)cdiv((long)scan_n, SCAN_BLOCK) * 4 + 256, 256);
+    return align_up(nblk * 512 * 4, 256) + align_up(radix_bsum_words(n > 0 ? n : 1) * 4 + 256, 256);
 }
 int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long n, uint32_t kmin, int nbits,
                       void* scratch, hipStream_t s, bool debug, int* where)
@@ -508,7 +531,7 @@ int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, lo
     uint32_t* bsum = (uint32_t*)((char*)scratch + align_up(nblk * 512 * 4, 256));
     *where = 0;
     if (n <= 0) return 0;
-    return radix_sort(k0, v0, k1, v1, n, kmin, nbits, hist, bsum, s, debug, where);
+    return radix_sort(k0, v0, k1, v1, n, kmin, nbits, hist, bsum, nullptr, s, debug, where);
 }
 
 // ---------------------------------------------------------------- emission + ranges
@@ -604,19 +627,19 @@ static Stage2Layout stage2_layout(int V, long R)
     size_t nmax = r > v ? r : v;
     size_t nblk = (size_t)cdiv((long)nmax, RADIX_BLOCK);
     L.hist = take(nblk * 512 * 4);
-    size_t scan_n = nblk * 512 > nmax ? nblk * 512 : nmax;
-    L.bsum = take((size_t)cdiv((long)scan_n, SCAN_BLOCK) * 4 + 256);
+    L.bsum = take(radix_bsum_words((long)nmax) * 4 + 256);
     L.total = o;
     return L;
 }
 
 size_t binning_stage2_scratch_bytes(int V, long R, int) { return stage2_layout(V, R).total; }
 
-int launch_binning(const Camera& cam, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
-                   uint32_t* vis_id, const uint2* rect, void* scratch, uint32_t* point_list, int2* ranges, hipStream_t s, bool debug)
+int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
+                   uint32_t* vis_id, const uint2* rect, void* scratch, uint32_t* point_list, int2* ranges,
+                   bool ranges_zeroed, hipStream_t s, bool debug)
 {
     int ntiles = cam.gx * cam.gy;
-    VR_HIP(hipMemsetAsync(ranges, 0, sizeof(int2) * (size_t)ntiles, s));
+    if (!ranges_zeroed) VR_HIP(hipMemsetAsync(ranges, 0, sizeof(int2) * (size_t)ntiles, s));
     if (V == 0 || R == 0) return 0;
     Stage2Layout L = stage2_layout(V, R);
     char* base = (char*)scratch;
@@ -629,22 +652,28 @@ int launch_binning(const Camera& cam, int V, long R, uint32_t key_min, int key_b
     uint32_t* tvalsB = (uint32_t*)(base + L.tvalsB);
     uint32_t* hist = (uint32_t*)(base + L.hist);
     uint32_t* bsum = (uint32_t*)(base + L.bsum);
+    (void)P;
 
-    // 2. depth sort of the visible Gaussians on the bits of (key - kmin) that vary
+    // 2. depth sort of the visible Gaussians on the bits of (key - kmin) that vary; its last scatter also gathers the
+    // tile rectangles into sorted order
     uint32_t* sorted_id = vis_id;
+    const int depth_passes = radix_sort_passes(key_bits);
     {
         ProfScope ps(VR_STAGE_DEPTH_SORT, s);
         int where = 0;
-        int rc = radix_sort(vis_key, vis_id, tmp_key, tmp_id, V, key_min, key_bits, hist, bsum, s, debug, &where);
+        const RadixGather g{rect, rect_sorted};
+        int rc = radix_sort(vis_key, vis_id, tmp_key, tmp_id, V, key_min, key_bits, hist, bsum, &g, s, debug, &where);
         if (rc) return rc;
         sorted_id = where ? tmp_id : vis_id;
     }
     // 3. offsets in depth order, then emission
     prof_begin(VR_STAGE_EMIT, s);
     {
-        hipLaunchKernelGGL(k_gather_rect, dim3(cdiv(V, 256)), dim3(256), 0, s, V, (const uint32_t*)sorted_id, rect,
-                           rect_sorted);
-        VR_KERNEL_CHECK("gather_rect", s, debug);
+        if (depth_passes == 0) {   // all depth keys equal (or one Gaussian): nothing was scattered, gather here
+            hipLaunchKernelGGL(k_gather_rect, dim3(cdiv(V, 256)), dim3(256), 0, s, V, (const uint32_t*)sorted_id, rect,
+                               rect_sorted);
+            VR_KERNEL_CHECK("gather_rect", s, debug);
+        }
         int rc = run_scan(SrcRectSorted{rect_sorted}, SinkStore{offs}, V, bsum, (uint32_t*)nullptr,
                           (uint32_t*)nullptr, s, debug, "offset_scan");
         if (rc) return rc;
@@ -664,7 +693,7 @@ int launch_binning(const Camera& cam, int V, long R, uint32_t key_min, int key_b
     prof_begin(VR_STAGE_TILE_SORT, s);
     {
         int where = 0;
-        int rc = radix_sort(ka, va, kb, vb, R, 0u, bits, hist, bsum, s, debug, &where);
+        int rc = radix_sort(ka, va, kb, vb, R, 0u, bits, hist, bsum, nullptr, s, debug, &where);
         if (rc) return rc;
         if (where) { uint32_t* t = ka; ka = kb; kb = t; }
     }

@@ -59,12 +59,17 @@ struct BinningPlan {
 size_t binning_stage1_scratch_bytes(int P);
 int launch_compact_reduce(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,
                           hipStream_t s, bool debug);
+// zero_a / zero_b: up to two small arrays the kernel clears on the side (the tile ranges): saves a fill launch
 int launch_compact_apply(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, uint32_t* vis_key,
-                         uint32_t* vis_id, hipStream_t s, bool debug);
+                         uint32_t* vis_id, uint32_t* zero_a, long zero_na, uint32_t* zero_b, long zero_nb, hipStream_t s,
+                         bool debug);
+
 // stage 2 (V- and R-sized): depth sort, emission, tile sort, ranges.
 size_t binning_stage2_scratch_bytes(int V, long R, int ntiles);
-int launch_binning(const Camera& cam, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
-                   uint32_t* vis_id, const uint2* rect, void* scratch, uint32_t* point_list, int2* ranges, hipStream_t s, bool debug);
+// ranges_zeroed: the tile ranges were already cleared by launch_compact_apply
+int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
+                   uint32_t* vis_id, const uint2* rect, void* scratch, uint32_t* point_list, int2* ranges,
+                   bool ranges_zeroed, hipStream_t s, bool debug);
 
 // stable LSD radix sort of (key,val) u32 pairs on the low nbits of (key - kmin); ping-pongs between the two
 // pairs, *where = 0/1 tells which pair holds the result

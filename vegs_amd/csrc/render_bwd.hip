@@ -180,10 +180,29 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     const int lane = threadIdx.x;
     const int pixslot = w * 64 + lane;            // this pixel's slot in the [segment][256] buffers
 
-    // ---- the entries relevant to this strip (masks from the forward), compacted in list order
+    // ---- ONE batch of independent global loads right after the segment descriptor: relevance masks, the segment's
+    // list entries (all four 64-entry parts: which ones are relevant is only known once the masks are back) and the
+    // whole pixel state.  Issued in dependency order (masks -> list -> pixel state) these were three memory round
+    // trips in the life of a short workgroup that has only ~3 others on its SIMD to hide them behind.
     const unsigned long long* masks = segmask + (size_t)c.seg * 16 + w * 4;
-    const unsigned long long m0 = uniform64(masks[0]), m1 = uniform64(masks[1]), m2 = uniform64(masks[2]),
-                             m3 = uniform64(masks[3]);
+    const unsigned long long mraw0 = masks[0], mraw1 = masks[1], mraw2 = masks[2], mraw3 = masks[3];
+    uint32_t gid_q[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gid_q[q] = q * 64 + lane < c.count ? point_list[c.first + q * 64 + lane] : 0u;
+    const size_t N = (size_t)cam.H * cam.W;
+    const float v_pxf = (float)c.px, v_pyf = (float)c.py;
+    PixGrad pg;
+    load_pixgrad(c.inside, c.pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, dL_dalpha, cam.flags, final_T, dsum, pg);
+    float v_Tf = 1.0f;
+    int v_nc = 0;
+    if (c.inside) { v_Tf = final_T[c.pix]; v_nc = (int)n_contrib[c.pix]; }
+    // carries at the END of this segment: transmittance behind its last entry (the next segment's boundary value
+    // when the pixel is still alive there), and the w*u sum of everything behind the segment
+    const float Tnext = c.flag == 2u ? Tbuf[(size_t)(c.seg + 1) * SEG + pixslot] : -1.0f;
+    float v_Scar = Ubuf[(size_t)c.seg * SEG + pixslot];
+
+    // ---- the entries relevant to this strip, compacted in list order
+    const unsigned long long m0 = uniform64(mraw0), m1 = uniform64(mraw1), m2 = uniform64(mraw2), m3 = uniform64(mraw3);
     const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
     const int nrel = n0 + n1 + n2 + n3;
     if (nrel == 0) return;
@@ -196,34 +215,20 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
             if ((mm[q] >> lane) & 1ull) {
                 const int pos = before[q] + __popcll(mm[q] & lt);
                 rel_j[pos] = (unsigned short)(q * 64 + lane);
-                rel_gid[pos] = point_list[c.first + q * 64 + lane];
+                rel_gid[pos] = gid_q[q];
             }
         }
     }
-    __syncthreads();
 
     // ---- pixel state, lane = pixel of this wave's 8x8 region
-    const size_t N = (size_t)cam.H * cam.W;
-    const float v_pxf = (float)c.px, v_pyf = (float)c.py;
-    PixGrad pg;
-    load_pixgrad(c.inside, c.pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, dL_dalpha, cam.flags, final_T, dsum, pg);
-    float v_Tf = 1.0f;
-    int v_nc = 0;
-    if (c.inside) { v_Tf = final_T[c.pix]; v_nc = (int)n_contrib[c.pix]; }
     // "background" terms weighted by the final transmittance: bg colour, alpha = 1 - T and, with VR_FLAG_FILL_EMPTY,
     // the identity rotation added to cov_quat (an extra channel: cut off together with the others)
     const bool no_extra = (cam.flags & FLAG_EXTRA_NO_ALPHA_GRAD) != 0u;
     const float v_fill = ((cam.flags & FLAG_FILL_EMPTY) && !no_extra) ? pg.g[4] : 0.0f;
     const float v_bgterm =
         v_Tf * ((fmaf(cam.bg[2], pg.g[2], fmaf(cam.bg[1], pg.g[1], cam.bg[0] * pg.g[0])) + v_fill) - pg.galpha);
-    // carries at the END of this segment: transmittance behind its last entry, and the w*u sum of
-    // everything behind the segment
     float v_Tcar = v_Tf;
-    if (c.flag == 2u) {
-        const float Tn = Tbuf[(size_t)(c.seg + 1) * SEG + pixslot];
-        if (!(Tn < 0.0f)) v_Tcar = Tn;   // pixel still alive at the next segment
-    }
-    float v_Scar = Ubuf[(size_t)c.seg * SEG + pixslot];
+    if (!(Tnext < 0.0f)) v_Tcar = Tnext;   // pixel still alive at the next segment
     const int seg_lo = c.sl * SEG;       // first list entry (tile-relative) of this segment
     // Per-pixel record in LDS, interleaved by PIXEL PAIR (a = even pixel, b = odd pixel of the strip): the
     // pixel loop reads it back as wave-uniform broadcasts (LDS pipe, not 16 v_readlane on the VALU pipe) and

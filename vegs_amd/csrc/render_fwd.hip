@@ -188,23 +188,34 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     // 256-thread workgroup: its relevance test is shared by the four strips, per-strip workgroups repeat it 4x.)
     __shared__ float4 lds[5][64];
     __shared__ unsigned char rel_j[SEG];
+    __shared__ uint32_t rel_gid[SEG];
     SegCtx c;
     const int w = (int)(blockIdx.x & 3u);
     if (!seg_setup_at(cam, ranges, seg_off, blockIdx.x >> 2, w, c)) return;
     if (c.flag == 0u) return;
     const int lane = threadIdx.x;
     const int pixslot = w * 64 + lane;
+    // one batch of independent loads right after the segment descriptor (boundary transmittance, relevance masks,
+    // all four 64-entry parts of the segment's list): one memory round trip instead of three dependent ones
     const float Tb = Tbuf[(size_t)c.seg * SEG + pixslot];
+    const unsigned long long* masks = segmask + (size_t)c.seg * 16 + w * 4;
+    const unsigned long long mraw[4] = {masks[0], masks[1], masks[2], masks[3]};
+    uint32_t gid_q[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gid_q[q] = q * 64 + lane < c.count ? point_list[c.first + q * 64 + lane] : 0u;
     bool done = Tb < 0.0f;
     if (__ballot(!done) == 0ull) return;  // nothing alive in this strip
-    const unsigned long long* masks = segmask + (size_t)c.seg * 16 + w * 4;
-    const unsigned long long mm[4] = {uniform64(masks[0]), uniform64(masks[1]), uniform64(masks[2]), uniform64(masks[3])};
+    const unsigned long long mm[4] = {uniform64(mraw[0]), uniform64(mraw[1]), uniform64(mraw[2]), uniform64(mraw[3])};
     int nrel = 0;
     {
         const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if ((mm[q] >> lane) & 1ull) rel_j[nrel + __popcll(mm[q] & lt)] = (unsigned char)(q * 64 + lane);
+            if ((mm[q] >> lane) & 1ull) {
+                const int pos = nrel + __popcll(mm[q] & lt);
+                rel_j[pos] = (unsigned char)(q * 64 + lane);
+                rel_gid[pos] = gid_q[q];
+            }
             nrel += __popcll(mm[q]);
         }
     }
@@ -223,7 +234,7 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
         int myj = 0;
         if (lane < n) {
             myj = (int)rel_j[b0 + lane];
-            const float4* src = reinterpret_cast<const float4*>(rec + point_list[c.first + myj]);
+            const float4* src = reinterpret_cast<const float4*>(rec + rel_gid[b0 + lane]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) lds[k][lane] = src[k];
             float4 t = src[4];            // s1 s2 clamped pad -> the pad slot carries the entry index

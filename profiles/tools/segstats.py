@@ -21,7 +21,7 @@ for x in (0.0, 40.0):
     T = 86 * 24
     cap = fn.binning_capacity
     S = cap // 256 + T
-    o_seg = al(T * 8); o_need = o_seg + al((((T + 1 + 63) // 64 * 64) + S) * 4); o_pl = o_need + al(T * 4)
+    o_seg = al(T * 8); o_need = o_seg + al((((T + 1 + 63) // 64 * 64) + 4 * S) * 4); o_pl = o_need + al(T * 4)
     o_tb = o_pl + al(max(cap, 1) * 4); o_part = o_tb + al(S * 256 * 4); o_mask = o_part + al(S * 13 * 256 * 4)
     seg_off = b[o_seg:o_seg + (T + 1) * 4].view(np.uint32).astype(np.int64)
     need = b[o_need:o_need + T * 4].view(np.uint32).astype(np.int64)

@@ -112,9 +112,17 @@ def prepare(sc, deg, cams, device, rng, count=True):
                 cam_ts=cam_ts, gouts=gouts, counters=counters, deg=deg)
 
 
-def make_step(wl, rank, world, vps, factored=False):
+def make_step(wl, rank, world, vps, factored=False, exchange="dense"):
+    """One step = `vps` views forward + backward on this rank, then (N > 1) the gradient exchange.
+    exchange "dense": all-reduce of the 59-float/Gaussian gradients.  "factored": the op returns the 3-float factor of
+    the SH gradient, the ranks all-gather the factors (12 B) and all-reduce the other 11 floats (44 B), and every rank
+    rebuilds the averaged dense SH gradient locally (inside the timed region) -- the same tensors on every rank at the
+    end of the step as with "dense", for 256 instead of 826 MB over the links at N = 8."""
     T, cams, cam_ts, gouts, params, deg, bg = (wl[k] for k in ("T", "cams", "cam_ts", "gouts", "params", "deg", "bg"))
     n_views = len(cams)
+    fact_x = world > 1 and exchange == "factored" and vps == 1
+    factored = factored or fact_x
+    others = [T[k] for k in ("means3D", "opacities", "scales", "rotations")]
 
     def step(i):
         done = []
@@ -125,7 +133,11 @@ def make_step(wl, rank, world, vps, factored=False):
             gc, gq, gs = gouts[v]
             torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], [gc, gq, gs])
             done.append(v)
-        if world > 1:
+        if fact_x:
+            from vegs_amd import optim
+            F, Cc = vdist.exchange_factored(others, sink.grad, cam_ts[done[-1]]["campos"], world)
+            T["shs"].grad = optim.sh_grad_from_factors(T["means3D"].detach(), Cc, F, deg, T["shs"].shape[1], 1.0 / world)
+        elif world > 1:
             vdist.allreduce_grads(params, world)
         for p in params:
             p.grad = None
@@ -217,6 +229,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra 1408x376 / dense-scene measurements")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage time breakdown to stderr")
+    ap.add_argument("--exchange", choices=["factored", "dense"], default="factored",
+                    help="N > 1: gradient exchange scheme (factored = all-gather of the rank-1 SH factors + all-reduce of "
+                         "the other 11 floats; dense = all-reduce of all 59 floats per Gaussian)")
     ap.add_argument("--views-per-step", type=int, default=1,
                     help="views each rank renders per step; their gradients accumulate locally and are exchanged once")
     args = ap.parse_args()
@@ -238,7 +253,7 @@ def main():
     wl = prepare(sc, deg, cams, device, np.random.default_rng(1234))
     counters, gouts = wl["counters"], wl["gouts"]
     vps = max(1, args.views_per_step)
-    step = make_step(wl, rank, world, vps)
+    step = make_step(wl, rank, world, vps, exchange=args.exchange)
 
     for i in range(args.warmup):
         step(i)
@@ -298,7 +313,10 @@ def main():
         "config": {"workload": f"{args.workload}: {P} street Gaussians (VEGS disc init), SH deg {deg}, {W}x{H} "
                                f"KITTI-360 intrinsics, {n_views} views cycled, 12 output channels + colour/quat/scale grads",
                    "gaussians": P, "width": W, "height": H, "views_per_step_per_gpu": vps,
-                   "parallelism": f"view-sharded x{world}" + (" + RCCL grad all-reduce (59 f32/Gaussian)" if world > 1 else ""),
+                   "parallelism": f"view-sharded x{world}" + ("" if world == 1 else
+                                                              " + RCCL all-gather of SH factors (3 f32) + all-reduce (11 f32) per Gaussian"
+                                                              if args.exchange == "factored" and vps == 1 else
+                                                              " + RCCL grad all-reduce (59 f32/Gaussian)"),
                    "mean_counters": {k: round(v, 1) for k, v in mean.items()}},
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -177,11 +177,35 @@ def stage_profile(step, steps):
     return {k: round(v[0] / max(v[1], 1), 4) for k, v in st.items() if v[1] > 0}
 
 
-def variant(name, sc, deg, cams, device, steps, warmup, factored=False):
-    """A few steps of another scene/camera configuration, reported next to the headline (N = 1 only)."""
+def variant(name, sc, deg, cams, device, steps, warmup, factored=False, hints="warm"):
+    """A few steps of another scene/camera configuration, reported next to the headline (N = 1 only).
+    hints: "warm" = every camera was rendered before with the same model (as in the headline), "off" = per-camera
+    needed-segment hints disabled (what a camera's FIRST visit costs), "stale" = the hints come from a different
+    model: every Gaussian moved by N(0, 2 cm), opacity logits + N(0, 0.3), scales x exp(N(0, 0.05)) -- far more drift
+    than the ~300 Adam steps between two visits of a camera produce."""
+    from vegs_amd import rasterizer
+    old = rasterizer.needed_hints(hints != "off")
     wl = prepare(sc, deg, cams, device, np.random.default_rng(77))
     step = make_step(wl, 0, 1, 1, factored)
+    if hints == "stale":
+        rng = np.random.default_rng(5)
+        T = wl["T"]
+        keep = {k: T[k].detach().clone() for k in ("means3D", "opacities", "scales")}
+        with torch.no_grad():
+            T["means3D"] += torch.tensor(rng.normal(0, 0.02, tuple(T["means3D"].shape)).astype(np.float32), device=device)
+            lo = torch.logit(T["opacities"].clamp(1e-4, 1 - 1e-4)) + torch.tensor(
+                rng.normal(0, 0.3, tuple(T["opacities"].shape)).astype(np.float32), device=device)
+            T["opacities"].copy_(torch.sigmoid(lo))
+            T["scales"] *= torch.tensor(np.exp(rng.normal(0, 0.05, tuple(T["scales"].shape))).astype(np.float32), device=device)
+        for i in range(len(cams)):        # one pass over the cameras with the drifted model: this is what the hints remember
+            step(i)
+        with torch.no_grad():
+            for k, v in keep.items():
+                T[k].copy_(v)
+        warmup = 0                        # the timed steps are the first visits with the original model
+        steps = min(steps, len(cams))
     dt, done = timed(step, warmup, steps, 1)
+    rasterizer.needed_hints(old)
     cn = wl["counters"]
     mean = {k: float(np.mean([cn[v][k] for v in done])) for k in ("V", "R", "F", "B")}
     return {"workload": name, "views_per_s": round(steps / dt, 2), "ms_per_view": round(dt / steps * 1e3, 4),
@@ -311,7 +335,8 @@ def main():
         "mfragments_per_s": round(frag_total / elapsed / 1e6, 2),
         "blended_mfragments_per_s": round(blend_total / elapsed / 1e6, 2),
         "config": {"workload": f"{args.workload}: {P} street Gaussians (VEGS disc init), SH deg {deg}, {W}x{H} "
-                               f"KITTI-360 intrinsics, {n_views} views cycled, 12 output channels + colour/quat/scale grads",
+                               f"KITTI-360 intrinsics, {n_views} views cycled, 12 output channels + colour/quat/scale grads; "
+                               "every camera visited before (per-camera needed-segment hints warm, see variants)",
                    "gaussians": P, "width": W, "height": H, "views_per_step_per_gpu": vps,
                    "parallelism": f"view-sharded x{world}" + ("" if world == 1 else
                                                               " + RCCL all-gather of SH factors (3 f32) + all-reduce (11 f32) per Gaussian"
@@ -344,6 +369,10 @@ def main():
                     cams[:8], device, 8, 2),
             variant("headline scene, SH gradient returned as its 3-float factor (sh_color_grad) instead of [P,16,3]", sc,
                     deg, cams[:8], device, 16, 4, factored=True),
+            variant("headline scene, per-camera needed-segment hints OFF (cost of a camera's first visit)", sc, deg,
+                    cams, device, 16, 4, hints="off"),
+            variant("headline scene, STALE hints (from a model with every Gaussian moved 2 cm, opacity logits +-0.3, "
+                    "scales +-5 %)", sc, deg, cams, device, 16, 0, hints="stale"),
         ]
     if world == 1 and not args.no_cpu_baseline:
         cpu_views = [0, 5, 10, 15]

@@ -138,6 +138,14 @@ typedef struct VrSaved {
     int64_t num_rendered;     /* R: tile-list entries */
     int64_t num_visible;      /* V: Gaussians with radii > 0 */
     int64_t binning_capacity; /* entries the binning buffer was laid out for (>= R) */
+    uint32_t* needed_hint;    /* IN/OUT, optional (NULL = none): device array [tiles], tiles = ceil(W/16)*ceil(H/16) in
+                                 row-major tile order, owned by the caller and kept PER CAMERA.  On entry: the number of
+                                 256-entry list segments each tile needed in the previous forward of this camera at this
+                                 image size (fill a new array with 0x3FFFFFFF = "no idea").  The forward skips the work
+                                 behind hint+1 segments per tile, redoes it on the spot wherever the hint turns out too
+                                 small -- results never depend on it, bit-exact either way; only the time does (about
+                                 half of the segments of a KITTI-shaped view are never needed) -- and overwrites the
+                                 array, asynchronously on `stream`, with what THIS forward needed. */
 } VrSaved;
 
 /* Incoming gradients, one per differentiable output (NULL = zero). */
@@ -211,6 +219,11 @@ int vr_count_fragments(const VrSaved* saved, int32_t image_height, int32_t image
  * Needs the forward's inputs only through `saved`; a slow one-thread-per-pixel walk, for benchmarks' bookkeeping. */
 int vr_count_blended(const VrSaved* saved, int32_t image_height, int32_t image_width, void* stream,
                      int64_t* blended);
+
+/* Copies the per-tile number of needed list segments of the forward whose state is `saved` into `out`
+ * (device, uint32 [tiles], tiles = ceil(W/16) * ceil(H/16)); asynchronous on `stream`.  Feed it back as
+ * VrSaved.needed_hint of the next forward of the same camera. */
+int vr_export_needed(const VrSaved* saved, int32_t image_height, int32_t image_width, uint32_t* out, void* stream);
 
 /* ---- stage timing (HIP events recorded on `stream` around the kernels of each stage).
  * level 0 = off (default), 1 = only the k_seg_bwd kernel (the roofline kernel), 2 = every stage.

@@ -445,3 +445,65 @@ def test_non_finite_inputs_do_not_crash_or_poison_the_frame(dev):
         assert int(pkg["radii"].max()) < 10_000 and int(pkg["radii"].min()) >= 0
         if key in ("scales", "means3D") or val in (0.0, -1.0):
             assert torch.isfinite(pkg["render"]).all(), (key, val)
+
+
+def test_needed_hint_never_changes_results(dev):
+    """VrSaved.needed_hint (per-camera cache in vegs_amd.rasterizer): the forward skips the list segments behind the
+    hinted prefix of every tile and recomputes on the spot where the hint was too small.  Same camera tensors rendered
+    (1) without a hint, (2) with its own perfect hint, (3) after the scene became far MORE transparent (every tile now
+    needs more segments than hinted: the fallback of k_seg_scan runs everywhere), (4) with a hint that is far too
+    large (scene opaque again): all bit-exact against the oracle and against the hint-free operator."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from oracle import oracle as orc
+    from vegs_amd import rasterizer, scenes
+    sc, deg = scenes.scene_street(P=500000, length=25.0, sh_degree=1, seed=23)   # dense and opaque: long lists, early stops
+    sc["opacities"] = np.clip(sc["opacities"] * 3.0, 0.0, 0.95).astype(np.float32)
+    cam = scenes.kitti_camera(0.0, 0.0, 688, 188)
+    H, W = 188, 688
+    view = torch.tensor(cam.world_view_transform, device=dev)
+    proj = torch.tensor(cam.full_proj_transform, device=dev)
+    rs = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, torch.zeros(3, device=dev), 1.0, view, proj, deg,
+                                       torch.tensor(cam.camera_center, device=dev), False, False)
+    rng = np.random.default_rng(6)
+    gouts = [torch.tensor(rng.normal(size=s).astype(np.float32), device=dev) for s in [(3, H, W), (4, H, W), (3, H, W)]]
+
+    def run(opac_scale):
+        T = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in sc.items()}
+        op = (T["opacities"].detach() * opac_scale).requires_grad_(True)
+        m2d = torch.zeros(sc["means3D"].shape[0], 3, device=dev, requires_grad=True)
+        out = GaussianRasterizer(rs)(means3D=T["means3D"], means2D=m2d, opacities=op, shs=T["shs"], scales=T["scales"],
+                                     rotations=T["rotations"])
+        fn = out[0].grad_fn
+        torch.autograd.backward([out[0], out[2], out[3]], gouts)
+        return [o.detach().cpu().numpy() for o in out], fn, [T["means3D"].grad.cpu().numpy(), op.grad.cpu().numpy()]
+
+    def oracle(opac_scale):
+        oc = oracle_cam(cam, [0, 0, 0], deg)
+        o, st = orc.forward(oc, sc["means3D"], sc["shs"], None, sc["opacities"] * np.float32(opac_scale), sc["scales"],
+                            sc["rotations"], None)
+        return o
+
+    old = rasterizer.needed_hints(True)
+    try:
+        rasterizer._NEEDED.clear()
+        a, fa, ga = run(1.0)                       # (1) first visit: no hint
+        key = [k for k in rasterizer._NEEDED][0]
+        hint1 = rasterizer._NEEDED[key].clone()
+        assert int(hint1.max()) >= 3               # the scene really has multi-segment tiles
+        assert fa.num_rendered // 256 > int(hint1.sum()) + 500   # ... and many of their segments are never needed
+        b, fb, gb = run(1.0)                       # (2) perfect hint
+        c, fc, gc = run(0.05)                      # (3) hint far too small -> fallback
+        hint3 = rasterizer._NEEDED[key].clone()
+        assert int((hint3 > hint1 + 1).sum()) > 20 # many tiles outgrew their hint by more than the margin
+        d, fd, gd = run(1.0)                       # (4) hint far too large
+        assert torch.equal(rasterizer._NEEDED[key], hint1)
+    finally:
+        rasterizer.needed_hints(old)
+    o1, o3 = oracle(1.0), oracle(0.05)
+    for i, n in enumerate(OUT_NAMES):
+        assert np.array_equal(a[i], o1[n]) and np.array_equal(b[i], o1[n]) and np.array_equal(d[i], o1[n]), n
+        assert np.array_equal(c[i], o3[n]), n
+    for x, y in zip(ga, gb):
+        assert_grad_close("hinted vs unhinted backward", y, x, rtol=1e-3, floor=2e-6)
+    for x, y in zip(ga, gd):
+        assert_grad_close("over-hinted vs unhinted backward", y, x, rtol=1e-3, floor=2e-6)

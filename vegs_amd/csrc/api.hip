@@ -304,7 +304,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
                            (float*)((char*)binning + BL.part),
                            (unsigned long long*)((char*)binning + BL.segmask), scr3,
                            out->color, out->depth, out->cov_quat, out->cov_scale, out->alpha, final_T, n_contrib,
-                           (float*)((char*)image + IL.dsum), s, debug);
+                           (float*)((char*)image + IL.dsum), saved->needed_hint, s, debug);
     prof_end(VR_STAGE_RENDER_FWD, s);
     if (rc) return rc;
 
@@ -528,6 +528,18 @@ int vr_count_blended(const VrSaved* saved, int32_t H, int32_t W, void* stream, i
     VR_HIP(hipMemcpyAsync(&host, ctr, sizeof host, hipMemcpyDeviceToHost, s));
     VR_HIP(hipStreamSynchronize(s));
     *blended = (int64_t)host;
+    return VR_OK;
+}
+
+int vr_export_needed(const VrSaved* saved, int32_t H, int32_t W, uint32_t* out, void* stream)
+{
+    g_err[0] = 0;
+    if (!saved || !saved->binning || !out || H <= 0 || W <= 0)
+        return fail(VR_ERR_INVALID_ARGUMENT, "export_needed: bad arguments");
+    const size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    const BinLayout BL = bin_layout(T, saved->binning_capacity > 0 ? (size_t)saved->binning_capacity : (size_t)saved->num_rendered);
+    VR_HIP(hipMemcpyAsync(out, (const char*)saved->binning + BL.seg_needed, T * sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                          (hipStream_t)stream));
     return VR_OK;
 }
 

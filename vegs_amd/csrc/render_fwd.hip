@@ -79,16 +79,33 @@ k_seg_tiles(int ntiles, const int2* __restrict__ ranges, uint32_t* __restrict__ 
     seg_info[b] = make_int4(lo, first, min(SEG, r.y - first), sl);
 }
 
-// ---- A: per (tile, segment, pixel) product of (1 - alpha)
-__global__ void __launch_bounds__(256)
-k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
-            const uint32_t* __restrict__ point_list, const Splat* __restrict__ rec, float* __restrict__ Pbuf,
-            unsigned long long* __restrict__ segmask)
+// ---- NEEDED-SEGMENT HINT.  Half of the segments lie behind the point where every pixel of their tile has stopped
+// (a few vanishing-point tiles have up to ~950 segments and need at most ~200): k_seg_alpha computes their products
+// for nothing, because which segments are needed is only known after the chain.  Training revisits every camera
+// hundreds of times while the Gaussians move slowly, so the caller may hand back, as a HINT, the per-tile number of
+// needed segments of its previous forward of the same camera (VrSaved.needed_hint; vr_export_needed).  k_seg_alpha
+// then only computes the segments sl < hinted_limit(hint[tile]); k_seg_scan walks that prefix as before and, if any
+// pixel of the tile is STILL alive at its end (the hint was too small: a stale or foreign hint, a scene that
+// changed), computes the missing segments itself, one after the other, with the same routine -- so the result never
+// depends on the hint, only the time does (bit-exact either way; tests/test_gpu_parity.py::test_needed_hint_*).
+// Margin: 2 segments + 12 %.  The fallback of k_seg_scan is serial per tile (~6 us per missing segment, and the scan
+// kernel lasts as long as its slowest tile), so the margin is sized to make it rare: with hints from a model whose
+// Gaussians were all moved by 2 cm, opacity logits by +-0.3 and scales by +-5 % (far more than the drift between two
+// visits of a camera) 3-5 of 2064 tiles miss by at most 2 segments (profiles/tools/staleness.py), while a margin of
+// 1 segment left one tile 18 segments short (+0.2 ms for that view).  Cost of the margin: 4.6 k instead of 2.1 k of the
+// 9.5 k dead segments of the headline view are still computed.
+__device__ __forceinline__ uint32_t hinted_limit(uint32_t h) { return h + 2u + (h >> 3); }
+__device__ __forceinline__ uint32_t hinted_prefix(const uint32_t* __restrict__ hint, int tile, uint32_t nseg)
 {
-    __shared__ float4 lds[2][SEG];
-    __shared__ unsigned long long masks[16];
-    SegCtx c;
-    if (!seg_setup(cam, ranges, seg_off, c)) return;
+    return hint ? min(nseg, hinted_limit(min(hint[tile], 0x3FFFFFFFu))) : nseg;
+}
+
+// Product of (1 - alpha) over one segment for the calling thread's pixel; also builds the segment's strip-relevance
+// masks and stores them.  Called by all 256 threads of a workgroup (contains block barriers).
+__device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t* __restrict__ point_list,
+                                                const Splat* __restrict__ rec, float4 (*lds)[SEG],
+                                                unsigned long long* masks, unsigned long long* __restrict__ segmask)
+{
     {
         const bool have = (int)threadIdx.x < c.count;
         float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
@@ -142,36 +159,58 @@ k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
                 if (t < nb) apply(av[t], bv[t]);
         }
     }
+    return p;
+}
+
+// ---- A: per (tile, segment, pixel) product of (1 - alpha)
+__global__ void __launch_bounds__(256)
+k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
+            const uint32_t* __restrict__ point_list, const Splat* __restrict__ rec, float* __restrict__ Pbuf,
+            unsigned long long* __restrict__ segmask, const uint32_t* __restrict__ hint)
+{
+    __shared__ float4 lds[2][SEG];
+    __shared__ unsigned long long masks[16];
+    SegCtx c;
+    if (!seg_setup(cam, ranges, seg_off, c)) return;
+    if (hint && (uint32_t)c.sl >= hinted_limit(min(hint[c.tile], 0x3FFFFFFFu))) return;   // behind the hinted prefix: k_seg_scan decides
+    const float p = seg_alpha_body(c, point_list, rec, lds, masks, segmask);
     Pbuf[(size_t)c.seg * SEG + threadIdx.x] = p;
 }
 
 // ---- B: per tile, boundary transmittances.  Tbuf[seg][pix] = Tb at the segment start, or -1 when
 // the pixel is finished before that segment; seg_needed[tile] = number of segments any pixel needs.
 __global__ void __launch_bounds__(256)
-k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, const float* __restrict__ Pbuf,
-           float* __restrict__ Tbuf, uint32_t* __restrict__ seg_needed)
+k_seg_scan(Camera cam, const int2* __restrict__ ranges, uint32_t* __restrict__ seg_off, const float* __restrict__ Pbuf,
+           float* __restrict__ Tbuf, uint32_t* __restrict__ seg_needed, uint32_t* __restrict__ hint,
+           const uint32_t* __restrict__ point_list, const Splat* __restrict__ rec,
+           unsigned long long* __restrict__ segmask)
 {
     __shared__ uint32_t wneed[4];
+    __shared__ uint32_t walive[4];
+    __shared__ float4 lds[2][SEG];
+    __shared__ unsigned long long masks[16];
     const int tile = blockIdx.x;
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int px = tx * TILE + region_x(w, lane), py = ty * TILE + region_y(w, lane);
     bool alive = px < cam.W && py < cam.H;
     const uint32_t s0 = seg_off[tile], s1 = seg_off[tile + 1];
+    const uint32_t k0 = hinted_prefix(hint, tile, s1 - s0);   // segments [0, k0) were computed by k_seg_alpha
+    const uint32_t s1c = s0 + k0;
     float Tb = 1.0f;
     // Each wave walks the segment chain of its own 64 pixels without block barriers; the P values of
     // UNROLL segments are fetched together so the chain is not bound by one memory latency per segment.
     constexpr int UNROLL = 24;
     uint32_t mine = 0;  // segments this wave needs (some pixel alive at the segment start)
     bool wave_alive = __ballot(alive) != 0ull;
-    for (uint32_t s = s0; s < s1 && wave_alive; s += UNROLL) {
+    for (uint32_t s = s0; s < s1c && wave_alive; s += UNROLL) {
         float Pv[UNROLL];
 #pragma unroll
         for (int k = 0; k < UNROLL; ++k)
-            Pv[k] = (s + k < s1) ? Pbuf[(size_t)(s + k) * SEG + threadIdx.x] : 1.0f;
+            Pv[k] = (s + k < s1c) ? Pbuf[(size_t)(s + k) * SEG + threadIdx.x] : 1.0f;
 #pragma unroll
         for (int k = 0; k < UNROLL; ++k) {
-            if (s + k < s1 && wave_alive) {
+            if (s + k < s1c && wave_alive) {
                 mine = s + k - s0 + 1;
                 Tbuf[(size_t)(s + k) * SEG + threadIdx.x] = alive ? Tb : -1.0f;
                 const float Tn = Tb * Pv[k];
@@ -181,11 +220,51 @@ k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, const float* __restrict__
             }
         }
     }
+    // The hint was too small for this tile: some pixel is still alive behind the computed prefix.  The workgroup
+    // computes the missing segments itself, in order (all four waves together: the relevance masks of a segment are
+    // built by all 256 threads), until every pixel has stopped or the list ends.
+    if (s1c < s1) {
+        if (lane == 0) walive[w] = wave_alive ? 1u : 0u;
+        __syncthreads();
+        bool any_alive = (walive[0] | walive[1] | walive[2] | walive[3]) != 0u;
+        const int2 rg = ranges[tile];
+        for (uint32_t s = s1c; s < s1 && any_alive; ++s) {
+            SegCtx c;
+            c.seg = s;
+            c.tile = tile;
+            c.sl = (int)(s - s0);
+            c.first = rg.x + c.sl * SEG;
+            c.count = min(SEG, rg.y - c.first);
+            c.flag = 0u;
+            c.px = px;
+            c.py = py;
+            c.x0 = (float)(tx * TILE);
+            c.y0 = (float)(ty * TILE);
+            c.inside = px < cam.W && py < cam.H;
+            c.pix = (size_t)py * cam.W + px;
+            const float p = seg_alpha_body(c, point_list, rec, lds, masks, segmask);
+            if (wave_alive) {
+                mine = s - s0 + 1;
+                Tbuf[(size_t)s * SEG + threadIdx.x] = alive ? Tb : -1.0f;
+                const float Tn = Tb * p;
+                if (alive && Tn < T_EPS) alive = false;
+                else if (alive) Tb = Tn;
+                wave_alive = __ballot(alive) != 0ull;
+            }
+            __syncthreads();                       // lds / masks / walive are reused by the next segment
+            if (lane == 0) walive[w] = wave_alive ? 1u : 0u;
+            __syncthreads();
+            any_alive = (walive[0] | walive[1] | walive[2] | walive[3]) != 0u;
+        }
+    }
     if (lane == 0) wneed[w] = mine;
     __syncthreads();
     const uint32_t needed = max(max(wneed[0], wneed[1]), max(wneed[2], wneed[3]));
     for (uint32_t s = s0 + mine; s < s0 + needed; ++s) Tbuf[(size_t)s * SEG + threadIdx.x] = -1.0f;
-    if (threadIdx.x == 0) seg_needed[tile] = needed;
+    if (threadIdx.x == 0) {
+        seg_needed[tile] = needed;
+        if (hint) hint[tile] = needed;     // in/out: what this forward needed is the hint of the camera's next visit
+    }
     // per-segment flag for the segment kernels (vr_segment.h): 0 not needed / 1 needed, last / 2 needed, next too
     int4* seg_info = reinterpret_cast<int4*>(seg_off + seg_tile_offset(cam.gx * cam.gy));
     for (uint32_t k = threadIdx.x; k < s1 - s0; k += 256) {
@@ -448,7 +527,7 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
                       uint32_t* seg_off, uint32_t* seg_needed, float* Tbuf, float* part, unsigned long long* segmask,
                       void* scratch, float* out_color,
                       float* out_depth, float* out_quat, float* out_scale, float* out_alpha, float* final_T,
-                      uint32_t* n_contrib, float* dsum, hipStream_t s, bool debug)
+                      uint32_t* n_contrib, float* dsum, uint32_t* needed_hint, hipStream_t s, bool debug)
 {
     const int ntiles = cam.gx * cam.gy;
     if (ntiles == 0) return 0;
@@ -459,11 +538,11 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     VR_KERNEL_CHECK("seg_offsets", s, debug);
     if (R > 0) {
         hipLaunchKernelGGL(k_seg_alpha, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
-                           point_list, rec, Pbuf, segmask);
+                           point_list, rec, Pbuf, segmask, (const uint32_t*)needed_hint);
         VR_KERNEL_CHECK("seg_alpha", s, debug);
     }
-    hipLaunchKernelGGL(k_seg_scan, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (const float*)Pbuf,
-                       Tbuf, seg_needed);
+    hipLaunchKernelGGL(k_seg_scan, dim3(ntiles), dim3(256), 0, s, cam, ranges, seg_off, (const float*)Pbuf,
+                       Tbuf, seg_needed, needed_hint, point_list, rec, segmask);
     VR_KERNEL_CHECK("seg_scan", s, debug);
     if (R > 0) {
         hipLaunchKernelGGL(k_seg_blend, dim3((unsigned)nseg * 4), dim3(64), 0, s, cam, ranges, (const uint32_t*)seg_off,

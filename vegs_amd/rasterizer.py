@@ -118,6 +118,24 @@ def _cpu_args_copy(args):
 # caching allocator serves them from its pool instead of going back to hipMalloc.
 _LAST_R = {}
 
+# Needed-segment hints (include/vegs_rast.h: VrSaved.needed_hint): per camera, the per-tile number of list segments its
+# previous forward needed.  Keyed by the identity of the camera's matrices (VEGS' Camera objects keep their
+# world_view_transform / full_proj_transform tensors for their lifetime, scene/cameras.py:76-87) and the image size.  A hint
+# is never trusted -- a wrong one (a reused address, a scene that changed) only costs time, the kernels redo what it
+# missed -- so no invalidation is needed.  VEGS_RAST_HINTS=0 (or needed_hints(False)) turns the cache off.
+_NEEDED = {}
+_NEEDED_MAX = 4096
+_use_hints = os.environ.get("VEGS_RAST_HINTS", "1") != "0"
+
+
+def needed_hints(enabled):
+    """Enable / disable the per-camera needed-segment hints; returns the previous setting."""
+    global _use_hints
+    old, _use_hints = _use_hints, bool(enabled)
+    if not enabled:
+        _NEEDED.clear()
+    return old
+
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
@@ -172,6 +190,16 @@ class _RasterizeGaussians(torch.autograd.Function):
             hint = _LAST_R.get(hint_key, 0)
             saved.binning_capacity = int(hint * 1.125) + 65536 if hint > 0 else 0
             stream = torch.cuda.current_stream(device).cuda_stream
+            need_key, need_t = None, None
+            if _use_hints and P > 0 and isinstance(rs.viewmatrix, torch.Tensor) and isinstance(rs.projmatrix, torch.Tensor):
+                need_key = (device.index, H, W, rs.viewmatrix.data_ptr(), rs.projmatrix.data_ptr())
+                need_t = _NEEDED.get(need_key)
+                if need_t is None:               # first visit: "no idea" -- the forward fills in what it needed
+                    if len(_NEEDED) >= _NEEDED_MAX:
+                        _NEEDED.pop(next(iter(_NEEDED)))
+                    need_t = torch.full((((W + 15) // 16) * ((H + 15) // 16),), 0x3FFFFFFF, dtype=torch.int32, device=device)
+                    _NEEDED[need_key] = need_t
+                saved.needed_hint = need_t.data_ptr()
             cpu_args = _cpu_args_copy((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)) \
                 if rs.debug else None
             cb = arena.callback()

@@ -177,3 +177,29 @@ def test_bench_two_ranks_gloo_transport(tmp_path):
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
     assert res["config"]["gaussians"] == 200000 and "roofline" in res
+
+
+def test_bench_line_contract_single_gpu():
+    """bench.py's one JSON line carries everything the driver and the judge read (N = 1, small workload)."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--gaussians", "150000",
+           "--no-variants"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # ONE JSON line
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "mfragments_per_s",
+              "blended_mfragments_per_s"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "views/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0 < rf["frac"] < 1 and "traffic" in rf
+    assert set(("preprocess", "render_fwd", "render_bwd", "preprocess_bwd", "k_seg_bwd")) <= set(rf["stage_ms"])
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == "views/s"
+    assert d["blended_mfragments_per_s"] < d["mfragments_per_s"]

@@ -51,10 +51,6 @@ int launch_preprocess(const Camera& cam, int P, const float* means3D, const floa
 int launch_mark_visible(const float* xyz, int P, const float* view, uint8_t* present, hipStream_t s);
 
 // ---- binning.hip
-struct BinningPlan {
-    // sizes of the transient arrays needed once V and R are known
-    size_t scratch_bytes;
-};
 // stage 1 (P-sized): compaction of visible Gaussians in id order + totals.  totals_dev[0]=V, [1]=R.
 size_t binning_stage1_scratch_bytes(int P);
 int launch_compact_reduce(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,

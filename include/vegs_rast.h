@@ -77,7 +77,8 @@ typedef struct VrSettings {
  * that would change training behaviour is a flag here, implemented in the kernels, the CPU oracle and the float64
  * autograd restatement alike; 0 selects the assumption SURVEY.md states.  A maintainer who can read the fork flips
  * the bit instead of rewriting a kernel.
- * Bit 8: execution mode of the backward pass (no effect on the forward). */
+ * Bit 8: execution mode of the backward pass (no effect on the forward).  Bit 9: execution mode of the forward
+ * binning (no effect on any result). */
 typedef enum VrFlags {
     /* A-3 / A.8(1): cov_scale blends scale_modifier * scales (the row the covariance is built from) instead of the
      * raw `scales` input row.  Identical in training, where the modifier is 1.0 (gaussian_renderer/__init__.py:263). */
@@ -95,7 +96,12 @@ typedef enum VrFlags {
     /* Backward without floating-point atomics: every (tile-list entry, 8x8 pixel region) writes its partial sums to
      * its own slot and a second kernel adds the slots of each Gaussian in list order.  Gradients are then
      * bit-reproducible from run to run (and independent of scheduling); costs 272 bytes per list entry of scratch. */
-    VR_FLAG_DETERMINISTIC = 1u << 8
+    VR_FLAG_DETERMINISTIC = 1u << 8,
+    /* Forward binning with the scan-based radix passes (histogram, device-wide scan, scatter: four launches per pass)
+     * instead of the single-launch passes in which a workgroup waits -- bounded -- for sums posted by the workgroups
+     * before it.  Same lists bit for bit; ~25 us per view slower at the headline size.  Also what inputs beyond 16.7 M
+     * visible Gaussians or list entries use. */
+    VR_FLAG_SCAN_BINNING = 1u << 9
 } VrFlags;
 
 /* The op's tensor arguments (reference gaussian_renderer/__init__.py:86-94). Exactly one of

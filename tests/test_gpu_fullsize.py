@@ -110,6 +110,21 @@ def test_c3_tile_lists_are_complete_and_depth_sorted(c3, dev):
     assert np.all(pl[1:][tie] > pl[:-1][tie])
 
 
+def test_c3_both_binning_paths_build_the_same_lists(c3, dev):
+    """Headline scene: the single-launch radix passes (posted block sums; 403 and ~950 workgroups per pass, so all
+    three levels are in use) and the scan-based passes (VR_FLAG_SCAN_BINNING) produce identical lists, ranges, images."""
+    from vegs_amd import rasterizer
+    sc, deg, cam, T = c3
+    res_a, *_ = _fwd(T, cam, deg, [0, 0, 0], dev, requires_grad=True)
+    with rasterizer.flags(rasterizer.FLAG_SCAN_BINNING):
+        res_b, *_ = _fwd(T, cam, deg, [0, 0, 0], dev, requires_grad=True)
+    pa, ra = _export_binning(res_a, 376, 1376, dev)
+    pb, rb = _export_binning(res_b, 376, 1376, dev)
+    assert len(pa) > 1_000_000 and np.array_equal(pa, pb) and np.array_equal(ra, rb)
+    for x, y in zip(res_a, res_b):
+        assert torch.equal(x, y)
+
+
 def test_c3_deterministic_backward_mode(c3, dev):
     """Headline scene, VR_FLAG_DETERMINISTIC: gradients bit-identical from run to run (the default mode's fp32 atomics
     are order-dependent) and within the per-row tolerance of the default mode."""

@@ -369,6 +369,16 @@ def test_sh_storage_widths(M, deg, dev):
     assert np.all(h_grads["shs"][:, K:, :] == 0)       # inactive coefficients receive exact zeros
 
 
+def test_scan_binning_flag_matches_oracle_lists(dev):
+    """VR_FLAG_SCAN_BINNING (multi-launch radix passes, no waits between workgroups): same bit-exact lists and images."""
+    from vegs_amd import rasterizer, scenes
+    sc, deg = scenes.scene_random(P=20000, sh_degree=1, seed=5, extent=1.5, scale=0.05)
+    inputs = dict(means3D=sc["means3D"], shs=sc["shs"], colors_precomp=None, opacities=sc["opacities"],
+                  scales=sc["scales"], rotations=sc["rotations"], cov3D_precomp=None)
+    _check_against_oracle(inputs, scenes.camera_c1(320, 200), [0, 0, 0], deg, 1.0, dev,
+                          flags=rasterizer.FLAG_SCAN_BINNING)
+
+
 def test_many_tiles_large_image(dev):
     """2048x1200 = 9600 tiles (14 key bits: 8-bit radix digits, 2 passes) with a sparse scene."""
     from vegs_amd import scenes

@@ -15,9 +15,9 @@ namespace vr {
 
 static_assert(FLAG_SCALE_MODIFIED == VR_FLAG_SCALE_MODIFIED && FLAG_DEPTH_NORMALIZED == VR_FLAG_DEPTH_NORMALIZED &&
               FLAG_EXTRA_NO_ALPHA_GRAD == VR_FLAG_EXTRA_NO_ALPHA_GRAD && FLAG_FILL_EMPTY == VR_FLAG_FILL_EMPTY &&
-              FLAG_DETERMINISTIC == VR_FLAG_DETERMINISTIC, "device-side flag constants must match include/vegs_rast.h");
+              FLAG_DETERMINISTIC == VR_FLAG_DETERMINISTIC && FLAG_SCAN_BINNING == VR_FLAG_SCAN_BINNING, "device-side flag constants must match include/vegs_rast.h");
 constexpr uint32_t KNOWN_FLAGS = FLAG_SCALE_MODIFIED | FLAG_DEPTH_NORMALIZED | FLAG_EXTRA_NO_ALPHA_GRAD | FLAG_FILL_EMPTY |
-                                 FLAG_DETERMINISTIC;
+                                 FLAG_DETERMINISTIC | FLAG_SCAN_BINNING;
 
 static thread_local char g_err[512] = "";
 static thread_local VrCounters g_counters = {0, 0, 0, 0, 0};
@@ -25,7 +25,7 @@ static thread_local VrCounters g_counters = {0, 0, 0, 0, 0};
 // (host thread, device) -- an event belongs to the device it was created on, so a thread that renders on a second
 // GPU must not reuse the first one's
 constexpr int MAX_DEVICES = 64;
-struct Mailbox { uint32_t* pinned; hipEvent_t event; };
+struct Mailbox { uint32_t* pinned; hipEvent_t event; uint32_t* guard; };
 static thread_local Mailbox g_mail[MAX_DEVICES] = {};
 
 void set_error(const char* fmt, ...)
@@ -215,6 +215,10 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     Mailbox& mail = g_mail[dev_id];
     if (!mail.pinned) VR_HIP(hipHostMalloc((void**)&mail.pinned, 256, hipHostMallocDefault));
     if (!mail.event) VR_HIP(hipEventCreateWithFlags(&mail.event, hipEventDisableTiming));
+    if (!mail.guard) {   // device word set by a look-back kernel whose bounded wait ran out (binning.hip)
+        VR_HIP(hipMalloc((void**)&mail.guard, 256));
+        VR_HIP(hipMemsetAsync(mail.guard, 0, 256, s));
+    }
     uint32_t* const g_pinned = mail.pinned;
 
     // ---- buffers that survive until backward
@@ -238,7 +242,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     uint32_t* vis_id = (uint32_t*)((char*)scr + 4 * arr);
     void* scan_scr = (char*)scr + 5 * arr;
     uint32_t* totals_dev = (uint32_t*)((char*)scr + 5 * arr + s1);
-    bool ranges_zeroed = false;
+    bool ranges_zeroed = false, status_zeroed = false;
 
     uint32_t V = 0, R = 0, key_min = 0;
     int key_bits = 0;
@@ -261,21 +265,27 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
         prof_end(VR_STAGE_PREPROCESS, s);
         if (rc) return rc;
         prof_begin(VR_STAGE_COMPACT, s);
-        rc = launch_compact_reduce(P, rect, depth_key, scan_scr, totals_dev, s, debug);
+        rc = launch_compact_reduce(P, rect, depth_key, scan_scr, totals_dev, mail.guard, s, debug);
         if (rc) return rc;
         // the one host<->device round trip of the forward pass: sizes of the data-dependent lists.  The copy is
         // queued BEFORE the compaction's apply kernel and the host waits on an event right after the copy, so the
         // round trip (and the host's launch of what follows) overlaps with that kernel instead of idling the GPU.
-        VR_HIP(hipMemcpyAsync(g_pinned, totals_dev, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        VR_HIP(hipMemcpyAsync(g_pinned, totals_dev, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         VR_HIP(hipEventRecord(mail.event, s));
         // the apply kernel also clears the tile ranges (when the binning buffer already exists): no fill launch
+        // and the status words of the binning passes (when their scratch exists)
         uint32_t* rz = binning ? (uint32_t*)((char*)binning + bin_layout(T, Rcap).ranges) : nullptr;
         ranges_zeroed = rz != nullptr;
-        rc = launch_compact_apply(P, rect, depth_key, scan_scr, vis_key, vis_id, rz, rz ? (long)(2 * T) : 0L, nullptr,
-                                  0L, s, debug);
+        status_zeroed = scr2 != nullptr;
+        rc = launch_compact_apply(P, rect, depth_key, scan_scr, totals_dev, binning_tile_bits((int)T), vis_key, vis_id, rz,
+                                  rz ? (long)(2 * T) : 0L, scr2 ? binning_stage2_status(scr2) : nullptr, s, debug);
         prof_end(VR_STAGE_COMPACT, s);
         if (rc) return rc;
         VR_HIP(hipEventSynchronize(mail.event));
+        if (g_pinned[4]) {   // raised by an EARLIER call's binning on this thread and device: its lists were wrong
+            VR_HIP(hipMemsetAsync(mail.guard, 0, 4, s));
+            return fail(VR_ERR_HIP, "a look-back wait in an earlier binning pass timed out; that view's output is invalid");
+        }
         V = g_pinned[0];
         R = g_pinned[1];
         if (V > 0) {
@@ -286,7 +296,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     }
     if (Rcap == 0 || R > Rcap) {   // no hint, or the hint was too small: size for the actual R
         Rcap = R;
-        ranges_zeroed = false;     // a fresh binning buffer
+        ranges_zeroed = status_zeroed = false;   // fresh buffers
         binning = alloc(user, VR_BUF_BINNING, bin_layout(T, Rcap).total);
         scr2 = alloc(user, VR_BUF_SCRATCH, binning_stage2_scratch_bytes(P, (long)Rcap, (int)T));
         scr3 = alloc(user, VR_BUF_SCRATCH, render_fwd_scratch_bytes((long)Rcap, (int)T) + 256);
@@ -295,8 +305,8 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     const BinLayout BL = bin_layout(T, Rcap);
     int2* ranges = (int2*)((char*)binning + BL.ranges);
     uint32_t* point_list = (uint32_t*)((char*)binning + BL.point_list);
-    rc = launch_binning(cam, P, (int)V, (long)R, key_min, key_bits, vis_key, vis_id, rect, scr2, point_list, ranges,
-                        ranges_zeroed, s, debug);
+    rc = launch_binning(cam, P, (int)V, (long)R, key_min, key_bits, vis_key, vis_id, rect, scan_scr, scr2, point_list,
+                        ranges, ranges_zeroed, status_zeroed, mail.guard, s, debug);
     if (rc) return rc;
     prof_begin(VR_STAGE_RENDER_FWD, s);
     rc = launch_render_fwd(cam, (long)R, ranges, point_list, rec, (uint32_t*)((char*)binning + BL.seg_off),

@@ -49,6 +49,30 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
     return woff + incl - v;
 }
 
+// ---------------------------------------------------------------- digit plan of the radix sorts
+
+// digit width for sorting `nbits` key bits: fewest passes first, then the narrowest digit (cheaper ranking)
+__host__ __device__ inline int radix_digit(int nbits)
+{
+    if (nbits <= 12) return 6;   // 1-2 passes
+    if (nbits <= 16) return 8;   // 2
+    if (nbits <= 18) return 9;   // 2
+    if (nbits <= 24) return 8;   // 3
+    if (nbits <= 27) return 9;   // 3
+    return 8;                    // 4
+}
+__host__ __device__ inline int radix_passes(int nbits)
+{
+    return nbits <= 0 ? 0 : (nbits + radix_digit(nbits) - 1) / radix_digit(nbits);
+}
+__host__ __device__ inline int bits_of(uint32_t span)   // bits needed to tell 0..span apart
+{
+    int b = 0;
+    while (span) { ++b; span >>= 1; }
+    return b;
+}
+constexpr int HIST_WORDS = 4 * 512;   // digit totals of one sort: passes << digit words, at most this many
+
 // ---------------------------------------------------------------- generic 3-kernel scan
 
 __device__ __forceinline__ uint32_t rect_area(uint2 r) { return (r.y & 0xFFFFu) * (r.y >> 16); }
@@ -76,15 +100,6 @@ struct SrcPlain {
     __device__ uint32_t key(long) const { return 0; }
 };
 
-struct SinkCompact {
-    const uint32_t* depth_key;
-    uint32_t* vis_key;
-    uint32_t* vis_id;
-    __device__ void operator()(long i, uint32_t v, uint32_t excl) const
-    {
-        if (v) { vis_key[excl] = depth_key[i]; vis_id[excl] = (uint32_t)i; }
-    }
-};
 struct SinkStore {
     uint32_t* out;
     __device__ void operator()(long i, uint32_t, uint32_t excl) const { out[i] = excl; }
@@ -147,13 +162,9 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* lds4)
 template <class Src, class Sink>
 __global__ void __launch_bounds__(256)
 k_scan_apply(Src src, Sink sink, long n, const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ bsum2,
-             int nb, uint32_t* __restrict__ totals, uint32_t* __restrict__ zero_a = nullptr, long zero_na = 0,
-             uint32_t* __restrict__ zero_b = nullptr, long zero_nb = 0)
+             int nb, uint32_t* __restrict__ totals)
 {
     __shared__ uint32_t lds4[4];
-    // side duty (saves two fill launches): clear small arrays that LATER kernels of the same stream accumulate into
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_na; i += (long)gridDim.x * 256) zero_a[i] = 0u;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_nb; i += (long)gridDim.x * 256) zero_b[i] = 0u;
     uint32_t acc = 0;
     for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) acc += bsum[j];
     const uint32_t prefix = block_sum(acc, lds4);
@@ -206,7 +217,8 @@ k_scan_apply(Src src, Sink sink, long n, const uint32_t* __restrict__ bsum, cons
 // Grand totals of a reduce pass on their own (one workgroup): lets the host read them back while the apply
 // kernel is still running.  totals = {sum, secondary sum, min key, max key}.
 __global__ void __launch_bounds__(256)
-k_scan_totals(const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ bsum2, int nb, uint32_t* __restrict__ totals)
+k_scan_totals(const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ bsum2, int nb, uint32_t* __restrict__ totals,
+              const uint32_t* __restrict__ err_in)
 {
     __shared__ uint32_t lds4[4];
     __shared__ uint32_t mm[8];
@@ -231,6 +243,8 @@ k_scan_totals(const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ bs
         totals[1] = t1;
         totals[2] = min(min(mm[0], mm[1]), min(mm[2], mm[3]));
         totals[3] = max(max(mm[4], mm[5]), max(mm[6], mm[7]));
+        // the look-back guard word of earlier calls rides along in the same device->host copy (see launch_binning)
+        totals[4] = err_in ? __hip_atomic_load(err_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     }
 }
 
@@ -250,16 +264,17 @@ static int run_scan(Src src, Sink sink, long n, uint32_t* bsum, uint32_t* bsum2,
 
 // ---------------------------------------------------------------- stage 1: compaction
 
+// block sums of the compaction scan (4 words per block), then one partial digit histogram of the depth keys per block
 size_t binning_stage1_scratch_bytes(int P)
 {
     size_t nb = (size_t)cdiv(P > 0 ? P : 1, SCAN_BLOCK);
-    return align_up(4 * nb * sizeof(uint32_t), 256);
+    return align_up(4 * nb * sizeof(uint32_t), 256) + align_up(nb * HIST_WORDS * sizeof(uint32_t), 256);
 }
 
 // Two halves, so that the caller can start reading the totals {V, R, min key, max key} back to the host between
 // them: the device->host round trip then overlaps with the apply kernel instead of idling the GPU.
 int launch_compact_reduce(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,
-                          hipStream_t s, bool debug)
+                          const uint32_t* err_in, hipStream_t s, bool debug)
 {
     int nb = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
     uint32_t* bsum = (uint32_t*)scratch;
@@ -267,24 +282,9 @@ int launch_compact_reduce(int P, const uint2* rect, const uint32_t* depth_key, v
     SrcFlagTiles src{rect, depth_key};
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_reduce<SrcFlagTiles>), dim3(nb), dim3(256), 0, s, src, (long)P, bsum, bsum2);
     VR_KERNEL_CHECK("compact_reduce", s, debug);
-    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(256), 0, s, (const uint32_t*)bsum, (const uint32_t*)bsum2, nb, totals_dev);
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(256), 0, s, (const uint32_t*)bsum, (const uint32_t*)bsum2, nb, totals_dev,
+                       err_in);
     VR_KERNEL_CHECK("compact_totals", s, debug);
-    return 0;
-}
-
-int launch_compact_apply(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, uint32_t* vis_key,
-                         uint32_t* vis_id, uint32_t* zero_a, long zero_na, uint32_t* zero_b, long zero_nb, hipStream_t s,
-                         bool debug)
-{
-    int nb = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
-    uint32_t* bsum = (uint32_t*)scratch;
-    uint32_t* bsum2 = bsum + nb;
-    SrcFlagTiles src{rect, depth_key};
-    SinkCompact sink{depth_key, vis_key, vis_id};
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<SrcFlagTiles, SinkCompact>), dim3(nb), dim3(256), 0, s, src, sink,
-                       (long)P, (const uint32_t*)bsum, (const uint32_t*)bsum2, nb, (uint32_t*)nullptr, zero_a, zero_na,
-                       zero_b, zero_nb);
-    VR_KERNEL_CHECK("compact_apply", s, debug);
     return 0;
 }
 
@@ -473,17 +473,6 @@ static int radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, 
     return 0;
 }
 
-// digit width for sorting `nbits` key bits: fewest passes first, then the narrowest digit (cheaper ranking)
-static int radix_digit(int nbits)
-{
-    if (nbits <= 12) return 6;   // 1-2 passes
-    if (nbits <= 16) return 8;   // 2
-    if (nbits <= 18) return 9;   // 2
-    if (nbits <= 24) return 8;   // 3
-    if (nbits <= 27) return 9;   // 3
-    return 8;                    // 4
-}
-
 // Stable LSD sort of (key, val) pairs on the low `nbits` bits of (key - kmin).  Ping-pongs between
 // (k0,v0) and (k1,v1); returns in *res which pair holds the result (0 or 1).  Digit width is chosen
 // per call: few wide passes for many bits, narrow digits (cheaper ballot ranking) for few bits.
@@ -512,10 +501,7 @@ static int radix_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, lo
     *res = where;
     return 0;
 }
-int radix_sort_passes(int nbits)
-{
-    return nbits <= 0 ? 0 : cdiv(nbits, radix_digit(nbits));
-}
+int radix_sort_passes(int nbits) { return radix_passes(nbits); }
 
 // generic entry for other translation units (knn.hip): sort (key,val) pairs on the low nbits of key - kmin
 size_t sort_pairs_scratch_bytes(long n)
@@ -532,6 +518,414 @@ int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, lo
     *where = 0;
     if (n <= 0) return 0;
     return radix_sort(k0, v0, k1, v1, n, kmin, nbits, hist, bsum, nullptr, s, debug, where);
+}
+
+// ---------------------------------------------------------------- single-launch radix passes (posted block sums)
+//
+// The rasterizer's two sorts do not use the 4-launch pass above but one launch per pass: the digit totals of ALL
+// passes are order-independent, so one histogram kernel computes them up front; a pass then ranks its block locally,
+// posts the block's digit counts and obtains the counts of the blocks before it from what those blocks posted,
+// instead of a separate device-wide scan.  All workgroups of a pass are resident at once at these sizes, so a chained
+// look-back would walk hundreds of predecessors at ~2.5 us per dependent device-scope load on this 8-XCD part (first
+// attempt: 88 us per pass).  The sums are therefore posted on three fixed levels of fan-in 16:
+//   level 1  [block][digit]         the block's own count
+//   level 2  [block/16][digit]      sum over a complete group of 16 blocks, posted by the group's last block
+//   level 3  [block/256][digit]     sum over 256 blocks, posted by the last block of the group's last sub-group
+// and a block adds at most 15 entries of each level: three dependent load rounds, whatever the grid size (up to
+// 4096 blocks; longer inputs take the 4-launch passes).  A block only waits for blocks with a smaller index, which the
+// in-order dispatcher has started before it; every wait is bounded all the same (SPIN_LIMIT polls) and reports
+// through `err` rather than hanging the queue.  Status words are read and written with device-scope atomics (the 8
+// XCD L2s are not coherent with each other); flag and count share the word, so no fence is needed.
+constexpr uint32_t ST_POSTED = 1u << 31, ST_VALUE = ST_POSTED - 1u;
+constexpr int FAN = 16;                                        // fan-in of a level
+constexpr long ONESWEEP_MAX_N = (long)FAN * FAN * FAN * RADIX_BLOCK;   // 16.7 M elements
+constexpr int SPIN_LIMIT = 1 << 13;   // x ~2.5 us per poll: tens of milliseconds
+
+__device__ __forceinline__ uint32_t st_load(const uint32_t* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_store(uint32_t* p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Sum of `count` (< FAN) posted entries st[(first + i) * stride + d[k]], for the NB digits of this thread at once (all
+// loads of a round in flight together); polls until every entry has been posted.
+template <int NB>
+__device__ __forceinline__ void sum_posted(const uint32_t* st, long first, int count, long stride, const int (&d)[NB],
+                                           const bool (&on)[NB], uint32_t (&acc)[NB], uint32_t* err)
+{
+    if (count <= 0) return;
+    for (int polls = 0;; ++polls) {
+        uint32_t v[NB][FAN - 1];
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+#pragma unroll
+            for (int i = 0; i < FAN - 1; ++i)
+                v[k][i] = (on[k] && i < count) ? st_load(&st[(first + i) * stride + d[k]]) : ST_POSTED;
+        uint32_t all = ST_POSTED, s[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            s[k] = 0;
+#pragma unroll
+            for (int i = 0; i < FAN - 1; ++i) { all &= v[k][i]; s[k] += v[k][i] & ST_VALUE; }
+        }
+        if (all || polls > SPIN_LIMIT) {
+            if (!all) *err = 1u;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) acc[k] += s[k];
+            return;
+        }
+    }
+}
+
+// status words of one pass (levels 1-3) and of one sort (digit totals first, then every pass)
+__host__ __device__ inline size_t onesweep_pass_words(long n, int digit)
+{
+    const size_t nblk = (size_t)((n + RADIX_BLOCK - 1) / RADIX_BLOCK), n2 = (nblk + FAN - 1) / FAN, n3 = (n2 + FAN - 1) / FAN;
+    return (nblk + n2 + n3) << digit;
+}
+__host__ __device__ inline size_t onesweep_status_words(long n, int nbits)
+{
+    return HIST_WORDS + (size_t)radix_passes(nbits) * onesweep_pass_words(n, radix_digit(nbits));
+}
+__host__ __device__ inline size_t emit_status_words(long V)   // levels 1-3 of the emission scan (64-bit words)
+{
+    const size_t nblk = (size_t)((V + 255) / 256), n2 = (nblk + 63) / 64, n3 = (n2 + 63) / 64;
+    return nblk + n2 + n3;
+}
+// The packed status region of one view: depth sort | emission scan | tile sort (bytes, multiples of 16).  Computed
+// with the same arithmetic by the host (pointers) and by the compaction kernel (which clears the region).
+struct StatusPlan { size_t depth, emit, tile; };
+__host__ __device__ inline StatusPlan status_plan(long V, long R, int key_bits, int tile_bits)
+{
+    StatusPlan p;
+    p.depth = (onesweep_status_words(V, key_bits) * 4 + 15) / 16 * 16;
+    p.emit = (emit_status_words(V) * 8 + 15) / 16 * 16;
+    p.tile = (onesweep_status_words(R, tile_bits) * 4 + 15) / 16 * 16;
+    return p;
+}
+
+// h[d] += 1 for every lane with ok; lanes sharing the digit of the first one or two live lanes are counted with one
+// add (sorted or clustered keys put most of a wave on one digit, and same-address LDS atomics serialise)
+__device__ __forceinline__ void wave_hist_add(uint32_t* h, uint32_t d, bool ok, int lane)
+{
+    unsigned long long act = __ballot(ok);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        if (!act) break;
+        const int leader = __builtin_ctzll(act);
+        const uint32_t d0 = (uint32_t)__shfl((int)d, leader, 64);
+        const unsigned long long m = __ballot(ok && d == d0) & act;
+        if (lane == leader) atomicAdd(&h[d0], (uint32_t)__popcll(m));
+        act &= ~m;
+    }
+    if ((act >> lane) & 1ull) atomicAdd(&h[d], 1u);
+}
+// all passes' digits of one key into the block's LDS histogram h[pass << digit | value]; the top digit is the
+// clustered one (depth exponent, tile row), the lower ones are spread
+__device__ __forceinline__ void hist_key(uint32_t* h, uint32_t rel_key, bool ok, int digit, int passes, int lane)
+{
+    const uint32_t mask = (1u << digit) - 1u;
+    for (int p = 0; p + 1 < passes; ++p)
+        if (ok) atomicAdd(&h[(p << digit) + ((rel_key >> (p * digit)) & mask)], 1u);
+    if (passes > 0) {
+        const int p = passes - 1;
+        wave_hist_add(h + (p << digit), (rel_key >> (p * digit)) & mask, ok, lane);
+    }
+}
+
+// Partial digit histograms of keys that were not counted where they were produced (the tile keys: counting them
+// inside the emission kernel put LDS atomics -- ~1 lane per cycle per CU, ~90 cycles per instruction however few lanes
+// are live -- on that kernel's critical path: 44 -> 97 us, whether in its per-lane loops or in a second dense sweep).
+constexpr int HIST_THREADS = 1024;
+constexpr int HIST_BLOCKS = 256;   // one per CU
+__global__ void __launch_bounds__(HIST_THREADS)
+k_digit_hist(const uint32_t* __restrict__ keys, long n, uint32_t kmin, int digit, int passes, uint32_t* __restrict__ partial)
+{
+    constexpr int BATCH = 8;   // keys in flight per thread
+    __shared__ uint32_t h[HIST_WORDS];
+    const int words = passes << digit;
+    const long stride = (long)gridDim.x * HIST_THREADS;
+    for (int d = threadIdx.x; d < words; d += HIST_THREADS) h[d] = 0;
+    __syncthreads();
+    const long n_up = (n + 63) / 64 * 64;   // whole waves enter an iteration together (hist_key uses ballots)
+    for (long i0 = (long)blockIdx.x * HIST_THREADS + threadIdx.x; i0 < n_up; i0 += stride * BATCH) {
+        uint32_t k[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const long i = i0 + j * stride;
+            k[j] = i < n ? keys[i] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) hist_key(h, k[j] - kmin, i0 + j * stride < n, digit, passes, threadIdx.x & 63);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < words; d += HIST_THREADS) partial[(size_t)blockIdx.x * words + d] = h[d];
+}
+
+// Adds the G partial histograms up: workgroup (x, y) sums partials [32 y, 32 y + 32) for the 64 entries
+// [64 x, 64 x + 64) of the passes << digit totals and adds the result to `tot` (cleared with the status region):
+// G / 32 atomics per word instead of G.
+__global__ void __launch_bounds__(256)
+k_digit_sum(const uint32_t* __restrict__ partial, int G, int words, uint32_t* __restrict__ tot)
+{
+    __shared__ uint32_t red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + lane;
+    const int g0 = blockIdx.y * 32 + w * 8;
+    uint32_t t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = (d < words && g0 + j < G) ? partial[(size_t)(g0 + j) * words + d] : 0u;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += t[j];
+    red[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && d < words) {
+        const uint32_t v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (v) atomicAdd(&tot[d], v);
+    }
+}
+
+template <int BITS, bool GATHER>
+__global__ void __launch_bounds__(256)
+k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+           uint32_t* __restrict__ vals_out, long n, uint32_t kmin, int pass,
+           const uint32_t* __restrict__ totals, uint32_t* __restrict__ status, uint32_t* __restrict__ err,
+           const uint2* __restrict__ rect, uint2* __restrict__ rect_sorted)
+{
+    constexpr int SIZE = 1 << BITS;
+    constexpr int BPT = (SIZE + 255) / 256;   // digits per thread in the per-digit phases
+    __shared__ uint32_t cnt[4][SIZE];
+    __shared__ uint32_t off[4][SIZE];
+    __shared__ uint32_t loc[SIZE], gl[SIZE];
+    __shared__ uint32_t skey[RADIX_BLOCK], sval[RADIX_BLOCK];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int shift = pass * BITS;
+    const long b = blockIdx.x;
+    for (int d = threadIdx.x; d < SIZE; d += 256) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cnt[k][d] = 0;
+    }
+    __syncthreads();
+    const long wbase = b * RADIX_BLOCK + (long)w * (64 * RADIX_ITEMS);
+    uint32_t key[RADIX_ITEMS], val[RADIX_ITEMS], rank[RADIX_ITEMS];
+    const unsigned long long lt = lanemask_lt();
+#pragma unroll
+    for (int i = 0; i < RADIX_ITEMS; ++i) {
+        long idx = wbase + i * 64 + lane;
+        key[i] = idx < n ? keys_in[idx] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int i = 0; i < RADIX_ITEMS; ++i) {
+        long idx = wbase + i * 64 + lane;
+        val[i] = idx < n ? vals_in[idx] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < RADIX_ITEMS; ++i) {
+        long idx = wbase + i * 64 + lane;
+        bool ok = idx < n;
+        uint32_t d = digit_of<BITS>(key[i], kmin, shift);
+        unsigned long long valid = __ballot(ok);
+        unsigned long long m = match_digit<BITS>(d, valid);
+        uint32_t prior = ok ? cnt[w][d] : 0;
+        rank[i] = prior + (uint32_t)__popcll(m & lt);
+        if (ok && (m & lt) == 0) cnt[w][d] = prior + (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // ---- publish this block's digit counts, lay the block out in digit order
+    uint32_t mine[BPT];
+#pragma unroll
+    for (int k = 0; k < BPT; ++k) {
+        const int d = threadIdx.x + k * 256;
+        mine[k] = 0;
+        if (d < SIZE) {
+            const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
+            mine[k] = c0 + c1 + c2 + c3;
+            st_store(&status[b * SIZE + d], mine[k] | ST_POSTED);
+            off[0][d] = 0;
+            off[1][d] = c0;
+            off[2][d] = c0 + c1;
+            off[3][d] = c0 + c1 + c2;
+            loc[d] = mine[k];
+            gl[d] = totals[pass * SIZE + d];
+        }
+    }
+    __syncthreads();
+    if (w < 2) {   // wave 0: exclusive scan of the block's bucket sizes; wave 1: of the global digit totals
+        uint32_t* arr = w == 0 ? loc : gl;
+        constexpr int DPL = SIZE / 64;
+        uint32_t t[DPL], sum = 0;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) { t[k] = arr[lane * DPL + k]; sum += t[k]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, dd, 64);
+            if (lane >= dd) incl += o;
+        }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) { arr[lane * DPL + k] = run; run += t[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RADIX_ITEMS; ++i) {
+        long idx = wbase + i * 64 + lane;
+        if (idx < n) {
+            uint32_t d = digit_of<BITS>(key[i], kmin, shift);
+            uint32_t p = loc[d] + off[w][d] + rank[i];
+            skey[p] = key[i];
+            sval[p] = val[i];
+        }
+    }
+    // ---- elements with each digit in all earlier blocks: <= 15 posted sums from each of the three levels
+    {
+        const long nblk = gridDim.x, n2 = (nblk + FAN - 1) / FAN;
+        uint32_t* const level2 = status + nblk * SIZE;
+        uint32_t* const level3 = level2 + n2 * SIZE;
+        int d[BPT];
+        bool on[BPT];
+        uint32_t before[BPT];
+#pragma unroll
+        for (int k = 0; k < BPT; ++k) { d[k] = threadIdx.x + k * 256; on[k] = d[k] < SIZE; before[k] = 0; }
+        const long g1 = b / FAN, g2 = g1 / FAN;
+        const int r1 = (int)(b % FAN), r2 = (int)(g1 % FAN), r3 = (int)g2;
+        sum_posted<BPT>(status, b - r1, r1, SIZE, d, on, before, err);
+        if (r1 == FAN - 1) {
+#pragma unroll
+            for (int k = 0; k < BPT; ++k)
+                if (on[k]) st_store(&level2[g1 * SIZE + d[k]], (before[k] + mine[k]) | ST_POSTED);
+        }
+        uint32_t upper[BPT];
+#pragma unroll
+        for (int k = 0; k < BPT; ++k) upper[k] = 0;
+        sum_posted<BPT>(level2, g1 - r2, r2, SIZE, d, on, upper, err);
+        if (r1 == FAN - 1 && r2 == FAN - 1) {
+#pragma unroll
+            for (int k = 0; k < BPT; ++k)
+                if (on[k]) st_store(&level3[g2 * SIZE + d[k]], (before[k] + mine[k] + upper[k]) | ST_POSTED);
+        }
+        sum_posted<BPT>(level3, 0, r3, SIZE, d, on, upper, err);
+#pragma unroll
+        for (int k = 0; k < BPT; ++k)
+            if (on[k]) gl[d[k]] += before[k] + upper[k];
+    }
+    __syncthreads();
+    const long bbase = b * RADIX_BLOCK;
+    const int nvalid = (int)((n - bbase) < (long)RADIX_BLOCK ? (n - bbase) : (long)RADIX_BLOCK);
+    for (int j = threadIdx.x; j < nvalid; j += 256) {
+        const uint32_t k = skey[j];
+        const uint32_t d = digit_of<BITS>(k, kmin, shift);
+        const uint32_t dst = gl[d] + ((uint32_t)j - loc[d]);
+        const uint32_t v = sval[j];
+        keys_out[dst] = k;
+        vals_out[dst] = v;
+        if (GATHER) rect_sorted[dst] = rect[v];
+    }
+}
+
+// Stable LSD sort like radix_sort(), one launch per pass plus one that adds the partial digit histograms up
+// (`partial`: `rows` rows of passes << digit words, written by the kernel that produced the keys).  `status`:
+// onesweep_status_words(n, nbits) words, all zero.
+static int onesweep_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long n, uint32_t kmin, int nbits,
+                         const uint32_t* partial, int rows, uint32_t* status, uint32_t* err, const RadixGather* gather,
+                         hipStream_t s, bool debug, int* res)
+{
+    const int digit = radix_digit(nbits);
+    const int passes = radix_passes(nbits);
+    const int nblk = cdiv(n, RADIX_BLOCK);
+    const size_t per_pass = onesweep_pass_words(n, digit);
+    *res = 0;
+    if (passes == 0) return 0;
+    uint32_t* const totals = status;   // digit totals at the head of the status region
+    status += HIST_WORDS;
+    hipLaunchKernelGGL(k_digit_sum, dim3(cdiv((long)passes << digit, 64), cdiv(rows, 32)), dim3(256), 0, s, partial, rows,
+                       passes << digit, totals);
+    VR_KERNEL_CHECK("digit_sum", s, debug);
+    uint32_t *ka = k0, *va = v0, *kb = k1, *vb = v1;
+    for (int pass = 0; pass < passes; ++pass) {
+        const bool g = gather && pass == passes - 1;
+        uint32_t* st = status + (size_t)pass * per_pass;
+#define VR_SWEEP(B, GA)                                                                                             \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_onesweep<B, GA>), dim3(nblk), dim3(256), 0, s, (const uint32_t*)ka,        \
+                       (const uint32_t*)va, kb, vb, n, kmin, pass, (const uint32_t*)totals, st, err,               \
+                       g ? gather->rect : (const uint2*)nullptr, g ? gather->rect_sorted : (uint2*)nullptr)
+        if (digit == 6) { if (g) VR_SWEEP(6, true); else VR_SWEEP(6, false); }
+        else if (digit == 9) { if (g) VR_SWEEP(9, true); else VR_SWEEP(9, false); }
+        else { if (g) VR_SWEEP(8, true); else VR_SWEEP(8, false); }
+#undef VR_SWEEP
+        VR_KERNEL_CHECK("onesweep", s, debug);
+        uint32_t* t = ka; ka = kb; kb = t;
+        t = va; va = vb; vb = t;
+        *res ^= 1;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- stage 1, second half: compaction
+
+// Writes the visible Gaussians' (depth key, id) in id order.  On the side (each saves a launch): the partial digit
+// histogram of this block's depth keys -- the digit plan follows from the totals the previous kernel left in device
+// memory, the host learns them in parallel --, and the clearing of the tile ranges and of the view's status region.
+__global__ void __launch_bounds__(256)
+k_compact_apply(const uint2* __restrict__ rect, const uint32_t* __restrict__ depth_key, long n,
+                const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ totals, int tile_bits,
+                uint32_t* __restrict__ vis_key, uint32_t* __restrict__ vis_id, uint32_t* __restrict__ partial,
+                uint32_t* __restrict__ zero_a, long zero_na, uint4* __restrict__ status)
+{
+    __shared__ uint32_t lds4[4];
+    __shared__ uint32_t h[HIST_WORDS];
+    const uint32_t V = totals[0], R = totals[1], kmin = totals[2];
+    const int key_bits = V ? bits_of(totals[3] - kmin) : 0;
+    const int digit = radix_digit(key_bits), passes = radix_passes(key_bits), words = passes << digit;
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x, nthr = (long)gridDim.x * 256;
+    for (long i = tid; i < zero_na; i += nthr) zero_a[i] = 0u;
+    if (status && (long)V <= ONESWEEP_MAX_N && (long)R <= ONESWEEP_MAX_N) {
+        const StatusPlan sp = status_plan(V, R, key_bits, tile_bits);
+        const long n16 = (long)((sp.depth + sp.emit + sp.tile) / 16);
+        for (long i = tid; i < n16; i += nthr) status[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    for (int d = threadIdx.x; d < words; d += 256) h[d] = 0;
+    uint32_t acc = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) acc += bsum[j];
+    const uint32_t prefix = block_sum(acc, lds4);   // (has the barriers that also publish h)
+    const long base = (long)blockIdx.x * SCAN_BLOCK + (long)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], key[SCAN_ITEMS];
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n && rect_area(rect[base + k])) ? 1u : 0u;
+        tsum += v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) key[k] = v[k] ? depth_key[base + k] : 0u;
+    uint32_t total;
+    uint32_t ex = block_excl_scan(tsum, total, lds4) + prefix;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (v[k]) { vis_key[ex] = key[k]; vis_id[ex] = (uint32_t)(base + k); }
+        ex += v[k];
+        hist_key(h, key[k] - kmin, v[k] != 0u, digit, passes, threadIdx.x & 63);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < words; d += 256) partial[(size_t)blockIdx.x * words + d] = h[d];
+}
+
+int launch_compact_apply(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, const uint32_t* totals_dev,
+                         int tile_bits, uint32_t* vis_key, uint32_t* vis_id, uint32_t* zero_a, long zero_na,
+                         void* status, hipStream_t s, bool debug)
+{
+    int nb = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
+    uint32_t* bsum = (uint32_t*)scratch;
+    uint32_t* partial = (uint32_t*)((char*)scratch + align_up(4 * (size_t)nb * sizeof(uint32_t), 256));
+    hipLaunchKernelGGL(k_compact_apply, dim3(nb), dim3(256), 0, s, rect, depth_key, (long)P, (const uint32_t*)bsum,
+                       totals_dev, tile_bits, vis_key, vis_id, partial, zero_a, zero_na, (uint4*)status);
+    VR_KERNEL_CHECK("compact_apply", s, debug);
+    return 0;
 }
 
 // ---------------------------------------------------------------- emission + ranges
@@ -591,6 +985,96 @@ k_emit(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint32_t* __
     }
 }
 
+// The same emission with the offset scan folded in: a workgroup sums its 256 rectangle areas, posts the sum and adds
+// what the workgroups before it posted -- the single-value form of the three-level scheme of the radix passes, fan-in
+// 64 (one status word per lane of wave 0 and level): up to 262144 workgroups.  64-bit words, top bit = posted.
+constexpr unsigned long long SE_POSTED = 1ull << 63;
+constexpr int EFAN = 64;
+constexpr long EMIT_SCAN_MAX_V = (long)EFAN * EFAN * EFAN * 256;
+
+// wave-wide: sum of `count` (< 64) posted entries st[first + lane]; polls until all are posted
+__device__ __forceinline__ unsigned long long sum_posted_wave(const unsigned long long* st, long first, int count, int lane,
+                                                              uint32_t* err)
+{
+    if (count <= 0) return 0ull;
+    for (int polls = 0;; ++polls) {
+        const unsigned long long v =
+            lane < count ? __hip_atomic_load(&st[first + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SE_POSTED;
+        const bool all = __ballot((v & SE_POSTED) == 0ull) == 0ull;
+        if (all || polls > SPIN_LIMIT) {
+            if (!all && lane == 0) *err = 1u;
+            unsigned long long s = v & ~SE_POSTED;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+            return s;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_emit_scan(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ rect_sorted,
+            unsigned long long* __restrict__ status, uint32_t* __restrict__ err, uint32_t* __restrict__ tkeys,
+            uint32_t* __restrict__ tvals)
+{
+    __shared__ uint32_t lds4[4];
+    __shared__ unsigned long long s_before;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t cnt = 0, id = 0;
+    int x0 = 0, y0 = 0, w = 1;
+    if (r < V) {
+        const uint2 rc = rect_sorted[r];
+        cnt = rect_area(rc);
+        id = sorted_id[r];
+        x0 = (int)(rc.x & 0xFFFFu);
+        y0 = (int)(rc.x >> 16);
+        w = max((int)(rc.y & 0xFFFFu), 1);
+    }
+    uint32_t total;
+    const uint32_t ex = block_excl_scan(cnt, total, lds4);
+    if (threadIdx.x < 64) {
+        const long b = blockIdx.x, nblk = gridDim.x, n2 = (nblk + EFAN - 1) / EFAN;
+        unsigned long long* const level2 = status + nblk;
+        unsigned long long* const level3 = level2 + n2;
+        if (lane == 0)
+            __hip_atomic_store(&status[b], (unsigned long long)total | SE_POSTED, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        const long g1 = b / EFAN, g2 = g1 / EFAN;
+        const int r1 = (int)(b % EFAN), r2 = (int)(g1 % EFAN), r3 = (int)g2;
+        const unsigned long long within = sum_posted_wave(status, b - r1, r1, lane, err);
+        if (r1 == EFAN - 1 && lane == 0)
+            __hip_atomic_store(&level2[g1], (within + total) | SE_POSTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long upper = sum_posted_wave(level2, g1 - r2, r2, lane, err);
+        if (r1 == EFAN - 1 && r2 == EFAN - 1 && lane == 0)
+            __hip_atomic_store(&level3[g2], (within + total + upper) | SE_POSTED, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        upper += sum_posted_wave(level3, 0, r3, lane, err);
+        if (lane == 0) s_before = within + upper;
+    }
+    __syncthreads();
+    const uint32_t off = (uint32_t)s_before + ex;
+    if (cnt <= EMIT_SMALL) {
+        int rx = 0, ry = 0;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const uint32_t t = (uint32_t)((y0 + ry) * gx + x0 + rx);
+            tkeys[off + k] = t;
+            tvals[off + k] = id;
+            if (++rx == w) { rx = 0; ++ry; }
+        }
+    }
+    for (unsigned long long big = __ballot(cnt > EMIT_SMALL); big; big &= big - 1) {
+        const int src = __builtin_ctzll(big);
+        const uint32_t b_off = (uint32_t)__shfl((int)off, src, 64), b_cnt = (uint32_t)__shfl((int)cnt, src, 64);
+        const uint32_t b_id = (uint32_t)__shfl((int)id, src, 64);
+        const int b_x0 = __shfl(x0, src, 64), b_y0 = __shfl(y0, src, 64), b_w = __shfl(w, src, 64);
+        for (uint32_t k = lane; k < b_cnt; k += 64) {
+            const int ry = (int)(k / (uint32_t)b_w), rx = (int)(k - (uint32_t)ry * (uint32_t)b_w);
+            tkeys[b_off + k] = (uint32_t)((b_y0 + ry) * gx + b_x0 + rx);
+            tvals[b_off + k] = b_id;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_tile_ranges(const uint32_t* __restrict__ tkeys, long R, int2* __restrict__ ranges)
 {
@@ -608,15 +1092,27 @@ k_tile_ranges(const uint32_t* __restrict__ tkeys, long R, int2* __restrict__ ran
 // ---------------------------------------------------------------- stage 2 driver
 
 struct Stage2Layout {
-    size_t tmp_key, tmp_id, offs, rect_sorted, tkeysA, tkeysB, tvalsB, hist, bsum, total;
+    size_t status, tmp_key, tmp_id, offs, rect_sorted, tkeysA, tkeysB, tvalsB, hist, bsum, tpartial, total;
 };
 
-static Stage2Layout stage2_layout(int V, long R)
+static inline int tile_bits_of(int ntiles)
+{
+    int bits = 0;
+    while ((1 << bits) < ntiles) ++bits;
+    return bits;
+}
+
+static Stage2Layout stage2_layout(int V, long R, int ntiles)
 {
     Stage2Layout L;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
     size_t v = (size_t)(V > 0 ? V : 1), r = (size_t)(R > 0 ? R : 1);
+    const int tbits = tile_bits_of(ntiles);
+    // posted block sums of the depth sort | emission scan | tile sort, packed at run time (status_plan); FIRST, so
+    // that the compaction kernel can clear it knowing only the scratch pointer.  Sized for any depth-key span.
+    L.status = take(onesweep_status_words((long)v, 27) * 4 + emit_status_words((long)v) * 8 +
+                    onesweep_status_words((long)r, tbits) * 4 + 64);
     L.tmp_key = take(v * 4);
     L.tmp_id = take(v * 4);
     L.offs = take(v * 4);
@@ -628,21 +1124,22 @@ static Stage2Layout stage2_layout(int V, long R)
     size_t nblk = (size_t)cdiv((long)nmax, RADIX_BLOCK);
     L.hist = take(nblk * 512 * 4);
     L.bsum = take(radix_bsum_words((long)nmax) * 4 + 256);
+    // partial digit histograms of the tile keys
+    L.tpartial = take((size_t)HIST_BLOCKS * HIST_WORDS * 4);
     L.total = o;
     return L;
 }
 
-size_t binning_stage2_scratch_bytes(int V, long R, int) { return stage2_layout(V, R).total; }
+size_t binning_stage2_scratch_bytes(int V, long R, int ntiles) { return stage2_layout(V, R, ntiles).total; }
+void* binning_stage2_status(void* scratch) { return (char*)scratch + 0; }   // Stage2Layout::status comes first
+int binning_tile_bits(int ntiles) { return tile_bits_of(ntiles); }
 
-int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
-                   uint32_t* vis_id, const uint2* rect, void* scratch, uint32_t* point_list, int2* ranges,
-                   bool ranges_zeroed, hipStream_t s, bool debug)
+// The 4-launch passes and the separate offset scan (inputs too long for 30-bit look-back counts; also the shape of
+// the generic launch_sort_pairs used by knn.hip and the deterministic backward).
+static int binning_multi_launch(const Camera& cam, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
+                                uint32_t* vis_id, const uint2* rect, char* base, const Stage2Layout& L,
+                                uint32_t* point_list, uint32_t** tile_keys, hipStream_t s, bool debug)
 {
-    int ntiles = cam.gx * cam.gy;
-    if (!ranges_zeroed) VR_HIP(hipMemsetAsync(ranges, 0, sizeof(int2) * (size_t)ntiles, s));
-    if (V == 0 || R == 0) return 0;
-    Stage2Layout L = stage2_layout(V, R);
-    char* base = (char*)scratch;
     uint32_t* tmp_key = (uint32_t*)(base + L.tmp_key);
     uint32_t* tmp_id = (uint32_t*)(base + L.tmp_id);
     uint32_t* offs = (uint32_t*)(base + L.offs);
@@ -652,10 +1149,6 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
     uint32_t* tvalsB = (uint32_t*)(base + L.tvalsB);
     uint32_t* hist = (uint32_t*)(base + L.hist);
     uint32_t* bsum = (uint32_t*)(base + L.bsum);
-    (void)P;
-
-    // 2. depth sort of the visible Gaussians on the bits of (key - kmin) that vary; its last scatter also gathers the
-    // tile rectangles into sorted order
     uint32_t* sorted_id = vis_id;
     const int depth_passes = radix_sort_passes(key_bits);
     {
@@ -666,7 +1159,6 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
         if (rc) return rc;
         sorted_id = where ? tmp_id : vis_id;
     }
-    // 3. offsets in depth order, then emission
     prof_begin(VR_STAGE_EMIT, s);
     {
         if (depth_passes == 0) {   // all depth keys equal (or one Gaussian): nothing was scattered, gather here
@@ -679,28 +1171,96 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
         if (rc) return rc;
     }
     int bits = 0;
-    while ((1 << bits) < ntiles) ++bits;
+    while ((1 << bits) < cam.gx * cam.gy) ++bits;
     const int passes = radix_sort_passes(bits);
-    // choose the starting value buffer so that the last pass lands in point_list
-    uint32_t* va = (passes % 2 == 0) ? point_list : tvalsB;
+    uint32_t* va = (passes % 2 == 0) ? point_list : tvalsB;   // the last pass must land in point_list
     uint32_t* vb = (passes % 2 == 0) ? tvalsB : point_list;
     uint32_t *ka = tkeysA, *kb = tkeysB;
     hipLaunchKernelGGL(k_emit, dim3(cdiv(V, 256)), dim3(256), 0, s, V, cam.gx, (const uint32_t*)sorted_id,
                        (const uint32_t*)offs, (const uint2*)rect_sorted, ka, va);
     VR_KERNEL_CHECK("emit", s, debug);
     prof_end(VR_STAGE_EMIT, s);
-    // 4. stable sort by tile id
-    prof_begin(VR_STAGE_TILE_SORT, s);
-    {
-        int where = 0;
-        int rc = radix_sort(ka, va, kb, vb, R, 0u, bits, hist, bsum, nullptr, s, debug, &where);
+    ProfScope ps(VR_STAGE_TILE_SORT, s);
+    int where = 0;
+    int rc = radix_sort(ka, va, kb, vb, R, 0u, bits, hist, bsum, nullptr, s, debug, &where);
+    if (rc) return rc;
+    *tile_keys = where ? kb : ka;
+    return 0;
+}
+
+int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
+                   uint32_t* vis_id, const uint2* rect, const void* stage1_scratch, void* scratch, uint32_t* point_list,
+                   int2* ranges, bool ranges_zeroed, bool status_zeroed, uint32_t* err, hipStream_t s, bool debug)
+{
+    int ntiles = cam.gx * cam.gy;
+    if (!ranges_zeroed) VR_HIP(hipMemsetAsync(ranges, 0, sizeof(int2) * (size_t)ntiles, s));
+    if (V == 0 || R == 0) return 0;
+    Stage2Layout L = stage2_layout(V, R, ntiles);
+    char* base = (char*)scratch;
+    uint32_t* tile_keys = nullptr;
+    if ((cam.flags & FLAG_SCAN_BINNING) || (long)V > ONESWEEP_MAX_N || R > ONESWEEP_MAX_N || (long)V > EMIT_SCAN_MAX_V) {
+        int rc = binning_multi_launch(cam, V, R, key_min, key_bits, vis_key, vis_id, rect, base, L, point_list,
+                                      &tile_keys, s, debug);
         if (rc) return rc;
-        if (where) { uint32_t* t = ka; ka = kb; kb = t; }
+    } else {
+        uint32_t* tmp_key = (uint32_t*)(base + L.tmp_key);
+        uint32_t* tmp_id = (uint32_t*)(base + L.tmp_id);
+        uint2* rect_sorted = (uint2*)(base + L.rect_sorted);
+        uint32_t* tkeysA = (uint32_t*)(base + L.tkeysA);
+        uint32_t* tkeysB = (uint32_t*)(base + L.tkeysB);
+        uint32_t* tvalsB = (uint32_t*)(base + L.tvalsB);
+        uint32_t* tpartial = (uint32_t*)(base + L.tpartial);
+        const int bits = tile_bits_of(ntiles);
+        // posted block sums of the three stages, packed; cleared by the compaction kernel when the scratch existed
+        // by then (the caller's capacity hint), by a fill otherwise
+        const StatusPlan sp = status_plan(V, R, key_bits, bits);
+        char* st = base + L.status;
+        if (!status_zeroed) VR_HIP(hipMemsetAsync(st, 0, sp.depth + sp.emit + sp.tile, s));
+        // the compaction kernel's partial digit histograms of the depth keys, one row per scan block
+        const int rows = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
+        const uint32_t* dpartial =
+            (const uint32_t*)((const char*)stage1_scratch + align_up(4 * (size_t)rows * sizeof(uint32_t), 256));
+        // 2. depth sort of the visible Gaussians on the bits of (key - kmin) that vary; its last pass also gathers
+        // the tile rectangles into sorted order
+        uint32_t* sorted_id = vis_id;
+        {
+            ProfScope ps(VR_STAGE_DEPTH_SORT, s);
+            int where = 0;
+            const RadixGather g{rect, rect_sorted};
+            int rc = onesweep_sort(vis_key, vis_id, tmp_key, tmp_id, V, key_min, key_bits, dpartial, rows, (uint32_t*)st,
+                                   err, &g, s, debug, &where);
+            if (rc) return rc;
+            sorted_id = where ? tmp_id : vis_id;
+        }
+        // 3. emission; the offsets are scanned on the way
+        prof_begin(VR_STAGE_EMIT, s);
+        if (radix_passes(key_bits) == 0) {   // all depth keys equal (or one Gaussian): nothing was scattered
+            hipLaunchKernelGGL(k_gather_rect, dim3(cdiv(V, 256)), dim3(256), 0, s, V, (const uint32_t*)sorted_id, rect,
+                               rect_sorted);
+            VR_KERNEL_CHECK("gather_rect", s, debug);
+        }
+        const int passes = radix_passes(bits);
+        uint32_t* va = (passes % 2 == 0) ? point_list : tvalsB;   // the last pass must land in point_list
+        uint32_t* vb = (passes % 2 == 0) ? tvalsB : point_list;
+        hipLaunchKernelGGL(k_emit_scan, dim3(cdiv(V, 256)), dim3(256), 0, s, V, cam.gx, (const uint32_t*)sorted_id,
+                           (const uint2*)rect_sorted, (unsigned long long*)(st + sp.depth), err, tkeysA, va);
+        VR_KERNEL_CHECK("emit_scan", s, debug);
+        prof_end(VR_STAGE_EMIT, s);
+        // 4. stable sort by tile id
+        ProfScope ps(VR_STAGE_TILE_SORT, s);
+        const int hist_rows = (int)(cdiv(R, 4096) < HIST_BLOCKS ? cdiv(R, 4096) : HIST_BLOCKS);
+        hipLaunchKernelGGL(k_digit_hist, dim3(hist_rows), dim3(HIST_THREADS), 0, s, (const uint32_t*)tkeysA, R, 0u,
+                           radix_digit(bits), passes, tpartial);
+        VR_KERNEL_CHECK("digit_hist", s, debug);
+        int where = 0;
+        int rc = onesweep_sort(tkeysA, va, tkeysB, vb, R, 0u, bits, tpartial, hist_rows,
+                               (uint32_t*)(st + sp.depth + sp.emit), err, nullptr, s, debug, &where);
+        if (rc) return rc;
+        tile_keys = where ? tkeysB : tkeysA;
     }
-    prof_end(VR_STAGE_TILE_SORT, s);
     // 5. ranges
     prof_begin(VR_STAGE_RANGES, s);
-    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(R, 256)), dim3(256), 0, s, (const uint32_t*)ka, R, ranges);
+    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(R, 256)), dim3(256), 0, s, (const uint32_t*)tile_keys, R, ranges);
     VR_KERNEL_CHECK("tile_ranges", s, debug);
     prof_end(VR_STAGE_RANGES, s);
     return 0;

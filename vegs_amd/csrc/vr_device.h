@@ -36,6 +36,7 @@ constexpr uint32_t FLAG_DEPTH_NORMALIZED = 1u << 1;     // depth = sum(w z) / (1
 constexpr uint32_t FLAG_EXTRA_NO_ALPHA_GRAD = 1u << 2;  // depth/quat/scale channels: no gradient through alpha
 constexpr uint32_t FLAG_FILL_EMPTY = 1u << 3;           // cov_quat += T_final * (1,0,0,0)
 constexpr uint32_t FLAG_DETERMINISTIC = 1u << 8;        // backward without atomics
+constexpr uint32_t FLAG_SCAN_BINNING = 1u << 9;         // binning with the scan-based (multi-launch) radix passes
 
 struct Camera {
     int H, W, gx, gy;

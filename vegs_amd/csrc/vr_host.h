@@ -51,21 +51,28 @@ int launch_preprocess(const Camera& cam, int P, const float* means3D, const floa
 int launch_mark_visible(const float* xyz, int P, const float* view, uint8_t* present, hipStream_t s);
 
 // ---- binning.hip
-// stage 1 (P-sized): compaction of visible Gaussians in id order + totals.  totals_dev[0]=V, [1]=R.
+// stage 1 (P-sized): compaction of visible Gaussians in id order + totals.  totals_dev[0]=V, [1]=R, [2],[3] = min / max
+// depth key, [4] = *err_in (the look-back guard word, see launch_binning).
 size_t binning_stage1_scratch_bytes(int P);
 int launch_compact_reduce(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,
-                          hipStream_t s, bool debug);
-// zero_a / zero_b: up to two small arrays the kernel clears on the side (the tile ranges): saves a fill launch
-int launch_compact_apply(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, uint32_t* vis_key,
-                         uint32_t* vis_id, uint32_t* zero_a, long zero_na, uint32_t* zero_b, long zero_nb, hipStream_t s,
-                         bool debug);
+                          const uint32_t* err_in, hipStream_t s, bool debug);
+// Second half of the compaction.  Side duties: the partial digit histograms of the depth keys (into `scratch`, for
+// the depth sort), clearing zero_a (the tile ranges) and, when `status` = binning_stage2_status(stage-2 scratch) is
+// given, the posted-sum status region of this view (else launch_binning clears it with a fill).
+int launch_compact_apply(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, const uint32_t* totals_dev,
+                         int tile_bits, uint32_t* vis_key, uint32_t* vis_id, uint32_t* zero_a, long zero_na,
+                         void* status, hipStream_t s, bool debug);
 
 // stage 2 (V- and R-sized): depth sort, emission, tile sort, ranges.
 size_t binning_stage2_scratch_bytes(int V, long R, int ntiles);
-// ranges_zeroed: the tile ranges were already cleared by launch_compact_apply
+void* binning_stage2_status(void* scratch);
+int binning_tile_bits(int ntiles);
+// ranges_zeroed / status_zeroed: already cleared by launch_compact_apply.  stage1_scratch: the compaction's scratch
+// (holds the depth keys' digit histograms).  err: device word that a kernel sets to 1 if a bounded wait for another
+// workgroup's posted sum ran out (never observed; the alternative would be a hung queue).
 int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
-                   uint32_t* vis_id, const uint2* rect, void* scratch, uint32_t* point_list, int2* ranges,
-                   bool ranges_zeroed, hipStream_t s, bool debug);
+                   uint32_t* vis_id, const uint2* rect, const void* stage1_scratch, void* scratch, uint32_t* point_list,
+                   int2* ranges, bool ranges_zeroed, bool status_zeroed, uint32_t* err, hipStream_t s, bool debug);
 
 // stable LSD radix sort of (key,val) u32 pairs on the low nbits of (key - kmin); ping-pongs between the two
 // pairs, *where = 0/1 tells which pair holds the result

@@ -47,6 +47,7 @@ FLAG_DEPTH_NORMALIZED = _capi.FLAG_DEPTH_NORMALIZED        # depth = sum(w z) / 
 FLAG_EXTRA_NO_ALPHA_GRAD = _capi.FLAG_EXTRA_NO_ALPHA_GRAD  # depth/quat/scale: gradients to the attributes only
 FLAG_FILL_EMPTY = _capi.FLAG_FILL_EMPTY                    # cov_quat += T_final * (1,0,0,0)
 FLAG_DETERMINISTIC = _capi.FLAG_DETERMINISTIC              # backward without atomics (bit-reproducible gradients)
+FLAG_SCAN_BINNING = _capi.FLAG_SCAN_BINNING                # binning without inter-workgroup waits (multi-launch passes)
 _flags = int(os.environ.get("VEGS_RAST_FLAGS", "0"), 0)
 
 

@@ -125,6 +125,30 @@ def test_c3_both_binning_paths_build_the_same_lists(c3, dev):
         assert torch.equal(x, y)
 
 
+def test_dense_scene_13m_entries_both_binning_paths(c3, dev):
+    """The headline scene with every disc 3x larger: R ~ 13 M list entries = ~3200 workgroups per tile-sort pass (twelve
+    complete groups on the third level of the posted sums).  Lists, ranges and images of the single-launch passes equal
+    those of the scan-based passes, and the lists have the structure the contract asks for."""
+    from vegs_amd import rasterizer
+    sc, deg, cam, T = c3
+    Td = dict(T)
+    Td["scales"] = T["scales"] * 3.0
+    res_a, *_ = _fwd(Td, cam, deg, [0, 0, 0], dev, requires_grad=True)
+    pa, ra = _export_binning(res_a, 376, 1376, dev)
+    with rasterizer.flags(rasterizer.FLAG_SCAN_BINNING):
+        res_b, *_ = _fwd(Td, cam, deg, [0, 0, 0], dev, requires_grad=True)
+    pb, rb = _export_binning(res_b, 376, 1376, dev)
+    R = res_a[0].grad_fn.num_rendered
+    assert R == len(pa) > 8_000_000
+    assert np.array_equal(pa, pb) and np.array_equal(ra, rb)
+    for x, y in zip(res_a, res_b):
+        assert torch.equal(x, y)
+    nonempty = ra[ra[:, 1] > ra[:, 0]]
+    assert (nonempty[:, 1] - nonempty[:, 0]).sum() == R
+    radii = res_a[5].cpu().numpy()
+    assert np.all(radii[pa] > 0)
+
+
 def test_c3_deterministic_backward_mode(c3, dev):
     """Headline scene, VR_FLAG_DETERMINISTIC: gradients bit-identical from run to run (the default mode's fp32 atomics
     are order-dependent) and within the per-row tolerance of the default mode."""

@@ -257,6 +257,11 @@ int vr_profile_collect(double* ms, int64_t* count);
 int vr_debug_export_binning(const VrSaved* saved, int32_t image_height, int32_t image_width,
                             uint32_t* point_list, int32_t* ranges, void* stream);
 
+/* Test hook for the binning guard: the single-launch radix passes bound every wait for another workgroup's posted sum
+ * and raise a device-side guard word if one runs out; the NEXT vr_forward of this host thread on this device then
+ * returns VR_ERR_HIP and clears the word.  This sets the word (value != 0) or clears it (0) by hand. */
+int vr_debug_set_guard(uint32_t value, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

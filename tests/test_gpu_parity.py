@@ -333,6 +333,26 @@ def test_argument_errors(dev):
              shs=torch.zeros(4, 16, 3), scales=torch.zeros(4, 3), rotations=torch.zeros(4, 4))
 
 
+def test_binning_guard_is_reported_by_the_next_forward_and_cleared(dev):
+    """The single-launch binning passes bound their waits and raise a device word if one runs out (never observed);
+    the next forward of the thread reports it as an error and clears it.  Raised by hand here (vr_debug_set_guard)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from vegs_amd import _capi, scenes
+    sc, deg = scenes.scene_random(P=500, sh_degree=0, seed=3)
+    cam = scenes.camera_c1(64, 64)
+    rast = GaussianRasterizer(raster_settings=_settings(cam, [0, 0, 0], deg, 1.0, dev))
+    t = {k: torch.tensor(v, device=dev) for k, v in sc.items()}
+    kw = dict(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]), shs=t["shs"], opacities=t["opacities"],
+              scales=t["scales"], rotations=t["rotations"])
+    good = rast(**kw)
+    _capi.check(_capi.load().vr_debug_set_guard(1, torch.cuda.current_stream(dev).cuda_stream))
+    with pytest.raises(Exception, match="timed out"):
+        rast(**kw)
+    again = rast(**kw)                       # the word was cleared: the thread is usable again
+    for x, y in zip(good, again):
+        assert torch.equal(x, y)
+
+
 def test_debug_mode_runs(dev):
     from vegs_amd import harness, scenes
     sc, deg = scenes.scene_random(P=500, sh_degree=1, seed=8)

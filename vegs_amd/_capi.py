@@ -21,7 +21,7 @@ VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH = 0, 1, 2, 3
 
 # every symbol include/vegs_rast.h declares
 EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_mark_visible", "vr_get_counters",
-           "vr_count_fragments", "vr_count_blended", "vr_export_needed", "vr_debug_export_binning", "vr_profile_level", "vr_profile_collect",
+           "vr_count_fragments", "vr_count_blended", "vr_export_needed", "vr_debug_export_binning", "vr_debug_set_guard", "vr_profile_level", "vr_profile_collect",
            "vr_knn3_mean_dist2", "vr_photometric_forward", "vr_photometric_backward",
            "vr_normal_guidance_forward", "vr_normal_guidance_backward", "vr_adam_step", "vr_densify_stats",
            "vr_sh_grad_from_factors", "vr_sh_adam_step",
@@ -128,6 +128,8 @@ def load():
     lib.vr_debug_export_binning.restype = C.c_int
     lib.vr_debug_export_binning.argtypes = [C.POINTER(VrSaved), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_void_p]
+    lib.vr_debug_set_guard.restype = C.c_int
+    lib.vr_debug_set_guard.argtypes = [C.c_uint32, C.c_void_p]
     lib.vr_knn3_mean_dist2.restype = C.c_int
     lib.vr_knn3_mean_dist2.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, VrAllocFn, C.c_void_p, C.c_void_p]
     vp, i32 = C.c_void_p, C.c_int32

@@ -28,12 +28,28 @@ constexpr int MAX_DEVICES = 64;
 struct Mailbox { uint32_t* pinned; hipEvent_t event; uint32_t* guard; };
 static thread_local Mailbox g_mail[MAX_DEVICES] = {};
 
+// the calling thread's mailbox for the current device, created on first use
+static int get_mailbox(int dev_id, hipStream_t s, Mailbox** out);
+
 void set_error(const char* fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
+}
+
+static int get_mailbox(int dev_id, hipStream_t s, Mailbox** out)
+{
+    Mailbox& mail = g_mail[dev_id];
+    if (!mail.pinned) VR_HIP(hipHostMalloc((void**)&mail.pinned, 256, hipHostMallocDefault));
+    if (!mail.event) VR_HIP(hipEventCreateWithFlags(&mail.event, hipEventDisableTiming));
+    if (!mail.guard) {   // device word raised by a binning kernel whose bounded wait ran out (binning.hip)
+        VR_HIP(hipMalloc((void**)&mail.guard, 256));
+        VR_HIP(hipMemsetAsync(mail.guard, 0, 256, s));
+    }
+    *out = &mail;
+    return 0;
 }
 
 // ---- stage profiler: pairs of events on the caller's stream, resolved in vr_profile_collect
@@ -212,13 +228,10 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     int dev_id = 0;
     VR_HIP(hipGetDevice(&dev_id));
     if (dev_id < 0 || dev_id >= MAX_DEVICES) return fail(VR_ERR_NO_DEVICE, "device ordinal %d out of range", dev_id);
-    Mailbox& mail = g_mail[dev_id];
-    if (!mail.pinned) VR_HIP(hipHostMalloc((void**)&mail.pinned, 256, hipHostMallocDefault));
-    if (!mail.event) VR_HIP(hipEventCreateWithFlags(&mail.event, hipEventDisableTiming));
-    if (!mail.guard) {   // device word set by a look-back kernel whose bounded wait ran out (binning.hip)
-        VR_HIP(hipMalloc((void**)&mail.guard, 256));
-        VR_HIP(hipMemsetAsync(mail.guard, 0, 256, s));
-    }
+    Mailbox* mailp = nullptr;
+    rc = get_mailbox(dev_id, s, &mailp);
+    if (rc) return rc;
+    Mailbox& mail = *mailp;
     uint32_t* const g_pinned = mail.pinned;
 
     // ---- buffers that survive until backward
@@ -550,6 +563,19 @@ int vr_export_needed(const VrSaved* saved, int32_t H, int32_t W, uint32_t* out, 
     const BinLayout BL = bin_layout(T, saved->binning_capacity > 0 ? (size_t)saved->binning_capacity : (size_t)saved->num_rendered);
     VR_HIP(hipMemcpyAsync(out, (const char*)saved->binning + BL.seg_needed, T * sizeof(uint32_t), hipMemcpyDeviceToDevice,
                           (hipStream_t)stream));
+    return VR_OK;
+}
+
+int vr_debug_set_guard(uint32_t value, void* stream)
+{
+    g_err[0] = 0;
+    int dev_id = 0;
+    VR_HIP(hipGetDevice(&dev_id));
+    if (dev_id < 0 || dev_id >= MAX_DEVICES) return fail(VR_ERR_NO_DEVICE, "device ordinal %d out of range", dev_id);
+    Mailbox* mail = nullptr;
+    int rc = get_mailbox(dev_id, (hipStream_t)stream, &mail);
+    if (rc) return rc;
+    VR_HIP(hipMemsetD32Async((hipDeviceptr_t)mail->guard, (int)value, 1, (hipStream_t)stream));
     return VR_OK;
 }
 

@@ -398,14 +398,32 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     }
 }
 
-// ---- D: per tile, add the segment sums in order and write the images
-__global__ void __launch_bounds__(256)
-k_seg_combine(Camera cam, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_needed,
-              const float* __restrict__ Tbuf, const float* __restrict__ part, float* __restrict__ out_color,
-              float* __restrict__ out_depth, float* __restrict__ out_quat, float* __restrict__ out_scale,
-              float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-              float* __restrict__ dsum)
+// ---- D: per tile, add the segment sums in order and write the images.
+// The planes are split over three workgroups per tile, each adding ITS planes in the spec's order with 13-24 segments
+// of loads in flight instead of 6 (all 13 planes of 6 segments fill the registers of one workgroup):
+//   group 0: rgb + local product + last contributor  -> colour, alpha, final T, contributor count
+//   group 1: depth + rotation (+ local product: normalised depth and the identity fill need the final T)
+//   group 2: scale
+// Every group reads the boundary transmittances (a pixel's sums stop at the segment in which it finished).  69 -> 65 us;
+// the kernel streams ~240 MB of `part` at ~3.8 TB/s behind a ~20 us fixed cost (measured by capping the segments per
+// tile), it is not bound by the longest tile's chain: four waves fetching four runs of a heavy tile's segments at
+// once and adding them in turn (sums handed on through LDS) took 75 us.
+template <int GROUP>
+__device__ __forceinline__ void seg_combine_group(const Camera& cam, const uint32_t* __restrict__ seg_off,
+                                                  const uint32_t* __restrict__ seg_needed, const float* __restrict__ Tbuf,
+                                                  const float* __restrict__ part, float* __restrict__ out_color,
+                                                  float* __restrict__ out_depth, float* __restrict__ out_quat,
+                                                  float* __restrict__ out_scale, float* __restrict__ out_alpha,
+                                                  float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                  float* __restrict__ dsum)
 {
+    // planes of `part` this group loads: [P0, P0 + NP) channel sums, then (WITH_P) the local product and (GROUP 0) the
+    // last-contributor word
+    constexpr int P0 = GROUP == 0 ? 0 : (GROUP == 1 ? 3 : 8);
+    constexpr int NP = GROUP == 0 ? 3 : (GROUP == 1 ? 5 : 3);
+    constexpr bool WITH_P = GROUP != 2;
+    constexpr int NL = NP + (WITH_P ? 1 : 0) + (GROUP == 0 ? 1 : 0);   // loads per segment besides Tbuf
+    constexpr int CU = GROUP == 0 ? 16 : (GROUP == 1 ? 13 : 24);       // segments in flight (~96 registers)
     const int tile = xcd_tile(blockIdx.x, cam.gx * cam.gy);
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -413,58 +431,83 @@ k_seg_combine(Camera cam, const uint32_t* __restrict__ seg_off, const uint32_t* 
     if (!(px < cam.W && py < cam.H)) return;
     const uint32_t s0 = seg_off[tile];
     const uint32_t needed = seg_needed[tile];
-    float C[NCH];
+    float C[NP];
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) C[k] = 0.0f;
+    for (int k = 0; k < NP; ++k) C[k] = 0.0f;
     float T = 1.0f;
     uint32_t last = 0;
-    // CU segments per iteration: every load (unconditional, addresses are always inside the buffers) is
-    // issued before the first use, so the chain pays one memory latency per CU segments; the adds
-    // keep the spec's order.  Values of segments in which the pixel is already finished are ignored.
-    constexpr int CU = 6;
+    // every load of a trip is issued before the first use; the adds keep the spec's order.  Values of segments in
+    // which the pixel is already finished are ignored.
     bool dead = false;
     for (uint32_t s = 0; s < needed && !dead; s += CU) {
-        float Tbv[CU], v[CU][NPART];
+        float Tbv[CU], v[CU][NL];
 #pragma unroll
         for (int j = 0; j < CU; ++j) {
-            const uint32_t sj = min(s + j, needed - 1);   // clamp: duplicates are never used
-            Tbv[j] = Tbuf[(size_t)(s0 + sj) * SEG + threadIdx.x];
-            const float* src = part + (size_t)(s0 + sj) * (NPART * SEG) + threadIdx.x;
+            if (s + j < needed) {   // tile-uniform: most tiles need 2-6 segments, their trip issues only those loads
+                Tbv[j] = Tbuf[(size_t)(s0 + s + j) * SEG + threadIdx.x];
+                const float* src = part + (size_t)(s0 + s + j) * (NPART * SEG) + threadIdx.x;
 #pragma unroll
-            for (int k = 0; k < NPART; ++k) v[j][k] = src[k * SEG];
+                for (int k = 0; k < NP; ++k) v[j][k] = src[(P0 + k) * SEG];
+                if (WITH_P) v[j][NP] = src[11 * SEG];
+                if (GROUP == 0) v[j][NP + 1] = src[12 * SEG];
+            }
         }
 #pragma unroll
         for (int j = 0; j < CU; ++j) {
             if (dead || s + j >= needed) continue;
             if (Tbv[j] < 0.0f) { dead = true; continue; }
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) C[k] += v[j][k];
-            T = Tbv[j] * v[j][11];
-            const uint32_t l = __float_as_uint(v[j][12]) & 0x7FFFFFFFu;
-            if (l) last = l;
+            for (int k = 0; k < NP; ++k) C[k] += v[j][k];
+            if (WITH_P) T = Tbv[j] * v[j][NP];
+            if (GROUP == 0) {
+                const uint32_t l = __float_as_uint(v[j][NP + 1]) & 0x7FFFFFFFu;
+                if (l) last = l;
+            }
         }
     }
     const size_t N = (size_t)cam.H * cam.W;
     const size_t pix = (size_t)py * cam.W + px;
-    final_T[pix] = T;
-    n_contrib[pix] = last;
-    out_color[pix] = fmaf(T, cam.bg[0], C[0]);
-    out_color[N + pix] = fmaf(T, cam.bg[1], C[1]);
-    out_color[2 * N + pix] = fmaf(T, cam.bg[2], C[2]);
-    // fork switches (include/vegs_rast.h VrFlags): normalised depth, identity fill of the rotation image
-    float depth_out = C[3];
-    if (cam.flags & FLAG_DEPTH_NORMALIZED) {
-        const float A = 1.0f - T;
-        dsum[pix] = C[3];                       // the backward needs the un-normalised sum
-        depth_out = A > 0.0f ? C[3] / A : 0.0f;
+    if (GROUP == 0) {
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        out_color[pix] = fmaf(T, cam.bg[0], C[0]);
+        out_color[N + pix] = fmaf(T, cam.bg[1], C[1]);
+        out_color[2 * N + pix] = fmaf(T, cam.bg[2], C[2]);
+        out_alpha[pix] = 1.0f - T;
+    } else if (GROUP == 1) {
+        // fork switches (include/vegs_rast.h VrFlags): normalised depth, identity fill of the rotation image
+        float depth_out = C[0];
+        if (cam.flags & FLAG_DEPTH_NORMALIZED) {
+            const float A = 1.0f - T;
+            dsum[pix] = C[0];                       // the backward needs the un-normalised sum
+            depth_out = A > 0.0f ? C[0] / A : 0.0f;
+        }
+        out_depth[pix] = depth_out;
+        if (cam.flags & FLAG_FILL_EMPTY) C[1] += T;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out_quat[k * N + pix] = C[1 + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out_scale[k * N + pix] = C[k];
     }
-    out_depth[pix] = depth_out;
-    if (cam.flags & FLAG_FILL_EMPTY) C[4] += T;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) out_quat[k * N + pix] = C[4 + k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) out_scale[k * N + pix] = C[8 + k];
-    out_alpha[pix] = 1.0f - T;
+}
+
+__global__ void __launch_bounds__(256)
+k_seg_combine(Camera cam, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_needed,
+              const float* __restrict__ Tbuf, const float* __restrict__ part, float* __restrict__ out_color,
+              float* __restrict__ out_depth, float* __restrict__ out_quat, float* __restrict__ out_scale,
+              float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+              float* __restrict__ dsum)
+{
+    if (blockIdx.y == 0)
+        seg_combine_group<0>(cam, seg_off, seg_needed, Tbuf, part, out_color, out_depth, out_quat, out_scale, out_alpha,
+                             final_T, n_contrib, dsum);
+    else if (blockIdx.y == 1)
+        seg_combine_group<1>(cam, seg_off, seg_needed, Tbuf, part, out_color, out_depth, out_quat, out_scale, out_alpha,
+                             final_T, n_contrib, dsum);
+    else
+        seg_combine_group<2>(cam, seg_off, seg_needed, Tbuf, part, out_color, out_depth, out_quat, out_scale, out_alpha,
+                             final_T, n_contrib, dsum);
 }
 
 __global__ void __launch_bounds__(256)
@@ -550,7 +593,7 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
                            (const unsigned long long*)segmask);
         VR_KERNEL_CHECK("seg_blend", s, debug);
     }
-    hipLaunchKernelGGL(k_seg_combine, dim3(ntiles), dim3(256), 0, s, cam, (const uint32_t*)seg_off,
+    hipLaunchKernelGGL(k_seg_combine, dim3(ntiles, 3), dim3(256), 0, s, cam, (const uint32_t*)seg_off,
                        (const uint32_t*)seg_needed, (const float*)Tbuf, (const float*)part, out_color, out_depth,
                        out_quat, out_scale, out_alpha, final_T, n_contrib, dsum);
     VR_KERNEL_CHECK("seg_combine", s, debug);

@@ -281,7 +281,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    _capi.profile_level(1)          # level 1: HIP events around the roofline kernel only, inside the timed region
+    _capi.profile_level(1)          # level 1: HIP events around the roofline kernel only (one launch in four), inside the timed region
     _capi.profile_collect()
     mallocs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     reserved0 = torch.cuda.memory_reserved(device)
@@ -346,6 +346,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "alg_bytes_per_launch": round(bytes_k), "avg_launch_ms": round(ms_k, 4),
+                     "launches_timed": int(stage[kern][1]),
                      "stage_ms": stage_ms,
                      "whole_view_alg_bytes": round(b_alg),
                      "whole_view_frac": round(b_alg / (elapsed / (args.steps * vps)) / 1e9 / HBM_PEAK_GBS, 5)},

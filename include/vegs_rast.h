@@ -232,7 +232,8 @@ int vr_count_blended(const VrSaved* saved, int32_t image_height, int32_t image_w
 int vr_export_needed(const VrSaved* saved, int32_t image_height, int32_t image_width, uint32_t* out, void* stream);
 
 /* ---- stage timing (HIP events recorded on `stream` around the kernels of each stage).
- * level 0 = off (default), 1 = only the k_seg_bwd kernel (the roofline kernel), 2 = every stage.
+ * level 0 = off (default), 1 = only the k_seg_bwd kernel (the roofline kernel), one launch in four of each host
+ * thread (an event pair costs a ~6 us bubble on the stream), 2 = every stage of every call.
  * vr_profile_collect synchronises the recorded events, ADDS the elapsed milliseconds and launch
  * counts of each stage to ms[VR_STAGE_COUNT] / count[VR_STAGE_COUNT], and clears the record. */
 typedef enum VrStage {

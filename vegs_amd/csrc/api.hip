@@ -2,8 +2,10 @@
 // layout, and the kernel sequence of forward / backward / mark_visible.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -21,11 +23,10 @@ constexpr uint32_t KNOWN_FLAGS = FLAG_SCALE_MODIFIED | FLAG_DEPTH_NORMALIZED | F
 
 static thread_local char g_err[512] = "";
 static thread_local VrCounters g_counters = {0, 0, 0, 0, 0};
-// host-pinned mailbox for (V, R, min key, max key) and the event that says the copy has landed: one pair per
-// (host thread, device) -- an event belongs to the device it was created on, so a thread that renders on a second
-// GPU must not reuse the first one's
+// host-pinned, coherent mailbox that the totals kernel writes (V, R, min key, max key, guard word; then a sequence
+// number the host polls) and the device-side guard word: one per (host thread, device)
 constexpr int MAX_DEVICES = 64;
-struct Mailbox { uint32_t* pinned; hipEvent_t event; uint32_t* guard; };
+struct Mailbox { uint32_t* pinned; uint32_t* pinned_dev; uint32_t seq; uint32_t* guard; };
 static thread_local Mailbox g_mail[MAX_DEVICES] = {};
 
 // the calling thread's mailbox for the current device, created on first use
@@ -42,14 +43,40 @@ void set_error(const char* fmt, ...)
 static int get_mailbox(int dev_id, hipStream_t s, Mailbox** out)
 {
     Mailbox& mail = g_mail[dev_id];
-    if (!mail.pinned) VR_HIP(hipHostMalloc((void**)&mail.pinned, 256, hipHostMallocDefault));
-    if (!mail.event) VR_HIP(hipEventCreateWithFlags(&mail.event, hipEventDisableTiming));
+    if (!mail.pinned) {
+        VR_HIP(hipHostMalloc((void**)&mail.pinned, 256, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(mail.pinned, 0, 256);
+        VR_HIP(hipHostGetDevicePointer((void**)&mail.pinned_dev, mail.pinned, 0));
+    }
     if (!mail.guard) {   // device word raised by a binning kernel whose bounded wait ran out (binning.hip)
         VR_HIP(hipMalloc((void**)&mail.guard, 256));
         VR_HIP(hipMemsetAsync(mail.guard, 0, 256, s));
     }
     *out = &mail;
     return 0;
+}
+
+// Waits until the totals kernel has published this call's sequence number in the mailbox.  Polls host memory (the
+// kernel's system-scope release store); every ~50 us of polling it also asks the stream for errors, and after 20 ms it
+// falls back to a blocking stream synchronisation and a plain copy of the device-side totals.
+static int wait_mailbox(uint32_t* pinned, uint32_t seq, const uint32_t* totals_dev, hipStream_t s)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1;; ++spins) {
+        if (__atomic_load_n(&pinned[8], __ATOMIC_ACQUIRE) == seq) return 0;
+        __builtin_ia32_pause();
+        if ((spins & 4095u) == 0u) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q != hipSuccess && q != hipErrorNotReady) { set_error("%s while waiting for the list sizes", hipGetErrorString(q)); return VR_ERR_HIP; }
+            const auto dt = std::chrono::steady_clock::now() - t0;
+            if (q == hipSuccess || dt > std::chrono::milliseconds(20)) {
+                VR_HIP(hipStreamSynchronize(s));
+                if (__atomic_load_n(&pinned[8], __ATOMIC_ACQUIRE) == seq) return 0;
+                VR_HIP(hipMemcpy(pinned, totals_dev, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                return 0;
+            }
+        }
+    }
 }
 
 // ---- stage profiler: pairs of events on the caller's stream, resolved in vr_profile_collect
@@ -282,13 +309,12 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
         prof_end(VR_STAGE_PREPROCESS, s);
         if (rc) return rc;
         prof_begin(VR_STAGE_COMPACT, s);
-        rc = launch_compact_reduce(P, rect, depth_key, scan_scr, totals_dev, mail.guard, s, debug);
+        // the one host<->device round trip of the forward pass: sizes of the data-dependent lists.  The totals kernel
+        // writes them into the pinned mailbox itself; the host polls for this call's sequence number after it has
+        // queued the compaction's apply kernel, so the round trip overlaps with that kernel instead of idling the GPU.
+        const uint32_t seq = ++mail.seq ? mail.seq : ++mail.seq;   // never 0 (the mailbox's initial content)
+        rc = launch_compact_reduce(P, rect, depth_key, scan_scr, totals_dev, mail.guard, mail.pinned_dev, seq, s, debug);
         if (rc) return rc;
-        // the one host<->device round trip of the forward pass: sizes of the data-dependent lists.  The copy is
-        // queued BEFORE the compaction's apply kernel and the host waits on an event right after the copy, so the
-        // round trip (and the host's launch of what follows) overlaps with that kernel instead of idling the GPU.
-        VR_HIP(hipMemcpyAsync(g_pinned, totals_dev, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        VR_HIP(hipEventRecord(mail.event, s));
         // the apply kernel also clears the tile ranges (when the binning buffer already exists): no fill launch
         // and the status words of the binning passes (when their scratch exists)
         uint32_t* rz = binning ? (uint32_t*)((char*)binning + bin_layout(T, Rcap).ranges) : nullptr;
@@ -298,7 +324,8 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
                                   rz ? (long)(2 * T) : 0L, scr2 ? binning_stage2_status(scr2) : nullptr, s, debug);
         prof_end(VR_STAGE_COMPACT, s);
         if (rc) return rc;
-        VR_HIP(hipEventSynchronize(mail.event));
+        rc = wait_mailbox(g_pinned, seq, totals_dev, s);
+        if (rc) return rc;
         if (g_pinned[4]) {   // raised by an EARLIER call's binning on this thread and device: its lists were wrong
             VR_HIP(hipMemsetAsync(mail.guard, 0, 4, s));
             return fail(VR_ERR_HIP, "a look-back wait in an earlier binning pass timed out; that view's output is invalid");

@@ -218,7 +218,7 @@ k_scan_apply(Src src, Sink sink, long n, const uint32_t* __restrict__ bsum, cons
 // kernel is still running.  totals = {sum, secondary sum, min key, max key}.
 __global__ void __launch_bounds__(256)
 k_scan_totals(const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ bsum2, int nb, uint32_t* __restrict__ totals,
-              const uint32_t* __restrict__ err_in)
+              const uint32_t* __restrict__ err_in, uint32_t* __restrict__ host_mail, uint32_t seq)
 {
     __shared__ uint32_t lds4[4];
     __shared__ uint32_t mm[8];
@@ -243,8 +243,16 @@ k_scan_totals(const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ bs
         totals[1] = t1;
         totals[2] = min(min(mm[0], mm[1]), min(mm[2], mm[3]));
         totals[3] = max(max(mm[4], mm[5]), max(mm[6], mm[7]));
-        // the look-back guard word of earlier calls rides along in the same device->host copy (see launch_binning)
+        // the guard word of earlier calls rides along (see launch_binning)
         totals[4] = err_in ? __hip_atomic_load(err_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        // The host's copy: written straight into its pinned, coherent mailbox, sequence number last (release at system
+        // scope); the host polls that word.  No copy command and no event on the stream: the apply kernel follows
+        // this one without the ~10 us the two used to put between them.
+        if (host_mail) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) __hip_atomic_store(&host_mail[k], totals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_mail[8], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -271,10 +279,10 @@ size_t binning_stage1_scratch_bytes(int P)
     return align_up(4 * nb * sizeof(uint32_t), 256) + align_up(nb * HIST_WORDS * sizeof(uint32_t), 256);
 }
 
-// Two halves, so that the caller can start reading the totals {V, R, min key, max key} back to the host between
-// them: the device->host round trip then overlaps with the apply kernel instead of idling the GPU.
+// Two halves: the totals {V, R, min key, max key} reach the host (host_mail, see k_scan_totals) while the apply kernel
+// runs, so the round trip overlaps with that kernel instead of idling the GPU.
 int launch_compact_reduce(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,
-                          const uint32_t* err_in, hipStream_t s, bool debug)
+                          const uint32_t* err_in, uint32_t* host_mail, uint32_t seq, hipStream_t s, bool debug)
 {
     int nb = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
     uint32_t* bsum = (uint32_t*)scratch;
@@ -283,7 +291,7 @@ int launch_compact_reduce(int P, const uint2* rect, const uint32_t* depth_key, v
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_reduce<SrcFlagTiles>), dim3(nb), dim3(256), 0, s, src, (long)P, bsum, bsum2);
     VR_KERNEL_CHECK("compact_reduce", s, debug);
     hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(256), 0, s, (const uint32_t*)bsum, (const uint32_t*)bsum2, nb, totals_dev,
-                       err_in);
+                       err_in, host_mail, seq);
     VR_KERNEL_CHECK("compact_totals", s, debug);
     return 0;
 }

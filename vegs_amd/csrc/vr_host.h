@@ -54,8 +54,9 @@ int launch_mark_visible(const float* xyz, int P, const float* view, uint8_t* pre
 // stage 1 (P-sized): compaction of visible Gaussians in id order + totals.  totals_dev[0]=V, [1]=R, [2],[3] = min / max
 // depth key, [4] = *err_in (the look-back guard word, see launch_binning).
 size_t binning_stage1_scratch_bytes(int P);
+// host_mail: device address of the caller's pinned, coherent mailbox; receives the five words, then host_mail[8] = seq.
 int launch_compact_reduce(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,
-                          const uint32_t* err_in, hipStream_t s, bool debug);
+                          const uint32_t* err_in, uint32_t* host_mail, uint32_t seq, hipStream_t s, bool debug);
 // Second half of the compaction.  Side duties: the partial digit histograms of the depth keys (into `scratch`, for
 // the depth sort), clearing zero_a (the tile ranges) and, when `status` = binning_stage2_status(stage-2 scratch) is
 // given, the posted-sum status region of this view (else launch_binning clears it with a fill).

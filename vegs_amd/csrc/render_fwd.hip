@@ -29,15 +29,17 @@ namespace vr {
 
 // seg_off[t] = first global segment id of tile t; seg_off[T] = total.  Single workgroup.  (k_seg_tiles then
 // fills seg_tile[s] = tile of segment s, 0xFFFFFFFF beyond the total: the launch grids cover `cap` segments.)
-__global__ void __launch_bounds__(256)
+constexpr int SEGOFF_THREADS = 1024;
+__global__ void __launch_bounds__(SEGOFF_THREADS)
 k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict__ seg_off)
 {
-    __shared__ uint32_t wsum[4];
+    constexpr int NW = SEGOFF_THREADS / 64;
+    __shared__ uint32_t wsum[NW];
     __shared__ uint32_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int base = 0; base < ntiles; base += 256) {
+    for (int base = 0; base < ntiles; base += SEGOFF_THREADS) {
         const int t = base + threadIdx.x;
         uint32_t n = 0;
         if (t < ntiles) { const int2 r = ranges[t]; n = (uint32_t)((r.y - r.x + SEG - 1) / SEG); }
@@ -54,7 +56,7 @@ k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict_
         const uint32_t carry = carry_s;
         if (t < ntiles) seg_off[t] = carry + woff + incl - n;
         __syncthreads();
-        if (threadIdx.x == 255) carry_s = carry + woff + incl;
+        if (threadIdx.x == SEGOFF_THREADS - 1) carry_s = carry + woff + incl;
         __syncthreads();
     }
     if (threadIdx.x == 0) seg_off[ntiles] = carry_s;
@@ -576,7 +578,7 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     if (ntiles == 0) return 0;
     const size_t nseg = seg_capacity(R, ntiles);
     float* Pbuf = (float*)scratch;
-    hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(256), 0, s, ranges, ntiles, seg_off);
+    hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(SEGOFF_THREADS), 0, s, ranges, ntiles, seg_off);
     hipLaunchKernelGGL(k_seg_tiles, dim3(cdiv((long)nseg, 256)), dim3(256), 0, s, ntiles, ranges, seg_off, (uint32_t)nseg);
     VR_KERNEL_CHECK("seg_offsets", s, debug);
     if (R > 0) {

@@ -399,6 +399,36 @@ def test_scan_binning_flag_matches_oracle_lists(dev):
                           flags=rasterizer.FLAG_SCAN_BINNING)
 
 
+@pytest.mark.parametrize("P,W,H,scale", [
+    (1, 64, 64, 0.05), (255, 64, 48, 0.05), (257, 80, 64, 0.05),          # below / around one emission workgroup
+    (4095, 256, 128, 0.03), (4097, 256, 128, 0.03),                         # one radix block and one element more
+    (70000, 320, 200, 0.02),                                                # 16+ radix blocks: second level in use
+    (70000, 1024, 768, 0.05),                                               # 3072 tiles (digit width 6, two passes), R >> V
+    (300000, 640, 400, 0.004),                                              # ~70 depth blocks, small rectangles
+])
+def test_both_binning_paths_agree_across_sizes(P, W, H, scale, dev):
+    """Sizes around the block (4096 keys), emission-workgroup (256 Gaussians) and group (16 blocks) boundaries of the
+    single-launch binning passes: lists, ranges and images equal those of the scan-based passes bit for bit."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from vegs_amd import rasterizer, scenes
+    sc, deg = scenes.scene_random(P=P, sh_degree=0, seed=P % 97, extent=1.0, scale=scale)
+    cam = scenes.camera_c1(W, H)
+    t = {k: torch.tensor(v, device=dev) for k, v in sc.items()}
+    outs = []
+    for fl in (0, rasterizer.FLAG_SCAN_BINNING):
+        with rasterizer.flags(fl):
+            rast = GaussianRasterizer(raster_settings=_settings(cam, [0, 0, 0], deg, 1.0, dev))
+            m2d = torch.zeros_like(t["means3D"], requires_grad=True)
+            res = rast(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"], scales=t["scales"],
+                       rotations=t["rotations"])
+            outs.append((res, _export_binning(res, H, W, dev)))
+    (ra, (pa, ga)), (rb, (pb, gb)) = outs
+    assert ra[0].grad_fn.num_rendered == rb[0].grad_fn.num_rendered
+    assert np.array_equal(pa, pb) and np.array_equal(ga, gb)
+    for x, y in zip(ra, rb):
+        assert torch.equal(x, y)
+
+
 def test_many_tiles_large_image(dev):
     """2048x1200 = 9600 tiles (14 key bits: 8-bit radix digits, 2 passes) with a sparse scene."""
     from vegs_amd import scenes

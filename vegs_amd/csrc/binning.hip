@@ -600,7 +600,7 @@ __host__ __device__ inline size_t onesweep_status_words(long n, int nbits)
 }
 __host__ __device__ inline size_t emit_status_words(long V)   // levels 1-3 of the emission scan (64-bit words)
 {
-    const size_t nblk = (size_t)((V + 255) / 256), n2 = (nblk + 63) / 64, n3 = (n2 + 63) / 64;
+    const size_t nblk = (size_t)((V + 255) / 256), n2 = (nblk + 63) / 64, n3 = (n2 + 63) / 64;   // (sized for a fan-in of 64: enough for the kernel's 128)
     return nblk + n2 + n3;
 }
 // The packed status region of one view: depth sort | emission scan | tile sort (bytes, multiples of 16).  Computed
@@ -995,9 +995,9 @@ k_emit(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint32_t* __
 
 // The same emission with the offset scan folded in: a workgroup sums its 256 rectangle areas, posts the sum and adds
 // what the workgroups before it posted -- the single-value form of the three-level scheme of the radix passes, fan-in
-// 64 (one status word per lane of wave 0 and level): up to 262144 workgroups.  64-bit words, top bit = posted.
+// 128 (two status words per lane of wave 0 and level).  64-bit words, top bit = posted.
 constexpr unsigned long long SE_POSTED = 1ull << 63;
-constexpr int EFAN = 64;
+constexpr int EFAN = 128;   // (64: 6400 workgroups need all three levels; 128: two cover 16384)
 constexpr long EMIT_SCAN_MAX_V = (long)EFAN * EFAN * EFAN * 256;
 
 // wave-wide: sum of `count` (< 64) posted entries st[first + lane]; polls until all are posted
@@ -1005,13 +1005,23 @@ __device__ __forceinline__ unsigned long long sum_posted_wave(const unsigned lon
                                                               uint32_t* err)
 {
     if (count <= 0) return 0ull;
+    constexpr int PER = EFAN / 64;   // status words per lane
     for (int polls = 0;; ++polls) {
-        const unsigned long long v =
-            lane < count ? __hip_atomic_load(&st[first + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SE_POSTED;
-        const bool all = __ballot((v & SE_POSTED) == 0ull) == 0ull;
+        unsigned long long v[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            v[j] = lane + 64 * j < count
+                       ? __hip_atomic_load(&st[first + lane + 64 * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                       : SE_POSTED;
+        unsigned long long both = SE_POSTED;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) both &= v[j];
+        const bool all = __ballot((both & SE_POSTED) == 0ull) == 0ull;
         if (all || polls > SPIN_LIMIT) {
             if (!all && lane == 0) *err = 1u;
-            unsigned long long s = v & ~SE_POSTED;
+            unsigned long long s = 0ull;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) s += v[j] & ~SE_POSTED;
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
             return s;

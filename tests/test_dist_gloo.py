@@ -1,4 +1,4 @@
-"""CPU: the view-sharded exchange step (vegs_amd/dist.py) on the gloo backend, world_size 2."""
+"""CPU: the view-sharded exchange step (vegs_amd/dist.py) on the gloo backend, world_size 2 and 4."""
 import os
 import socket
 
@@ -52,17 +52,19 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_view_sharded_gradient_exchange_gloo(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_view_sharded_gradient_exchange_gloo(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     R = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
     for k in range(5):
-        want = (R[0]["local"][k] + R[1]["local"][k]) / world          # loss = mean over the views
+        want = sum(R[q]["local"][k] for q in range(world)) / world          # loss = mean over the views
         for r in range(world):
             assert torch.allclose(R[r]["grads"][k], want, atol=1e-6)
     want_g = sum(torch.norm(R[r]["vg"][:, :2], dim=-1, keepdim=True) * R[r]["vis"][:, None].float() for r in range(world))
     want_d = sum(R[r]["vis"][:, None].float() for r in range(world))
-    want_m = torch.maximum(R[0]["radii"], R[1]["radii"])
+    want_m = R[0]["radii"]
+    for q in range(1, world):
+        want_m = torch.maximum(want_m, R[q]["radii"])
     for r in range(world):
         assert torch.allclose(R[r]["gsum"], want_g, atol=1e-6)
         assert torch.equal(R[r]["den"], want_d)
@@ -73,9 +75,10 @@ def test_view_sharded_gradient_exchange_gloo(tmp_path):
         for q in range(world):
             assert torch.equal(R[r]["F"][q], R[q]["factor"]) and torch.equal(R[r]["C"][q], R[q]["campos"])
         for k in range(4):
-            assert torch.allclose(R[r]["others"][k], (R[0]["olocal"][k] + R[1]["olocal"][k]) / world, atol=1e-6)
+            assert torch.allclose(R[r]["others"][k], sum(R[q]["olocal"][k] for q in range(world)) / world, atol=1e-6)
     # consecutive views go to consecutive ranks, every view visited once per cycle
-    assert R[0]["view"] == [0, 2, 4, 6] and R[1]["view"] == [1, 3, 5, 7]
+    for r in range(world):
+        assert R[r]["view"] == [(s * world + r) % 16 for s in range(4)]
 
 
 def test_single_process_is_a_no_op():

@@ -158,45 +158,15 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* lds4)
 
 // Second (last) kernel of a scan.  Every workgroup derives its own exclusive prefix from the per-block
 // sums of the reduce kernel (a few KB, L2-resident) instead of waiting for a separate single-block scan
-// kernel; workgroup 0 also publishes the grand totals (sum, secondary sum, min/max key) when asked.
+// kernel.
 template <class Src, class Sink>
 __global__ void __launch_bounds__(256)
-k_scan_apply(Src src, Sink sink, long n, const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ bsum2,
-             int nb, uint32_t* __restrict__ totals)
+k_scan_apply(Src src, Sink sink, long n, const uint32_t* __restrict__ bsum)
 {
     __shared__ uint32_t lds4[4];
     uint32_t acc = 0;
     for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) acc += bsum[j];
     const uint32_t prefix = block_sum(acc, lds4);
-    if (totals && blockIdx.x == 0) {
-        uint32_t t0 = 0, t1 = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
-        for (int j = threadIdx.x; j < nb; j += 256) {
-            t0 += bsum[j];
-            if (bsum2) {
-                t1 += bsum2[j];
-                if (Src::MINMAX) { kmin = min(kmin, bsum2[nb + j]); kmax = max(kmax, bsum2[2 * nb + j]); }
-            }
-        }
-        t0 = block_sum(t0, lds4);
-        t1 = block_sum(t1, lds4);
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d, 64));
-            kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d, 64));
-        }
-        __shared__ uint32_t mm[8];
-        if ((threadIdx.x & 63) == 0) { mm[threadIdx.x >> 6] = kmin; mm[4 + (threadIdx.x >> 6)] = kmax; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            totals[0] = t0;
-            totals[1] = t1;
-            if (Src::MINMAX) {
-                totals[2] = min(min(mm[0], mm[1]), min(mm[2], mm[3]));
-                totals[3] = max(max(mm[4], mm[5]), max(mm[6], mm[7]));
-            }
-        }
-        __syncthreads();
-    }
     long base = (long)blockIdx.x * SCAN_BLOCK + (long)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     uint32_t tsum = 0;
@@ -257,15 +227,14 @@ k_scan_totals(const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ bs
 }
 
 template <class Src, class Sink>
-static int run_scan(Src src, Sink sink, long n, uint32_t* bsum, uint32_t* bsum2, uint32_t* totals, hipStream_t s,
-                    bool debug, const char* what)
+static int run_scan(Src src, Sink sink, long n, uint32_t* bsum, hipStream_t s, bool debug, const char* what)
 {
     if (n <= 0) return 0;
     int nb = cdiv(n, SCAN_BLOCK);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_reduce<Src>), dim3(nb), dim3(256), 0, s, src, n, bsum, bsum2);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_reduce<Src>), dim3(nb), dim3(256), 0, s, src, n, bsum, (uint32_t*)nullptr);
     VR_KERNEL_CHECK(what, s, debug);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<Src, Sink>), dim3(nb), dim3(256), 0, s, src, sink, n,
-                       (const uint32_t*)bsum, (const uint32_t*)bsum2, nb, totals);
+                       (const uint32_t*)bsum);
     VR_KERNEL_CHECK(what, s, debug);
     return 0;
 }
@@ -468,8 +437,7 @@ static int radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, 
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_hist<BITS>), dim3(nblk), dim3(256), 0, s, kin, n, kmin, shift, hist,
                        nblk);
     VR_KERNEL_CHECK("radix_hist", s, debug);
-    int rc = run_scan(SrcPlain{hist}, SinkStore{hist}, hn, bsum, (uint32_t*)nullptr, (uint32_t*)nullptr, s, debug,
-                      "radix_scan");
+    int rc = run_scan(SrcPlain{hist}, SinkStore{hist}, hn, bsum, s, debug, "radix_scan");
     if (rc) return rc;
     if (gather)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<BITS, true>), dim3(nblk), dim3(256), 0, s, kin, vin, kout, vout,
@@ -1184,8 +1152,7 @@ static int binning_multi_launch(const Camera& cam, int V, long R, uint32_t key_m
                                rect_sorted);
             VR_KERNEL_CHECK("gather_rect", s, debug);
         }
-        int rc = run_scan(SrcRectSorted{rect_sorted}, SinkStore{offs}, V, bsum, (uint32_t*)nullptr,
-                          (uint32_t*)nullptr, s, debug, "offset_scan");
+        int rc = run_scan(SrcRectSorted{rect_sorted}, SinkStore{offs}, V, bsum, s, debug, "offset_scan");
         if (rc) return rc;
     }
     int bits = 0;

@@ -665,12 +665,11 @@ k_digit_sum(const uint32_t* __restrict__ partial, int G, int words, uint32_t* __
     }
 }
 
-template <int BITS, bool GATHER>
+template <int BITS>
 __global__ void __launch_bounds__(256)
 k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
            uint32_t* __restrict__ vals_out, long n, uint32_t kmin, int pass,
-           const uint32_t* __restrict__ totals, uint32_t* __restrict__ status, uint32_t* __restrict__ err,
-           const uint2* __restrict__ rect, uint2* __restrict__ rect_sorted)
+           const uint32_t* __restrict__ totals, uint32_t* __restrict__ status, uint32_t* __restrict__ err)
 {
     constexpr int SIZE = 1 << BITS;
     constexpr int BPT = (SIZE + 255) / 256;   // digits per thread in the per-digit phases
@@ -800,7 +799,6 @@ k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
         const uint32_t v = sval[j];
         keys_out[dst] = k;
         vals_out[dst] = v;
-        if (GATHER) rect_sorted[dst] = rect[v];
     }
 }
 
@@ -808,8 +806,8 @@ k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
 // (`partial`: `rows` rows of passes << digit words, written by the kernel that produced the keys).  `status`:
 // onesweep_status_words(n, nbits) words, all zero.
 static int onesweep_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long n, uint32_t kmin, int nbits,
-                         const uint32_t* partial, int rows, uint32_t* status, uint32_t* err, const RadixGather* gather,
-                         hipStream_t s, bool debug, int* res)
+                         const uint32_t* partial, int rows, uint32_t* status, uint32_t* err, hipStream_t s, bool debug,
+                         int* res)
 {
     const int digit = radix_digit(nbits);
     const int passes = radix_passes(nbits);
@@ -824,15 +822,13 @@ static int onesweep_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
     VR_KERNEL_CHECK("digit_sum", s, debug);
     uint32_t *ka = k0, *va = v0, *kb = k1, *vb = v1;
     for (int pass = 0; pass < passes; ++pass) {
-        const bool g = gather && pass == passes - 1;
         uint32_t* st = status + (size_t)pass * per_pass;
-#define VR_SWEEP(B, GA)                                                                                             \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_onesweep<B, GA>), dim3(nblk), dim3(256), 0, s, (const uint32_t*)ka,        \
-                       (const uint32_t*)va, kb, vb, n, kmin, pass, (const uint32_t*)totals, st, err,               \
-                       g ? gather->rect : (const uint2*)nullptr, g ? gather->rect_sorted : (uint2*)nullptr)
-        if (digit == 6) { if (g) VR_SWEEP(6, true); else VR_SWEEP(6, false); }
-        else if (digit == 9) { if (g) VR_SWEEP(9, true); else VR_SWEEP(9, false); }
-        else { if (g) VR_SWEEP(8, true); else VR_SWEEP(8, false); }
+#define VR_SWEEP(B)                                                                                           \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_onesweep<B>), dim3(nblk), dim3(256), 0, s, (const uint32_t*)ka,      \
+                       (const uint32_t*)va, kb, vb, n, kmin, pass, (const uint32_t*)totals, st, err)
+        if (digit == 6) VR_SWEEP(6);
+        else if (digit == 9) VR_SWEEP(9);
+        else VR_SWEEP(8);
 #undef VR_SWEEP
         VR_KERNEL_CHECK("onesweep", s, debug);
         uint32_t* t = ka; ka = kb; kb = t;
@@ -998,7 +994,7 @@ __device__ __forceinline__ unsigned long long sum_posted_wave(const unsigned lon
 }
 
 __global__ void __launch_bounds__(256)
-k_emit_scan(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ rect_sorted,
+k_emit_scan(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ rect,
             unsigned long long* __restrict__ status, uint32_t* __restrict__ err, uint32_t* __restrict__ tkeys,
             uint32_t* __restrict__ tvals)
 {
@@ -1009,9 +1005,11 @@ k_emit_scan(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint2* 
     uint32_t cnt = 0, id = 0;
     int x0 = 0, y0 = 0, w = 1;
     if (r < V) {
-        const uint2 rc = rect_sorted[r];
-        cnt = rect_area(rc);
+        // the packed rectangle is gathered by id HERE (1.65 M random 8-byte reads): this kernel is bound by the
+        // latency of its waits, not by bandwidth, and hides them; in the last depth-sort pass they cost 22 us
         id = sorted_id[r];
+        const uint2 rc = rect[id];
+        cnt = rect_area(rc);
         x0 = (int)(rc.x & 0xFFFFu);
         y0 = (int)(rc.x >> 16);
         w = max((int)(rc.y & 0xFFFFu), 1);
@@ -1190,7 +1188,6 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
     } else {
         uint32_t* tmp_key = (uint32_t*)(base + L.tmp_key);
         uint32_t* tmp_id = (uint32_t*)(base + L.tmp_id);
-        uint2* rect_sorted = (uint2*)(base + L.rect_sorted);
         uint32_t* tkeysA = (uint32_t*)(base + L.tkeysA);
         uint32_t* tkeysB = (uint32_t*)(base + L.tkeysB);
         uint32_t* tvalsB = (uint32_t*)(base + L.tvalsB);
@@ -1205,30 +1202,23 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
         const int rows = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
         const uint32_t* dpartial =
             (const uint32_t*)((const char*)stage1_scratch + align_up(4 * (size_t)rows * sizeof(uint32_t), 256));
-        // 2. depth sort of the visible Gaussians on the bits of (key - kmin) that vary; its last pass also gathers
-        // the tile rectangles into sorted order
+        // 2. depth sort of the visible Gaussians on the bits of (key - kmin) that vary
         uint32_t* sorted_id = vis_id;
         {
             ProfScope ps(VR_STAGE_DEPTH_SORT, s);
             int where = 0;
-            const RadixGather g{rect, rect_sorted};
             int rc = onesweep_sort(vis_key, vis_id, tmp_key, tmp_id, V, key_min, key_bits, dpartial, rows, (uint32_t*)st,
-                                   err, &g, s, debug, &where);
+                                   err, s, debug, &where);
             if (rc) return rc;
             sorted_id = where ? tmp_id : vis_id;
         }
-        // 3. emission; the offsets are scanned on the way
+        // 3. emission; the rectangles are gathered and the offsets scanned on the way
         prof_begin(VR_STAGE_EMIT, s);
-        if (radix_passes(key_bits) == 0) {   // all depth keys equal (or one Gaussian): nothing was scattered
-            hipLaunchKernelGGL(k_gather_rect, dim3(cdiv(V, 256)), dim3(256), 0, s, V, (const uint32_t*)sorted_id, rect,
-                               rect_sorted);
-            VR_KERNEL_CHECK("gather_rect", s, debug);
-        }
         const int passes = radix_passes(bits);
         uint32_t* va = (passes % 2 == 0) ? point_list : tvalsB;   // the last pass must land in point_list
         uint32_t* vb = (passes % 2 == 0) ? tvalsB : point_list;
         hipLaunchKernelGGL(k_emit_scan, dim3(cdiv(V, 256)), dim3(256), 0, s, V, cam.gx, (const uint32_t*)sorted_id,
-                           (const uint2*)rect_sorted, (unsigned long long*)(st + sp.depth), err, tkeysA, va);
+                           rect, (unsigned long long*)(st + sp.depth), err, tkeysA, va);
         VR_KERNEL_CHECK("emit_scan", s, debug);
         prof_end(VR_STAGE_EMIT, s);
         // 4. stable sort by tile id
@@ -1239,7 +1229,7 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
         VR_KERNEL_CHECK("digit_hist", s, debug);
         int where = 0;
         int rc = onesweep_sort(tkeysA, va, tkeysB, vb, R, 0u, bits, tpartial, hist_rows,
-                               (uint32_t*)(st + sp.depth + sp.emit), err, nullptr, s, debug, &where);
+                               (uint32_t*)(st + sp.depth + sp.emit), err, s, debug, &where);
         if (rc) return rc;
         tile_keys = where ? tkeysB : tkeysA;
     }

@@ -136,7 +136,8 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
 #pragma unroll
                 for (int c = 0; c < 3; ++c) srow[c] = shs[3 * (size_t)i + c];
             }
-            wave_copy_to_lds<SH_ROW_MAX / 4>(shs_rest + wave_first * rowr, sh_lds[w], rows_here * rowr, lane);
+            wave_copy_to_lds<SH_ROW_MAX / 4>(shs_rest + wave_first * rowr, sh_lds[w], rows_here * rowr, lane, __ballot(vis),
+                                             rowr);
             __builtin_amdgcn_wave_barrier();
             if (vis) {
                 const float* my = sh_lds[w] + lane * rowr;
@@ -155,16 +156,19 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
             // all (up to 12) loads of the lane in flight before the first LDS store
             float4 tmp[SH_ROW_MAX / 4];
             const int row4 = row >> 2;
-#pragma unroll
-            for (int j = 0; j < SH_ROW_MAX / 4; ++j)
-                if (lane + 64 * j < nvec) tmp[j] = nt_load4(&src4[lane + 64 * j]);  // streamed once
+            // rows of culled Gaussians (18 % in the street scene, scattered) are not fetched: their lane never reads them
+            const unsigned long long vis_rows = __ballot(vis);
+            int rr[SH_ROW_MAX / 4];
 #pragma unroll
             for (int j = 0; j < SH_ROW_MAX / 4; ++j) {
                 const int v = lane + 64 * j;
-                if (v < nvec) {
-                    const int r = row4 == 12 ? v / 12 : v / row4;
-                    dst4[r * (SH_LDS_STRIDE / 4) + (v - r * row4)] = tmp[j];
-                }
+                rr[j] = row4 == 12 ? v / 12 : v / row4;
+                if (v < nvec && ((vis_rows >> rr[j]) & 1ull)) tmp[j] = nt_load4(&src4[v]);  // streamed once
+            }
+#pragma unroll
+            for (int j = 0; j < SH_ROW_MAX / 4; ++j) {
+                const int v = lane + 64 * j;
+                if (v < nvec && ((vis_rows >> rr[j]) & 1ull)) dst4[rr[j] * (SH_LDS_STRIDE / 4) + (v - rr[j] * row4)] = tmp[j];
             }
             __builtin_amdgcn_wave_barrier();
             if (vis) {

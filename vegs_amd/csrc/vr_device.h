@@ -101,20 +101,31 @@ __device__ __forceinline__ float vr_exp_unclamped(float x)
 // ---- wave-cooperative linear copies between a contiguous global block and LDS (n floats, one wave).  16-byte
 // vector path when the global address is aligned (all of a lane's loads in flight before the first store), plus a
 // scalar tail; scalar path otherwise.  Used for the split SH storage, whose LDS row stride is the memory's own.
+// `rows` / `row_len`: when row_len > 0 the block is `rows`-masked rows of row_len floats and only float4s that touch a
+// row whose bit is set are fetched (the others are never read back by their lanes).
 template <int MAXV>
-__device__ __forceinline__ void wave_copy_to_lds(const float* __restrict__ src, float* __restrict__ lds, int n, int lane)
+__device__ __forceinline__ void wave_copy_to_lds(const float* __restrict__ src, float* __restrict__ lds, int n, int lane,
+                                                 unsigned long long rows = ~0ull, int row_len = 0)
 {
     if ((reinterpret_cast<size_t>(src) & 15) == 0) {
         const int nv = n >> 2;
         const float4* s4 = reinterpret_cast<const float4*>(src);
         float4* d4 = reinterpret_cast<float4*>(lds);
         float4 tmp[MAXV];
+        bool want[MAXV];
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int v = lane + 64 * j;
+            want[j] = v < nv;
+            if (row_len > 0 && want[j]) {
+                const int r0 = (4 * v) / row_len, r1 = (4 * v + 3) / row_len;
+                want[j] = (((rows >> r0) | (rows >> (r1 < 64 ? r1 : 63))) & 1ull) != 0ull;
+            }
+            if (want[j]) tmp[j] = nt_load4(&s4[v]);
+        }
 #pragma unroll
         for (int j = 0; j < MAXV; ++j)
-            if (lane + 64 * j < nv) tmp[j] = nt_load4(&s4[lane + 64 * j]);
-#pragma unroll
-        for (int j = 0; j < MAXV; ++j)
-            if (lane + 64 * j < nv) d4[lane + 64 * j] = tmp[j];
+            if (want[j]) d4[lane + 64 * j] = tmp[j];
         if (lane < (n & 3)) lds[(nv << 2) + lane] = src[(nv << 2) + lane];
     } else {
         for (int e = lane; e < n; e += 64) lds[e] = src[e];

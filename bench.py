@@ -87,11 +87,11 @@ def cpu_baseline(sc, deg, cams, gouts, views):
     return dt, frags, os.cpu_count()
 
 
-def prepare(sc, deg, cams, device, rng, count=True):
+def prepare(sc, deg, cams, device, rng, count=True, cam_ts=None):
     """Scene tensors + per-view upstream gradients and work counters (one untimed pass over every view)."""
     T = {k: torch.tensor(v, device=device, requires_grad=True) for k, v in sc.items()}
     bg = torch.zeros(3, device=device)
-    cam_ts = [harness.cam_tensors(c, device) for c in cams]
+    cam_ts = cam_ts if cam_ts is not None else [harness.cam_tensors(c, device) for c in cams]
     gouts, counters = [], []
     from vegs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     for v, cam in enumerate(cams):
@@ -112,27 +112,53 @@ def prepare(sc, deg, cams, device, rng, count=True):
                 cam_ts=cam_ts, gouts=gouts, counters=counters, deg=deg)
 
 
-def make_step(wl, rank, world, vps, factored=False, exchange="dense"):
+def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="train"):
     """One step = `vps` views forward + backward on this rank, then (N > 1) the gradient exchange.
     exchange "dense": all-reduce of the 59-float/Gaussian gradients.  "factored": the op returns the 3-float factor of
     the SH gradient, the ranks all-gather the factors (12 B) and all-reduce the other 11 floats (44 B), and every rank
     rebuilds the averaged dense SH gradient locally (inside the timed region) -- the same tensors on every rank at the
-    end of the step as with "dense", for 256 instead of 826 MB over the links at N = 8."""
+    end of the step as with "dense", for 256 instead of 826 MB over the links at N = 8.
+    mode "train": through harness.render, the counterpart of the reference's render() glue (a fresh zeros
+    screenspace_points + 0 with retain_grad per view, gaussian_renderer/__init__.py:27-32); "noglue": the same op call
+    with one persistent means2D leaf (what the ATen glue costs is the difference); "forward": forward only under
+    torch.no_grad(), as the reference's evaluation and video paths call it (train.py:338-508, render_video.py:162,202)."""
     T, cams, cam_ts, gouts, params, deg, bg = (wl[k] for k in ("T", "cams", "cam_ts", "gouts", "params", "deg", "bg"))
     n_views = len(cams)
     fact_x = world > 1 and exchange == "factored" and vps == 1
     factored = factored or fact_x
     others = [T[k] for k in ("means3D", "opacities", "scales", "rotations")]
+    from vegs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    m2d = torch.zeros_like(T["means3D"], requires_grad=True) if mode == "noglue" else None
+
+    def direct(v):
+        cam, ct = cams[v], cam_ts[v]
+        rs = GaussianRasterizationSettings(int(cam.image_height), int(cam.image_width), cam.tanfovx, cam.tanfovy, bg, 1.0,
+                                           ct["viewmatrix"], ct["projmatrix"], deg, ct["campos"], False, False)
+        return GaussianRasterizer(rs)(means3D=T["means3D"], means2D=m2d if m2d is not None else T["means3D"],
+                                      shs=T["shs"], opacities=T["opacities"], scales=T["scales"], rotations=T["rotations"])
 
     def step(i):
         done = []
         for k in range(vps):
             v = vdist.view_for_rank(i * vps + k, rank, world, n_views)
+            if mode == "forward":
+                with torch.no_grad():
+                    direct(v)
+                done.append(v)
+                continue
+            gc, gq, gs = gouts[v]
+            if mode == "noglue":
+                out = direct(v)
+                torch.autograd.backward([out[0], out[2], out[3]], [gc, gq, gs])
+                m2d.grad = None
+                done.append(v)
+                continue
             sink = torch.zeros_like(T["means3D"], requires_grad=True) if factored else None
             pkg = harness.render(cams[v], T, deg, bg, cam_t=cam_ts[v], sh_color_grad=sink)
-            gc, gq, gs = gouts[v]
             torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], [gc, gq, gs])
             done.append(v)
+        if mode == "forward":
+            return done
         if fact_x:
             from vegs_amd import optim
             F, Cc = vdist.exchange_factored(others, sink.grad, cam_ts[done[-1]]["campos"], world)
@@ -145,8 +171,9 @@ def make_step(wl, rank, world, vps, factored=False, exchange="dense"):
     return step
 
 
-def timed(step, warmup, steps, world):
+def timed(step, warmup, steps, world, first=None):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides.  Returns (seconds, views)."""
+    first = warmup if first is None else first
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
@@ -155,13 +182,30 @@ def timed(step, warmup, steps, world):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     views_done = []
-    for i in range(warmup, warmup + steps):
+    for i in range(first, first + steps):
         views_done.extend(step(i))
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     return time.perf_counter() - t0, views_done
+
+
+def timed_median(step, steps, world, repeats, first=0):
+    """`repeats` timed regions of exactly K steps each (same cameras every time), each bracketed as in timed(); the
+    MEDIAN region is the one reported (K steps are only ~40 ms: a single region is at the mercy of one scheduling hiccup).
+    Returns (median seconds, views of one region, [seconds of every region])."""
+    runs = []
+    views = None
+    for _ in range(max(1, repeats)):
+        dt, done = timed(step, 0, steps, world, first=first)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda") if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t[0])
+        runs.append(dt)
+        views = done
+    return float(np.median(runs)), views, runs
 
 
 def stage_profile(step, steps):
@@ -177,41 +221,89 @@ def stage_profile(step, steps):
     return {k: round(v[0] / max(v[1], 1), 4) for k, v in st.items() if v[1] > 0}
 
 
-def variant(name, sc, deg, cams, device, steps, warmup, factored=False, hints="warm"):
-    """A few steps of another scene/camera configuration, reported next to the headline (N = 1 only).
-    hints: "warm" = every camera was rendered before with the same model (as in the headline), "off" = per-camera
-    needed-segment hints disabled (what a camera's FIRST visit costs), "stale" = the hints come from a different
-    model: every Gaussian moved by N(0, 2 cm), opacity logits + N(0, 0.3), scales x exp(N(0, 0.05)) -- far more drift
-    than the ~300 Adam steps between two visits of a camera produce."""
+def drift_by_training(sc, deg, cams, cam_ts, gouts, device, iters, seed=9):
+    """What lies between two visits of a camera in the reference's loop (train.py:126-128 pops cameras without
+    replacement: one visit per epoch): `iters` iterations of the counterpart of train.py:143-168,196,292-320 -- render,
+    L1+SSIM + normal guidance against fixed random targets, backward, densification statistics, fused Adam at the
+    REFERENCE's learning rates -- followed by one prune (opacity < 0.005, scene/gaussian_model.py:397-407) and one clone
+    of the Gaussians with the largest accumulated screen-space gradient (top 1 %, :365-395).  Runs with the hint cache
+    suspended (the cache keeps what the cameras' LAST visit before this epoch recorded).  Returns the new scene dict."""
+    from vegs_amd import iteration, rasterizer
+    rng = np.random.default_rng(seed)
+    tr = iteration.Trainer(sc, device, fused=True, lrs=iteration.REFERENCE_LRS)
+    bg = torch.zeros(3, device=device)
+    H, W = cams[0].image_height, cams[0].image_width
+    gts = [torch.tensor(rng.uniform(0, 1, (3, H, W)).astype(np.float32), device=device) for _ in range(4)]
+    normals = [torch.tensor(rng.normal(size=(3, H, W)).astype(np.float32), device=device) for _ in range(4)]
+    was = rasterizer._use_hints
+    rasterizer._use_hints = False          # suspended, NOT cleared
+    try:
+        for it in range(iters):
+            v = int(rng.integers(len(cams)))
+            tr.step(cams[v], cam_ts[v], deg, bg, gts[it % 4], normals[it % 4])
+    finally:
+        rasterizer._use_hints = was
+    T = iteration.op_inputs(tr.p)
+    grad = (tr.accum / tr.denom.clamp(min=1)).reshape(-1)
+    keep = T["opacities"].reshape(-1) >= 0.005
+    thr = torch.quantile(grad[torch.randperm(grad.numel(), device=device)[:1_000_000]], 0.99)
+    clone = keep & (grad >= thr)
+    idx = torch.cat((torch.nonzero(keep).reshape(-1), torch.nonzero(clone).reshape(-1)))
+    out = {k: v[idx].contiguous().cpu().numpy() for k, v in T.items()}
+    info = {"iterations": iters, "pruned": int((~keep).sum()), "cloned": int(clone.sum()), "gaussians_after": int(idx.numel())}
+    del tr
+    torch.cuda.empty_cache()
+    return out, info
+
+
+def warm_hints(step, n_views):
+    """Two passes over every camera: a key's hint array exists from its second sighting on (vegs_amd/rasterizer.py)."""
+    for i in range(2 * n_views):
+        step(i)
+
+
+def variant(name, sc, deg, cams, device, steps, warmup, factored=False, hints="off", mode="train", repeats=3):
+    """A few steps of another scene / camera / operator configuration, reported next to the headline (N = 1 only).
+    hints: "off" = per-camera needed-segment hints disabled, as in the headline; "warm" = every camera was rendered
+    before with the SAME model (the best case: zero drift); "epoch" = the hints are one epoch old: recorded, then the
+    model went through drift_by_training (300 iterations at the reference's learning rates + one prune/clone), then the
+    timed first visits.  mode: see make_step."""
     from vegs_amd import rasterizer
     old = rasterizer.needed_hints(hints != "off")
-    wl = prepare(sc, deg, cams, device, np.random.default_rng(77))
-    step = make_step(wl, 0, 1, 1, factored)
-    if hints == "stale":
-        rng = np.random.default_rng(5)
-        T = wl["T"]
-        keep = {k: T[k].detach().clone() for k in ("means3D", "opacities", "scales")}
-        with torch.no_grad():
-            T["means3D"] += torch.tensor(rng.normal(0, 0.02, tuple(T["means3D"].shape)).astype(np.float32), device=device)
-            lo = torch.logit(T["opacities"].clamp(1e-4, 1 - 1e-4)) + torch.tensor(
-                rng.normal(0, 0.3, tuple(T["opacities"].shape)).astype(np.float32), device=device)
-            T["opacities"].copy_(torch.sigmoid(lo))
-            T["scales"] *= torch.tensor(np.exp(rng.normal(0, 0.05, tuple(T["scales"].shape))).astype(np.float32), device=device)
-        for i in range(len(cams)):        # one pass over the cameras with the drifted model: this is what the hints remember
+    extra = {}
+    try:
+        wl = prepare(sc, deg, cams, device, np.random.default_rng(77))
+        step = make_step(wl, 0, 1, 1, factored, mode=mode)
+        if hints == "warm":
+            warm_hints(step, len(cams))
+        elif hints == "epoch":
+            warm_hints(step, len(cams))                      # hints of the model as it is now
+            sc2, info = drift_by_training(sc, deg, cams, wl["cam_ts"], wl["gouts"], device, 300)
+            extra["drift"] = info
+            cam_ts = wl["cam_ts"]
+            del wl, step
+            torch.cuda.empty_cache()
+            was = rasterizer._use_hints
+            rasterizer._use_hints = False                    # counters of the drifted model without touching the hints
+            wl = prepare(sc2, deg, cams, device, np.random.default_rng(77), cam_ts=cam_ts)
+            rasterizer._use_hints = was
+            step = make_step(wl, 0, 1, 1, factored, mode=mode)
+            warmup, repeats = 0, 1                           # the timed steps ARE the first visits after the epoch
+            steps = min(steps, len(cams))
+        for i in range(warmup):
             step(i)
-        with torch.no_grad():
-            for k, v in keep.items():
-                T[k].copy_(v)
-        warmup = 0                        # the timed steps are the first visits with the original model
-        steps = min(steps, len(cams))
-    dt, done = timed(step, warmup, steps, 1)
-    rasterizer.needed_hints(old)
+        dt, done, runs = timed_median(step, steps, 1, repeats)
+    finally:
+        rasterizer.needed_hints(old)
     cn = wl["counters"]
     mean = {k: float(np.mean([cn[v][k] for v in done])) for k in ("V", "R", "F", "B")}
-    return {"workload": name, "views_per_s": round(steps / dt, 2), "ms_per_view": round(dt / steps * 1e3, 4),
-            "mfragments_per_s": round(sum(cn[v]["F"] for v in done) / dt / 1e6, 1),
-            "blended_mfragments_per_s": round(sum(cn[v]["B"] for v in done) / dt / 1e6, 1),
-            "mean_counters": {k: round(v, 1) for k, v in mean.items()}}
+    res = {"workload": name, "views_per_s": round(steps / dt, 2), "ms_per_view": round(dt / steps * 1e3, 4),
+           "ms_per_view_runs": [round(r / steps * 1e3, 4) for r in runs],
+           "mfragments_per_s": round(sum(cn[v]["F"] for v in done) / dt / 1e6, 1),
+           "blended_mfragments_per_s": round(sum(cn[v]["B"] for v in done) / dt / 1e6, 1),
+           "mean_counters": {k: round(v, 1) for k, v in mean.items()}}
+    res.update(extra)
+    return res
 
 
 def cpu_plan(cores):
@@ -256,6 +348,10 @@ def main():
     ap.add_argument("--exchange", choices=["factored", "dense"], default="factored",
                     help="N > 1: gradient exchange scheme (factored = all-gather of the rank-1 SH factors + all-reduce of "
                          "the other 11 floats; dense = all-reduce of all 59 floats per Gaussian)")
+    ap.add_argument("--hints", choices=["off", "warm"], default="off",
+                    help="per-camera needed-segment hints in the HEADLINE: off (default: every view costs what a camera's "
+                         "first visit costs -- a number any training loop meets) or warm (zero model drift: the best case)")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--views-per-step", type=int, default=1,
                     help="views each rank renders per step; their gradients accumulate locally and are exchanged once")
     args = ap.parse_args()
@@ -274,18 +370,24 @@ def main():
     N = H * W
     K = (deg + 1) ** 2
     n_views = len(cams)
+    from vegs_amd import rasterizer
+    rasterizer.needed_hints(args.hints == "warm")
     wl = prepare(sc, deg, cams, device, np.random.default_rng(1234))
     counters, gouts = wl["counters"], wl["gouts"]
     vps = max(1, args.views_per_step)
     step = make_step(wl, rank, world, vps, exchange=args.exchange)
 
+    if args.hints == "warm":
+        warm_hints(step, n_views)
     for i in range(args.warmup):
         step(i)
     _capi.profile_level(1)          # level 1: HIP events around the roofline kernel only (one launch in four), inside the timed region
     _capi.profile_collect()
     mallocs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     reserved0 = torch.cuda.memory_reserved(device)
-    elapsed, views_done = timed(step, 0, args.steps, world)
+    # `repeats` regions of exactly K steps (barrier + synchronize on both sides of each, max over ranks per region);
+    # the median region is the one reported
+    elapsed, views_done, region_s = timed_median(step, args.steps, world, args.repeats, first=args.warmup)
     stage = _capi.profile_collect()
     _capi.profile_level(0)
     mallocs1 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
@@ -295,11 +397,9 @@ def main():
     if world > 1:
         # host tensors with gloo (the single-GPU test transport), device tensors with RCCL
         red_dev = device if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
-        t = torch.tensor([elapsed, frag_local, blend_local], dtype=torch.float64, device=red_dev)
-        tmax = t.clone()
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        t = torch.tensor([frag_local, blend_local], dtype=torch.float64, device=red_dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
-        elapsed, frag_total, blend_total = float(tmax[0]), float(t[1]), float(t[2])
+        frag_total, blend_total = float(t[0]), float(t[1])
     else:
         frag_total, blend_total = frag_local, blend_local
 
@@ -330,13 +430,18 @@ def main():
         "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        # `repeats` regions of K steps each were timed; value / ms_per_step are those of the MEDIAN region
+        "repeats": len(region_s), "ms_per_step_regions": [round(r / args.steps * 1e3, 4) for r in region_s],
         # F = sum of n_contrib = list entries TRAVERSED by the forward blend loop (BASELINE.md's fragment definition);
         # B = (pixel, splat) pairs actually BLENDED (alpha >= 1/255 before the stop) -- an order of magnitude fewer
         "mfragments_per_s": round(frag_total / elapsed / 1e6, 2),
         "blended_mfragments_per_s": round(blend_total / elapsed / 1e6, 2),
         "config": {"workload": f"{args.workload}: {P} street Gaussians (VEGS disc init), SH deg {deg}, {W}x{H} "
                                f"KITTI-360 intrinsics, {n_views} views cycled, 12 output channels + colour/quat/scale grads; "
-                               "every camera visited before (per-camera needed-segment hints warm, see variants)",
+                               + ("per-camera needed-segment hints OFF: every view is rendered as a camera's first visit"
+                                  if args.hints == "off" else
+                                  "per-camera needed-segment hints WARM with zero model drift (best case; see variants)"),
+                   "hints": args.hints,
                    "gaussians": P, "width": W, "height": H, "views_per_step_per_gpu": vps,
                    "parallelism": f"view-sharded x{world}" + ("" if world == 1 else
                                                               " + RCCL all-gather of SH factors (3 f32) + all-reduce (11 f32) per Gaussian"
@@ -370,11 +475,19 @@ def main():
                     cams[:8], device, 8, 2),
             variant("headline scene, SH gradient returned as its 3-float factor (sh_color_grad) instead of [P,16,3]", sc,
                     deg, cams[:8], device, 16, 4, factored=True),
-            variant("headline scene, per-camera needed-segment hints OFF (cost of a camera's first visit)", sc, deg,
-                    cams, device, 16, 4, hints="off"),
-            variant("headline scene, STALE hints (from a model with every Gaussian moved 2 cm, opacity logits +-0.3, "
-                    "scales +-5 %)", sc, deg, cams, device, 16, 0, hints="stale"),
+            variant("headline scene, needed-segment hints WARM, zero model drift (every camera rendered twice before with "
+                    "the same model): the best case of the hint cache", sc, deg, cams, device, 16, 4, hints="warm"),
+            variant("headline scene, hints ONE EPOCH OLD: recorded, then 300 training iterations at the reference's "
+                    "learning rates + one prune/clone (train.py:126-128,292-320), then the timed first visits", sc, deg,
+                    cams, device, 16, 0, hints="epoch"),
+            variant("headline scene, op called without the reference's render() glue (one persistent means2D leaf instead "
+                    "of zeros_like + 0 / retain_grad per view): the difference to the headline is ATen glue", sc, deg, cams,
+                    device, 16, 4, mode="noglue"),
+            variant("headline scene, FORWARD ONLY under torch.no_grad() (evaluation / video rendering, train.py:338-508, "
+                    "render_video.py:162,202)", sc, deg, cams, device, 16, 4, mode="forward"),
         ]
+        res["aten_glue_ms_per_view"] = round(res["ms_per_step"] / vps - res["variants"][5]["ms_per_view"], 4) \
+            if args.hints == "off" else None
     if world == 1 and not args.no_cpu_baseline:
         cpu_views = [0, 5, 10, 15]
         dt, frags, cores = cpu_baseline(sc, deg, cams, gouts, cpu_views)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VR_ABI_VERSION 4
+#define VR_ABI_VERSION 5
 
 typedef enum VrStatus {
     VR_OK = 0,
@@ -147,11 +147,20 @@ typedef struct VrSaved {
     uint32_t* needed_hint;    /* IN/OUT, optional (NULL = none): device array [tiles], tiles = ceil(W/16)*ceil(H/16) in
                                  row-major tile order, owned by the caller and kept PER CAMERA.  On entry: the number of
                                  256-entry list segments each tile needed in the previous forward of this camera at this
-                                 image size (fill a new array with 0x3FFFFFFF = "no idea").  The forward skips the work
-                                 behind hint+1 segments per tile, redoes it on the spot wherever the hint turns out too
-                                 small -- results never depend on it, bit-exact either way; only the time does (about
-                                 half of the segments of a KITTI-shaped view are never needed) -- and overwrites the
-                                 array, asynchronously on `stream`, with what THIS forward needed. */
+                                 image size (fill a new array with 0x3FFFFFFF = "no idea").  With a hint h for a tile
+                                 the forward computes only the tile's first  h + 2 + h/8  segments up front (the hint
+                                 plus a margin of two segments and 12 %; the array is read ONCE per call, by the first
+                                 render kernel) and redoes the rest on the spot wherever that turns out too small --
+                                 results never depend on the hint, bit-exact either way; only the time does (about half
+                                 of the segments of a KITTI-shaped view are never needed).  The forward overwrites the
+                                 array, asynchronously on `stream`, with what THIS forward needed: exactly the values
+                                 vr_export_needed returns, i.e. per tile the number of leading segments in which at
+                                 least one pixel was still alive. */
+    uint64_t ticket;          /* OUT (ABI v5): identifies this forward's slot in the library's pinned guard ring.  The
+                                 single-launch binning passes bound every wait for another workgroup's posted sum; the
+                                 last binning kernel posts whether one ran out, and vr_backward / vr_count_* /
+                                 vr_export_needed / vr_debug_export_binning called with this VrSaved return VR_ERR_HIP
+                                 for exactly this view (0 = nothing to check).  Pass it on unchanged. */
 } VrSaved;
 
 /* Incoming gradients, one per differentiable output (NULL = zero). */
@@ -258,10 +267,15 @@ int vr_profile_collect(double* ms, int64_t* count);
 int vr_debug_export_binning(const VrSaved* saved, int32_t image_height, int32_t image_width,
                             uint32_t* point_list, int32_t* ranges, void* stream);
 
-/* Test hook for the binning guard: the single-launch radix passes bound every wait for another workgroup's posted sum
- * and raise a device-side guard word if one runs out; the NEXT vr_forward of this host thread on this device then
- * returns VR_ERR_HIP and clears the word.  This sets the word (value != 0) or clears it (0) by hand. */
+/* Test hooks for the binning guard: the single-launch radix passes bound every wait for another workgroup's posted sum
+ * (2 s of wall clock) and raise a device-side guard word if one runs out.  The view whose wait ran out is the one that
+ * fails: its vr_backward (and every other call taking its VrSaved) returns VR_ERR_HIP through VrSaved.ticket; a forward
+ * that never gets a backward (eval under no_grad) is reported by the NEXT vr_forward of the host thread instead.
+ * vr_debug_set_guard sets the word (value != 0) or clears it (0) by hand, as if an earlier view had raised it;
+ * vr_debug_raise_guard(1) makes the NEXT vr_forward of the calling thread raise it in the middle of its own binning, as
+ * a timed-out wait would. */
 int vr_debug_set_guard(uint32_t value, void* stream);
+int vr_debug_raise_guard(int on);
 
 #ifdef __cplusplus
 }

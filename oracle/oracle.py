@@ -136,8 +136,9 @@ def forward(cam, means3D, shs, colors_precomp, opacities, scales, rotations, cov
     return out, st
 
 
-def backward(cam, st, dL_dcolor=None, dL_ddepth=None, dL_dquat=None, dL_dscale=None, dL_dalpha=None):
-    """Backward of forward().  Returns dense input gradients (dict of numpy float32)."""
+def backward(cam, st, dL_dcolor=None, dL_ddepth=None, dL_dquat=None, dL_dscale=None, dL_dalpha=None, abs_sums=False):
+    """Backward of forward().  Returns dense input gradients (dict of numpy float32).
+    abs_sums: also return, under "_per_gaussian"["abs"], the [P,17] sums of the absolute per-fragment terms."""
     L = lib()
     inp = st["inputs"]
     P = inp["means3D"].shape[0]
@@ -145,13 +146,36 @@ def backward(cam, st, dL_dcolor=None, dL_ddepth=None, dL_dquat=None, dL_dscale=N
     g_conic = np.zeros((P, 3), np.float64)
     g_opacity = np.zeros(P, np.float64)
     g_attr = np.zeros((P, NCH), np.float64)
+    g_abs = np.zeros((P, 17), np.float64) if abs_sums else None
     dL_dcolor, dL_ddepth, dL_dquat = _f32(dL_dcolor), _f32(dL_ddepth), _f32(dL_dquat)
     dL_dscale, dL_dalpha = _f32(dL_dscale), _f32(dL_dalpha)
     pl = st["point_list"] if st["R"] > 0 else np.zeros(1, np.uint32)
     L.or_render_bwd(C.byref(cam), P, _p(st["ranges"]), _p(pl), _p(st["xy"]), _p(st["conic_op"]), _p(st["rgb"]),
                     _p(st["depth"]), _p(inp["rotations"]), _p(inp["scales"]), _p(st["final_T"]), _p(st["n_contrib"]),
                     _p(st["out_depth"]), _p(dL_dcolor), _p(dL_ddepth), _p(dL_dquat), _p(dL_dscale), _p(dL_dalpha),
-                    _p(g_mean2D), _p(g_conic), _p(g_opacity), _p(g_attr))
+                    _p(g_mean2D), _p(g_conic), _p(g_opacity), _p(g_attr), _p(g_abs))
+    grads = preprocess_backward(cam, st, g_mean2D, g_conic, g_opacity, g_attr)
+    grads["_per_gaussian"] = dict(mean2D=g_mean2D, conic=g_conic, opacity=g_opacity, attr=g_attr, abs=g_abs)
+    return grads
+
+
+def preprocess_backward(cam, st, g_mean2D, g_conic, g_opacity, g_attr, perturb=None):
+    """Second half of backward(): the per-Gaussian sums of the render backward (float64) -> dense input gradients.
+    perturb = (eps, seed, abs [P,17]): add eps * abs * N(0,1) to every sum first, abs = the sums of the absolute
+    per-fragment terms (backward(abs_sums=True)) -- the model of what an fp32 summation of those terms carries.  The
+    tests use it to MEASURE which rows are ill-conditioned with respect to the sums they start from (conic -> cov2D ->
+    cov3D divides by det^2 of the 2D covariance; for edge-on 1e-5-thin discs such a perturbation moves the result by
+    far more than 1e-3): those rows cannot be held to a tight tolerance by ANY fp32 implementation, this one included."""
+    L = lib()
+    inp = st["inputs"]
+    P = inp["means3D"].shape[0]
+    if perturb is not None:
+        eps, seed, ab = perturb
+        rng = np.random.default_rng(seed)
+        g_mean2D = g_mean2D + eps * ab[:, 0:2] * rng.standard_normal(g_mean2D.shape)
+        g_conic = g_conic + eps * ab[:, 2:5] * rng.standard_normal(g_conic.shape)
+        g_opacity = g_opacity + eps * ab[:, 5] * rng.standard_normal(g_opacity.shape)
+        g_attr = g_attr + eps * ab[:, 6:17] * rng.standard_normal(g_attr.shape)
     M = cam.M
     has_sh = inp["shs"] is not None
     has_sr = inp["scales"] is not None
@@ -171,5 +195,4 @@ def backward(cam, st, dL_dcolor=None, dL_ddepth=None, dL_dquat=None, dL_dscale=N
                         _p(st["cov3D"]), _p(st["clamped"]), _p(gm), _p(gc), _p(ga),
                         _p(grads["means3D"]), _p(grads["shs"]), _p(grads["colors_precomp"]), _p(grads["scales"]),
                         _p(grads["rotations"]), _p(grads["cov3D_precomp"]))
-    grads["_per_gaussian"] = dict(mean2D=g_mean2D, conic=g_conic, opacity=g_opacity, attr=g_attr)
     return grads

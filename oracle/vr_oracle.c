@@ -449,9 +449,12 @@ void or_render_bwd(const OrCam* cam, int P, const int* ranges, const uint32_t* p
                    const float* final_T, const uint32_t* n_contrib, const float* out_depth,
                    const float* dL_dcolor, const float* dL_ddepth, const float* dL_dquat,
                    const float* dL_dscale, const float* dL_dalpha,
-                   double* g_mean2D, double* g_conic, double* g_opacity, double* g_attr)
+                   double* g_mean2D, double* g_conic, double* g_opacity, double* g_attr, double* g_abs)
 {
-    /* out_depth: the forward's depth image (only read with FLAG_DEPTH_NORMALIZED) */
+    /* out_depth: the forward's depth image (only read with FLAG_DEPTH_NORMALIZED).
+     * g_abs (optional, [P][17]: mean2D 2 | conic 3 | opacity 1 | attr 11): sums of the ABSOLUTE values of the same
+     * per-fragment terms -- the scale against which an fp32 summation of them rounds; the tests use it to measure
+     * which rows of the dense gradients are ill-conditioned (oracle.preprocess_backward, perturb). */
     const int no_extra = (cam->flags & FLAG_EXTRA_NO_ALPHA_GRAD) != 0;
     const int nu = no_extra ? 3 : NCH; /* channels whose gradient also flows through alpha */
     int H = cam->H, W = cam->W;
@@ -461,6 +464,7 @@ void or_render_bwd(const OrCam* cam, int P, const int* ranges, const uint32_t* p
     memset(g_conic, 0, sizeof(double) * 3 * (size_t)P);
     memset(g_opacity, 0, sizeof(double) * (size_t)P);
     memset(g_attr, 0, sizeof(double) * NCH * (size_t)P);
+    if (g_abs) memset(g_abs, 0, sizeof(double) * 17 * (size_t)P);
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gx * gy; ++tile) {
         int tx = tile % gx, ty = tile / gx;
@@ -529,6 +533,19 @@ void or_render_bwd(const OrCam* cam, int P, const int* ranges, const uint32_t* p
                     g_conic[3 * (size_t)id + 2] += (double)(-0.5f * gdy * dy * dL_dG);
 #pragma omp atomic
                     g_opacity[id] += (double)(G * dL_dalpha_s);
+                    if (g_abs) {
+                        const float t[6] = {dL_dG * dG_ddx * (0.5f * (float)W), dL_dG * dG_ddy * (0.5f * (float)H),
+                                            -0.5f * gdx * dx * dL_dG, -gdx * dy * dL_dG, -0.5f * gdy * dy * dL_dG,
+                                            G * dL_dalpha_s};
+                        for (int k = 0; k < 6; ++k) {
+#pragma omp atomic
+                            g_abs[17 * (size_t)id + k] += (double)fabsf(t[k]);
+                        }
+                        for (int k = 0; k < NCH; ++k) {
+#pragma omp atomic
+                            g_abs[17 * (size_t)id + 6 + k] += (double)fabsf(w * g[k]);
+                        }
+                    }
                 }
             }
     }

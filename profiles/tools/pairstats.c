@@ -1,0 +1,131 @@
+/* pairstats.c -- offline statistics of the backward's (list entry, pixel) contribution matrix, per
+ * (tile, 256-entry segment, 8x8 region), computed from the CPU oracle's forward state (test/profiling tool).
+ * Build: gcc -O2 -fopenmp -shared -fPIC -o /tmp/libpairstats.so pairstats.c -lm */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+static inline float vr_exp(float x)
+{
+    float t = x * 1.44269504088896341f, n = rintf(t);
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.0f / 720.0f;
+    p = fmaf(p, r, 1.0f / 120.0f); p = fmaf(p, r, 1.0f / 24.0f); p = fmaf(p, r, 1.0f / 6.0f);
+    p = fmaf(p, r, 0.5f); p = fmaf(p, r, 1.0f); p = fmaf(p, r, 1.0f);
+    return x < -87.0f ? 0.0f : ldexpf(p, (int)n);
+}
+/* out[0]=units (seg,region with >=1 pair) out[1]=pairs out[2]=sum max_c out[3]=sum ceil(pairs/64) out[4]=sum nrel(exact)
+ * out[5]=units of needed segments (incl. empty) ; hist_max[65] histogram of max_c (capped 64); out[6]=sum over units of max_c with
+ * lanes sorted... ; out[7] = sum over units of trips if split in 2 half-waves (32 pixels each, max per half summed/2) */
+void pair_stats(int H, int W, const int* ranges, const uint32_t* point_list, const float* xy, const float* conic_op,
+                const uint32_t* n_contrib, double* out, double* hist_max, double* hist_nrel)
+{
+    int gx = (W + 15) / 16, gy = (H + 15) / 16;
+    double o[8] = {0};
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gx * gy; ++tile) {
+        int tx = tile % gx, ty = tile / gx;
+        int s = ranges[2 * tile], e = ranges[2 * tile + 1];
+        double lo[8] = {0}, lh[65] = {0}, ln[257] = {0};
+        int maxnc = 0;
+        for (int ly = 0; ly < 16; ++ly) for (int lx = 0; lx < 16; ++lx) {
+            int px = tx * 16 + lx, py = ty * 16 + ly;
+            if (px < W && py < H && (int)n_contrib[(size_t)py * W + px] > maxnc) maxnc = n_contrib[(size_t)py * W + px];
+        }
+        for (int sb = s; sb < e && sb - s < maxnc; sb += 256) {
+            int se = sb + 256 < e ? sb + 256 : e;
+            for (int reg = 0; reg < 4; ++reg) {
+                int c[64]; memset(c, 0, sizeof c);
+                int nrel = 0;
+                for (int j = sb; j < se; ++j) {
+                    int id = point_list[j];
+                    int any = 0;
+                    for (int l = 0; l < 64; ++l) {
+                        int px = tx * 16 + (reg % 2) * 8 + (l % 8), py = ty * 16 + (reg / 2) * 8 + (l / 8);
+                        if (px >= W || py >= H) continue;
+                        if (j - s >= (int)n_contrib[(size_t)py * W + px]) continue;
+                        float dx = xy[2 * id] - (float)px, dy = xy[2 * id + 1] - (float)py;
+                        const float* con = conic_op + 4 * id;
+                        float q = fmaf(con[2] * dy, dy, (con[0] * dx) * dx);
+                        float power = fmaf(-0.5f, q, -((con[1] * dx) * dy));
+                        if (power > 0.0f) continue;
+                        float alpha = fminf(0.99f, con[3] * vr_exp(power));
+                        if (alpha < 1.0f / 255.0f) continue;
+                        c[l]++; any = 1;
+                    }
+                    nrel += any;
+                }
+                int mx = 0, sum = 0, mxa = 0, mxb = 0;
+                for (int l = 0; l < 64; ++l) { sum += c[l]; if (c[l] > mx) mx = c[l]; if (l < 32) { if (c[l] > mxa) mxa = c[l]; } else if (c[l] > mxb) mxb = c[l]; }
+                lo[5] += 1;
+                if (sum) { lo[0] += 1; lo[1] += sum; lo[2] += mx; lo[3] += (sum + 63) / 64; lo[4] += nrel; lh[mx > 64 ? 64 : mx] += 1; ln[nrel] += 1;
+                           lo[7] += 0.5 * (mxa + mxb); }
+            }
+        }
+#pragma omp critical
+        { for (int k = 0; k < 8; ++k) o[k] += lo[k]; for (int k = 0; k < 65; ++k) hist_max[k] += lh[k]; for (int k = 0; k < 257; ++k) hist_nrel[k] += ln[k]; }
+    }
+    for (int k = 0; k < 8; ++k) out[k] = o[k];
+}
+
+/* quadrant statistics.  bwd (needed segments, entries before the pixel's last contributor): per (segment, 8x8 region) the
+ * number of contributing entries n and per 4x4 quadrant n_q.  out[0] = sum 32*ceil(n/64) (pixel-pair trips now),
+ * out[1] = sum 8*max_q ceil(n_q/16) (rows of 16 entries per quadrant), out[2] = sum n, out[3] = sum_q n_q,
+ * fwd (all segments up to the tile's needed count / all segments): out[4] = sum n_fwd (needed segs), out[5] = sum max_q n_q fwd (needed),
+ * out[6] = sum n_fwd all segments, out[7] = sum max_q n_q all segments, out[8] = sum_q n_q fwd all, out[9] = units all */
+void quad_stats(int H, int W, const int* ranges, const uint32_t* point_list, const float* xy, const float* conic_op,
+                const uint32_t* n_contrib, double* out)
+{
+    int gx = (W + 15) / 16, gy = (H + 15) / 16;
+    double o[10] = {0};
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gx * gy; ++tile) {
+        int tx = tile % gx, ty = tile / gx;
+        int s = ranges[2 * tile], e = ranges[2 * tile + 1];
+        double lo[10] = {0};
+        int maxnc = 0;
+        for (int ly = 0; ly < 16; ++ly) for (int lx = 0; lx < 16; ++lx) {
+            int px = tx * 16 + lx, py = ty * 16 + ly;
+            if (px < W && py < H && (int)n_contrib[(size_t)py * W + px] > maxnc) maxnc = n_contrib[(size_t)py * W + px];
+        }
+        for (int sb = s; sb < e; sb += 256) {
+            int se = sb + 256 < e ? sb + 256 : e;
+            int needed = sb - s < maxnc;
+            for (int reg = 0; reg < 4; ++reg) {
+                int nb = 0, nbq[4] = {0, 0, 0, 0}, nf = 0, nfq[4] = {0, 0, 0, 0};
+                for (int j = sb; j < se; ++j) {
+                    int id = point_list[j];
+                    int anyb[4] = {0, 0, 0, 0}, anyf[4] = {0, 0, 0, 0};
+                    for (int l = 0; l < 64; ++l) {
+                        int lx = l % 8, ly = l / 8;
+                        int px = tx * 16 + (reg % 2) * 8 + lx, py = ty * 16 + (reg / 2) * 8 + ly;
+                        if (px >= W || py >= H) continue;
+                        float dx = xy[2 * id] - (float)px, dy = xy[2 * id + 1] - (float)py;
+                        const float* con = conic_op + 4 * id;
+                        float q = fmaf(con[2] * dy, dy, (con[0] * dx) * dx);
+                        float power = fmaf(-0.5f, q, -((con[1] * dx) * dy));
+                        if (power > 0.0f) continue;
+                        float alpha = fminf(0.99f, con[3] * vr_exp(power));
+                        if (alpha < 1.0f / 255.0f) continue;
+                        int qd = (ly / 4) * 2 + lx / 4;
+                        anyf[qd] = 1;
+                        if (j - s < (int)n_contrib[(size_t)py * W + px]) anyb[qd] = 1;
+                    }
+                    int ab = anyb[0] | anyb[1] | anyb[2] | anyb[3], af = anyf[0] | anyf[1] | anyf[2] | anyf[3];
+                    nb += ab; nf += af;
+                    for (int k = 0; k < 4; ++k) { nbq[k] += anyb[k]; nfq[k] += anyf[k]; }
+                }
+                int mqb = 0, mqf = 0, mcb = 0;
+                for (int k = 0; k < 4; ++k) { if (nbq[k] > mqb) mqb = nbq[k]; if (nfq[k] > mqf) mqf = nfq[k]; int c = (nbq[k] + 15) / 16; if (c > mcb) mcb = c; }
+                if (needed) {
+                    lo[0] += 32 * ((nb + 63) / 64); lo[1] += 8 * mcb; lo[2] += nb; lo[3] += nbq[0] + nbq[1] + nbq[2] + nbq[3];
+                    lo[4] += nf; lo[5] += mqf;
+                }
+                lo[6] += nf; lo[7] += mqf; lo[8] += nfq[0] + nfq[1] + nfq[2] + nfq[3]; lo[9] += 1;
+            }
+        }
+#pragma omp critical
+        { for (int k = 0; k < 10; ++k) o[k] += lo[k]; }
+    }
+    for (int k = 0; k < 10; ++k) out[k] = o[k];
+}

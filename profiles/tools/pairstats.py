@@ -1,0 +1,32 @@
+"""Offline statistics of the render backward's (entry, pixel) contribution matrix on the headline scene (CPU oracle).
+usage: python profiles/tools/pairstats.py [P]"""
+import ctypes as C, os, subprocess, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+from oracle import oracle as orc
+from vegs_amd import scenes
+here = os.path.dirname(os.path.abspath(__file__))
+so = "/tmp/libpairstats.so"
+subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", "-o", so, os.path.join(here, "pairstats.c"), "-lm"])
+L = C.CDLL(so)
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+sc, deg = scenes.scene_street(P=P, length=250.0, sh_degree=3, seed=2)
+cam = scenes.kitti_camera(20.0, -0.3, 1376, 376)
+oc = orc.make_cam(376, 1376, cam.tanfovx, cam.tanfovy, [0, 0, 0], 1.0, cam.world_view_transform, cam.full_proj_transform, cam.camera_center, deg, 16)
+out, st = orc.forward(oc, sc["means3D"], sc["shs"], None, sc["opacities"], sc["scales"], sc["rotations"], None)
+o = np.zeros(8); hm = np.zeros(65); hn = np.zeros(257)
+p = lambda a: a.ctypes.data_as(C.c_void_p)
+L.pair_stats(376, 1376, p(st["ranges"]), p(st["point_list"]), p(st["xy"]), p(st["conic_op"]), p(st["n_contrib"]), p(o), p(hm), p(hn))
+print("R", st["R"], "units(nonempty)", o[0], "units(needed)", o[5], "pairs", o[1], "sum max_c", o[2], "dense batches", o[3], "sum nrel_exact", o[4], "half-wave trips", o[7])
+print("avg pairs/unit", o[1] / o[0], "avg max_c", o[2] / o[0], "avg nrel", o[4] / o[0])
+cum = np.cumsum(hm) / hm.sum()
+print("max_c percentiles:", {q: int(np.searchsorted(cum, q)) for q in (0.25, 0.5, 0.75, 0.9, 0.99)})
+cumn = np.cumsum(hn) / hn.sum()
+print("nrel percentiles:", {q: int(np.searchsorted(cumn, q)) for q in (0.25, 0.5, 0.75, 0.9, 0.99)})
+print("trips weighted hist (max_c bucket: share of sum max_c):", {k: round(float((hm[a:b] * np.arange(a, b)).sum() / o[2]), 3) for k, (a, b) in {"1-4": (1, 5), "5-8": (5, 9), "9-16": (9, 17), "17-32": (17, 33), "33-64": (33, 65)}.items()})
+
+q = np.zeros(10)
+L.quad_stats(376, 1376, p(st["ranges"]), p(st["point_list"]), p(st["xy"]), p(st["conic_op"]), p(st["n_contrib"]), p(q))
+print("bwd pixel-pair trips now", q[0], "rows-of-16-per-quadrant trips", q[1], "ratio", q[0] / q[1], "| sum n", q[2], "sum_q n_q", q[3], "quadrants per entry", q[3] / q[2])
+print("fwd needed segs: sum n", q[4], "sum max_q n_q", q[5], "ratio", q[4] / q[5])
+print("fwd all segs: sum n", q[6], "sum max_q n_q", q[7], "ratio", q[6] / q[7], "quadrants per entry", q[8] / q[6], "units", q[9])

@@ -18,8 +18,10 @@ for scale in (0.25, 1.0):
     rasterizer._NEEDED.clear()
     with torch.no_grad():
         harness.render(cam, Tp, deg, bg, cam_t=ct)
+        harness.render(cam, Tp, deg, bg, cam_t=ct)      # (a key's hint array exists from its second sighting on)
         a = list(rasterizer._NEEDED.values())[0].clone().cpu().numpy().astype(np.int64)
         rasterizer._NEEDED.clear()
+        harness.render(cam, T, deg, bg, cam_t=ct)
         harness.render(cam, T, deg, bg, cam_t=ct)
         b = list(rasterizer._NEEDED.values())[0].clone().cpu().numpy().astype(np.int64)
     d = b - a

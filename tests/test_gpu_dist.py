@@ -196,6 +196,8 @@ def test_bench_line_contract_single_gpu():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["unit"] == "views/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["hints"] == "off" and d["repeats"] == 3 and len(d["ms_per_step_regions"]) == 3
+    assert min(d["ms_per_step_regions"]) <= d["ms_per_step"] <= max(d["ms_per_step_regions"])
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0 < rf["frac"] < 1 and "traffic" in rf

@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import OUT_NAMES, assert_grad_close, oracle_cam, rel_err
+from helpers import (OUT_NAMES, assert_grad_close, grad_mismatch, ill_conditioned, oracle_cam, rel_err,
+                     summation_sensitivity)
 from test_gpu_parity import _export_binning, _run_hip, _settings
 
 pytestmark = pytest.mark.gpu
@@ -44,8 +45,11 @@ def test_c2_500k_forward_matches_oracle_bit_exact(dev):
     for n in OUT_NAMES:
         assert np.array_equal(h_out[n], o_out[n]), n
     o_grads = orc.backward(oc, st, *gouts)
+    ill, explain = ill_conditioned(st)
     for k in ("means3D", "shs", "opacities", "scales", "rotations", "means2D"):
-        assert_grad_close(k, h_grads[k], o_grads[k], rtol=1e-3)
+        # default (atomic) mode: no row beyond 10x unless its conic is ill-conditioned (printed)
+        assert_grad_close(k, h_grads[k], o_grads[k], rtol=1e-3, explain=explain, ill=ill)
+    _oracle_parity("c2", _inputs(sc), deg, cam, dev)                     # deterministic mode: the tight comparison
 
 
 @pytest.fixture(scope="module")
@@ -55,6 +59,19 @@ def c3(dev):
     cam = scenes.kitti_camera(20.0, -0.3, 1376, 376)
     T = {k: torch.tensor(v, device=dev) for k, v in sc.items()}
     return sc, deg, cam, T
+
+
+_C3_ILL = {}
+
+
+def _c3_ill(c3):
+    """Ill-conditioned rows of the c3 fixture's view (from the oracle's forward state, computed once)."""
+    if "v" not in _C3_ILL:
+        from oracle import oracle as orc
+        sc, deg, cam, T = c3
+        _, st = orc.forward(oracle_cam(cam, [0, 0, 0], deg), **_inputs(sc))
+        _C3_ILL["v"] = ill_conditioned(st)
+    return _C3_ILL["v"]
 
 
 def _fwd(T, cam, deg, bg, dev, requires_grad=False):
@@ -166,8 +183,10 @@ def test_c3_deterministic_backward_mode(c3, dev):
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     c = grads(0)
+    ill, explain = _c3_ill(c3)
     for name, x, y in zip(("means3D", "shs", "opacities", "scales", "rotations", "means2D"), c, a):
-        assert_grad_close("c3 atomic vs deterministic " + name, x.cpu().numpy(), y.cpu().numpy(), rtol=1e-3, floor=2e-6)
+        assert_grad_close("c3 atomic vs deterministic " + name, x.cpu().numpy(), y.cpu().numpy(), rtol=1e-3, floor=2e-6,
+                          explain=explain, ill=ill)
 
 
 def test_c3_backward_is_linear_in_upstream_gradients(c3, dev):
@@ -183,15 +202,135 @@ def test_c3_backward_is_linear_in_upstream_gradients(c3, dev):
         return [t[k].grad for k in ("means3D", "shs", "opacities", "scales", "rotations")] + [m2d.grad]
     a, b = grads(g1), grads(g2)
     c = grads([x + y for x, y in zip(g1, g2)])
+    ill, explain = _c3_ill(c3)
     for x, y, z in zip(a, b, c):
         assert torch.isfinite(z).all()
-        # (both sides carry fp32-atomic noise, and the preprocess backward amplifies it without bound for the few
-        # 1e-5-thin discs whose conic gradient nearly cancels: no cap on the worst row here, only on how many)
-        assert_grad_close("linearity", (x + y).cpu().numpy(), z.cpu().numpy(), rtol=1e-3, floor=2e-6, cap=1e9)
+        # (both sides carry fp32-atomic noise, and the preprocess backward amplifies it without bound for the
+        # 1e-5-thin discs seen edge-on: only rows whose conic is ill-conditioned may leave the 10x cap; printed)
+        assert_grad_close("linearity", (x + y).cpu().numpy(), z.cpu().numpy(), rtol=1e-3, floor=2e-6, explain=explain, ill=ill)
     assert c[5][:, 2].abs().max().item() == 0.0
     radii = _fwd(T, cam, deg, [0, 0, 0], dev)[0][5]
     culled = radii == 0
     assert culled.any() and all(g[culled].abs().max().item() == 0.0 for g in c)   # dense, zero where culled
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The headline workloads under the oracle (round 3).  Forward: radii, tile lists, ranges and all five images BIT-EXACT.
+# Gradients: the backward runs in VR_FLAG_DETERMINISTIC (per-(entry, region) partial sums added in list order: no
+# order-dependent atomics) and is compared PER ROW with the oracle's double sums.
+#   * means2D, opacities, shs are plain sums of per-fragment terms: rtol 2e-4, at most 0.001 % of the rows outside it
+#     (measured: 0 or 1 row of 2-5 M -- a sum of mixed-sign terms that cancels), each explained as below.
+#   * means3D, scales, rotations go on through conic -> cov2D -> cov3D (k_preprocess_bwd), which divides by det^2 of
+#     the 2D covariance: for edge-on discs (VEGS initialises 1e-5-thin discs) that chain amplifies the fp32 rounding
+#     of the sums it starts from without bound.  Which rows those are is MEASURED (helpers.summation_sensitivity): the
+#     oracle's own fp32 preprocess backward is re-run on its per-Gaussian sums perturbed by 2e-6 x (sum of the absolute
+#     per-fragment terms) -- what an fp32 summation of those terms carries; a row that moves by m allowances cannot be
+#     held closer than that by any fp32 chain, the oracle's included.  EVERY row outside rtol 2e-4 must be within 8x of
+#     its measured movement (asserted; the conic conditioning (A+C)^2/4det of the offenders is printed: 70x .. 3000x the
+#     median); all other rows -- > 99.5 % -- pass at 2e-4, and at most 0.01 % of all rows are off by more than 3x.
+
+
+def _oracle_parity(name, sc_inputs, deg, cam, dev, hip_runs=1):
+    """sc_inputs: op kwargs (numpy).  Renders `hip_runs` times through the operator (same camera tensors: with the hint
+    cache on, the third run uses a warm needed-segment hint), checks every run bit-exact against the oracle's forward and
+    the last run's deterministic-mode gradients per row against the oracle's backward."""
+    from oracle import oracle as orc
+    from vegs_amd import rasterizer
+    H, W = cam.image_height, cam.image_width
+    oc = oracle_cam(cam, [0, 0, 0], deg)
+    o_out, st = orc.forward(oc, **sc_inputs)
+    rng = np.random.default_rng(31)
+    gouts = [rng.normal(size=s).astype(np.float32) * 1e-3 if m else None
+             for s, m in zip([(3, H, W), (1, H, W), (4, H, W), (3, H, W), (1, H, W)], (1, 0, 1, 1, 0))]
+    settings = _settings(cam, [0, 0, 0], deg, 1.0, dev)        # ONE set of camera tensors: the hint key
+    old = rasterizer.needed_hints(True)
+    try:
+        rasterizer._NEEDED.clear()
+        for run in range(hip_runs):
+            last = run == hip_runs - 1
+            h_out, h_grads, res = _run_hip(settings, sc_inputs, dev, gouts if last else None,
+                                           flags=rasterizer.FLAG_DETERMINISTIC if last else 0)
+            assert np.array_equal(h_out["radii"], o_out["radii"]), (name, run)
+            pl, rg = _export_binning(res, H, W, dev)
+            assert res[0].grad_fn.num_rendered == st["R"]
+            assert np.array_equal(rg, st["ranges"]) and np.array_equal(pl, st["point_list"]), (name, run)
+            for n in OUT_NAMES:
+                assert np.array_equal(h_out[n], o_out[n]), (name, run, n, np.abs(h_out[n] - o_out[n]).max())
+        if hip_runs >= 3:
+            hint = list(rasterizer._NEEDED.values())[0]
+            assert hint is not None and int(hint.max()) < 0x3FFFFFFF      # the last run really had a recorded hint
+    finally:
+        rasterizer.needed_hints(old)
+    og = orc.backward(oc, st, *gouts, abs_sums=True)
+    _, explain = ill_conditioned(st)
+    names = ("means2D", "opacities", "shs", "means3D", "scales", "rotations")
+    moved = summation_sensitivity(oc, st, og, names=names)
+    for k in names:
+        plain = k in ("means2D", "opacities", "shs")
+        ill = moved[k] > 0.25
+        assert ill.mean() < 5e-2, (name, k, "fraction of rows the oracle itself cannot resolve to a quarter allowance", float(ill.mean()))
+        bad = assert_grad_close(f"{name} det {k}", h_grads[k], og[k], rtol=2e-4, floor=2e-7, outliers=1e-5 if plain else 1e-4,
+                                near=1e-5 if plain else 1e-3, cap=3.0, explain=explain, ill=ill)
+        # EVERY offender is explained: its error is within 8x of what the summation-rounding model moves the oracle's
+        # own result by (plus the allowance) -- the model takes the largest of three 1-sigma draws, the actual rounding
+        # may sit at 3 sigma
+        _, ratio = grad_mismatch(h_grads[k], og[k], 2e-4, 2e-7)
+        unexplained = bad[ratio[bad] > 1.0 + 8.0 * moved[k][bad]]
+        assert len(unexplained) == 0, (name, k, "rows outside 2e-4 beyond what fp32 summation explains",
+                                       [(int(i), float(ratio[i]), float(moved[k][i])) for i in unexplained[:8]])
+    return st
+
+
+def _bench_cams():
+    from vegs_amd import scenes
+    cams = []
+    for s in range(8):                       # bench.py build_workload: stations every 10 m, stereo pair
+        for y in (0.3, -0.3):
+            cams.append(scenes.kitti_camera(10.0 * s, y, 1376, 376))
+    return cams
+
+
+def test_c3_headline_views_match_oracle(c3, dev):
+    """BASELINE config C3 (2 M Gaussians, the headline): two of bench.py's 16 cameras under the oracle, one of them
+    rendered three times so that its last forward runs with a recorded needed-segment hint."""
+    sc, deg, cam, T = c3
+    cams = _bench_cams()
+    st = _oracle_parity("c3 cam5", _inputs(sc), deg, cams[5], dev, hip_runs=3)
+    assert st["R"] > 3_000_000
+    _oracle_parity("c3 cam10", _inputs(sc), deg, cams[10], dev)
+
+
+def test_c3_dense_13m_entries_matches_oracle(c3, dev):
+    """The dense variant of the headline scene (every disc 3x larger: ~13 M list entries, the heaviest lists of the
+    bench line) under the oracle."""
+    sc, deg, cam, T = c3
+    dense = dict(_inputs(sc))
+    dense["scales"] = (sc["scales"] * 3.0).astype(np.float32)
+    st = _oracle_parity("dense", dense, deg, _bench_cams()[0], dev)
+    assert st["R"] > 8_000_000
+
+
+def test_c5_concatenated_inputs_match_oracle(dev):
+    """BASELINE config C5's op call: 5 M static Gaussians + 8 box instances x 8,196 carried into the world frame and
+    concatenated (gaussian_renderer/__init__.py:121-186, 263-333) -- the rasterizer on exactly those inputs under the
+    oracle (forward bit-exact, gradients of the op inputs per row)."""
+    from vegs_amd import harness, iteration, scenes
+    P, NB = 5_000_000, 8
+    sc, deg = scenes.scene_street(P=P, length=250.0, sh_degree=3, seed=3)
+    cam = scenes.kitti_camera(10.0, 0.3, 1376, 376)
+    with torch.no_grad():
+        static = {k: torch.tensor(v, device=dev) for k, v in sc.items()}
+        boxes = iteration.make_boxes(NB, dev)
+        kw = harness.prepare_rasterization(static)
+        for t, b2w in boxes:
+            kw = harness.merge_kwargs(kw, harness.prepare_rasterization({k: v.detach() for k, v in t.items()}, b2w.detach()))
+        inputs = {k: v.cpu().numpy() for k, v in kw.items()}
+    del static, boxes, kw
+    torch.cuda.empty_cache()
+    assert inputs["means3D"].shape[0] == P + NB * 8196
+    inputs.update(colors_precomp=None, cov3D_precomp=None)
+    st = _oracle_parity("c5", inputs, deg, cam, dev)
+    assert int((st["radii"][P:] > 0).sum()) > 1000          # the box instances are in view
 
 
 def test_c5_full_step_5m_plus_box_instances(dev):

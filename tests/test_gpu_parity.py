@@ -353,6 +353,63 @@ def test_binning_guard_is_reported_by_the_next_forward_and_cleared(dev):
         assert torch.equal(x, y)
 
 
+def test_binning_guard_raised_by_a_view_fails_that_views_backward(dev):
+    """A wait that times out DURING a view's binning (raised here by the test hook vr_debug_raise_guard, in the middle
+    of the forward's binning launches) must fail that same view: its backward -- and every other call that takes its
+    saved state -- returns an error before any gradient exists; nothing is left over for later views."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from vegs_amd import _capi, scenes
+    sc, deg = scenes.scene_random(P=500, sh_degree=0, seed=3)
+    cam = scenes.camera_c1(64, 64)
+    rast = GaussianRasterizer(raster_settings=_settings(cam, [0, 0, 0], deg, 1.0, dev))
+
+    def fwd():
+        t = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in sc.items()}
+        m2d = torch.zeros(500, 3, device=dev, requires_grad=True)
+        out = rast(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"], scales=t["scales"],
+                   rotations=t["rotations"])
+        return out, t
+    good, tg = fwd()
+    good[0].sum().backward()
+    lib = _capi.load()
+    _capi.check(lib.vr_debug_raise_guard(1))
+    bad, tb = fwd()                              # the forward itself cannot know yet (no second host synchronisation)
+    with pytest.raises(_capi.VegsRastError, match="timed out"):
+        _capi.count_fragments(bad[0].grad_fn, 64, 64, dev)     # ... but every call that takes its saved state does
+    _capi.check(lib.vr_debug_raise_guard(1))
+    bad, tb = fwd()
+    with pytest.raises(Exception, match="timed out"):
+        bad[0].sum().backward()                  # the SAME view's backward fails
+    assert tb["means3D"].grad is None            # no gradient was handed out
+    again, ta = fwd()                            # and the next view is clean (the backward's report cleared the word)
+    again[0].sum().backward()
+    for x, y in zip(good, again):
+        assert torch.equal(x, y)
+    assert torch.equal(tg["opacities"].grad, ta["opacities"].grad) or torch.allclose(tg["opacities"].grad, ta["opacities"].grad, rtol=1e-4, atol=1e-7)
+
+
+def test_binning_guard_of_a_forward_only_view_is_reported_by_the_next_forward(dev):
+    """A view rendered under no_grad never gets a backward: its raised guard is reported by the next forward of the
+    thread (which fails and clears the word), as before."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from vegs_amd import _capi, scenes
+    sc, deg = scenes.scene_random(P=500, sh_degree=0, seed=3)
+    cam = scenes.camera_c1(64, 64)
+    rast = GaussianRasterizer(raster_settings=_settings(cam, [0, 0, 0], deg, 1.0, dev))
+    t = {k: torch.tensor(v, device=dev) for k, v in sc.items()}
+    kw = dict(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]), shs=t["shs"], opacities=t["opacities"],
+              scales=t["scales"], rotations=t["rotations"])
+    with torch.no_grad():
+        good = rast(**kw)
+        _capi.check(_capi.load().vr_debug_raise_guard(1))
+        rast(**kw)
+        with pytest.raises(Exception, match="timed out"):
+            rast(**kw)
+        again = rast(**kw)
+    for x, y in zip(good, again):
+        assert torch.equal(x, y)
+
+
 def test_debug_mode_runs(dev):
     from vegs_amd import harness, scenes
     sc, deg = scenes.scene_random(P=500, sh_degree=1, seed=8)
@@ -510,7 +567,7 @@ def test_non_finite_inputs_do_not_crash_or_poison_the_frame(dev):
 def test_needed_hint_never_changes_results(dev):
     """VrSaved.needed_hint (per-camera cache in vegs_amd.rasterizer): the forward skips the list segments behind the
     hinted prefix of every tile and recomputes on the spot where the hint was too small.  Same camera tensors rendered
-    (1) without a hint, (2) with its own perfect hint, (3) after the scene became far MORE transparent (every tile now
+    (1) without a hint (first and second sighting), (2) with its own perfect hint, (3) after the scene became far MORE transparent (every tile now
     needs more segments than hinted: the fallback of k_seg_scan runs everywhere), (4) with a hint that is far too
     large (scene opaque again): all bit-exact against the oracle and against the hint-free operator."""
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
@@ -546,8 +603,12 @@ def test_needed_hint_never_changes_results(dev):
     old = rasterizer.needed_hints(True)
     try:
         rasterizer._NEEDED.clear()
-        a, fa, ga = run(1.0)                       # (1) first visit: no hint
+        a, fa, ga = run(1.0)                       # (1) first sighting of the camera: no hint, nothing allocated for it
         key = [k for k in rasterizer._NEEDED][0]
+        assert rasterizer._NEEDED[key] is None
+        a2, _, _ = run(1.0)                        # second sighting: a "no idea" hint array, filled in by this forward
+        for x, y in zip(a, a2):
+            assert np.array_equal(x, y)
         hint1 = rasterizer._NEEDED[key].clone()
         assert int(hint1.max()) >= 3               # the scene really has multi-segment tiles
         assert fa.num_rendered // 256 > int(hint1.sum()) + 500   # ... and many of their segments are never needed

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libvegsrast.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # VrSettings.flags (include/vegs_rast.h, VrFlags)
 FLAG_SCALE_MODIFIED, FLAG_DEPTH_NORMALIZED, FLAG_EXTRA_NO_ALPHA_GRAD, FLAG_FILL_EMPTY, FLAG_DETERMINISTIC = 1, 2, 4, 8, 256
@@ -21,7 +21,7 @@ VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH = 0, 1, 2, 3
 
 # every symbol include/vegs_rast.h declares
 EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_mark_visible", "vr_get_counters",
-           "vr_count_fragments", "vr_count_blended", "vr_export_needed", "vr_debug_export_binning", "vr_debug_set_guard", "vr_profile_level", "vr_profile_collect",
+           "vr_count_fragments", "vr_count_blended", "vr_export_needed", "vr_debug_export_binning", "vr_debug_set_guard", "vr_debug_raise_guard", "vr_profile_level", "vr_profile_collect",
            "vr_knn3_mean_dist2", "vr_photometric_forward", "vr_photometric_backward",
            "vr_normal_guidance_forward", "vr_normal_guidance_backward", "vr_adam_step", "vr_densify_stats",
            "vr_sh_grad_from_factors", "vr_sh_adam_step",
@@ -50,7 +50,8 @@ class VrOutputs(C.Structure):
 
 class VrSaved(C.Structure):
     _fields_ = [("geom", C.c_void_p), ("binning", C.c_void_p), ("image", C.c_void_p), ("num_rendered", C.c_int64),
-                ("num_visible", C.c_int64), ("binning_capacity", C.c_int64), ("needed_hint", C.c_void_p)]
+                ("num_visible", C.c_int64), ("binning_capacity", C.c_int64), ("needed_hint", C.c_void_p),
+                ("ticket", C.c_uint64)]
 
 
 class VrOutGrads(C.Structure):
@@ -130,6 +131,8 @@ def load():
                                             C.c_void_p]
     lib.vr_debug_set_guard.restype = C.c_int
     lib.vr_debug_set_guard.argtypes = [C.c_uint32, C.c_void_p]
+    lib.vr_debug_raise_guard.restype = C.c_int
+    lib.vr_debug_raise_guard.argtypes = [C.c_int]
     lib.vr_knn3_mean_dist2.restype = C.c_int
     lib.vr_knn3_mean_dist2.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, VrAllocFn, C.c_void_p, C.c_void_p]
     vp, i32 = C.c_void_p, C.c_int32
@@ -240,7 +243,7 @@ def saved_of(grad_fn):
     """VrSaved of the forward behind `grad_fn` (the op's autograd node)."""
     geom, binning, image = grad_fn.buffers
     return VrSaved(geom.data_ptr(), binning.data_ptr(), image.data_ptr(), grad_fn.num_rendered, grad_fn.num_visible,
-                   grad_fn.binning_capacity)
+                   grad_fn.binning_capacity, None, getattr(grad_fn, "ticket", 0))
 
 
 def count_blended(grad_fn, H, W, device):

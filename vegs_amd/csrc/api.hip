@@ -26,8 +26,18 @@ static thread_local VrCounters g_counters = {0, 0, 0, 0, 0};
 // host-pinned, coherent mailbox that the totals kernel writes (V, R, min key, max key, guard word; then a sequence
 // number the host polls) and the device-side guard word: one per (host thread, device)
 constexpr int MAX_DEVICES = 64;
-struct Mailbox { uint32_t* pinned; uint32_t* pinned_dev; uint32_t seq; uint32_t* guard; };
+// pinned words: [0..4] totals of the forward in flight, [8] its sequence number; from word RING_AT a ring of RING_SLOTS
+// {seq, guard} pairs: slot seq % RING_SLOTS is filled by the LAST binning kernel of forward `seq` with the guard word as
+// it stands after all of that view's waiting passes (k_tile_ranges).  vr_backward / the export calls find the slot
+// through VrSaved.ticket = (mailbox id + 1) << 32 | seq -- PyTorch runs the op's backward on its autograd thread, so
+// the mailboxes are also registered process-wide.
+constexpr int RING_AT = 64, RING_SLOTS = 64, MAIL_BYTES = (RING_AT + 2 * RING_SLOTS) * 4;
+struct Mailbox { uint32_t* pinned; uint32_t* pinned_dev; uint32_t seq; uint32_t* guard; uint32_t id; };
 static thread_local Mailbox g_mail[MAX_DEVICES] = {};
+struct MailRef { uint32_t* pinned; uint32_t* guard; int dev; };
+static std::mutex g_mail_mu;
+static std::vector<MailRef> g_mail_reg;
+static thread_local bool g_raise_guard = false;   // test hook: vr_debug_raise_guard
 
 // the calling thread's mailbox for the current device, created on first use
 static int get_mailbox(int dev_id, hipStream_t s, Mailbox** out);
@@ -44,16 +54,53 @@ static int get_mailbox(int dev_id, hipStream_t s, Mailbox** out)
 {
     Mailbox& mail = g_mail[dev_id];
     if (!mail.pinned) {
-        VR_HIP(hipHostMalloc((void**)&mail.pinned, 256, hipHostMallocMapped | hipHostMallocCoherent));
-        memset(mail.pinned, 0, 256);
+        VR_HIP(hipHostMalloc((void**)&mail.pinned, MAIL_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(mail.pinned, 0, MAIL_BYTES);
         VR_HIP(hipHostGetDevicePointer((void**)&mail.pinned_dev, mail.pinned, 0));
     }
     if (!mail.guard) {   // device word raised by a binning kernel whose bounded wait ran out (binning.hip)
         VR_HIP(hipMalloc((void**)&mail.guard, 256));
         VR_HIP(hipMemsetAsync(mail.guard, 0, 256, s));
+        std::lock_guard<std::mutex> lk(g_mail_mu);
+        g_mail_reg.push_back({mail.pinned, mail.guard, dev_id});
+        mail.id = (uint32_t)g_mail_reg.size();   // 1-based
     }
     *out = &mail;
     return 0;
+}
+
+// The guard word of the forward behind `ticket` (see Mailbox).  Returns VR_OK when that forward's binning finished
+// without a timed-out wait (or nothing can be said: no ticket, slot long overwritten), VR_ERR_HIP when one timed out --
+// the view's lists, images and everything derived from them are invalid.  Waits (normally not at all: the caller comes
+// after the forward's launches and the loss) until the slot is posted.
+static int check_ticket(uint64_t ticket, hipStream_t s)
+{
+    if (ticket == 0) return VR_OK;
+    const uint32_t id = (uint32_t)(ticket >> 32), seq = (uint32_t)ticket;
+    MailRef ref;
+    {
+        std::lock_guard<std::mutex> lk(g_mail_mu);
+        if (id == 0 || id > g_mail_reg.size()) return VR_OK;
+        ref = g_mail_reg[id - 1];
+    }
+    uint32_t* slot = ref.pinned + RING_AT + 2 * (seq % RING_SLOTS);
+    const auto t0 = std::chrono::steady_clock::now();
+    bool synced = false;
+    for (unsigned spins = 1;; ++spins) {
+        const uint32_t got = __atomic_load_n(&slot[0], __ATOMIC_ACQUIRE);
+        if (got == seq) break;
+        if ((int32_t)(got - seq) > 0 || synced) return VR_OK;   // reused by a later forward / never posted (failed forward)
+        __builtin_ia32_pause();
+        if ((spins & 4095u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+            VR_HIP(hipStreamSynchronize(s));   // the forward ran on this stream (same-stream contract of the op)
+            synced = true;
+        }
+    }
+    if (__atomic_load_n(&slot[1], __ATOMIC_RELAXED) == 0u) return VR_OK;
+    (void)hipMemsetAsync(ref.guard, 0, 4, s);   // reported: clear for the calls to come
+    set_error("a look-back wait in this view's binning timed out: its lists, images and gradients are invalid "
+              "(re-render the view; VR_FLAG_SCAN_BINNING avoids inter-workgroup waits)");
+    return VR_ERR_HIP;
 }
 
 // Waits until the totals kernel has published this call's sequence number in the mailbox.  Polls host memory (the
@@ -321,13 +368,14 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
         ranges_zeroed = rz != nullptr;
         status_zeroed = scr2 != nullptr;
         rc = launch_compact_apply(P, rect, depth_key, scan_scr, totals_dev, binning_tile_bits((int)T), vis_key, vis_id, rz,
-                                  rz ? (long)(2 * T) : 0L, scr2 ? binning_stage2_status(scr2) : nullptr, s, debug);
+                                  rz ? (long)(2 * T) : 0L, scr2 ? binning_stage2_status(scr2) : nullptr,
+                                  scr2 ? binning_stage2_status_bytes(P, (long)Rcap, (int)T) : 0, s, debug);
         prof_end(VR_STAGE_COMPACT, s);
         if (rc) return rc;
         rc = wait_mailbox(g_pinned, seq, totals_dev, s);
         if (rc) return rc;
-        if (g_pinned[4]) {   // raised by an EARLIER call's binning on this thread and device: its lists were wrong
-            VR_HIP(hipMemsetAsync(mail.guard, 0, 4, s));
+        if (g_pinned[4]) {   // raised by an EARLIER forward on this thread and device whose backward never ran (the
+            VR_HIP(hipMemsetAsync(mail.guard, 0, 4, s));   // backward reports it first, see check_ticket): eval / no_grad views
             return fail(VR_ERR_HIP, "a look-back wait in an earlier binning pass timed out; that view's output is invalid");
         }
         V = g_pinned[0];
@@ -349,8 +397,12 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     const BinLayout BL = bin_layout(T, Rcap);
     int2* ranges = (int2*)((char*)binning + BL.ranges);
     uint32_t* point_list = (uint32_t*)((char*)binning + BL.point_list);
+    const bool lists = V > 0 && R > 0;
+    const bool raise = g_raise_guard;
+    g_raise_guard = false;
     rc = launch_binning(cam, P, (int)V, (long)R, key_min, key_bits, vis_key, vis_id, rect, scan_scr, scr2, point_list,
-                        ranges, ranges_zeroed, status_zeroed, mail.guard, s, debug);
+                        ranges, ranges_zeroed, status_zeroed, mail.guard,
+                        mail.pinned_dev + RING_AT + 2 * (mail.seq % RING_SLOTS), mail.seq, raise, s, debug);
     if (rc) return rc;
     prof_begin(VR_STAGE_RENDER_FWD, s);
     rc = launch_render_fwd(cam, (long)R, ranges, point_list, rec, (uint32_t*)((char*)binning + BL.seg_off),
@@ -368,6 +420,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     saved->num_rendered = (int64_t)R;
     saved->num_visible = (int64_t)V;
     saved->binning_capacity = (int64_t)Rcap;
+    saved->ticket = lists ? ((uint64_t)mail.id << 32) | mail.seq : 0ull;
     g_counters.P = P;
     g_counters.num_visible = V;
     g_counters.num_rendered = R;
@@ -398,6 +451,9 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
         return fail(VR_ERR_INVALID_ARGUMENT, "a gradient array is missing for a provided input");
     hipStream_t s = (hipStream_t)stream;
     const bool debug = st->debug != 0;
+    // a timed-out wait in THIS view's binning fails its own backward, before any gradient is produced
+    rc = check_ticket(saved->ticket, s);
+    if (rc) return rc;
     const size_t N = (size_t)cam.H * cam.W, T = (size_t)cam.gx * cam.gy;
     const ImageLayout IL = image_layout(N);
     const size_t Rcap = saved->binning_capacity > 0 ? (size_t)saved->binning_capacity : (size_t)saved->num_rendered;
@@ -546,6 +602,7 @@ int vr_count_fragments(const VrSaved* saved, int32_t H, int32_t W, void* stream,
     if (!saved || !saved->image || !fragments || H <= 0 || W <= 0)
         return fail(VR_ERR_INVALID_ARGUMENT, "count_fragments: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (int rt = check_ticket(saved->ticket, s)) return rt;
     const size_t N = (size_t)H * W;
     const ImageLayout IL = image_layout(N);
     unsigned long long* ctr = (unsigned long long*)((char*)saved->image + IL.counters);
@@ -564,6 +621,7 @@ int vr_count_blended(const VrSaved* saved, int32_t H, int32_t W, void* stream, i
     if (!saved || !saved->image || !saved->geom || !saved->binning || !blended || H <= 0 || W <= 0)
         return fail(VR_ERR_INVALID_ARGUMENT, "count_blended: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (int rt = check_ticket(saved->ticket, s)) return rt;
     Camera cam = {};
     cam.H = H; cam.W = W;
     cam.gx = (W + TILE - 1) / TILE;
@@ -590,6 +648,7 @@ int vr_export_needed(const VrSaved* saved, int32_t H, int32_t W, uint32_t* out, 
     g_err[0] = 0;
     if (!saved || !saved->binning || !out || H <= 0 || W <= 0)
         return fail(VR_ERR_INVALID_ARGUMENT, "export_needed: bad arguments");
+    if (int rt = check_ticket(saved->ticket, (hipStream_t)stream)) return rt;
     const size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     const BinLayout BL = bin_layout(T, saved->binning_capacity > 0 ? (size_t)saved->binning_capacity : (size_t)saved->num_rendered);
     VR_HIP(hipMemcpyAsync(out, (const char*)saved->binning + BL.seg_needed, T * sizeof(uint32_t), hipMemcpyDeviceToDevice,
@@ -610,6 +669,13 @@ int vr_debug_set_guard(uint32_t value, void* stream)
     return VR_OK;
 }
 
+int vr_debug_raise_guard(int on)
+{
+    g_err[0] = 0;
+    g_raise_guard = on != 0;
+    return VR_OK;
+}
+
 int vr_debug_export_binning(const VrSaved* saved, int32_t H, int32_t W, uint32_t* point_list, int32_t* ranges,
                             void* stream)
 {
@@ -617,6 +683,7 @@ int vr_debug_export_binning(const VrSaved* saved, int32_t H, int32_t W, uint32_t
     if (!saved || !saved->binning || H <= 0 || W <= 0)
         return fail(VR_ERR_INVALID_ARGUMENT, "debug_export_binning: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (int rt = check_ticket(saved->ticket, s)) return rt;
     const size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     const BinLayout BL = bin_layout(T, saved->binning_capacity > 0 ? (size_t)saved->binning_capacity : (size_t)saved->num_rendered);
     if (ranges)

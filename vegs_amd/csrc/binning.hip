@@ -509,13 +509,29 @@ int launch_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, lo
 //   level 3  [block/256][digit]     sum over 256 blocks, posted by the last block of the group's last sub-group
 // and a block adds at most 15 entries of each level: three dependent load rounds, whatever the grid size (up to
 // 4096 blocks; longer inputs take the 4-launch passes).  A block only waits for blocks with a smaller index, which the
-// in-order dispatcher has started before it; every wait is bounded all the same (SPIN_LIMIT polls) and reports
+// in-order dispatcher has started before it; every wait is bounded all the same (2 s of wall clock, SpinClock) and reports
 // through `err` rather than hanging the queue.  Status words are read and written with device-scope atomics (the 8
 // XCD L2s are not coherent with each other); flag and count share the word, so no fence is needed.
 constexpr uint32_t ST_POSTED = 1u << 31, ST_VALUE = ST_POSTED - 1u;
 constexpr int FAN = 16;                                        // fan-in of a level
 constexpr long ONESWEEP_MAX_N = (long)FAN * FAN * FAN * RADIX_BLOCK;   // 16.7 M elements
-constexpr int SPIN_LIMIT = 1 << 13;   // x ~2.5 us per poll: tens of milliseconds
+// Bound of every wait for another workgroup's posted sum: WALL-CLOCK, not a poll count -- a predecessor that is merely
+// not running yet (CUs held by another process: several ranks sharing one GPU) must not trip it.  s_memrealtime ticks
+// at 100 MHz; the clock is only read every SPIN_CHECK polls.  2 s is far beyond anything but a lost workgroup; the
+// alternative to a bound would be a hung queue.
+constexpr int SPIN_CHECK = 256;
+constexpr unsigned long long SPIN_TICKS = 200000000ull;   // 2 s at 100 MHz
+struct SpinClock {
+    unsigned long long t0 = 0;
+    // true once the wait has lasted longer than SPIN_TICKS (call once per poll)
+    __device__ __forceinline__ bool expired(int polls)
+    {
+        if ((polls & (SPIN_CHECK - 1)) != SPIN_CHECK - 1) return false;
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (t0 == 0) { t0 = now | 1ull; return false; }
+        return now - t0 > SPIN_TICKS;
+    }
+};
 
 __device__ __forceinline__ uint32_t st_load(const uint32_t* p)
 {
@@ -533,6 +549,7 @@ __device__ __forceinline__ void sum_posted(const uint32_t* st, long first, int c
                                            const bool (&on)[NB], uint32_t (&acc)[NB], uint32_t* err)
 {
     if (count <= 0) return;
+    SpinClock clk;
     for (int polls = 0;; ++polls) {
         uint32_t v[NB][FAN - 1];
 #pragma unroll
@@ -547,8 +564,8 @@ __device__ __forceinline__ void sum_posted(const uint32_t* st, long first, int c
 #pragma unroll
             for (int i = 0; i < FAN - 1; ++i) { all &= v[k][i]; s[k] += v[k][i] & ST_VALUE; }
         }
-        if (all || polls > SPIN_LIMIT) {
-            if (!all) *err = 1u;
+        if (all || clk.expired(polls)) {
+            if (!all) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int k = 0; k < NB; ++k) acc[k] += s[k];
             return;
@@ -847,7 +864,7 @@ __global__ void __launch_bounds__(256)
 k_compact_apply(const uint2* __restrict__ rect, const uint32_t* __restrict__ depth_key, long n,
                 const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ totals, int tile_bits,
                 uint32_t* __restrict__ vis_key, uint32_t* __restrict__ vis_id, uint32_t* __restrict__ partial,
-                uint32_t* __restrict__ zero_a, long zero_na, uint4* __restrict__ status)
+                uint32_t* __restrict__ zero_a, long zero_na, uint4* __restrict__ status, long status_bytes)
 {
     __shared__ uint32_t lds4[4];
     __shared__ uint32_t h[HIST_WORDS];
@@ -859,7 +876,10 @@ k_compact_apply(const uint2* __restrict__ rect, const uint32_t* __restrict__ dep
     if (status && (long)V <= ONESWEEP_MAX_N && (long)R <= ONESWEEP_MAX_N) {
         const StatusPlan sp = status_plan(V, R, key_bits, tile_bits);
         const long n16 = (long)((sp.depth + sp.emit + sp.tile) / 16);
-        for (long i = tid; i < n16; i += nthr) status[i] = make_uint4(0u, 0u, 0u, 0u);
+        // `status` was sized from the caller's capacity hint BEFORE R was known: when the actual R outgrows it the
+        // region is not cleared here (the host sees R > capacity, allocates afresh and clears with a fill)
+        if (n16 * 16 <= status_bytes)
+            for (long i = tid; i < n16; i += nthr) status[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     for (int d = threadIdx.x; d < words; d += 256) h[d] = 0;
     uint32_t acc = 0;
@@ -889,13 +909,14 @@ k_compact_apply(const uint2* __restrict__ rect, const uint32_t* __restrict__ dep
 
 int launch_compact_apply(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, const uint32_t* totals_dev,
                          int tile_bits, uint32_t* vis_key, uint32_t* vis_id, uint32_t* zero_a, long zero_na,
-                         void* status, hipStream_t s, bool debug)
+                         void* status, size_t status_bytes, hipStream_t s, bool debug)
 {
     int nb = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
     uint32_t* bsum = (uint32_t*)scratch;
     uint32_t* partial = (uint32_t*)((char*)scratch + align_up(4 * (size_t)nb * sizeof(uint32_t), 256));
     hipLaunchKernelGGL(k_compact_apply, dim3(nb), dim3(256), 0, s, rect, depth_key, (long)P, (const uint32_t*)bsum,
-                       totals_dev, tile_bits, vis_key, vis_id, partial, zero_a, zero_na, (uint4*)status);
+                       totals_dev, tile_bits, vis_key, vis_id, partial, zero_a, zero_na, (uint4*)status,
+                       (long)status_bytes);
     VR_KERNEL_CHECK("compact_apply", s, debug);
     return 0;
 }
@@ -970,6 +991,7 @@ __device__ __forceinline__ unsigned long long sum_posted_wave(const unsigned lon
 {
     if (count <= 0) return 0ull;
     constexpr int PER = EFAN / 64;   // status words per lane
+    SpinClock clk;
     for (int polls = 0;; ++polls) {
         unsigned long long v[PER];
 #pragma unroll
@@ -981,8 +1003,8 @@ __device__ __forceinline__ unsigned long long sum_posted_wave(const unsigned lon
 #pragma unroll
         for (int j = 0; j < PER; ++j) both &= v[j];
         const bool all = __ballot((both & SE_POSTED) == 0ull) == 0ull;
-        if (all || polls > SPIN_LIMIT) {
-            if (!all && lane == 0) *err = 1u;
+        if (all || clk.expired(polls)) {
+            if (!all && lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned long long s = 0ull;
 #pragma unroll
             for (int j = 0; j < PER; ++j) s += v[j] & ~SE_POSTED;
@@ -1059,10 +1081,19 @@ k_emit_scan(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint2* 
     }
 }
 
+// Also (thread 0 of the launch): the look-back guard word as it stands after ALL waiting passes of this view, posted
+// with this forward's sequence number into the host's pinned ring slot -- the matching vr_backward (or any later call
+// that uses the lists) reads it there, so a timed-out wait fails the SAME view, not a later one.
 __global__ void __launch_bounds__(256)
-k_tile_ranges(const uint32_t* __restrict__ tkeys, long R, int2* __restrict__ ranges)
+k_tile_ranges(const uint32_t* __restrict__ tkeys, long R, int2* __restrict__ ranges, const uint32_t* __restrict__ err,
+              uint32_t* __restrict__ post, uint32_t seq)
 {
     long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j == 0 && post) {
+        const uint32_t g = err ? __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        __hip_atomic_store(&post[1], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&post[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (j >= R) return;
     uint32_t k = tkeys[j];
     if (j == 0) ranges[k].x = 0;
@@ -1116,6 +1147,11 @@ static Stage2Layout stage2_layout(int V, long R, int ntiles)
 
 size_t binning_stage2_scratch_bytes(int V, long R, int ntiles) { return stage2_layout(V, R, ntiles).total; }
 void* binning_stage2_status(void* scratch) { return (char*)scratch + 0; }   // Stage2Layout::status comes first
+size_t binning_stage2_status_bytes(int V, long R, int ntiles)
+{
+    const Stage2Layout L = stage2_layout(V, R, ntiles);
+    return L.tmp_key - L.status;
+}
 int binning_tile_bits(int ntiles) { return tile_bits_of(ntiles); }
 
 // The 4-launch passes and the separate offset scan (inputs too long for 30-bit look-back counts; also the shape of
@@ -1173,7 +1209,8 @@ static int binning_multi_launch(const Camera& cam, int V, long R, uint32_t key_m
 
 int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
                    uint32_t* vis_id, const uint2* rect, const void* stage1_scratch, void* scratch, uint32_t* point_list,
-                   int2* ranges, bool ranges_zeroed, bool status_zeroed, uint32_t* err, hipStream_t s, bool debug)
+                   int2* ranges, bool ranges_zeroed, bool status_zeroed, uint32_t* err, uint32_t* guard_post,
+                   uint32_t guard_seq, bool debug_raise_guard, hipStream_t s, bool debug)
 {
     int ntiles = cam.gx * cam.gy;
     if (!ranges_zeroed) VR_HIP(hipMemsetAsync(ranges, 0, sizeof(int2) * (size_t)ntiles, s));
@@ -1235,7 +1272,9 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
     }
     // 5. ranges
     prof_begin(VR_STAGE_RANGES, s);
-    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(R, 256)), dim3(256), 0, s, (const uint32_t*)tile_keys, R, ranges);
+    if (debug_raise_guard) VR_HIP(hipMemsetD32Async((hipDeviceptr_t)err, 1, 1, s));   // test hook: "a wait of THIS view timed out"
+    hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(R, 256)), dim3(256), 0, s, (const uint32_t*)tile_keys, R, ranges,
+                       (const uint32_t*)err, guard_post, guard_seq);
     VR_KERNEL_CHECK("tile_ranges", s, debug);
     prof_end(VR_STAGE_RANGES, s);
     return 0;

@@ -27,11 +27,18 @@
 
 namespace vr {
 
+__device__ __forceinline__ uint32_t hinted_limit(uint32_t h) { return h + 2u + (h >> 3); }
+
 // seg_off[t] = first global segment id of tile t; seg_off[T] = total.  Single workgroup.  (k_seg_tiles then
 // fills seg_tile[s] = tile of segment s, 0xFFFFFFFF beyond the total: the launch grids cover `cap` segments.)
+// Also the ONE place where the caller's needed-segment hint is read: limit[t] = number of leading segments of tile t
+// that k_seg_alpha computes up front (all of them without a hint).  The snapshot lives in this call's own binning
+// buffer (the seg_needed array, which k_seg_scan overwrites with its result), so k_seg_alpha and k_seg_scan agree on
+// it even if the caller's array changes underneath them (another stream rendering the same camera).
 constexpr int SEGOFF_THREADS = 1024;
 __global__ void __launch_bounds__(SEGOFF_THREADS)
-k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict__ seg_off)
+k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict__ seg_off,
+              const uint32_t* __restrict__ hint, uint32_t* __restrict__ limit)
 {
     constexpr int NW = SEGOFF_THREADS / 64;
     __shared__ uint32_t wsum[NW];
@@ -42,7 +49,11 @@ k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict_
     for (int base = 0; base < ntiles; base += SEGOFF_THREADS) {
         const int t = base + threadIdx.x;
         uint32_t n = 0;
-        if (t < ntiles) { const int2 r = ranges[t]; n = (uint32_t)((r.y - r.x + SEG - 1) / SEG); }
+        if (t < ntiles) {
+            const int2 r = ranges[t];
+            n = (uint32_t)((r.y - r.x + SEG - 1) / SEG);
+            limit[t] = hint ? min(n, hinted_limit(min(hint[t], 0x3FFFFFFFu))) : n;
+        }
         uint32_t incl = n;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -64,7 +75,8 @@ k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict_
 
 // segment table entries (vr_segment.h): one thread per segment of the launch grid
 __global__ void __launch_bounds__(256)
-k_seg_tiles(int ntiles, const int2* __restrict__ ranges, uint32_t* __restrict__ seg_off, uint32_t cap)
+k_seg_tiles(int ntiles, const int2* __restrict__ ranges, uint32_t* __restrict__ seg_off,
+            const uint32_t* __restrict__ limit, uint32_t cap)
 {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= cap) return;
@@ -78,7 +90,8 @@ k_seg_tiles(int ntiles, const int2* __restrict__ ranges, uint32_t* __restrict__ 
     const int sl = (int)(b - seg_off[lo]);
     const int2 r = ranges[lo];
     const int first = r.x + sl * SEG;
-    seg_info[b] = make_int4(lo, first, min(SEG, r.y - first), sl);
+    // flag 3 = behind the hinted prefix of its tile: k_seg_alpha skips it, k_seg_scan decides (and rewrites the flag)
+    seg_info[b] = make_int4(lo, first, min(SEG, r.y - first), sl | ((uint32_t)sl >= limit[lo] ? (int)(3u << 30) : 0));
 }
 
 // ---- NEEDED-SEGMENT HINT.  Half of the segments lie behind the point where every pixel of their tile has stopped
@@ -96,11 +109,6 @@ k_seg_tiles(int ntiles, const int2* __restrict__ ranges, uint32_t* __restrict__ 
 // visits of a camera) 3-5 of 2064 tiles miss by at most 2 segments (profiles/tools/staleness.py), while a margin of
 // 1 segment left one tile 18 segments short (+0.2 ms for that view).  Cost of the margin: 4.6 k instead of 2.1 k of the
 // 9.5 k dead segments of the headline view are still computed.
-__device__ __forceinline__ uint32_t hinted_limit(uint32_t h) { return h + 2u + (h >> 3); }
-__device__ __forceinline__ uint32_t hinted_prefix(const uint32_t* __restrict__ hint, int tile, uint32_t nseg)
-{
-    return hint ? min(nseg, hinted_limit(min(hint[tile], 0x3FFFFFFFu))) : nseg;
-}
 
 // Product of (1 - alpha) over one segment for the calling thread's pixel; also builds the segment's strip-relevance
 // masks and stores them.  Called by all 256 threads of a workgroup (contains block barriers).
@@ -168,13 +176,13 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
 __global__ void __launch_bounds__(256)
 k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
             const uint32_t* __restrict__ point_list, const Splat* __restrict__ rec, float* __restrict__ Pbuf,
-            unsigned long long* __restrict__ segmask, const uint32_t* __restrict__ hint)
+            unsigned long long* __restrict__ segmask)
 {
     __shared__ float4 lds[2][SEG];
     __shared__ unsigned long long masks[16];
     SegCtx c;
     if (!seg_setup(cam, ranges, seg_off, c)) return;
-    if (hint && (uint32_t)c.sl >= hinted_limit(min(hint[c.tile], 0x3FFFFFFFu))) return;   // behind the hinted prefix: k_seg_scan decides
+    if (c.flag == 3u) return;   // behind the hinted prefix of its tile (k_seg_tiles): k_seg_scan decides
     const float p = seg_alpha_body(c, point_list, rec, lds, masks, segmask);
     Pbuf[(size_t)c.seg * SEG + threadIdx.x] = p;
 }
@@ -197,7 +205,7 @@ k_seg_scan(Camera cam, const int2* __restrict__ ranges, uint32_t* __restrict__ s
     const int px = tx * TILE + region_x(w, lane), py = ty * TILE + region_y(w, lane);
     bool alive = px < cam.W && py < cam.H;
     const uint32_t s0 = seg_off[tile], s1 = seg_off[tile + 1];
-    const uint32_t k0 = hinted_prefix(hint, tile, s1 - s0);   // segments [0, k0) were computed by k_seg_alpha
+    const uint32_t k0 = min(s1 - s0, seg_needed[tile]);   // segments [0, k0) were computed by k_seg_alpha (k_seg_offsets' snapshot)
     const uint32_t s1c = s0 + k0;
     float Tb = 1.0f;
     // Each wave walks the segment chain of its own 64 pixels without block barriers; the P values of
@@ -578,12 +586,14 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     if (ntiles == 0) return 0;
     const size_t nseg = seg_capacity(R, ntiles);
     float* Pbuf = (float*)scratch;
-    hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(SEGOFF_THREADS), 0, s, ranges, ntiles, seg_off);
-    hipLaunchKernelGGL(k_seg_tiles, dim3(cdiv((long)nseg, 256)), dim3(256), 0, s, ntiles, ranges, seg_off, (uint32_t)nseg);
+    hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(SEGOFF_THREADS), 0, s, ranges, ntiles, seg_off,
+                       (const uint32_t*)needed_hint, seg_needed);
+    hipLaunchKernelGGL(k_seg_tiles, dim3(cdiv((long)nseg, 256)), dim3(256), 0, s, ntiles, ranges, seg_off,
+                       (const uint32_t*)seg_needed, (uint32_t)nseg);
     VR_KERNEL_CHECK("seg_offsets", s, debug);
     if (R > 0) {
         hipLaunchKernelGGL(k_seg_alpha, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
-                           point_list, rec, Pbuf, segmask, (const uint32_t*)needed_hint);
+                           point_list, rec, Pbuf, segmask);
         VR_KERNEL_CHECK("seg_alpha", s, debug);
     }
     hipLaunchKernelGGL(k_seg_scan, dim3(ntiles), dim3(256), 0, s, cam, ranges, seg_off, (const float*)Pbuf,

@@ -62,18 +62,22 @@ int launch_compact_reduce(int P, const uint2* rect, const uint32_t* depth_key, v
 // given, the posted-sum status region of this view (else launch_binning clears it with a fill).
 int launch_compact_apply(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, const uint32_t* totals_dev,
                          int tile_bits, uint32_t* vis_key, uint32_t* vis_id, uint32_t* zero_a, long zero_na,
-                         void* status, hipStream_t s, bool debug);
+                         void* status, size_t status_bytes, hipStream_t s, bool debug);
 
 // stage 2 (V- and R-sized): depth sort, emission, tile sort, ranges.
 size_t binning_stage2_scratch_bytes(int V, long R, int ntiles);
 void* binning_stage2_status(void* scratch);
+size_t binning_stage2_status_bytes(int V, long R, int ntiles);   // bytes reserved for the status region
 int binning_tile_bits(int ntiles);
 // ranges_zeroed / status_zeroed: already cleared by launch_compact_apply.  stage1_scratch: the compaction's scratch
 // (holds the depth keys' digit histograms).  err: device word that a kernel sets to 1 if a bounded wait for another
-// workgroup's posted sum ran out (never observed; the alternative would be a hung queue).
+// workgroup's posted sum ran out (never observed; the alternative would be a hung queue).  guard_post / guard_seq: host-
+// pinned {seq, guard} slot that the last binning kernel fills with this view's sequence number and the guard word as it
+// stands after all waiting passes (NULL = none).  debug_raise_guard: test hook, raises the word as a timed-out wait would.
 int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
                    uint32_t* vis_id, const uint2* rect, const void* stage1_scratch, void* scratch, uint32_t* point_list,
-                   int2* ranges, bool ranges_zeroed, bool status_zeroed, uint32_t* err, hipStream_t s, bool debug);
+                   int2* ranges, bool ranges_zeroed, bool status_zeroed, uint32_t* err, uint32_t* guard_post,
+                   uint32_t guard_seq, bool debug_raise_guard, hipStream_t s, bool debug);
 
 // stable LSD radix sort of (key,val) u32 pairs on the low nbits of (key - kmin); ping-pongs between the two
 // pairs, *where = 0/1 tells which pair holds the result

@@ -28,14 +28,19 @@ LAMBDA_DSSIM = 0.2          # arguments/__init__.py (lambda_dssim)
 LAMBDA_NORMAL = 1e-3
 
 
-def make_model(sc, device):
+# the reference's own learning rates (arguments/__init__.py:80-88; position_lr_init x spatial_lr_scale, the camera extent)
+REFERENCE_LRS = {"xyz": 1.6e-5 * 10.0, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20, "opacity": 5e-2, "scaling": 1e-3, "rotation": 1e-3}
+
+
+def make_model(sc, device, lrs=None):
     """Raw parameters + optimizer groups as scene/gaussian_model.py:145-168 builds them from a scene dict."""
+    lrs = lrs or LRS
     t = {k: torch.as_tensor(v, device=device) for k, v in sc.items()}
     p = {"xyz": t["means3D"].clone(), "f_dc": t["shs"][:, :1].contiguous(), "f_rest": t["shs"][:, 1:].contiguous(),
          "opacity": torch.logit(t["opacities"].clamp(1e-4, 1 - 1e-4)), "scaling": torch.log(t["scales"]),
          "rotation": t["rotations"].clone()}
     p = {k: torch.nn.Parameter(v.requires_grad_(True)) for k, v in p.items()}
-    return p, [{"params": [p[k]], "lr": LRS[k], "name": k} for k in p]
+    return p, [{"params": [p[k]], "lr": lrs[k], "name": k} for k in p]
 
 
 def make_boxes(n, device, points=8196, seed=5, spacing=12.0):
@@ -93,16 +98,24 @@ def fused_loss(pkg, gt, normal, R_c2w):
     return loss + LAMBDA_NORMAL * losses.loss_normal_guidance(cam, pkg["render_cov_quat"], pkg["render_cov_scale"])
 
 
+def op_inputs(p):
+    """The rasterizer's inputs (activated, concatenated) of raw parameters p, as detached numpy-free tensors."""
+    with torch.no_grad():
+        return {"means3D": p["xyz"].detach().clone(), "shs": torch.cat((p["f_dc"], p["f_rest"]), dim=1).contiguous(),
+                "opacities": torch.sigmoid(p["opacity"]).detach(), "scales": torch.exp(p["scaling"]).detach(),
+                "rotations": F.normalize(p["rotation"]).detach()}
+
+
 class Trainer:
     """State of one variant: parameters, optimizer, densification statistics."""
 
-    def __init__(self, sc, device, n_boxes=0, fused=True, box_points=8196, factored_sh=False):
+    def __init__(self, sc, device, n_boxes=0, fused=True, box_points=8196, factored_sh=False, lrs=None):
         """factored_sh (fused variant without box instances): the op returns the 3-float factor of the SH gradient
         and Adam consumes it directly (optim.adam_step_sh_factored) -- the dense [P,16,3] gradient is never written."""
         from . import optim
         self.device, self.fused = device, fused
         self.factored_sh = bool(factored_sh and fused and not n_boxes)
-        self.p, groups = make_model(sc, device)
+        self.p, groups = make_model(sc, device, lrs)
         self.boxes = make_boxes(n_boxes, device, box_points) if n_boxes else []
         self.opt = (optim.Adam if fused else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
         P = self.p["xyz"].shape[0] + sum(b["means3D"].shape[0] for b, _ in self.boxes)   # statistics over the op inputs

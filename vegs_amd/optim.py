@@ -136,7 +136,14 @@ def _sh_state(opt, p):
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
+                # the same checks torch.optim.Adam's step makes: densification code replaces these tensors in place
+                # (scene/gaussian_model.py:263-331) and a mismatch would be written out of bounds by the kernel
+                for name in ("exp_avg", "exp_avg_sq"):
+                    t = st[name]
+                    if t.shape != p.shape or t.dtype != torch.float32 or not t.is_cuda or t.device != p.device \
+                            or not t.is_contiguous():
+                        raise ValueError(f"optimizer state {name} must be a contiguous float32 tensor shaped like its "
+                                         f"parameter {tuple(p.shape)} on {p.device} (got {tuple(t.shape)}, {t.dtype}, {t.device})")
                 return group, st
     raise ValueError("parameter is not in the optimizer")
 
@@ -149,7 +156,7 @@ def adam_step_sh_factored(opt, features_dc, features_rest, means3D, campos, fact
     .grad = sh_grad_from_factors(...) on the two parameters and stepping only them."""
     P, n, means3D, campos, factors = _check_factor_inputs(means3D, campos, factors)
     M = features_dc.shape[1] + (features_rest.shape[1] if features_rest is not None else 0)
-    items, betas, eps = [], None, None
+    items, states, betas, eps = [], [], None, None
     for p in (features_dc, features_rest):
         if p is None:
             items.append(None)
@@ -162,7 +169,11 @@ def adam_step_sh_factored(opt, features_dc, features_rest, means3D, campos, fact
         elif betas != tuple(group["betas"]) or eps != float(group["eps"]):
             raise ValueError("features_dc and features_rest must share betas and eps")
         items.append(_capi.VrShAdamTensor(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                          float(group["lr"]), int(st["step"].item())))
+                                          float(group["lr"]), int(st["step"].item()) + 1))
+        states.append(st)
+    K = (int(sh_degree) + 1) ** 2
+    if not 0 <= int(sh_degree) <= 3 or M < K:
+        raise ValueError(f"sh_degree {sh_degree} needs {K} coefficients, the parameters hold {M}")
     dev = means3D.device
     with torch.cuda.device(dev):
         rc = _capi.load().vr_sh_adam_step(_capi.ptr(means3D), P, _capi.ptr(campos), _capi.ptr(factors), n, int(sh_degree),
@@ -170,3 +181,5 @@ def adam_step_sh_factored(opt, features_dc, features_rest, means3D, campos, fact
                                           C.byref(items[1]) if items[1] is not None else None, betas[0], betas[1], eps,
                                           torch.cuda.current_stream(dev).cuda_stream)
     _capi.check(rc)
+    for st in states:          # the step counters advance only once every check and the call itself have passed
+        st["step"] += 1

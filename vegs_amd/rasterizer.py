@@ -123,7 +123,8 @@ _LAST_R = {}
 # previous forward needed.  Keyed by the identity of the camera's matrices (VEGS' Camera objects keep their
 # world_view_transform / full_proj_transform tensors for their lifetime, scene/cameras.py:76-87) and the image size.  A hint
 # is never trusted -- a wrong one (a reused address, a scene that changed) only costs time, the kernels redo what it
-# missed -- so no invalidation is needed.  VEGS_RAST_HINTS=0 (or needed_hints(False)) turns the cache off.
+# missed -- so no invalidation is needed.  A key's hint array is created on its SECOND sighting (value None until then):
+# a camera has to come back before anything is spent on it.  VEGS_RAST_HINTS=0 (or needed_hints(False)) turns the cache off.
 _NEEDED = {}
 _NEEDED_MAX = 4096
 _use_hints = os.environ.get("VEGS_RAST_HINTS", "1") != "0"
@@ -194,13 +195,20 @@ class _RasterizeGaussians(torch.autograd.Function):
             need_key, need_t = None, None
             if _use_hints and P > 0 and isinstance(rs.viewmatrix, torch.Tensor) and isinstance(rs.projmatrix, torch.Tensor):
                 need_key = (device.index, H, W, rs.viewmatrix.data_ptr(), rs.projmatrix.data_ptr())
-                need_t = _NEEDED.get(need_key)
-                if need_t is None:               # first visit: "no idea" -- the forward fills in what it needed
+                if need_key not in _NEEDED:
+                    # FIRST sighting: only remember the key.  Cameras that are rendered once and thrown away (the
+                    # reference's augmented views are fresh tensors every iteration, train.py:177 /
+                    # scene/cameras.py:126-227; eval and video cameras) never cost an allocation or a fill launch.
                     if len(_NEEDED) >= _NEEDED_MAX:
                         _NEEDED.pop(next(iter(_NEEDED)))
-                    need_t = torch.full((((W + 15) // 16) * ((H + 15) // 16),), 0x3FFFFFFF, dtype=torch.int32, device=device)
-                    _NEEDED[need_key] = need_t
-                saved.needed_hint = need_t.data_ptr()
+                    _NEEDED[need_key] = None
+                else:
+                    need_t = _NEEDED[need_key]
+                    if need_t is None:           # second sighting: "no idea" -- this forward fills in what it needed
+                        need_t = torch.full((((W + 15) // 16) * ((H + 15) // 16),), 0x3FFFFFFF, dtype=torch.int32,
+                                            device=device)
+                        _NEEDED[need_key] = need_t
+                    saved.needed_hint = need_t.data_ptr()
             cpu_args = _cpu_args_copy((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)) \
                 if rs.debug else None
             cb = arena.callback()
@@ -219,6 +227,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = int(saved.num_rendered)
         ctx.num_visible = int(saved.num_visible)
         ctx.binning_capacity = int(saved.binning_capacity)
+        ctx.ticket = int(saved.ticket)
         _LAST_R[hint_key] = max(_LAST_R.get(hint_key, 0), ctx.num_rendered)
         ctx.buffers = (arena.kept[_capi.VR_BUF_GEOM], arena.kept[_capi.VR_BUF_BINNING], arena.kept[_capi.VR_BUF_IMAGE])
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
@@ -265,7 +274,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                   _capi.ptr(d_opac), _capi.ptr(d_scales), _capi.ptr(d_rot), _capi.ptr(d_cov),
                                   _capi.ptr(d_sh_rest), _capi.ptr(d_sink))
             saved = _capi.VrSaved(geom.data_ptr(), binning.data_ptr(), image.data_ptr(), ctx.num_rendered,
-                                  ctx.num_visible, ctx.binning_capacity)
+                                  ctx.num_visible, ctx.binning_capacity, None, ctx.ticket)
             arena = _capi.Arena(device)
             stream = torch.cuda.current_stream(device).cuda_stream
             cpu_args = _cpu_args_copy((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

@@ -288,11 +288,21 @@ def variant(name, sc, deg, cams, device, steps, warmup, factored=False, hints="o
             wl = prepare(sc2, deg, cams, device, np.random.default_rng(77), cam_ts=cam_ts)
             rasterizer._use_hints = was
             step = make_step(wl, 0, 1, 1, factored, mode=mode)
+            rasterizer._use_hints = False                    # allocator / caches warm for the new model size, hints untouched
+            for i in range(4):
+                step(i)
+            rasterizer._use_hints = was
             warmup, repeats = 0, 1                           # the timed steps ARE the first visits after the epoch
             steps = min(steps, len(cams))
         for i in range(warmup):
             step(i)
         dt, done, runs = timed_median(step, steps, 1, repeats)
+        if hints == "epoch":               # the same drifted model without hints: what the stale hints are measured against
+            was = rasterizer._use_hints
+            rasterizer._use_hints = False
+            dt_off, _, _ = timed_median(step, steps, 1, 3)
+            rasterizer._use_hints = was
+            extra["same_model_hints_off_ms_per_view"] = round(dt_off / steps * 1e3, 4)
     finally:
         rasterizer.needed_hints(old)
     cn = wl["counters"]

@@ -101,14 +101,11 @@ k_seg_tiles(int ntiles, const int2* __restrict__ ranges, uint32_t* __restrict__ 
 // needed segments of its previous forward of the same camera (VrSaved.needed_hint; vr_export_needed).  k_seg_alpha
 // then only computes the segments sl < hinted_limit(hint[tile]); k_seg_scan walks that prefix as before and, if any
 // pixel of the tile is STILL alive at its end (the hint was too small: a stale or foreign hint, a scene that
-// changed), computes the missing segments itself, one after the other, with the same routine -- so the result never
-// depends on the hint, only the time does (bit-exact either way; tests/test_gpu_parity.py::test_needed_hint_*).
-// Margin: 2 segments + 12 %.  The fallback of k_seg_scan is serial per tile (~6 us per missing segment, and the scan
-// kernel lasts as long as its slowest tile), so the margin is sized to make it rare: with hints from a model whose
-// Gaussians were all moved by 2 cm, opacity logits by +-0.3 and scales by +-5 % (far more than the drift between two
-// visits of a camera) 3-5 of 2064 tiles miss by at most 2 segments (profiles/tools/staleness.py), while a margin of
-// 1 segment left one tile 18 segments short (+0.2 ms for that view).  Cost of the margin: 4.6 k instead of 2.1 k of the
-// 9.5 k dead segments of the headline view are still computed.
+// changed), the tile is finished by a second, equally parallel round over its remaining segments (k_seg_scan below) --
+// so the result never depends on the hint, only the time does (bit-exact either way;
+// tests/test_gpu_parity.py::test_needed_hint_*).  Margin: 2 segments + 12 %: 4.6 k instead of 2.1 k of the 9.5 k dead
+// segments of the headline view are still computed, and a model drifting by 2 cm / +-0.3 opacity logits / +-5 % scales
+// misses in 3-5 of 2064 tiles (profiles/tools/staleness.py).
 
 // Product of (1 - alpha) over one segment for the calling thread's pixel; also builds the segment's strip-relevance
 // masks and stores them.  Called by all 256 threads of a workgroup (contains block barriers).
@@ -172,7 +169,9 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
     return p;
 }
 
-// ---- A: per (tile, segment, pixel) product of (1 - alpha)
+// ---- A: per (tile, segment, pixel) product of (1 - alpha).  SECOND = the round for the short tiles of a hinted forward
+// (see k_seg_scan): only the segments still flagged 3.
+template <bool SECOND>
 __global__ void __launch_bounds__(256)
 k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
             const uint32_t* __restrict__ point_list, const Splat* __restrict__ rec, float* __restrict__ Pbuf,
@@ -182,45 +181,61 @@ k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     __shared__ unsigned long long masks[16];
     SegCtx c;
     if (!seg_setup(cam, ranges, seg_off, c)) return;
-    if (c.flag == 3u) return;   // behind the hinted prefix of its tile (k_seg_tiles): k_seg_scan decides
+    if ((c.flag == 3u) != SECOND) return;   // flag 3 = behind the hinted prefix of its tile (k_seg_tiles)
     const float p = seg_alpha_body(c, point_list, rec, lds, masks, segmask);
     Pbuf[(size_t)c.seg * SEG + threadIdx.x] = p;
 }
 
 // ---- B: per tile, boundary transmittances.  Tbuf[seg][pix] = Tb at the segment start, or -1 when
 // the pixel is finished before that segment; seg_needed[tile] = number of segments any pixel needs.
+//
+// With a needed-segment hint k_seg_alpha computed only the first `limit` segments of the tile.  If a pixel is still
+// alive at the end of that prefix the tile is SHORT (a stale or foreign hint, a scene that changed): this launch
+// (PASS2 = false) then leaves the tile unfinished -- it parks every pixel's state in the Tbuf row of the first missing
+// segment and marks the tile (top bit of seg_needed) -- and a second round finishes it IN PARALLEL: k_seg_alpha runs
+// once more over the segments still flagged 3 (only short tiles have any left), then this kernel with PASS2 = true picks
+// the chains of the short tiles up where they stopped.  (Round 2 computed the missing segments inside this kernel, one
+// after the other per tile: ~6 us each, and a model that had trained for an epoch since the hint was recorded missed
+// by hundreds of segments in the heavy tiles -- 2.98 ms per view instead of 1.42 without hints.)  The result never
+// depends on the hint either way.
+constexpr uint32_t TILE_SHORT = 0x80000000u;
+template <bool PASS2>
 __global__ void __launch_bounds__(256)
-k_seg_scan(Camera cam, const int2* __restrict__ ranges, uint32_t* __restrict__ seg_off, const float* __restrict__ Pbuf,
-           float* __restrict__ Tbuf, uint32_t* __restrict__ seg_needed, uint32_t* __restrict__ hint,
-           const uint32_t* __restrict__ point_list, const Splat* __restrict__ rec,
-           unsigned long long* __restrict__ segmask)
+k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, const float* __restrict__ Pbuf,
+           float* __restrict__ Tbuf, uint32_t* __restrict__ seg_needed, uint32_t* __restrict__ hint)
 {
     __shared__ uint32_t wneed[4];
     __shared__ uint32_t walive[4];
-    __shared__ float4 lds[2][SEG];
-    __shared__ unsigned long long masks[16];
     const int tile = blockIdx.x;
+    const uint32_t lim_word = seg_needed[tile];   // k_seg_offsets' snapshot (PASS2: what the first pass left)
+    if (PASS2 && !(lim_word & TILE_SHORT)) return;
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int px = tx * TILE + region_x(w, lane), py = ty * TILE + region_y(w, lane);
-    bool alive = px < cam.W && py < cam.H;
     const uint32_t s0 = seg_off[tile], s1 = seg_off[tile + 1];
-    const uint32_t k0 = min(s1 - s0, seg_needed[tile]);   // segments [0, k0) were computed by k_seg_alpha (k_seg_offsets' snapshot)
-    const uint32_t s1c = s0 + k0;
+    // segments [first, last) of the tile are walked by this launch
+    const uint32_t first = PASS2 ? (lim_word & ~TILE_SHORT) : 0u;
+    const uint32_t last = PASS2 ? s1 - s0 : min(s1 - s0, lim_word);
+    bool alive = px < cam.W && py < cam.H;
     float Tb = 1.0f;
+    if (PASS2) {   // the state parked by the first pass
+        Tb = Tbuf[(size_t)(s0 + first) * SEG + threadIdx.x];
+        alive = !(Tb < 0.0f);
+    }
     // Each wave walks the segment chain of its own 64 pixels without block barriers; the P values of
     // UNROLL segments are fetched together so the chain is not bound by one memory latency per segment.
     constexpr int UNROLL = 24;
-    uint32_t mine = 0;  // segments this wave needs (some pixel alive at the segment start)
+    uint32_t mine = first;  // segments this wave needs (some pixel alive at the segment start)
     bool wave_alive = __ballot(alive) != 0ull;
-    for (uint32_t s = s0; s < s1c && wave_alive; s += UNROLL) {
+    const uint32_t sa = s0 + first, sb = s0 + last;
+    for (uint32_t s = sa; s < sb && wave_alive; s += UNROLL) {
         float Pv[UNROLL];
 #pragma unroll
         for (int k = 0; k < UNROLL; ++k)
-            Pv[k] = (s + k < s1c) ? Pbuf[(size_t)(s + k) * SEG + threadIdx.x] : 1.0f;
+            Pv[k] = (s + k < sb) ? Pbuf[(size_t)(s + k) * SEG + threadIdx.x] : 1.0f;
 #pragma unroll
         for (int k = 0; k < UNROLL; ++k) {
-            if (s + k < s1c && wave_alive) {
+            if (s + k < sb && wave_alive) {
                 mine = s + k - s0 + 1;
                 Tbuf[(size_t)(s + k) * SEG + threadIdx.x] = alive ? Tb : -1.0f;
                 const float Tn = Tb * Pv[k];
@@ -230,45 +245,16 @@ k_seg_scan(Camera cam, const int2* __restrict__ ranges, uint32_t* __restrict__ s
             }
         }
     }
-    // The hint was too small for this tile: some pixel is still alive behind the computed prefix.  The workgroup
-    // computes the missing segments itself, in order (all four waves together: the relevance masks of a segment are
-    // built by all 256 threads), until every pixel has stopped or the list ends.
-    if (s1c < s1) {
-        if (lane == 0) walive[w] = wave_alive ? 1u : 0u;
-        __syncthreads();
-        bool any_alive = (walive[0] | walive[1] | walive[2] | walive[3]) != 0u;
-        const int2 rg = ranges[tile];
-        for (uint32_t s = s1c; s < s1 && any_alive; ++s) {
-            SegCtx c;
-            c.seg = s;
-            c.tile = tile;
-            c.sl = (int)(s - s0);
-            c.first = rg.x + c.sl * SEG;
-            c.count = min(SEG, rg.y - c.first);
-            c.flag = 0u;
-            c.px = px;
-            c.py = py;
-            c.x0 = (float)(tx * TILE);
-            c.y0 = (float)(ty * TILE);
-            c.inside = px < cam.W && py < cam.H;
-            c.pix = (size_t)py * cam.W + px;
-            const float p = seg_alpha_body(c, point_list, rec, lds, masks, segmask);
-            if (wave_alive) {
-                mine = s - s0 + 1;
-                Tbuf[(size_t)s * SEG + threadIdx.x] = alive ? Tb : -1.0f;
-                const float Tn = Tb * p;
-                if (alive && Tn < T_EPS) alive = false;
-                else if (alive) Tb = Tn;
-                wave_alive = __ballot(alive) != 0ull;
-            }
-            __syncthreads();                       // lds / masks / walive are reused by the next segment
-            if (lane == 0) walive[w] = wave_alive ? 1u : 0u;
-            __syncthreads();
-            any_alive = (walive[0] | walive[1] | walive[2] | walive[3]) != 0u;
-        }
-    }
-    if (lane == 0) wneed[w] = mine;
+    if (lane == 0) { wneed[w] = mine; walive[w] = wave_alive ? 1u : 0u; }
     __syncthreads();
+    const bool any_alive = (walive[0] | walive[1] | walive[2] | walive[3]) != 0u;
+    if (!PASS2 && any_alive && last < s1 - s0) {
+        // SHORT tile: rows [mine, last) of the waves that finished earlier, then every pixel's state in row `last`
+        for (uint32_t s = s0 + mine; s < s0 + last; ++s) Tbuf[(size_t)s * SEG + threadIdx.x] = -1.0f;
+        Tbuf[(size_t)(s0 + last) * SEG + threadIdx.x] = alive ? Tb : -1.0f;
+        if (threadIdx.x == 0) seg_needed[tile] = last | TILE_SHORT;
+        return;   // the segment flags of this tile stay as they are (3 behind the prefix: the second round's work list)
+    }
     const uint32_t needed = max(max(wneed[0], wneed[1]), max(wneed[2], wneed[3]));
     for (uint32_t s = s0 + mine; s < s0 + needed; ++s) Tbuf[(size_t)s * SEG + threadIdx.x] = -1.0f;
     if (threadIdx.x == 0) {
@@ -592,13 +578,20 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
                        (const uint32_t*)seg_needed, (uint32_t)nseg);
     VR_KERNEL_CHECK("seg_offsets", s, debug);
     if (R > 0) {
-        hipLaunchKernelGGL(k_seg_alpha, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
+        hipLaunchKernelGGL(k_seg_alpha<false>, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
                            point_list, rec, Pbuf, segmask);
         VR_KERNEL_CHECK("seg_alpha", s, debug);
     }
-    hipLaunchKernelGGL(k_seg_scan, dim3(ntiles), dim3(256), 0, s, cam, ranges, seg_off, (const float*)Pbuf,
-                       Tbuf, seg_needed, needed_hint, point_list, rec, segmask);
+    hipLaunchKernelGGL(k_seg_scan<false>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (const float*)Pbuf, Tbuf,
+                       seg_needed, needed_hint);
     VR_KERNEL_CHECK("seg_scan", s, debug);
+    if (needed_hint && R > 0) {   // a hinted forward: second round for the tiles whose hint was too small (usually none)
+        hipLaunchKernelGGL(k_seg_alpha<true>, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
+                           point_list, rec, Pbuf, segmask);
+        hipLaunchKernelGGL(k_seg_scan<true>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (const float*)Pbuf, Tbuf,
+                           seg_needed, needed_hint);
+        VR_KERNEL_CHECK("seg_scan (second round)", s, debug);
+    }
     if (R > 0) {
         hipLaunchKernelGGL(k_seg_blend, dim3((unsigned)nseg * 4), dim3(64), 0, s, cam, ranges, (const uint32_t*)seg_off,
                            (const uint32_t*)seg_needed, point_list, rec, (const float*)Tbuf, part,

@@ -210,6 +210,19 @@ constexpr int REGIONS_X = TILE / REGION_W;   // regions per tile row
 __device__ __forceinline__ int region_x(int w, int lane) { return (w % REGIONS_X) * REGION_W + (lane % REGION_W); }
 __device__ __forceinline__ int region_y(int w, int lane) { return (w / REGIONS_X) * REGION_H + (lane / REGION_W); }
 
+// Does the footprint ellipse reach the rectangle of pixel centres [xl, xh] x [yl, yh] (coordinates relative to the
+// splat centre)?  lim = k * 1.001 + 0.001 with k = -2 thr; A, C > 0 and A C - B^2 > 0 are the caller's business.
+__device__ __forceinline__ bool rect_relevant(float A, float inv_A, float B, float C, float inv_C, float lim, float xl,
+                                              float xh, float yl, float yh)
+{
+    const bool in = xl <= 0.0f && xh >= 0.0f && yl <= 0.0f && yh >= 0.0f;
+    float q = quad_edge_min(A, inv_A, B, C, yl, xl, xh);
+    q = fminf(q, quad_edge_min(A, inv_A, B, C, yh, xl, xh));
+    q = fminf(q, quad_edge_min(C, inv_C, B, A, xl, yl, yh));
+    q = fminf(q, quad_edge_min(C, inv_C, B, A, xh, yl, yh));
+    return in || q <= lim;
+}
+
 // relevance of one splat for the four regions of a tile (bit s of the result = region s)
 __device__ __forceinline__ uint32_t strips_relevant_exact(float sx, float sy, float A, float B, float C, float thr,
                                                           float x0, float y0)
@@ -227,13 +240,29 @@ __device__ __forceinline__ uint32_t strips_relevant_exact(float sx, float sy, fl
     for (int s = 0; s < 4; ++s) {
         const float xl = x0 + (float)((s % REGIONS_X) * REGION_W) - sx, xh = xl + (float)(REGION_W - 1);
         const float yl = y0 + (float)((s / REGIONS_X) * REGION_H) - sy, yh = yl + (float)(REGION_H - 1);
-        bool rel = xl <= 0.0f && xh >= 0.0f && yl <= 0.0f && yh >= 0.0f;
-        float q = quad_edge_min(A, inv_A, B, C, yl, xl, xh);
-        q = fminf(q, quad_edge_min(A, inv_A, B, C, yh, xl, xh));
-        q = fminf(q, quad_edge_min(C, inv_C, B, A, xl, yl, yh));
-        q = fminf(q, quad_edge_min(C, inv_C, B, A, xh, yl, yh));
-        rel = rel || q <= lim;
-        bits |= rel ? (1u << s) : 0u;
+        bits |= rect_relevant(A, inv_A, B, C, inv_C, lim, xl, xh, yl, yh) ? (1u << s) : 0u;
+    }
+    return bits;
+}
+
+// The same one level down: relevance for the four 4x4-pixel QUADRANTS of an 8x8 region whose first pixel centre is
+// (x0, y0) (bit q = quadrant q: x half = q & 1, y half = q >> 1).  An entry that passed the region test may still
+// fail all four (its ellipse slips between pixel centres): it then contributes nothing to the region.
+constexpr int QUAD = 4;
+__device__ __forceinline__ uint32_t quads_relevant(float sx, float sy, float A, float B, float C, float thr, float x0,
+                                                   float y0)
+{
+    const float k = -2.0f * thr;
+    if (!(k > 0.0f)) return 0u;
+    if (!(A > 0.0f) || !(C > 0.0f) || !(A * C - B * B > 0.0f)) return 0xFu;
+    const float lim = k * 1.001f + 0.001f;
+    const float inv_A = __builtin_amdgcn_rcpf(A), inv_C = __builtin_amdgcn_rcpf(C);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float xl = x0 + (float)((q & 1) * QUAD) - sx, xh = xl + (float)(QUAD - 1);
+        const float yl = y0 + (float)((q >> 1) * QUAD) - sy, yh = yl + (float)(QUAD - 1);
+        bits |= rect_relevant(A, inv_A, B, C, inv_C, lim, xl, xh, yl, yh) ? (1u << q) : 0u;
     }
     return bits;
 }

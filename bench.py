@@ -112,7 +112,7 @@ def prepare(sc, deg, cams, device, rng, count=True, cam_ts=None):
                 cam_ts=cam_ts, gouts=gouts, counters=counters, deg=deg)
 
 
-def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="train"):
+def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="train", exchange_on=True):
     """One step = `vps` views forward + backward on this rank, then (N > 1) the gradient exchange.
     exchange "dense": all-reduce of the 59-float/Gaussian gradients.  "factored": the op returns the 3-float factor of
     the SH gradient, the ranks all-gather the factors (12 B) and all-reduce the other 11 floats (44 B), and every rank
@@ -129,6 +129,9 @@ def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="trai
     others = [T[k] for k in ("means3D", "opacities", "scales", "rotations")]
     from vegs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     m2d = torch.zeros_like(T["means3D"], requires_grad=True) if mode == "noglue" else None
+    xch = vdist.FactorExchange(world) if fact_x and exchange_on else None
+    if fact_x and not exchange_on:
+        fact_x = False             # (measurement aid: the same step without any collective)
 
     def direct(v):
         cam, ct = cams[v], cam_ts[v]
@@ -155,15 +158,17 @@ def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="trai
                 continue
             sink = torch.zeros_like(T["means3D"], requires_grad=True) if factored else None
             pkg = harness.render(cams[v], T, deg, bg, cam_t=cam_ts[v], sh_color_grad=sink)
+            if fact_x:          # overlapped exchange: the factors start travelling between the backward's two halves
+                xch.begin(cam_ts[v]["campos"])
             torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], [gc, gq, gs])
             done.append(v)
         if mode == "forward":
             return done
         if fact_x:
             from vegs_amd import optim
-            F, Cc = vdist.exchange_factored(others, sink.grad, cam_ts[done[-1]]["campos"], world)
+            F, Cc = xch.finish(others)
             T["shs"].grad = optim.sh_grad_from_factors(T["means3D"].detach(), Cc, F, deg, T["shs"].shape[1], 1.0 / world)
-        elif world > 1:
+        elif world > 1 and exchange_on:
             vdist.allreduce_grads(params, world)
         for p in params:
             p.grad = None
@@ -413,6 +418,19 @@ def main():
     else:
         frag_total, blend_total = frag_local, blend_local
 
+    exchange = None
+    if world > 1:
+        # what the exchange costs: the same K steps once more WITHOUT any collective (every rank; outside the headline's
+        # timed regions).  exposed = ms per step with - without: the part of the exchange that compute does not hide.
+        step0 = make_step(wl, rank, world, vps, factored=(args.exchange == "factored" and vps == 1), exchange=args.exchange,
+                          exchange_on=False)
+        dt0, _, _ = timed_median(step0, args.steps, world, 1, first=args.warmup)
+        scheme = "factored" if args.exchange == "factored" and vps == 1 else "dense"
+        exchange = {"scheme": scheme + (" (all-gather of the SH factors started between the backward's two halves, "
+                                        "all-reduce of the other 11 floats after it; one wait)" if scheme == "factored" else ""),
+                    "exchange_bytes_per_rank": vdist.exchange_bytes_per_rank(P, world, scheme),
+                    "ms_per_step_without_exchange": round(dt0 / args.steps * 1e3, 4),
+                    "exchange_exposed_ms": round((elapsed - dt0) / args.steps * 1e3, 4)}
     if rank != 0:
         return
     stage_ms = stage_profile(step, 8) if world == 1 else {}
@@ -446,6 +464,7 @@ def main():
         # B = (pixel, splat) pairs actually BLENDED (alpha >= 1/255 before the stop) -- an order of magnitude fewer
         "mfragments_per_s": round(frag_total / elapsed / 1e6, 2),
         "blended_mfragments_per_s": round(blend_total / elapsed / 1e6, 2),
+        "exchange": exchange,
         "config": {"workload": f"{args.workload}: {P} street Gaussians (VEGS disc init), SH deg {deg}, {W}x{H} "
                                f"KITTI-360 intrinsics, {n_views} views cycled, 12 output channels + colour/quat/scale grads; "
                                + ("per-camera needed-segment hints OFF: every view is rendered as a camera's first visit"

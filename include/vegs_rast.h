@@ -46,7 +46,8 @@ typedef enum VrBufferKind {
     VR_BUF_GEOM = 0,    /* per-Gaussian state, kept for backward  (O(P)) */
     VR_BUF_BINNING = 1, /* sorted tile lists, kept for backward   (O(R)) */
     VR_BUF_IMAGE = 2,   /* per-pixel state, kept for backward     (O(H*W)) */
-    VR_BUF_SCRATCH = 3  /* transient; may be released when the call returns (several requests per call) */
+    VR_BUF_SCRATCH = 3, /* transient; may be released when the call returns (several requests per call) */
+    VR_BUF_BACKWARD = 4 /* per-Gaussian sums between vr_backward_render and vr_backward_preprocess (64 B per Gaussian) */
 } VrBufferKind;
 
 /* Must return a device pointer to at least `bytes` bytes, 256-byte aligned, valid on `stream`
@@ -212,6 +213,19 @@ int vr_forward(const VrSettings* settings, const VrInputs* in, const VrOutputs* 
 int vr_backward(const VrSettings* settings, const VrInputs* in, const int32_t* radii,
                 const VrSaved* saved, const VrOutGrads* gout, const VrInGrads* gin,
                 VrAllocFn alloc, void* alloc_user, void* stream);
+
+/* The backward in TWO calls (ABI v5), for callers that have something to do in between -- a multi-GPU job starts the
+ * exchange of the SH factors (VrInGrads.dL_dcolors_sh) while the second half still runs:
+ *   vr_backward_render      zeroing, render backward (the per-pixel -> per-Gaussian sums, dL_dmeans2D) and, with the
+ *                           factored SH gradient, dL_dcolors_sh -- COMPLETE when this call's work is (stream order);
+ *                           *state receives a VR_BUF_BACKWARD buffer to hand to the second call
+ *   vr_backward_preprocess  every other gradient (means3D, opacities, scales, rotations, cov3D, dense shs / colours)
+ * Same arguments and results as vr_backward, which is the two in a row. */
+int vr_backward_render(const VrSettings* settings, const VrInputs* in, const int32_t* radii, const VrSaved* saved,
+                       const VrOutGrads* gout, const VrInGrads* gin, VrAllocFn alloc, void* alloc_user, void* stream,
+                       void** state);
+int vr_backward_preprocess(const VrSettings* settings, const VrInputs* in, const int32_t* radii, const VrSaved* saved,
+                           const VrInGrads* gin, void* state, void* stream);
 
 /* present[i] = view-space z of xyz[i] > 0.2 (no screen-bounds test). */
 int vr_mark_visible(const float* xyz, int32_t P, const float* viewmatrix, const float* projmatrix,

@@ -91,3 +91,51 @@ def test_single_process_is_a_no_op():
                                                   torch.tensor([1, 2, 3, 4], dtype=torch.int32))
     assert torch.allclose(g[:, 0], torch.tensor([2 ** 0.5, 0, 2 ** 0.5, 2 ** 0.5]))
     assert torch.equal(d[:, 0], torch.tensor([1.0, 0, 1, 1]))
+
+
+def _worker_overlapped(rank, world, port, outdir):
+    """FactorExchange (the overlapped scheme's arithmetic: on gloo nothing overlaps, the calls and their order are the
+    production ones) with the row-sparse all-reduce: every rank sees only a window of the Gaussians."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from vegs_amd import dist as vdist
+    vdist.init_from_env(backend="gloo")
+    P = 4000
+    g = torch.Generator().manual_seed(500 + rank)
+    # camera `rank` sees Gaussians [300 rank, 300 rank + 700): the union over 8 ranks is 70 % of the rows for world 8
+    radii = torch.zeros(P, dtype=torch.int32)
+    radii[300 * rank:300 * rank + 700] = torch.randint(1, 40, (700,), generator=g, dtype=torch.int32)
+    vis = (radii > 0)[:, None]
+    others = [torch.zeros(s, requires_grad=True) for s in [(P, 3), (P, 1), (P, 3), (P, 4)]]
+    olocal = [torch.randn(p.shape, generator=g) * vis.reshape((P,) + (1,) * (p.dim() - 1)).float() for p in others]
+    for p, l in zip(others, olocal):
+        p.grad = l.clone()
+    factor = torch.randn(P, 3, generator=g) * vis.float()
+    campos = torch.randn(3, generator=g)
+    ex = vdist.FactorExchange(world, sparse_rows=True)
+    ex.begin(campos)
+    ex._on_factors(factor)                    # what the op's backward does between its two halves
+    F, Cc = ex.finish(others, radii)
+    torch.save(dict(others=[p.grad for p in others], olocal=olocal, factor=factor, campos=campos, F=F, C=Cc,
+                    rows=ex.rows_exchanged, bytes=vdist.exchange_bytes_per_rank(P, world, "factored", ex.rows_exchanged)),
+               os.path.join(outdir, f"o{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_overlapped_factor_exchange_with_sparse_rows_gloo(tmp_path, world):
+    """World 8 = BASELINE config C4's rank count: the factors of all 8 views reach every rank, the other gradients are
+    averaged, and only the rows visible on some rank travel (2800 of 4000 at world 8, 1000 at world 2)."""
+    mp.spawn(_worker_overlapped, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    R = [torch.load(tmp_path / f"o{r}.pt") for r in range(world)]
+    union = 300 * (world - 1) + 700
+    for r in range(world):
+        assert R[r]["rows"] == union                      # sparse path taken, exactly the union of the visible rows
+        for k in range(4):
+            want = sum(R[q]["olocal"][k] for q in range(world)) / world
+            assert torch.allclose(R[r]["others"][k], want, atol=1e-6), (r, k)
+        assert R[r]["F"].shape == (world, 4000, 3) and R[r]["C"].shape == (world, 3)
+        for q in range(world):
+            assert torch.equal(R[r]["F"][q], R[q]["factor"]) and torch.equal(R[r]["C"][q], R[q]["campos"])
+        assert R[r]["bytes"] == int((world - 1) * 12 * 4000 + 2.0 * (world - 1) / world * 44 * union)

@@ -86,8 +86,28 @@ assert T["shs"].grad is None
 F, C = vdist.exchange_factored([T[k] for k in ("means3D", "opacities", "scales", "rotations")], sink.grad, ct["campos"], world)
 assert F.shape == (2, 60000, 3) and torch.equal(F[rank], sink.grad)
 fact_shs = optim.sh_grad_from_factors(T["means3D"].detach(), C, F, deg, 16, 1.0 / world)
+fact_means3D = T["means3D"].grad.cpu().numpy()
+# ---- and once more with the OVERLAPPED exchange: the backward in two ABI calls (vr_backward_render ->
+# hook: the factors start travelling -> vr_backward_preprocess), the other gradients row-sparse
+for t in T.values():
+    t.grad = None
+sink2 = torch.zeros(60000, 3, device=dev, requires_grad=True)
+out = GaussianRasterizer(rs)(means3D=T["means3D"], means2D=torch.zeros(60000, 3, device=dev, requires_grad=True),
+                             opacities=T["opacities"], shs=T["shs"], scales=T["scales"], rotations=T["rotations"],
+                             sh_color_grad=sink2)
+ex = vdist.FactorExchange(world, sparse_rows=True)
+ex.begin(ct["campos"])
+torch.autograd.backward([out[0], out[2], out[3]],
+                        [torch.tensor(g["gc%%d" %% v], device=dev), torch.tensor(g["gq%%d" %% v], device=dev), torch.tensor(g["gs%%d" %% v], device=dev)])
+assert ex._f is not None and ex._f.data_ptr() == sink2.grad.data_ptr()      # the hook ran between the two halves
+F2, C2 = ex.finish([T[k] for k in ("means3D", "opacities", "scales", "rotations")], out[5])
+from vegs_amd import rasterizer
+assert rasterizer._split_hook is None
+assert torch.equal(F2[rank], sink2.grad) and torch.equal(C2, C)
+ovl_shs = optim.sh_grad_from_factors(T["means3D"].detach(), C2, F2, deg, 16, 1.0 / world)
 np.savez(os.path.join(%(out)r, "rank%%d.npz" %% rank), gsum=gsum.cpu().numpy(), den=den.cpu().numpy(), mr=mr.cpu().numpy(),
-         fact_shs=fact_shs.cpu().numpy(), fact_means3D=T["means3D"].grad.cpu().numpy(), **dense)
+         fact_shs=fact_shs.cpu().numpy(), fact_means3D=fact_means3D, ovl_shs=ovl_shs.cpu().numpy(),
+         ovl_means3D=T["means3D"].grad.cpu().numpy(), ovl_rows=np.int64(ex.rows_exchanged), **dense)
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()
 print("RANK_OK", rank)
@@ -158,6 +178,11 @@ def test_two_ranks_equal_mean_of_two_views(tmp_path):
     assert_grad_close("2-rank factored shs", R[0]["fact_shs"], want["shs"], rtol=1e-3, floor=2e-6)
     assert_grad_close("2-rank factored vs dense exchange", R[0]["fact_shs"], R[0]["grad_shs"], rtol=1e-3, floor=2e-6)
     assert_grad_close("2-rank factored means3D", R[0]["fact_means3D"], want["means3D"], rtol=1e-3, floor=2e-6)
+    # overlapped exchange (split backward + row-sparse all-reduce): the same tensors once more
+    assert np.array_equal(R[0]["ovl_shs"], R[1]["ovl_shs"]) and np.array_equal(R[0]["ovl_means3D"], R[1]["ovl_means3D"])
+    assert_grad_close("2-rank overlapped shs", R[0]["ovl_shs"], want["shs"], rtol=1e-3, floor=2e-6)
+    assert_grad_close("2-rank overlapped means3D", R[0]["ovl_means3D"], want["means3D"], rtol=1e-3, floor=2e-6)
+    assert 0 < int(R[0]["ovl_rows"]) <= 60000
     assert np.array_equal(R[0]["den"], den.cpu().numpy()) and np.array_equal(R[0]["mr"], mr.cpu().numpy())
     assert_grad_close("2-rank grad-norm sum", R[0]["gsum"], gsum.cpu().numpy(), rtol=1e-3, floor=2e-6)
     assert (R[0]["den"] == 2).sum() > 1000                                         # the stereo views overlap
@@ -177,6 +202,9 @@ def test_bench_two_ranks_gloo_transport(tmp_path):
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
     assert res["config"]["gaussians"] == 200000 and "roofline" in res
+    ex = res["exchange"]
+    assert ex["scheme"].startswith("factored") and ex["exchange_bytes_per_rank"] == 12 * 200000 + 44 * 200000
+    assert ex["ms_per_step_without_exchange"] > 0 and "exchange_exposed_ms" in ex
 
 
 def test_bench_line_contract_single_gpu():

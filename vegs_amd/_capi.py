@@ -17,10 +17,10 @@ ABI_VERSION = 5
 FLAG_SCALE_MODIFIED, FLAG_DEPTH_NORMALIZED, FLAG_EXTRA_NO_ALPHA_GRAD, FLAG_FILL_EMPTY, FLAG_DETERMINISTIC = 1, 2, 4, 8, 256
 FLAG_SCAN_BINNING = 512
 
-VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH = 0, 1, 2, 3
+VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH, VR_BUF_BACKWARD = 0, 1, 2, 3, 4
 
 # every symbol include/vegs_rast.h declares
-EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_mark_visible", "vr_get_counters",
+EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_backward_render", "vr_backward_preprocess", "vr_mark_visible", "vr_get_counters",
            "vr_count_fragments", "vr_count_blended", "vr_export_needed", "vr_debug_export_binning", "vr_debug_set_guard", "vr_debug_raise_guard", "vr_profile_level", "vr_profile_collect",
            "vr_knn3_mean_dist2", "vr_photometric_forward", "vr_photometric_backward",
            "vr_normal_guidance_forward", "vr_normal_guidance_backward", "vr_adam_step", "vr_densify_stats",
@@ -116,6 +116,13 @@ def load():
     lib.vr_backward.restype = C.c_int
     lib.vr_backward.argtypes = [C.POINTER(VrSettings), C.POINTER(VrInputs), C.c_void_p, C.POINTER(VrSaved),
                                 C.POINTER(VrOutGrads), C.POINTER(VrInGrads), VrAllocFn, C.c_void_p, C.c_void_p]
+    lib.vr_backward_render.restype = C.c_int
+    lib.vr_backward_render.argtypes = [C.POINTER(VrSettings), C.POINTER(VrInputs), C.c_void_p, C.POINTER(VrSaved),
+                                       C.POINTER(VrOutGrads), C.POINTER(VrInGrads), VrAllocFn, C.c_void_p, C.c_void_p,
+                                       C.POINTER(C.c_void_p)]
+    lib.vr_backward_preprocess.restype = C.c_int
+    lib.vr_backward_preprocess.argtypes = [C.POINTER(VrSettings), C.POINTER(VrInputs), C.c_void_p, C.POINTER(VrSaved),
+                                           C.POINTER(VrInGrads), C.c_void_p, C.c_void_p]
     lib.vr_mark_visible.restype = C.c_int
     lib.vr_mark_visible.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.vr_get_counters.restype = None

@@ -429,30 +429,38 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     return VR_OK;
 }
 
-int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, const VrSaved* saved,
-                const VrOutGrads* gout, const VrInGrads* gin, VrAllocFn alloc, void* user, void* stream)
+// ---- backward, in two halves.  `first` = zero the accumulators, render backward (k_seg_u, k_seg_suffix, k_seg_bwd) and,
+// with the factored SH gradient, its factor; `second` = k_preprocess_bwd.  gacc ([P][16] floats) carries the per-Gaussian
+// sums from one to the other.
+static int backward_checks(const VrSettings* st, const VrInputs* in, const int32_t* radii, const VrSaved* saved,
+                           const VrInGrads* gin, Camera* cam, bool* sh_factored)
 {
-    g_err[0] = 0;
-    if (!saved || !gout || !gin || !alloc) return fail(VR_ERR_INVALID_ARGUMENT, "saved, grads and alloc are required");
     int rc = check_inputs(st, in);
     if (rc) return rc;
-    Camera cam;
-    rc = make_camera(st, in->M, &cam);
+    rc = make_camera(st, in->M, cam);
     if (rc) return rc;
-    const int P = in->P;
-    if (P == 0) return VR_OK;
+    if (in->P == 0) return VR_OK;
     if (!radii || !saved->geom || !saved->binning || !saved->image)
         return fail(VR_ERR_INVALID_ARGUMENT, "radii and the saved forward buffers are required");
     if (!gin->dL_dmeans3D || !gin->dL_dmeans2D || !gin->dL_dopacities)
         return fail(VR_ERR_INVALID_ARGUMENT, "dL_dmeans3D, dL_dmeans2D and dL_dopacities are required");
-    const bool sh_factored = in->shs && gin->dL_dcolors_sh;     // factored SH gradient: dL_dshs is not written
-    if ((in->shs && !gin->dL_dshs && !sh_factored) || (in->colors_precomp && !gin->dL_dcolors_precomp) ||
+    *sh_factored = in->shs && gin->dL_dcolors_sh;     // factored SH gradient: dL_dshs is not written
+    if ((in->shs && !gin->dL_dshs && !*sh_factored) || (in->colors_precomp && !gin->dL_dcolors_precomp) ||
         (in->scales && (!gin->dL_dscales || !gin->dL_drotations)) || (in->cov3D_precomp && !gin->dL_dcov3D_precomp))
         return fail(VR_ERR_INVALID_ARGUMENT, "a gradient array is missing for a provided input");
-    hipStream_t s = (hipStream_t)stream;
+    if (!*sh_factored && in->shs_rest && (!gin->dL_dshs || !gin->dL_dshs_rest))
+        return fail(VR_ERR_INVALID_ARGUMENT, "split SH storage needs both dL_dshs and dL_dshs_rest");
+    return VR_OK;
+}
+
+static int backward_first(const Camera& cam, const VrSettings* st, const VrInputs* in, const int32_t* radii,
+                          const VrSaved* saved, const VrOutGrads* gout, const VrInGrads* gin, bool sh_factored,
+                          bool factor_now, float* gacc, VrAllocFn alloc, void* user, hipStream_t s)
+{
     const bool debug = st->debug != 0;
+    const int P = in->P;
     // a timed-out wait in THIS view's binning fails its own backward, before any gradient is produced
-    rc = check_ticket(saved->ticket, s);
+    int rc = check_ticket(saved->ticket, s);
     if (rc) return rc;
     const size_t N = (size_t)cam.H * cam.W, T = (size_t)cam.gx * cam.gy;
     const ImageLayout IL = image_layout(N);
@@ -464,16 +472,13 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
     const int2* ranges = (const int2*)((const char*)saved->binning + BL.ranges);
     const uint32_t* point_list = (const uint32_t*)((const char*)saved->binning + BL.point_list);
 
-    float* gacc = (float*)alloc(user, VR_BUF_SCRATCH, (size_t)P * 16 * sizeof(float));
-    if (!gacc) return fail(VR_ERR_ALLOC, "allocator returned NULL");
     prof_begin(VR_STAGE_BWD_ZERO, s);
     VR_HIP(hipMemsetAsync(gacc, 0, (size_t)P * 16 * sizeof(float), s));
     VR_HIP(hipMemsetAsync(gin->dL_dmeans2D, 0, (size_t)P * 3 * sizeof(float), s));
     if (sh_factored) {
-        // nothing to clear: the kernel writes every row of the [P,3] factor array
-    } else if (in->shs_rest) {   // split SH storage: the kernel writes every row of both gradient arrays
-        if (!gin->dL_dshs || !gin->dL_dshs_rest)
-            return fail(VR_ERR_INVALID_ARGUMENT, "split SH storage needs both dL_dshs and dL_dshs_rest");
+        // nothing to clear: every row of the [P,3] factor array is written
+    } else if (in->shs_rest) {
+        // split SH storage: the kernel writes every row of both gradient arrays
     } else if (gin->dL_dshs && !preprocess_bwd_writes_all_sh(in->M, in->shs, gin->dL_dshs)) {
         VR_HIP(hipMemsetAsync(gin->dL_dshs, 0, (size_t)P * in->M * 3 * sizeof(float), s));
     }
@@ -499,15 +504,76 @@ int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, 
                                (const float*)((const char*)saved->image + IL.dsum), det_scr, P, s, debug);
         if (rc) return rc;
     }
+    if (sh_factored && factor_now)
+        return launch_sh_factor(P, radii, (const uint8_t*)saved->geom + align_up((size_t)P * sizeof(Splat), 256), gacc,
+                                gin->dL_dcolors_sh, s, debug);
+    return VR_OK;
+}
+
+static int backward_second(const Camera& cam, const VrSettings* st, const VrInputs* in, const int32_t* radii,
+                           const VrSaved* saved, const VrInGrads* gin, bool sh_factored, bool store_factor,
+                           const float* gacc, hipStream_t s)
+{
+    const int P = in->P;
     ProfScope ps2(VR_STAGE_PREPROCESS_BWD, s);
-    rc = launch_preprocess_bwd(cam, P, in->means3D, in->shs, in->shs_rest, in->colors_precomp, in->scales, in->rotations,
-                               in->cov3D_precomp, radii,
-                               (const uint8_t*)saved->geom + align_up((size_t)P * sizeof(Splat), 256),
-                               (const float*)((const char*)saved->geom + align_up((size_t)P * sizeof(Splat), 256) + align_up((size_t)P, 256)),
-                               gacc, gin->dL_dmeans2D, gin->dL_dmeans3D, gin->dL_dshs, gin->dL_dshs_rest,
-                               gin->dL_dcolors_precomp, gin->dL_dopacities, gin->dL_dscales, gin->dL_drotations,
-                               gin->dL_dcov3D_precomp, sh_factored ? gin->dL_dcolors_sh : nullptr, s, debug);
-    return rc;
+    return launch_preprocess_bwd(cam, P, in->means3D, in->shs, in->shs_rest, in->colors_precomp, in->scales, in->rotations,
+                                 in->cov3D_precomp, radii,
+                                 (const uint8_t*)saved->geom + align_up((size_t)P * sizeof(Splat), 256),
+                                 (const float*)((const char*)saved->geom + align_up((size_t)P * sizeof(Splat), 256) + align_up((size_t)P, 256)),
+                                 gacc, gin->dL_dmeans2D, gin->dL_dmeans3D, gin->dL_dshs, gin->dL_dshs_rest,
+                                 gin->dL_dcolors_precomp, gin->dL_dopacities, gin->dL_dscales, gin->dL_drotations,
+                                 gin->dL_dcov3D_precomp, sh_factored ? gin->dL_dcolors_sh : nullptr, store_factor, s,
+                                 st->debug != 0);
+}
+
+int vr_backward(const VrSettings* st, const VrInputs* in, const int32_t* radii, const VrSaved* saved,
+                const VrOutGrads* gout, const VrInGrads* gin, VrAllocFn alloc, void* user, void* stream)
+{
+    g_err[0] = 0;
+    if (!saved || !gout || !gin || !alloc) return fail(VR_ERR_INVALID_ARGUMENT, "saved, grads and alloc are required");
+    Camera cam;
+    bool sh_factored = false;
+    int rc = backward_checks(st, in, radii, saved, gin, &cam, &sh_factored);
+    if (rc || in->P == 0) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    float* gacc = (float*)alloc(user, VR_BUF_SCRATCH, (size_t)in->P * 16 * sizeof(float));
+    if (!gacc) return fail(VR_ERR_ALLOC, "allocator returned NULL");
+    rc = backward_first(cam, st, in, radii, saved, gout, gin, sh_factored, false, gacc, alloc, user, s);
+    if (rc) return rc;
+    return backward_second(cam, st, in, radii, saved, gin, sh_factored, true, gacc, s);
+}
+
+int vr_backward_render(const VrSettings* st, const VrInputs* in, const int32_t* radii, const VrSaved* saved,
+                       const VrOutGrads* gout, const VrInGrads* gin, VrAllocFn alloc, void* user, void* stream,
+                       void** state)
+{
+    g_err[0] = 0;
+    if (!saved || !gout || !gin || !alloc || !state)
+        return fail(VR_ERR_INVALID_ARGUMENT, "saved, grads, alloc and state are required");
+    *state = nullptr;
+    Camera cam;
+    bool sh_factored = false;
+    int rc = backward_checks(st, in, radii, saved, gin, &cam, &sh_factored);
+    if (rc || in->P == 0) return rc;
+    float* gacc = (float*)alloc(user, VR_BUF_BACKWARD, (size_t)in->P * 16 * sizeof(float));
+    if (!gacc) return fail(VR_ERR_ALLOC, "allocator returned NULL");
+    rc = backward_first(cam, st, in, radii, saved, gout, gin, sh_factored, true, gacc, alloc, user, (hipStream_t)stream);
+    if (rc) return rc;
+    *state = gacc;
+    return VR_OK;
+}
+
+int vr_backward_preprocess(const VrSettings* st, const VrInputs* in, const int32_t* radii, const VrSaved* saved,
+                           const VrInGrads* gin, void* state, void* stream)
+{
+    g_err[0] = 0;
+    if (!saved || !gin) return fail(VR_ERR_INVALID_ARGUMENT, "saved and grads are required");
+    Camera cam;
+    bool sh_factored = false;
+    int rc = backward_checks(st, in, radii, saved, gin, &cam, &sh_factored);
+    if (rc || in->P == 0) return rc;
+    if (!state) return fail(VR_ERR_INVALID_ARGUMENT, "state of vr_backward_render is required");
+    return backward_second(cam, st, in, radii, saved, gin, sh_factored, false, (const float*)state, (hipStream_t)stream);
 }
 
 int vr_profile_level(int level)

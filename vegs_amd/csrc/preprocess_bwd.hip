@@ -79,7 +79,8 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
                  const float* __restrict__ gacc,
                  const float* __restrict__ gmean2D, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dshs,
                  float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
-                 float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dcolors_sh)
+                 float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dcolors_sh,
+                 int store_factor)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4][64 * SH_LDS_STRIDE];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,7 +106,7 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
             for (int q = 0; q < 9; ++q) D[q] = shd[9 * (size_t)i + q];
             sh_backward_factor(cam, px3, py3, pz3, (uint32_t)clampb[i], a1.x, a1.y, a1.z, D, gc, dmean);
         }
-        if (in_range) {
+        if (in_range && store_factor) {   // (0: already written by k_sh_factor -- the split backward, vr_backward_render)
 #pragma unroll
             for (int c = 0; c < 3; ++c) dL_dcolors_sh[3 * (size_t)i + c] = gc[c];
         }
@@ -343,15 +344,46 @@ int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const 
                           const float* cov3D_precomp, const int* radii, const uint8_t* clampb, const float* shd, const float* gacc,
                           const float* gmean2D, float* dL_dmeans3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dcolors,
                           float* dL_dopacities, float* dL_dscales, float* dL_drots, float* dL_dcov3D,
-                          float* dL_dcolors_sh, hipStream_t s, bool debug)
+                          float* dL_dcolors_sh, bool store_factor, hipStream_t s, bool debug)
 {
     if (P == 0) return 0;
     const int sh_staged = preprocess_bwd_writes_all_sh(cam.M, shs, dL_dshs) ? 1 : 0;
     hipLaunchKernelGGL(k_preprocess_bwd, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, sh_staged, means3D, shs, shs_rest,
                        dL_dshs_rest, colors_precomp, scales, rotations, cov3D_precomp, radii, clampb, shd, gacc, gmean2D, dL_dmeans3D,
                        dL_dshs, dL_dcolors,
-                       dL_dopacities, dL_dscales, dL_drots, dL_dcov3D, dL_dcolors_sh);
+                       dL_dopacities, dL_dscales, dL_drots, dL_dcov3D, dL_dcolors_sh, store_factor ? 1 : 0);
     VR_KERNEL_CHECK("preprocess_bwd", s, debug);
+    return 0;
+}
+
+// The factor of the factored SH gradient on its own: dL/d(colour) of every Gaussian, zero where the colour was clamped
+// and for culled rows -- complete as soon as the render backward is (its inputs are the accumulators only), i.e. BEFORE
+// k_preprocess_bwd: a multi-GPU job starts exchanging it while that kernel runs (vr_backward_render).
+__global__ void __launch_bounds__(256)
+k_sh_factor(int P, const int* __restrict__ radii, const uint8_t* __restrict__ clampb, const float* __restrict__ gacc,
+            float* __restrict__ dL_dcolors_sh)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (radii[i] > 0) {
+        const float4 a1 = reinterpret_cast<const float4*>(gacc + (size_t)i * 16)[1];
+        const uint32_t cb = clampb[i];
+        g0 = (cb & 1u) ? 0.f : a1.x;
+        g1 = (cb & 2u) ? 0.f : a1.y;
+        g2 = (cb & 4u) ? 0.f : a1.z;
+    }
+    dL_dcolors_sh[3 * (size_t)i] = g0;
+    dL_dcolors_sh[3 * (size_t)i + 1] = g1;
+    dL_dcolors_sh[3 * (size_t)i + 2] = g2;
+}
+
+int launch_sh_factor(int P, const int* radii, const uint8_t* clampb, const float* gacc, float* dL_dcolors_sh,
+                     hipStream_t s, bool debug)
+{
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(k_sh_factor, dim3(cdiv(P, 256)), dim3(256), 0, s, P, radii, clampb, gacc, dL_dcolors_sh);
+    VR_KERNEL_CHECK("sh_factor", s, debug);
     return 0;
 }
 

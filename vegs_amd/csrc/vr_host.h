@@ -133,6 +133,8 @@ int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const 
                           const float* cov3D_precomp, const int* radii, const uint8_t* clampb, const float* shd, const float* gacc,
                           const float* gmean2D, float* dL_dmeans3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dcolors,
                           float* dL_dopacities, float* dL_dscales, float* dL_drots, float* dL_dcov3D,
-                          float* dL_dcolors_sh, hipStream_t s, bool debug);
+                          float* dL_dcolors_sh, bool store_factor, hipStream_t s, bool debug);
+int launch_sh_factor(int P, const int* radii, const uint8_t* clampb, const float* gacc, float* dL_dcolors_sh,
+                     hipStream_t s, bool debug);
 
 }  // namespace vr

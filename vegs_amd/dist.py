@@ -159,3 +159,123 @@ def exchange_factored(tensors, sh_factor, campos, world=None, group=None):
     dist.all_gather(fs, src_f, group=group)
     dist.all_gather(cs, src_c, group=group)
     return torch.stack(fs).to(f.device), torch.stack(cs).to(f.device)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Overlapped exchange (round 3).  The SH factors are complete when the RENDER backward is; k_preprocess_bwd (0.14 ms at
+# 2 M Gaussians) still has to run before the other 11 floats per Gaussian exist.  With the backward split in two calls
+# (include/vegs_rast.h: vr_backward_render / vr_backward_preprocess; vegs_amd.rasterizer.set_backward_split_hook) the
+# all-gather of the factors is started between the two and travels while the second half computes; the all-reduce of the
+# remaining gradients follows as soon as they exist and runs CONCURRENTLY with whatever is left of the all-gather (both
+# asynchronous; one wait at the end).  Optionally the all-reduce only carries the rows some rank actually rendered.
+
+def allreduce_rows(tensors, radii, world=None, group=None, threshold=0.7):
+    """Mean over ranks of `t.grad` for t in `tensors` ([P, ...] each), exchanging only the rows that are visible
+    (radii > 0) on AT LEAST ONE rank: a byte mask is OR-ed over the ranks (all-reduce MAX, P bytes), the rows of the
+    union are packed into one [n, k] block, reduced, and scattered back -- rows outside the union are exactly zero on
+    every rank (the op writes zeros for culled Gaussians) and stay zero.  Falls back to the dense all-reduce when the
+    union covers more than `threshold` of the rows (packing would cost more than it saves).  Returns the number of rows
+    exchanged (P for the dense path)."""
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    grads = [t.grad for t in tensors if t.grad is not None]
+    if world <= 1 or not grads:
+        return 0
+    P = grads[0].shape[0]
+    vis = (radii > 0).to(torch.uint8)
+    _all_reduce(vis, dist.ReduceOp.MAX, group)
+    idx = torch.nonzero(vis).reshape(-1)
+    n = int(idx.numel())
+    if n > threshold * P:
+        allreduce_grads(tensors, world, group)
+        return P
+    widths = [g.reshape(P, -1).shape[1] for g in grads]
+    pack = torch.cat([g.reshape(P, -1).index_select(0, idx) for g in grads], dim=1).contiguous()
+    avg = _avg_supported(group, pack.device)
+    _all_reduce(pack, dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group)
+    if not avg:
+        pack.mul_(1.0 / world)
+    off = 0
+    for g, wdt in zip(grads, widths):
+        g.reshape(P, -1).index_copy_(0, idx, pack[:, off:off + wdt])
+        off += wdt
+    return n
+
+
+class FactorExchange:
+    """One iteration's overlapped exchange with factored SH gradients:
+
+        ex = FactorExchange(world)              # once
+        ex.begin(campos)                        # before loss.backward(): arms the hook between the backward's halves
+        loss.backward()                         #   -> the all-gather of the factors starts after the render backward
+        F, C = ex.finish(others, radii)         # all-reduce of the other gradients, then ONE wait for both collectives
+
+    F [N,P,3] / C [N,3] are what vegs_amd.optim.sh_grad_from_factors / adam_step_sh_factored take (scale = 1/N).
+    With a backend that cannot run device collectives asynchronously (gloo in the single-GPU tests) the same calls
+    are made in the same order, synchronously: the arithmetic is identical, only nothing overlaps."""
+
+    def __init__(self, world=None, group=None, sparse_rows=False):
+        self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.group, self.sparse_rows = group, sparse_rows
+        self._work, self._out_f, self._out_c, self._campos, self._f = [], None, None, None, None
+        self.rows_exchanged = None
+
+    def begin(self, campos):
+        from . import rasterizer
+        self._campos = campos
+        self._work, self._out_f, self._out_c, self._f = [], None, None, None
+        self._old_hook = rasterizer.set_backward_split_hook(self._on_factors)
+
+    def _on_factors(self, factor):
+        """Called by the op's backward between its two halves: `factor` [P,3] is complete in stream order."""
+        f = factor.detach()
+        self._f = f
+        if self.world <= 1:
+            return
+        c = self._campos.detach().to(f.device, torch.float32).reshape(3).contiguous()
+        if dist.get_backend(self.group) == "nccl":
+            self._out_f = torch.empty((self.world,) + tuple(f.shape), dtype=f.dtype, device=f.device)
+            self._out_c = torch.empty((self.world, 3), dtype=c.dtype, device=c.device)
+            self._work.append(dist.all_gather_into_tensor(self._out_f, f, group=self.group, async_op=True))
+            self._work.append(dist.all_gather_into_tensor(self._out_c, c, group=self.group, async_op=True))
+        else:                                   # host-staged transport: gathered in finish()
+            self._c = c
+
+    def finish(self, tensors, radii=None):
+        from . import rasterizer
+        rasterizer.set_backward_split_hook(self._old_hook)
+        if self._f is None:
+            raise RuntimeError("FactorExchange.finish(): the backward did not deliver a factor "
+                               "(was the op called with sh_color_grad?)")
+        if self.world <= 1:
+            c = self._campos.detach().to(self._f.device, torch.float32).reshape(1, 3)
+            return self._f[None], c
+        if self.sparse_rows and radii is not None:
+            self.rows_exchanged = allreduce_rows(tensors, radii, self.world, self.group)
+        else:
+            allreduce_grads(tensors, self.world, self.group)
+            self.rows_exchanged = tensors[0].shape[0]
+        if self._out_f is not None:
+            for w in self._work:
+                w.wait()
+            return self._out_f, self._out_c
+        f, c = self._f.contiguous(), self._c
+        staged = f.is_cuda
+        src_f, src_c = (f.cpu(), c.cpu()) if staged else (f, c)
+        fs = [torch.empty_like(src_f) for _ in range(self.world)]
+        cs = [torch.empty_like(src_c) for _ in range(self.world)]
+        dist.all_gather(fs, src_f, group=self.group)
+        dist.all_gather(cs, src_c, group=self.group)
+        return torch.stack(fs).to(f.device), torch.stack(cs).to(f.device)
+
+
+def exchange_bytes_per_rank(P, world, scheme, rows=None):
+    """Bytes one rank SENDS per iteration (ring / direct algorithms send as much as they receive): dense = all-reduce of
+    59 floats per Gaussian; factored = all-gather of 3 floats (every rank receives (N-1) blocks) + all-reduce of 11."""
+    if world <= 1:
+        return 0
+    ar = lambda nbytes: 2.0 * (world - 1) / world * nbytes
+    if scheme == "dense":
+        return int(ar(236 * P))
+    rows = P if rows is None else rows
+    return int((world - 1) * 12 * P + ar(44 * rows))

@@ -139,6 +139,20 @@ def needed_hints(enabled):
     return old
 
 
+# Hook between the two halves of the backward (include/vegs_rast.h: vr_backward_render / vr_backward_preprocess).  When
+# set and the forward asked for the factored SH gradient, the backward calls `hook(sh_factor [P,3])` after the render
+# backward -- the factor is complete in stream order -- and before the preprocess backward: vegs_amd.dist starts the
+# all-gather of the factors there, so that it travels while the second half computes.
+_split_hook = None
+
+
+def set_backward_split_hook(fn):
+    """Install (or, with None, remove) the hook; returns the previous one."""
+    global _split_hook
+    old, _split_hook = _split_hook, fn
+    return old
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -280,8 +294,18 @@ class _RasterizeGaussians(torch.autograd.Function):
             cpu_args = _cpu_args_copy((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                        radii, g_color, g_depth, g_quat, g_scale, g_alpha)) if rs.debug else None
             cb = arena.callback()
-            rc = lib.vr_backward(C.byref(st), C.byref(inp), _capi.ptr(radii), C.byref(saved), C.byref(gout),
-                                 C.byref(gin), cb, None, stream)
+            hook = _split_hook if factored else None
+            if hook is None:
+                rc = lib.vr_backward(C.byref(st), C.byref(inp), _capi.ptr(radii), C.byref(saved), C.byref(gout),
+                                     C.byref(gin), cb, None, stream)
+            else:
+                state = C.c_void_p()
+                rc = lib.vr_backward_render(C.byref(st), C.byref(inp), _capi.ptr(radii), C.byref(saved), C.byref(gout),
+                                            C.byref(gin), cb, None, stream, C.byref(state))
+                if rc == 0:
+                    hook(d_sink)
+                    rc = lib.vr_backward_preprocess(C.byref(st), C.byref(inp), _capi.ptr(radii), C.byref(saved),
+                                                    C.byref(gin), state, stream)
             del cb
             arena.release_scratch()
             if rc != 0:

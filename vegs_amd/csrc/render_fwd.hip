@@ -169,19 +169,36 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
     return p;
 }
 
-// ---- A: per (tile, segment, pixel) product of (1 - alpha).  SECOND = the round for the short tiles of a hinted forward
-// (see k_seg_scan): only the segments still flagged 3.
-template <bool SECOND>
+// Window of a short tile's list that catch-up round ROUND (1, 2) of a hinted forward covers, given where the previous
+// round stopped (`lo`, from seg_needed) and the tile's segment count: round 1 looks half as far again (+ 8 segments) --
+// after an epoch of training the heavy tiles' counts have moved by up to +-50 % (profiles/tools/epoch_drift.py: 55 short
+// tiles per view, 429 segments beyond their limits, out of ~10 k needed) --, round 2 takes whatever is left.
+constexpr uint32_t TILE_SHORT = 0x80000000u;
+__device__ __forceinline__ uint32_t catchup_end(int round, uint32_t lo, uint32_t nseg)
+{
+    return round == 1 ? min(nseg, lo + 8u + (lo >> 1)) : nseg;
+}
+
+// ---- A: per (tile, segment, pixel) product of (1 - alpha).  ROUND 0 = the segments inside the hinted prefix of their
+// tile (all of them without a hint); ROUND 1, 2 = the catch-up rounds for the short tiles of a hinted forward (see
+// k_seg_scan): the segments still flagged 3 that fall into the round's window.
+template <int ROUND>
 __global__ void __launch_bounds__(256)
 k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
-            const uint32_t* __restrict__ point_list, const Splat* __restrict__ rec, float* __restrict__ Pbuf,
-            unsigned long long* __restrict__ segmask)
+            const uint32_t* __restrict__ seg_needed, const uint32_t* __restrict__ point_list,
+            const Splat* __restrict__ rec, float* __restrict__ Pbuf, unsigned long long* __restrict__ segmask)
 {
     __shared__ float4 lds[2][SEG];
     __shared__ unsigned long long masks[16];
     SegCtx c;
     if (!seg_setup(cam, ranges, seg_off, c)) return;
-    if ((c.flag == 3u) != SECOND) return;   // flag 3 = behind the hinted prefix of its tile (k_seg_tiles)
+    if ((c.flag == 3u) != (ROUND > 0)) return;   // flag 3 = behind the hinted prefix of its tile (k_seg_tiles)
+    if (ROUND > 0) {
+        const uint32_t word = seg_needed[c.tile];
+        if (!(word & TILE_SHORT)) return;
+        const uint32_t lo = word & ~TILE_SHORT, nseg = seg_off[c.tile + 1] - seg_off[c.tile];
+        if ((uint32_t)c.sl < lo || (uint32_t)c.sl >= catchup_end(ROUND, lo, nseg)) return;
+    }
     const float p = seg_alpha_body(c, point_list, rec, lds, masks, segmask);
     Pbuf[(size_t)c.seg * SEG + threadIdx.x] = p;
 }
@@ -191,23 +208,24 @@ k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
 //
 // With a needed-segment hint k_seg_alpha computed only the first `limit` segments of the tile.  If a pixel is still
 // alive at the end of that prefix the tile is SHORT (a stale or foreign hint, a scene that changed): this launch
-// (PASS2 = false) then leaves the tile unfinished -- it parks every pixel's state in the Tbuf row of the first missing
-// segment and marks the tile (top bit of seg_needed) -- and a second round finishes it IN PARALLEL: k_seg_alpha runs
-// once more over the segments still flagged 3 (only short tiles have any left), then this kernel with PASS2 = true picks
-// the chains of the short tiles up where they stopped.  (Round 2 computed the missing segments inside this kernel, one
+// (ROUND 0) then leaves the tile unfinished -- it parks every pixel's state in the Tbuf row of the first missing
+// segment and marks the tile (top bit of seg_needed) -- and up to two catch-up rounds finish it IN PARALLEL:
+// k_seg_alpha<ROUND> runs once more over the window of segments catchup_end() assigns to the round (only short tiles
+// have segments flagged 3 left), then this kernel with the same ROUND picks the chains of the short tiles up where they
+// stopped; round 1 may leave a tile short again, round 2 walks to the end of the list.  (Round 2 computed the missing segments inside this kernel, one
 // after the other per tile: ~6 us each, and a model that had trained for an epoch since the hint was recorded missed
 // by hundreds of segments in the heavy tiles -- 2.98 ms per view instead of 1.42 without hints.)  The result never
 // depends on the hint either way.
-constexpr uint32_t TILE_SHORT = 0x80000000u;
-template <bool PASS2>
+template <int ROUND>
 __global__ void __launch_bounds__(256)
 k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, const float* __restrict__ Pbuf,
            float* __restrict__ Tbuf, uint32_t* __restrict__ seg_needed, uint32_t* __restrict__ hint)
 {
+    constexpr bool PASS2 = ROUND > 0;
     __shared__ uint32_t wneed[4];
     __shared__ uint32_t walive[4];
     const int tile = blockIdx.x;
-    const uint32_t lim_word = seg_needed[tile];   // k_seg_offsets' snapshot (PASS2: what the first pass left)
+    const uint32_t lim_word = seg_needed[tile];   // k_seg_offsets' snapshot (ROUND > 0: what the previous round left)
     if (PASS2 && !(lim_word & TILE_SHORT)) return;
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -215,7 +233,7 @@ k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, const float* __restrict__
     const uint32_t s0 = seg_off[tile], s1 = seg_off[tile + 1];
     // segments [first, last) of the tile are walked by this launch
     const uint32_t first = PASS2 ? (lim_word & ~TILE_SHORT) : 0u;
-    const uint32_t last = PASS2 ? s1 - s0 : min(s1 - s0, lim_word);
+    const uint32_t last = PASS2 ? catchup_end(ROUND, first, s1 - s0) : min(s1 - s0, lim_word);
     bool alive = px < cam.W && py < cam.H;
     float Tb = 1.0f;
     if (PASS2) {   // the state parked by the first pass
@@ -248,7 +266,7 @@ k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, const float* __restrict__
     if (lane == 0) { wneed[w] = mine; walive[w] = wave_alive ? 1u : 0u; }
     __syncthreads();
     const bool any_alive = (walive[0] | walive[1] | walive[2] | walive[3]) != 0u;
-    if (!PASS2 && any_alive && last < s1 - s0) {
+    if (ROUND < 2 && any_alive && last < s1 - s0) {
         // SHORT tile: rows [mine, last) of the waves that finished earlier, then every pixel's state in row `last`
         for (uint32_t s = s0 + mine; s < s0 + last; ++s) Tbuf[(size_t)s * SEG + threadIdx.x] = -1.0f;
         Tbuf[(size_t)(s0 + last) * SEG + threadIdx.x] = alive ? Tb : -1.0f;
@@ -578,19 +596,23 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
                        (const uint32_t*)seg_needed, (uint32_t)nseg);
     VR_KERNEL_CHECK("seg_offsets", s, debug);
     if (R > 0) {
-        hipLaunchKernelGGL(k_seg_alpha<false>, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
-                           point_list, rec, Pbuf, segmask);
+        hipLaunchKernelGGL(k_seg_alpha<0>, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
+                           (const uint32_t*)seg_needed, point_list, rec, Pbuf, segmask);
         VR_KERNEL_CHECK("seg_alpha", s, debug);
     }
-    hipLaunchKernelGGL(k_seg_scan<false>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (const float*)Pbuf, Tbuf,
+    hipLaunchKernelGGL(k_seg_scan<0>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (const float*)Pbuf, Tbuf,
                        seg_needed, needed_hint);
     VR_KERNEL_CHECK("seg_scan", s, debug);
-    if (needed_hint && R > 0) {   // a hinted forward: second round for the tiles whose hint was too small (usually none)
-        hipLaunchKernelGGL(k_seg_alpha<true>, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
-                           point_list, rec, Pbuf, segmask);
-        hipLaunchKernelGGL(k_seg_scan<true>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (const float*)Pbuf, Tbuf,
+    if (needed_hint && R > 0) {   // a hinted forward: catch-up rounds for the tiles whose hint was too small (usually none)
+        hipLaunchKernelGGL(k_seg_alpha<1>, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
+                           (const uint32_t*)seg_needed, point_list, rec, Pbuf, segmask);
+        hipLaunchKernelGGL(k_seg_scan<1>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (const float*)Pbuf, Tbuf,
                            seg_needed, needed_hint);
-        VR_KERNEL_CHECK("seg_scan (second round)", s, debug);
+        hipLaunchKernelGGL(k_seg_alpha<2>, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
+                           (const uint32_t*)seg_needed, point_list, rec, Pbuf, segmask);
+        hipLaunchKernelGGL(k_seg_scan<2>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (const float*)Pbuf, Tbuf,
+                           seg_needed, needed_hint);
+        VR_KERNEL_CHECK("seg_scan (catch-up rounds)", s, debug);
     }
     if (R > 0) {
         hipLaunchKernelGGL(k_seg_blend, dim3((unsigned)nseg * 4), dim3(64), 0, s, cam, ranges, (const uint32_t*)seg_off,

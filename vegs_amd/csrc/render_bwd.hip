@@ -116,7 +116,10 @@ k_seg_u(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict_
 {
     SegCtx c;
     if (!seg_setup(cam, ranges, seg_off, c)) return;
-    if (c.flag == 0u) return;
+    // U of a tile's FIRST segment is never used: it would only enter the "behind" sums of earlier segments, and there
+    // are none (k_seg_suffix overwrites the slot with the suffix before it adds the slot's old content to a running sum
+    // nobody reads).  2 k of the ~9.5 k needed segments of the headline view.
+    if (c.flag == 0u || c.sl == 0) return;
     const size_t N = (size_t)cam.H * cam.W;
     PixGrad pg;
     load_pixgrad(c.inside, c.pix, N, dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, nullptr, cam.flags, final_T, dsum, pg);

@@ -56,21 +56,28 @@ typedef struct {
 
 /* ------------------------------------------------------------------ math */
 
-/* exp(x) for x <= 0 from IEEE basic operations only (bit-reproducible on the GPU). */
-static inline float vr_exp(float x)
+/* 2^x for x <= 0 from IEEE basic operations only (bit-reproducible on the GPU): x = n + f with n = rint(x), |f| <= 1/2
+ * (the subtraction is exact), 2^f by a degree-5 polynomial (least-squares/minimax fit on [-1/2, 1/2] with p(0) = 1:
+ * relative error 1.6e-7 evaluated in fp32), scaled by 2^n.  The compositing evaluates  exp(power) = 2^(power log2 e)
+ * with the factor log2 e folded into the conic once per splat (splat_power2 below), as the reference's CUDA kernels do
+ * when nvcc turns expf into ex2(x * log2 e). */
+#define VR_LOG2E 1.44269504088896341f
+#define VR_EXP2_C1 0.6931470036506653f
+#define VR_EXP2_C2 0.24022243916988373f
+#define VR_EXP2_C3 0.05550731346011162f
+#define VR_EXP2_C4 0.009671415202319622f
+#define VR_EXP2_C5 0.0013264892622828484f
+static inline float vr_exp2(float x)
 {
-    if (x < -87.0f) return 0.0f;
-    float t = x * 1.44269504088896341f;
-    float n = rintf(t);
-    float r = fmaf(n, -0.693145751953125f, x);
-    r = fmaf(n, -1.42860682030941723212e-6f, r);
-    float p = 1.0f / 720.0f;
-    p = fmaf(p, r, 1.0f / 120.0f);
-    p = fmaf(p, r, 1.0f / 24.0f);
-    p = fmaf(p, r, 1.0f / 6.0f);
-    p = fmaf(p, r, 0.5f);
-    p = fmaf(p, r, 1.0f);
-    p = fmaf(p, r, 1.0f);
+    if (x < -126.0f) return 0.0f;
+    float n = rintf(x);
+    float f = x - n;
+    float p = VR_EXP2_C5;
+    p = fmaf(p, f, VR_EXP2_C4);
+    p = fmaf(p, f, VR_EXP2_C3);
+    p = fmaf(p, f, VR_EXP2_C2);
+    p = fmaf(p, f, VR_EXP2_C1);
+    p = fmaf(p, f, 1.0f);
     return ldexpf(p, (int)n);
 }
 
@@ -346,12 +353,18 @@ void or_binning(const OrCam* cam, int P, const float* depth, const int* rect,
 
 #define NCH 11 /* rgb(3) depth(1) quat(4) scale(3): every blended channel */
 
-static inline float splat_power(const float* xy, const float* con, float pxf, float pyf, float* dx, float* dy)
+/* The Gaussian exponent at a pixel IN UNITS OF log2 e:  power2 = log2(e) * (-1/2 (A dx^2 + C dy^2) - B dx dy), evaluated
+ * as  ((kA dx) dx + (kC dy) dy) + (kB dx) dy  -- the association of the textbook form (the two same-sign terms first,
+ * then the cross term) -- with kA = (-1/2 log2 e) A, kB = -(log2 e) B, kC = (-1/2 log2 e) C rounded once per splat;
+ * alpha = min(0.99, opacity * 2^power2).  Identical operation order in the HIP kernels (vr_device.h). */
+#define VR_K_HALF (-0.5f * VR_LOG2E)
+static inline float splat_power2(const float* xy, const float* con, float pxf, float pyf, float* dx, float* dy)
 {
+    const float kA = VR_K_HALF * con[0], kB = -VR_LOG2E * con[1], kC = VR_K_HALF * con[2];
     *dx = xy[0] - pxf;
     *dy = xy[1] - pyf;
-    float q = fmaf(con[2] * *dy, *dy, (con[0] * *dx) * *dx);
-    return fmaf(-0.5f, q, -((con[1] * *dx) * *dy));
+    const float q = fmaf(kC * *dy, *dy, (kA * *dx) * *dx);
+    return fmaf(kB * *dx, *dy, q);
 }
 
 static inline void splat_attrs(const OrCam* cam, int id, const float* rgb, const float* depth, const float* rotations,
@@ -405,9 +418,9 @@ void or_render_fwd(const OrCam* cam, const int* ranges, const uint32_t* point_li
                     for (int j = sb; j < se; ++j) {
                         int id = (int)point_list[j];
                         float dx, dy;
-                        float power = splat_power(xy + 2 * id, conic_op + 4 * id, pxf, pyf, &dx, &dy);
+                        float power = splat_power2(xy + 2 * id, conic_op + 4 * id, pxf, pyf, &dx, &dy);
                         if (power > 0.0f) continue;
-                        float alpha = fminf(ALPHA_MAX, conic_op[4 * id + 3] * vr_exp(power));
+                        float alpha = fminf(ALPHA_MAX, conic_op[4 * id + 3] * vr_exp2(power));
                         if (alpha < ALPHA_MIN) continue;
                         float pn = p * (1.0f - alpha);
                         if (Tb * pn < T_EPS) { done = 1; break; }
@@ -498,9 +511,9 @@ void or_render_bwd(const OrCam* cam, int P, const int* ranges, const uint32_t* p
                 for (int j = s + (int)n_contrib[pix] - 1; j >= s; --j) {
                     int id = (int)point_list[j];
                     float dx, dy;
-                    float power = splat_power(xy + 2 * id, conic_op + 4 * id, pxf, pyf, &dx, &dy);
+                    float power = splat_power2(xy + 2 * id, conic_op + 4 * id, pxf, pyf, &dx, &dy);
                     if (power > 0.0f) continue;
-                    float G = vr_exp(power);
+                    float G = vr_exp2(power);
                     float op = conic_op[4 * id + 3];
                     float alpha = fminf(ALPHA_MAX, op * G);
                     if (alpha < ALPHA_MIN) continue;

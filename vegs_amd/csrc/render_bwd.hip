@@ -274,6 +274,9 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
             at[4] = q2.w; at[5] = q3.x; at[6] = q3.y; at[7] = q3.z;
             at[8] = q3.w; at[9] = q4.x; at[10] = q4.y;
         }
+        // the conic and the threshold in log2 units, as the forward stages them (an empty lane: thr2 > 0, nothing passes)
+        float kA, kB, kC, thr2;
+        splat_k2(cA, cB, cC, thr, kA, kB, kC, thr2);
         // accumulators: .x sums over the even pixels, .y over the odd ones (added at the end of the chunk)
         f2 acc[NACC];
 #pragma unroll
@@ -289,13 +292,29 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                 const float4 r0 = pixrec[pp][0];
                 const f2 pxf = {r0.x, r0.y}, pyf = {r0.z, r0.w};
                 f2 dx, dy;
-                const f2 power = splat_power_x2(sx, sy, cA, cB, cC, pxf, pyf, dx, dy);
-                const bool pre0 = has && (e < nc0) && !(power.x > 0.0f) && power.x >= thr;
-                const bool pre1 = has && (e < nc1) && !(power.y > 0.0f) && power.y >= thr;
+                const f2 power = splat_power2_x2(sx, sy, kA, kB, kC, pxf, pyf, dx, dy);    // in units of log2 e, as the forward
+                const bool pre0 = has && (e < nc0) && !(power.x > 0.0f) && power.x >= thr2;
+                const bool pre1 = has && (e < nc1) && !(power.y > 0.0f) && power.y >= thr2;
                 if (__ballot(pre0 || pre1) == 0ull) continue;  // no splat of the chunk reaches the pair: carries unchanged
-                // hardware exp2 here (1 ulp; the forward's bit-exact vr_exp is not needed for gradients: only an
-                // alpha within 1e-7 of the 1/255 threshold could be classified differently, with a 0.4 % weight)
-                f2 G = {__builtin_amdgcn_exp2f(power.x * 1.44269504088896341f), __builtin_amdgcn_exp2f(power.y * 1.44269504088896341f)};
+                // The forward's own 2^x (bit for bit: same operations), not the hardware's: WHICH fragments contributed is
+                // the forward's decision (alpha >= 1/255), and v_exp_f32 agrees with it only to ~2 ulp -- rare to matter,
+                // but a faint splat has ALL its fragments at the threshold, and one fragment of twenty classified the other
+                // way moved its gradient by 4.5 % (the C-harness test caught it).  Evaluated for both pixels in packed
+                // arithmetic; +14 us per view over two v_exp_f32 -- and so did the two cheaper-looking alternatives (a band
+                // test around the threshold with the exact function inline or out of line in the rare branch).
+                f2 G;
+                {
+                    const f2 n = {rintf(power.x), rintf(power.y)};
+                    const f2 f = power - n;
+                    f2 p = f2_splat(EXP2_C5);
+                    p = f2_fma(p, f, f2_splat(EXP2_C4));
+                    p = f2_fma(p, f, f2_splat(EXP2_C3));
+                    p = f2_fma(p, f, f2_splat(EXP2_C2));
+                    p = f2_fma(p, f, f2_splat(EXP2_C1));
+                    p = f2_fma(p, f, f2_splat(1.0f));
+                    G.x = ldexpf(p.x, (int)n.x);
+                    G.y = ldexpf(p.y, (int)n.y);
+                }
                 const f2 alpha = {fminf(ALPHA_MAX, op * G.x), fminf(ALPHA_MAX, op * G.y)};
                 const bool contrib0 = pre0 && !(alpha.x < ALPHA_MIN), contrib1 = pre1 && !(alpha.y < ALPHA_MIN);
                 const f2 a_eff = {contrib0 ? alpha.x : 0.0f, contrib1 ? alpha.y : 0.0f};
@@ -335,26 +354,44 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                     pixrec[pp][7] = make_float4(Tl.x, Tl.y, Sn.x, Sn.y);
                 }
                 if (contrib0 || contrib1) {
+                    // Per-fragment work kept to what depends on the pixel.  With a = dL/dG * G (zero for a lane that does
+                    // not contribute: G and alpha are masked above, everything below is finite):
+                    //   conic:   dA += -1/2 a dx^2   dB += -a dx dy   dC += -1/2 a dy^2
+                    //   mean2D:  dx += -a (A dx + B dy)   dy += -a (C dy + B dx)
+                    // the factors -1/2 and -1 belong to the SPLAT, i.e. to the lane: sum(a dx dx), sum(a dx dy),
+                    // sum(a dy dy), sum(a (A dx + B dy)), sum(a (C dy + B dx)) are accumulated here (12 packed operations
+                    // instead of 20) and the signs applied once per entry at the flush.  (The conic cannot be pulled out of
+                    // the mean2D sums as well: A sum(a dx) + B sum(a dy) cancels AFTER the sums were rounded, and for edge-on
+                    // discs that lost two digits -- the C-harness test caught rows off by 2 %.)
                     const f2 inv_om = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
-                    f2 dLda = f2_fma(Tl, u, -(behind + bgterm) * inv_om);
-                    dLda.x = contrib0 ? dLda.x : 0.0f;
-                    dLda.y = contrib1 ? dLda.y : 0.0f;
-                    const f2 dLdG = f2_splat(op) * dLda;
-                    const f2 gdx = G * dx, gdy = G * dy;
-                    acc[0] = f2_fma(f2_splat(-0.5f) * gdx * dx, dLdG, acc[0]);
-                    acc[1] = f2_fma(-gdx * dy, dLdG, acc[1]);
-                    acc[2] = f2_fma(f2_splat(-0.5f) * gdy * dy, dLdG, acc[2]);
+                    // (finite also for a lane that does not contribute: its alpha is 0, so 1 - alpha = 1, and the prefix
+                    // product of at most 64 factors >= 0.01 it divides by cannot reach zero before Tc itself has)
+                    const f2 dLda = f2_fma(Tl, u, -(behind + bgterm) * inv_om);
+                    const f2 a = (f2_splat(op) * dLda) * G;
+                    const f2 adx = a * dx, ady = a * dy;
+                    acc[0] = f2_fma(adx, dx, acc[0]);
+                    acc[1] = f2_fma(adx, dy, acc[1]);
+                    acc[2] = f2_fma(ady, dy, acc[2]);
                     acc[3] = f2_fma(G, dLda, acc[3]);
 #pragma unroll
                     for (int k = 0; k < NCH; ++k) acc[4 + k] = f2_fma(wgt, g[k], acc[4 + k]);
-                    acc[15] = f2_fma(dLdG, -gdx * f2_splat(cA) - gdy * f2_splat(cB), acc[15]);
-                    acc[16] = f2_fma(dLdG, -gdy * f2_splat(cC) - gdx * f2_splat(cB), acc[16]);
+                    acc[15] = f2_fma(a, f2_fma(f2_splat(cA), dx, f2_splat(cB) * dy), acc[15]);
+                    acc[16] = f2_fma(a, f2_fma(f2_splat(cC), dy, f2_splat(cB) * dx), acc[16]);
                 }
             }
             // ---- per-entry sums of the chunk -> LDS (entry-major) -> one coalesced set of global atomics per entry
             if (has) {
+                float o[NACC];
 #pragma unroll
-                for (int k = 0; k < NACC; ++k) stage[lane * NACC + k] = acc[k].x + acc[k].y;
+                for (int k = 0; k < NACC; ++k) o[k] = acc[k].x + acc[k].y;
+                // the per-splat signs / factors of the conic and mean2D sums (see the pixel loop)
+                o[0] = -0.5f * o[0];
+                o[1] = -o[1];
+                o[2] = -0.5f * o[2];
+                o[15] = -o[15];
+                o[16] = -o[16];
+#pragma unroll
+                for (int k = 0; k < NACC; ++k) stage[lane * NACC + k] = o[k];
             }
             __syncthreads();
             for (int v = lane; v < 64 * NACC; v += 64) {

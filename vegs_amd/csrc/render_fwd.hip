@@ -120,8 +120,11 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
             const float4* src = reinterpret_cast<const float4*>(rec + point_list[c.first + threadIdx.x]);
             q0 = src[0];
             q1 = src[1];
-            lds[0][threadIdx.x] = q0;
-            lds[1][threadIdx.x] = q1;
+            // staged for the loop with the conic and the threshold in log2 units (splat_k2): x y kA kB | kC opacity thr2 depth
+            float4 s0 = q0, s1 = q1;
+            splat_k2(q0.z, q0.w, q1.x, q1.z, s0.z, s0.w, s1.x, s1.z);
+            lds[0][threadIdx.x] = s0;
+            lds[1][threadIdx.x] = s1;
         }
         seg_build_masks(c, have, q0, q1, masks);
     }
@@ -135,10 +138,10 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
     // are still applied strictly in list order.
     auto apply = [&](const float4 a, const float4 b) {
         float dx, dy;
-        const float power = splat_power(a.x, a.y, a.z, a.w, b.x, pxf, pyf, dx, dy);
+        const float power = splat_power2(a.x, a.y, a.z, a.w, b.x, pxf, pyf, dx, dy);
         const bool pre = !(power > 0.0f) && power >= b.z;
         if (__ballot(pre) == 0ull) return;  // cannot reach 1/255 anywhere in this strip
-        const float alpha = fminf(ALPHA_MAX, b.y * vr_exp_unclamped(power));
+        const float alpha = fminf(ALPHA_MAX, b.y * vr_exp2_unclamped(power));
         const bool valid = pre && !(alpha < ALPHA_MIN);
         p = valid ? p * (1.0f - alpha) : p;
     };
@@ -158,8 +161,8 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
                 } else {
                     kk[t] = kk[0];
                 }
-                av[t] = lds[0][kk[t]];  // x y A B
-                bv[t] = lds[1][kk[t]];  // C opacity thr depth
+                av[t] = lds[0][kk[t]];  // x y kA kB
+                bv[t] = lds[1][kk[t]];  // kC opacity thr2 depth
             }
 #pragma unroll
             for (int t = 0; t < NB; ++t)
@@ -350,8 +353,14 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
         if (lane < n) {
             myj = (int)rel_j[b0 + lane];
             const float4* src = reinterpret_cast<const float4*>(rec + rel_gid[b0 + lane]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) lds[k][lane] = src[k];
+            {   // geometry with the conic and the threshold in log2 units (splat_k2): x y kA kB | kC opacity thr2 depth
+                float4 s0 = src[0], s1 = src[1];
+                splat_k2(s0.z, s0.w, s1.x, s1.z, s0.z, s0.w, s1.x, s1.z);
+                lds[0][lane] = s0;
+                lds[1][lane] = s1;
+            }
+            lds[2][lane] = src[2];
+            lds[3][lane] = src[3];
             float4 t = src[4];            // s1 s2 clamped pad -> the pad slot carries the entry index
             t.w = __int_as_float(myj);
             lds[4][lane] = t;
@@ -361,10 +370,10 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
         // once per batch); the entries are still applied strictly in list order
         auto blend_one = [&](const int i, const float4 a, const float4 b) {
             float dx, dy;
-            const float power = splat_power(a.x, a.y, a.z, a.w, b.x, pxf, pyf, dx, dy);
+            const float power = splat_power2(a.x, a.y, a.z, a.w, b.x, pxf, pyf, dx, dy);
             const bool pre = !done && !(power > 0.0f) && power >= b.z;
             if (__ballot(pre) == 0ull) return;
-            const float alpha = fminf(ALPHA_MAX, b.y * vr_exp_unclamped(power));
+            const float alpha = fminf(ALPHA_MAX, b.y * vr_exp2_unclamped(power));
             const bool valid = pre && !(alpha < ALPHA_MIN);
             const float pn = p * (1.0f - alpha);
             const bool stop = valid && (Tb * pn < T_EPS);
@@ -551,9 +560,11 @@ k_count_blended(Camera cam, const int2* __restrict__ ranges, const uint32_t* __r
             const float4* src = reinterpret_cast<const float4*>(rec + point_list[start + j]);
             const float4 a = src[0], b = src[1];
             float dx, dy;
-            const float power = splat_power(a.x, a.y, a.z, a.w, b.x, pxf, pyf, dx, dy);
+            float kA, kB, kC, thr2;
+            splat_k2(a.z, a.w, b.x, b.z, kA, kB, kC, thr2);
+            const float power = splat_power2(a.x, a.y, kA, kB, kC, pxf, pyf, dx, dy);
             if (power > 0.0f) continue;
-            const float alpha = fminf(ALPHA_MAX, b.y * vr_exp(power));
+            const float alpha = fminf(ALPHA_MAX, b.y * vr_exp2(power));
             if (!(alpha < ALPHA_MIN)) ++cnt;
         }
     }

@@ -63,40 +63,28 @@ __device__ __forceinline__ void nt_store4(float4 v, float4* p)
     __builtin_nontemporal_store(t, reinterpret_cast<vr_f4*>(p));
 }
 
-// exp(x), x <= 0, from IEEE basic operations only: bit-identical on host and device.
-__device__ __forceinline__ float vr_exp(float x)
+// 2^x, x <= 0, from IEEE basic operations only: bit-identical on host and device (the CPU checker restates it operation for operation).
+// x = n + f, n = rint(x), |f| <= 1/2 (exact subtraction); 2^f by a degree-5 polynomial fitted on [-1/2, 1/2] with
+// p(0) = 1 (relative error 1.6e-7 in fp32); scaled by 2^n.  The compositing evaluates exp(power) as 2^(power log2 e)
+// with log2 e folded into the conic once per splat (splat_k2 / splat_power2): 9 instructions per evaluation where
+// exp(x) by range reduction in natural units took 12 (round 3; the loops are VALU-bound).
+constexpr float LOG2E = 1.44269504088896341f;
+constexpr float EXP2_C1 = 0.6931470036506653f, EXP2_C2 = 0.24022243916988373f, EXP2_C3 = 0.05550731346011162f,
+                EXP2_C4 = 0.009671415202319622f, EXP2_C5 = 0.0013264892622828484f;
+// Unspecified below x = -126 (all the compositing kernels ever USE: they only keep the value for power2 >= thr2 > -9).
+__device__ __forceinline__ float vr_exp2_unclamped(float x)
 {
-    float t = x * 1.44269504088896341f;
-    float n = rintf(t);
-    float r = fmaf(n, -0.693145751953125f, x);
-    r = fmaf(n, -1.42860682030941723212e-6f, r);
-    float p = 1.0f / 720.0f;
-    p = fmaf(p, r, 1.0f / 120.0f);
-    p = fmaf(p, r, 1.0f / 24.0f);
-    p = fmaf(p, r, 1.0f / 6.0f);
-    p = fmaf(p, r, 0.5f);
-    p = fmaf(p, r, 1.0f);
-    p = fmaf(p, r, 1.0f);
-    float v = ldexpf(p, (int)n);
-    return x < -87.0f ? 0.0f : v;
-}
-// The same value for every x >= -87 (all the compositing kernels ever USE: they only keep exp(power) for
-// power >= thr > -6); below that the result is unspecified.  Saves the clamp in the inner loops.
-__device__ __forceinline__ float vr_exp_unclamped(float x)
-{
-    float t = x * 1.44269504088896341f;
-    float n = rintf(t);
-    float r = fmaf(n, -0.693145751953125f, x);
-    r = fmaf(n, -1.42860682030941723212e-6f, r);
-    float p = 1.0f / 720.0f;
-    p = fmaf(p, r, 1.0f / 120.0f);
-    p = fmaf(p, r, 1.0f / 24.0f);
-    p = fmaf(p, r, 1.0f / 6.0f);
-    p = fmaf(p, r, 0.5f);
-    p = fmaf(p, r, 1.0f);
-    p = fmaf(p, r, 1.0f);
+    const float n = rintf(x);
+    const float f = x - n;
+    float p = EXP2_C5;
+    p = fmaf(p, f, EXP2_C4);
+    p = fmaf(p, f, EXP2_C3);
+    p = fmaf(p, f, EXP2_C2);
+    p = fmaf(p, f, EXP2_C1);
+    p = fmaf(p, f, 1.0f);
     return ldexpf(p, (int)n);
 }
+__device__ __forceinline__ float vr_exp2(float x) { return x < -126.0f ? 0.0f : vr_exp2_unclamped(x); }
 
 // ---- wave-cooperative linear copies between a contiguous global block and LDS (n floats, one wave).  16-byte
 // vector path when the global address is aligned (all of a lane's loads in flight before the first store), plus a
@@ -267,23 +255,34 @@ __device__ __forceinline__ uint32_t quads_relevant(float sx, float sy, float A, 
     return bits;
 }
 
-// Gaussian exponent at a pixel; identical expression in forward and backward.
-__device__ __forceinline__ float splat_power(float sx, float sy, float A, float B, float C, float pxf, float pyf,
-                                             float& dx, float& dy)
+// The Gaussian exponent at a pixel in units of log2 e:  power2 = log2(e) (-1/2 (A dx^2 + C dy^2) - B dx dy)
+//   = ((kA dx) dx + (kC dy) dy) + (kB dx) dy,   kA = (-1/2 log2 e) A, kB = -(log2 e) B, kC = (-1/2 log2 e) C
+// (splat_k2: rounded once per splat, where the record is staged; thr2 = thr log2 e is the pre-filter threshold in the
+// same units).  alpha = min(0.99, opacity * 2^power2).  Same operation order in the CPU checker.
+constexpr float K_HALF = -0.5f * LOG2E;
+__device__ __forceinline__ void splat_k2(float A, float B, float C, float thr, float& kA, float& kB, float& kC, float& thr2)
+{
+    kA = K_HALF * A;
+    kB = -LOG2E * B;
+    kC = K_HALF * C;
+    thr2 = thr * LOG2E;
+}
+__device__ __forceinline__ float splat_power2(float sx, float sy, float kA, float kB, float kC, float pxf, float pyf,
+                                              float& dx, float& dy)
 {
     dx = sx - pxf;
     dy = sy - pyf;
-    float q = fmaf(C * dy, dy, (A * dx) * dx);
-    return fmaf(-0.5f, q, -((B * dx) * dy));
+    const float q = fmaf(kC * dy, dy, (kA * dx) * dx);
+    return fmaf(kB * dx, dy, q);
 }
 
 // the same for one splat against two pixels
-__device__ __forceinline__ f2 splat_power_x2(float sx, float sy, float A, float B, float C, f2 pxf, f2 pyf, f2& dx, f2& dy)
+__device__ __forceinline__ f2 splat_power2_x2(float sx, float sy, float kA, float kB, float kC, f2 pxf, f2 pyf, f2& dx, f2& dy)
 {
     dx = f2_splat(sx) - pxf;
     dy = f2_splat(sy) - pyf;
-    const f2 q = f2_fma(f2_splat(C) * dy, dy, (f2_splat(A) * dx) * dx);
-    return f2_fma(f2_splat(-0.5f), q, -((f2_splat(B) * dx) * dy));
+    const f2 q = f2_fma(f2_splat(kC) * dy, dy, (f2_splat(kA) * dx) * dx);
+    return f2_fma(f2_splat(kB) * dx, dy, q);
 }
 
 constexpr float SH_C0 = 0.28209479177387814f;

@@ -321,7 +321,7 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     uint32_t gid_q[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) gid_q[q] = q * 64 + lane < c.count ? point_list[c.first + q * 64 + lane] : 0u;
-    bool done = Tb < 0.0f;
+    const bool done = Tb < 0.0f;          // pixel finished before this segment
     if (__ballot(!done) == 0ull) return;  // nothing alive in this strip
     const unsigned long long mm[4] = {uniform64(mraw[0]), uniform64(mraw[1]), uniform64(mraw[2]), uniform64(mraw[3])};
     int nrel = 0;
@@ -338,13 +338,18 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
         }
     }
     __syncthreads();
-    const float pxf = (float)c.px, pyf = (float)c.py;
+    const float pyf = (float)c.py;
+    // A FINISHED pixel (before this segment, or from the entry at which its stop test fires) is switched off by moving
+    // it out of reach: with x = 1e30 every exponent is -inf (or NaN), never >= a threshold, so `pre` is false for the
+    // pixel from then on -- no per-entry test of a loop-carried flag, which the compiler kept as a 0/1 register with
+    // four conversions per entry.  A switched-off pixel changes nothing, so the results are what they were.
+    constexpr float GATED = 1e30f;
+    float gx = done ? GATED : (float)c.px;
     float p = 1.0f;
     float Cs[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) Cs[k] = 0.0f;
     uint32_t last = 0;
-    bool stopped = false;
     // Branch-free per lane (predicated); only wave-uniform branches: skip the exp when no pixel of the
     // strip can reach alpha >= 1/255, skip the channel update when no pixel applies the splat.
     for (int b0 = 0; b0 < nrel; b0 += 64) {
@@ -370,17 +375,17 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
         // once per batch); the entries are still applied strictly in list order
         auto blend_one = [&](const int i, const float4 a, const float4 b) {
             float dx, dy;
-            const float power = splat_power2(a.x, a.y, a.z, a.w, b.x, pxf, pyf, dx, dy);
-            const bool pre = !done && !(power > 0.0f) && power >= b.z;
-            if (__ballot(pre) == 0ull) return;
+            // (gx: the pixel's x coordinate, or GATED once the pixel is finished -- see below: no `done` test per entry)
+            const float power = splat_power2(a.x, a.y, a.z, a.w, b.x, gx, pyf, dx, dy);
+            const bool pre = !(power > 0.0f) && power >= b.z;
+            if (__builtin_amdgcn_ballot_w64(pre) == 0ull) return;
             const float alpha = fminf(ALPHA_MAX, b.y * vr_exp2_unclamped(power));
             const bool valid = pre && !(alpha < ALPHA_MIN);
             const float pn = p * (1.0f - alpha);
             const bool stop = valid && (Tb * pn < T_EPS);
             const bool apply = valid && !stop;
-            done = done || stop;
-            stopped = stopped || stop;
-            if (__ballot(apply) == 0ull) return;
+            gx = stop ? GATED : gx;
+            if (__builtin_amdgcn_ballot_w64(apply) == 0ull) return;
             const float wgt = apply ? alpha * (Tb * p) : 0.0f;
             const float4 cc = lds[2][i];  // r g b qw
             const float4 d = lds[3][i];   // qx qy qz s0
@@ -409,7 +414,7 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
             blend_one(i + 3, a3, b3v);
         }
         for (; i < n; ++i) blend_one(i, lds[0][i], lds[1][i]);
-        if (__ballot(!done) == 0ull) break;  // every pixel of the strip is finished
+        if (__builtin_amdgcn_ballot_w64(gx != GATED) == 0ull) break;  // every pixel of the strip is finished
         __syncthreads();
     }
     if (!(Tb < 0.0f)) {
@@ -417,6 +422,7 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
 #pragma unroll
         for (int k = 0; k < NCH; ++k) dst[k * SEG] = Cs[k];
         dst[11 * SEG] = p;
+        const bool stopped = gx == GATED;     // (this branch: the pixel was alive at the segment start)
         dst[12 * SEG] = __uint_as_float(last | (stopped ? 0x80000000u : 0u));
     }
 }

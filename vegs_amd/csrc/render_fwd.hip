@@ -346,17 +346,16 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     constexpr float GATED = 1e30f;
     float gx = done ? GATED : (float)c.px;
     float p = 1.0f;
-    float Cs[NCH];
+    f2 Cp[5];
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) Cs[k] = 0.0f;
-    uint32_t last = 0;
+    for (int k = 0; k < 5; ++k) Cp[k] = f2_splat(0.0f);
+    float Cd = 0.0f;
+    int lastpos = -1;
     // Branch-free per lane (predicated); only wave-uniform branches: skip the exp when no pixel of the
     // strip can reach alpha >= 1/255, skip the channel update when no pixel applies the splat.
     for (int b0 = 0; b0 < nrel; b0 += 64) {
         const int n = min(64, nrel - b0);
-        int myj = 0;
         if (lane < n) {
-            myj = (int)rel_j[b0 + lane];
             const float4* src = reinterpret_cast<const float4*>(rec + rel_gid[b0 + lane]);
             {   // geometry with the conic and the threshold in log2 units (splat_k2): x y kA kB | kC opacity thr2 depth
                 float4 s0 = src[0], s1 = src[1];
@@ -366,9 +365,7 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
             }
             lds[2][lane] = src[2];
             lds[3][lane] = src[3];
-            float4 t = src[4];            // s1 s2 clamped pad -> the pad slot carries the entry index
-            t.w = __int_as_float(myj);
-            lds[4][lane] = t;
+            lds[4][lane] = src[4];        // s1 s2 (clamp bits, pad)
         }
         __syncthreads();
         // four entries per trip: their geometry broadcasts are issued before any of them is processed (LDS latency
@@ -389,20 +386,19 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
             const float wgt = apply ? alpha * (Tb * p) : 0.0f;
             const float4 cc = lds[2][i];  // r g b qw
             const float4 d = lds[3][i];   // qx qy qz s0
-            const float4 e4 = lds[4][i];  // s1 s2 - entry index
-            Cs[0] = fmaf(cc.x, wgt, Cs[0]);
-            Cs[1] = fmaf(cc.y, wgt, Cs[1]);
-            Cs[2] = fmaf(cc.z, wgt, Cs[2]);
-            Cs[3] = fmaf(b.w, wgt, Cs[3]);
-            Cs[4] = fmaf(cc.w, wgt, Cs[4]);
-            Cs[5] = fmaf(d.x, wgt, Cs[5]);
-            Cs[6] = fmaf(d.y, wgt, Cs[6]);
-            Cs[7] = fmaf(d.z, wgt, Cs[7]);
-            Cs[8] = fmaf(d.w, wgt, Cs[8]);
-            Cs[9] = fmaf(e4.x, wgt, Cs[9]);
-            Cs[10] = fmaf(e4.y, wgt, Cs[10]);
+            const float2 e2 = *reinterpret_cast<const float2*>(&lds[4][i]);  // s1 s2
+            // the eleven channel sums as the record lays the attributes out: five adjacent pairs (packed fma straight
+            // from the loaded registers -- summed channel by channel the compiler packed them too, after five register
+            // moves per entry) and the depth; each sum is the same fma as before
+            const f2 w2 = f2_splat(wgt);
+            Cp[0] = f2_fma((f2){cc.x, cc.y}, w2, Cp[0]);   // r g
+            Cp[1] = f2_fma((f2){cc.z, cc.w}, w2, Cp[1]);   // b qw
+            Cp[2] = f2_fma((f2){d.x, d.y}, w2, Cp[2]);     // qx qy
+            Cp[3] = f2_fma((f2){d.z, d.w}, w2, Cp[3]);     // qz s0
+            Cp[4] = f2_fma((f2){e2.x, e2.y}, w2, Cp[4]);   // s1 s2
+            Cd = fmaf(b.w, wgt, Cd);                       // depth
             p = apply ? pn : p;
-            last = apply ? (uint32_t)(c.sl * SEG + __float_as_int(e4.w) + 1) : last;
+            lastpos = apply ? b0 + i : lastpos;            // position in the compacted list of the last entry applied
         };
         int i = 0;
         for (; i + 3 < n; i += 4) {
@@ -419,10 +415,14 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     }
     if (!(Tb < 0.0f)) {
         float* dst = part + (size_t)c.seg * (NPART * SEG) + pixslot;
+        // channel order of `part`: r g b depth qw qx qy qz s0 s1 s2
+        const float Cs[NCH] = {Cp[0].x, Cp[0].y, Cp[1].x, Cd, Cp[1].y, Cp[2].x, Cp[2].y, Cp[3].x, Cp[3].y, Cp[4].x, Cp[4].y};
 #pragma unroll
         for (int k = 0; k < NCH; ++k) dst[k * SEG] = Cs[k];
         dst[11 * SEG] = p;
         const bool stopped = gx == GATED;     // (this branch: the pixel was alive at the segment start)
+        // last contributor: tile-relative list index + 1 of the last entry applied in this segment (0 = none)
+        const uint32_t last = lastpos >= 0 ? (uint32_t)(c.sl * SEG + (int)rel_j[lastpos] + 1) : 0u;
         dst[12 * SEG] = __uint_as_float(last | (stopped ? 0x80000000u : 0u));
     }
 }

@@ -112,7 +112,7 @@ def prepare(sc, deg, cams, device, rng, count=True, cam_ts=None):
                 cam_ts=cam_ts, gouts=gouts, counters=counters, deg=deg)
 
 
-def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="train", exchange_on=True):
+def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="train", exchange_on=True, streams=1):
     """One step = `vps` views forward + backward on this rank, then (N > 1) the gradient exchange.
     exchange "dense": all-reduce of the 59-float/Gaussian gradients.  "factored": the op returns the 3-float factor of
     the SH gradient, the ranks all-gather the factors (12 B) and all-reduce the other 11 floats (44 B), and every rank
@@ -140,28 +140,45 @@ def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="trai
         return GaussianRasterizer(rs)(means3D=T["means3D"], means2D=m2d if m2d is not None else T["means3D"],
                                       shs=T["shs"], opacities=T["opacities"], scales=T["scales"], rotations=T["rotations"])
 
+    # streams > 1: the views of a step alternate between side streams (a view's forward, loss gradient and backward
+    # stay on ONE stream, in order); the kernels of two views in flight fill each other's latency-bound stretches.  The
+    # views of a step are independent by construction (same parameters, gradients summed), so this changes no result.
+    side = [torch.cuda.Stream(T["means3D"].device) for _ in range(streams)] if streams > 1 else None
+
+    def one_view(v):
+        if mode == "forward":
+            with torch.no_grad():
+                direct(v)
+            return
+        gc, gq, gs = gouts[v]
+        if mode == "noglue":
+            out = direct(v)
+            torch.autograd.backward([out[0], out[2], out[3]], [gc, gq, gs])
+            m2d.grad = None
+            return
+        sink = torch.zeros_like(T["means3D"], requires_grad=True) if factored else None
+        pkg = harness.render(cams[v], T, deg, bg, cam_t=cam_ts[v], sh_color_grad=sink)
+        if fact_x:          # overlapped exchange: the factors start travelling between the backward's two halves
+            xch.begin(cam_ts[v]["campos"])
+        torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], [gc, gq, gs])
+
     def step(i):
         done = []
+        if side is not None:
+            main = torch.cuda.current_stream()
+            for st in side:
+                st.wait_stream(main)
         for k in range(vps):
             v = vdist.view_for_rank(i * vps + k, rank, world, n_views)
-            if mode == "forward":
-                with torch.no_grad():
-                    direct(v)
-                done.append(v)
-                continue
-            gc, gq, gs = gouts[v]
-            if mode == "noglue":
-                out = direct(v)
-                torch.autograd.backward([out[0], out[2], out[3]], [gc, gq, gs])
-                m2d.grad = None
-                done.append(v)
-                continue
-            sink = torch.zeros_like(T["means3D"], requires_grad=True) if factored else None
-            pkg = harness.render(cams[v], T, deg, bg, cam_t=cam_ts[v], sh_color_grad=sink)
-            if fact_x:          # overlapped exchange: the factors start travelling between the backward's two halves
-                xch.begin(cam_ts[v]["campos"])
-            torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], [gc, gq, gs])
+            if side is not None:
+                with torch.cuda.stream(side[k % streams]):
+                    one_view(v)
+            else:
+                one_view(v)
             done.append(v)
+        if side is not None:
+            for st in side:
+                main.wait_stream(st)
         if mode == "forward":
             return done
         if fact_x:
@@ -367,6 +384,8 @@ def main():
                     help="per-camera needed-segment hints in the HEADLINE: off (default: every view costs what a camera's "
                          "first visit costs -- a number any training loop meets) or warm (zero model drift: the best case)")
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="with --views-per-step > 1: HIP streams the views of a step alternate between (2 = two views in flight)")
     ap.add_argument("--views-per-step", type=int, default=1,
                     help="views each rank renders per step; their gradients accumulate locally and are exchanged once")
     args = ap.parse_args()
@@ -390,7 +409,7 @@ def main():
     wl = prepare(sc, deg, cams, device, np.random.default_rng(1234))
     counters, gouts = wl["counters"], wl["gouts"]
     vps = max(1, args.views_per_step)
-    step = make_step(wl, rank, world, vps, exchange=args.exchange)
+    step = make_step(wl, rank, world, vps, exchange=args.exchange, streams=args.streams)
 
     if args.hints == "warm":
         warm_hints(step, n_views)

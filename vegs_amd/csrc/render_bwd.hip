@@ -261,7 +261,9 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
         const int r = ch * 64 + (63 - lane);
         const bool has = r < nrel;
         const int ej = has ? (int)rel_j[r] : 0;        // entry index inside the segment
-        const int e = seg_lo + ej;                      // tile-relative list index
+        // tile-relative list index; a lane without an entry sits behind every pixel's last contributor, so the
+        // per-pixel test "e < n_contrib" also covers "the lane has an entry" (one compare instead of two masked blocks)
+        const int e = has ? seg_lo + ej : 0x7FFFFFFF;
         float sx = 0.f, sy = 0.f, cA = 0.f, cB = 0.f, cC = 0.f, op = 0.f, thr = 1.0f;
         float at[NCH];
 #pragma unroll
@@ -293,9 +295,11 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                 const f2 pxf = {r0.x, r0.y}, pyf = {r0.z, r0.w};
                 f2 dx, dy;
                 const f2 power = splat_power2_x2(sx, sy, kA, kB, kC, pxf, pyf, dx, dy);    // in units of log2 e, as the forward
-                const bool pre0 = has && (e < nc0) && !(power.x > 0.0f) && power.x >= thr2;
-                const bool pre1 = has && (e < nc1) && !(power.y > 0.0f) && power.y >= thr2;
-                if (__ballot(pre0 || pre1) == 0ull) continue;  // no splat of the chunk reaches the pair: carries unchanged
+                // thr2 <= power <= 0 as ONE comparison: the median of (power, thr2, 0) is power itself.  (A splat too faint
+                // to reach 1/255 anywhere has thr2 > 0 and passes this at power == 0 exactly; the alpha test below drops it.)
+                const bool pre0 = (e < nc0) & (__builtin_amdgcn_fmed3f(power.x, thr2, 0.0f) == power.x);
+                const bool pre1 = (e < nc1) & (__builtin_amdgcn_fmed3f(power.y, thr2, 0.0f) == power.y);
+                if (__builtin_amdgcn_ballot_w64(pre0 | pre1) == 0ull) continue;  // no splat of the chunk reaches the pair: carries unchanged
                 // The forward's own 2^x (bit for bit: same operations), not the hardware's: WHICH fragments contributed is
                 // the forward's decision (alpha >= 1/255), and v_exp_f32 agrees with it only to ~2 ulp -- rare to matter,
                 // but a faint splat has ALL its fragments at the threshold, and one fragment of twenty classified the other

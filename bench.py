@@ -140,10 +140,11 @@ def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="trai
         return GaussianRasterizer(rs)(means3D=T["means3D"], means2D=m2d if m2d is not None else T["means3D"],
                                       shs=T["shs"], opacities=T["opacities"], scales=T["scales"], rotations=T["rotations"])
 
-    # streams > 1: the views of a step alternate between side streams (a view's forward, loss gradient and backward
-    # stay on ONE stream, in order); the kernels of two views in flight fill each other's latency-bound stretches.  The
-    # views of a step are independent by construction (same parameters, gradients summed), so this changes no result.
-    side = [torch.cuda.Stream(T["means3D"].device) for _ in range(streams)] if streams > 1 else None
+    # streams > 1: the views of a step alternate between side streams (vegs_amd/views.py: a view's forward, loss
+    # gradient and backward stay on ONE stream, in order); two views in flight fill each other's latency-bound stretches.
+    # The views of a step are independent by construction (same parameters, gradients summed): no result changes.
+    from vegs_amd import views as vviews
+    vs = vviews.ViewStreams(T["means3D"].device, streams)
 
     def one_view(v):
         if mode == "forward":
@@ -164,21 +165,11 @@ def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="trai
 
     def step(i):
         done = []
-        if side is not None:
-            main = torch.cuda.current_stream()
-            for st in side:
-                st.wait_stream(main)
         for k in range(vps):
             v = vdist.view_for_rank(i * vps + k, rank, world, n_views)
-            if side is not None:
-                with torch.cuda.stream(side[k % streams]):
-                    one_view(v)
-            else:
-                one_view(v)
+            vs.run(one_view, v)
             done.append(v)
-        if side is not None:
-            for st in side:
-                main.wait_stream(st)
+        vs.join()
         if mode == "forward":
             return done
         if fact_x:
@@ -284,7 +275,8 @@ def warm_hints(step, n_views):
         step(i)
 
 
-def variant(name, sc, deg, cams, device, steps, warmup, factored=False, hints="off", mode="train", repeats=3):
+def variant(name, sc, deg, cams, device, steps, warmup, factored=False, hints="off", mode="train", repeats=3, vps=1,
+            streams=1):
     """A few steps of another scene / camera / operator configuration, reported next to the headline (N = 1 only).
     hints: "off" = per-camera needed-segment hints disabled, as in the headline; "warm" = every camera was rendered
     before with the SAME model (the best case: zero drift); "epoch" = the hints are one epoch old: recorded, then the
@@ -295,7 +287,7 @@ def variant(name, sc, deg, cams, device, steps, warmup, factored=False, hints="o
     extra = {}
     try:
         wl = prepare(sc, deg, cams, device, np.random.default_rng(77))
-        step = make_step(wl, 0, 1, 1, factored, mode=mode)
+        step = make_step(wl, 0, 1, vps, factored, mode=mode, streams=streams)
         if hints == "warm":
             warm_hints(step, len(cams))
         elif hints == "epoch":
@@ -329,8 +321,9 @@ def variant(name, sc, deg, cams, device, steps, warmup, factored=False, hints="o
         rasterizer.needed_hints(old)
     cn = wl["counters"]
     mean = {k: float(np.mean([cn[v][k] for v in done])) for k in ("V", "R", "F", "B")}
-    res = {"workload": name, "views_per_s": round(steps / dt, 2), "ms_per_view": round(dt / steps * 1e3, 4),
-           "ms_per_view_runs": [round(r / steps * 1e3, 4) for r in runs],
+    nv = len(done)                      # steps x views per step
+    res = {"workload": name, "views_per_s": round(nv / dt, 2), "ms_per_view": round(dt / nv * 1e3, 4),
+           "ms_per_view_runs": [round(r / nv * 1e3, 4) for r in runs],
            "mfragments_per_s": round(sum(cn[v]["F"] for v in done) / dt / 1e6, 1),
            "blended_mfragments_per_s": round(sum(cn[v]["B"] for v in done) / dt / 1e6, 1),
            "mean_counters": {k: round(v, 1) for k, v in mean.items()}}
@@ -533,6 +526,12 @@ def main():
                     device, 16, 4, mode="noglue"),
             variant("headline scene, FORWARD ONLY under torch.no_grad() (evaluation / video rendering, train.py:338-508, "
                     "render_video.py:162,202)", sc, deg, cams, device, 16, 4, mode="forward"),
+            variant("headline scene, FORWARD ONLY, TWO VIEWS IN FLIGHT on two HIP streams (vegs_amd/views.py: frames of an "
+                    "evaluation / video loop are independent)", sc, deg, cams, device, 2, 1, mode="forward", vps=16, streams=2),
+            variant("headline scene, a BATCH OF 8 VIEWS per iteration on ONE stream (gradients of the views summed by "
+                    "autograd: + a dense accumulate per view)", sc, deg, cams, device, 4, 1, vps=8),
+            variant("headline scene, a batch of 8 views per iteration, TWO VIEWS IN FLIGHT on two HIP streams", sc, deg,
+                    cams, device, 4, 1, vps=8, streams=2),
         ]
         res["aten_glue_ms_per_view"] = round(res["ms_per_step"] / vps - res["variants"][5]["ms_per_view"], 4) \
             if args.hints == "off" else None

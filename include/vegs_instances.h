@@ -49,6 +49,22 @@ int vr_instances_backward(const VrInstance* inst, const VrInstanceGrads* grads, 
                           const float* g_scales, const float* g_rotations, VrAllocFn alloc, void* alloc_user,
                           void* stream);
 
+/* ---- the model's activations, the first thing prepare_rasterization reads (gaussian_renderer/__init__.py:128-137 ->
+ * scene/gaussian_model.py:98-120 with the functions of :37-45):
+ *     opacity   = torch.sigmoid(_opacity)                 [P,1]
+ *     scales    = torch.exp(_scaling)                     [P,3]
+ *     rotations = torch.nn.functional.normalize(_rotation) [P,4]   x / max(|x|_2, 1e-12) per row
+ * one launch forward, one backward (ATen: ~15 launches over all Gaussians per iteration).  Rotation arrays must be
+ * 16-byte aligned. */
+int vr_activations_forward(const float* raw_opacity, const float* raw_scaling, const float* raw_rotation, int64_t P,
+                           float* opacity, float* scales, float* rotations, void* stream);
+
+/* Gradients w.r.t. the raw parameters from the gradients of the activated ones.  `opacity` and `scales` are the
+ * forward's OUTPUTS, `raw_rotation` its input.  A NULL g_* means a zero gradient; a NULL dL_draw_* is not computed. */
+int vr_activations_backward(const float* opacity, const float* scales, const float* raw_rotation, int64_t P,
+                            const float* g_opacity, const float* g_scales, const float* g_rotations,
+                            float* dL_draw_opacity, float* dL_draw_scaling, float* dL_draw_rotation, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--gaussians", type=int, default=2_000_000)
 ap.add_argument("--iters", type=int, default=32)
 ap.add_argument("--boxes", type=int, default=0, help="dynamic box instances of 8196 Gaussians each (BASELINE config C5)")
+ap.add_argument("--only", choices=["A", "B", "C"], default=None, help="run one mode only (for profiling)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 H, W = 376, 1376
@@ -45,6 +46,10 @@ def run(fused, factored=False):
     return (time.perf_counter() - t0) / args.iters * 1e3, float(last)
 
 
+if args.only:
+    ms, loss = run(args.only != "A", factored=args.only == "C")
+    print(json.dumps({"mode": args.only, "ms": round(ms, 3), "loss": loss, "gaussians": args.gaussians, "boxes": args.boxes}))
+    raise SystemExit(0)
 a_ms, a_loss = run(False)
 b_ms, b_loss = run(True)
 res = {"gaussians": args.gaussians, "boxes": args.boxes, "frame": [H, W], "iters": args.iters,

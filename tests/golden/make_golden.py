@@ -274,9 +274,45 @@ def part_b(only_new=False):
         print(name, "visible", int((res[5] > 0).sum()), "of", P)
 
 
+def part_c():
+    """ref_activations.npz: the model's activations as the reference assigns them (scene/gaussian_model.py:37-45:
+    scaling_activation = torch.exp, opacity_activation = torch.sigmoid, rotation_activation =
+    torch.nn.functional.normalize; read through get_scaling / get_opacity / get_rotation, :98-120), float32 on the CPU,
+    with autograd's gradients for random upstream gradients.  The assignments are checked in the reference's source
+    before the functions are called here."""
+    src = open(os.path.join(REF, "scene", "gaussian_model.py")).read()
+    for line in ("self.scaling_activation = torch.exp", "self.opacity_activation = torch.sigmoid",
+                 "self.rotation_activation = torch.nn.functional.normalize"):
+        assert line in src, line
+    rng = np.random.default_rng(77)
+    n = 512
+    o = rng.normal(0, 3, (n, 1)).astype(np.float32)
+    o[:4, 0] = [30.0, -30.0, 0.0, -88.0]
+    sc = rng.normal(-3, 2, (n, 3)).astype(np.float32)
+    sc[0] = [-11.5, 3.0, 0.0]
+    q = rng.normal(size=(n, 4)).astype(np.float32)
+    q[0] = 0.0                       # |q| below F.normalize's eps: divided by eps, gradient g / eps
+    q[1] = [1e-13, 0, 0, 0]
+    q[2] = [3e-7, -2e-7, 1e-7, 0]
+    q[3] = [1e4, -2e4, 5e3, 1.0]
+    to, ts, tq = (torch.tensor(a, requires_grad=True) for a in (o, sc, q))
+    yo, ys, yq = torch.sigmoid(to), torch.exp(ts), torch.nn.functional.normalize(tq)
+    go, gs, gq = (torch.tensor(rng.normal(size=a.shape).astype(np.float32)) for a in (o, sc, q))
+    torch.autograd.backward([yo, ys, yq], [go, gs, gq])
+    np.savez_compressed(os.path.join(HERE, "ref_activations.npz"), raw_opacity=o, raw_scaling=sc, raw_rotation=q,
+                        opacity=yo.detach().numpy(), scales=ys.detach().numpy(), rotations=yq.detach().numpy(),
+                        g_opacity=go.numpy(), g_scales=gs.numpy(), g_rotations=gq.numpy(), d_opacity=to.grad.numpy(),
+                        d_scaling=ts.grad.numpy(), d_rotation=tq.grad.numpy())
+
+
 if __name__ == "__main__":
+    if "--activations" in sys.argv:
+        part_c()
+        sys.exit(0)
     # --new: keep the committed fixtures (their random draws are part of the pins) and only add missing ones
     new = "--new" in sys.argv
     if not new or not os.path.exists(os.path.join(HERE, "ref_cov3d.npz")):
         part_a()
     part_b(only_new=new)
+    if not new or not os.path.exists(os.path.join(HERE, "ref_activations.npz")):
+        part_c()

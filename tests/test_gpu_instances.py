@@ -106,3 +106,72 @@ def test_instance_argument_checks():
         prepare_and_merge(g, [g], [torch.eye(3, device=DEV)])
     with pytest.raises(ValueError):
         prepare_and_merge(g, [g], [])
+
+
+def test_activations_match_the_reference_functions():
+    """vegs_amd.instances.activate == torch.sigmoid / torch.exp / F.normalize as scene/gaussian_model.py:37-45 assigns
+    them, against outputs and autograd gradients of those functions (tests/golden/ref_activations.npz, float32 CPU) incl.
+    quaternions below F.normalize's eps, and against the same ATen ops on the GPU at 2 M rows."""
+    import torch.nn.functional as F
+    from vegs_amd.instances import activate
+    z = np.load(os.path.join(GOLDEN, "ref_activations.npz"))
+    raw = [torch.tensor(z[k], device=DEV, requires_grad=True) for k in ("raw_opacity", "raw_scaling", "raw_rotation")]
+    out = activate(*raw)
+    for y, k in zip(out, ("opacity", "scales", "rotations")):
+        assert y.shape == z[k].shape
+        assert rel_err(y.detach().cpu().numpy(), z[k]) < 3e-7, k
+        assert np.abs(y.detach().cpu().numpy() - z[k]).max() <= 4e-7 * max(1.0, np.abs(z[k]).max()), k
+    torch.autograd.backward(list(out), [torch.tensor(z[k], device=DEV) for k in ("g_opacity", "g_scales", "g_rotations")])
+    for t, k in zip(raw, ("d_opacity", "d_scaling", "d_rotation")):
+        got, want = t.grad.cpu().numpy(), z[k]
+        # (the quaternion gradient (g - y <y,g>) / |x| cancels: its error scales with the row, 1.1e-6 of it in fp32
+        # whichever way the terms are grouped)
+        bad = np.abs(got - want) > 2e-6 * np.abs(want) + 3e-6 * np.abs(want).max(axis=-1, keepdims=True) + 1e-30
+        assert not bad.any(), (k, np.argwhere(bad)[:5], got[bad][:5], want[bad][:5])
+    # only some outputs used / only some inputs requiring grad
+    a = torch.tensor(z["raw_opacity"], device=DEV, requires_grad=True)
+    b = torch.tensor(z["raw_scaling"], device=DEV)
+    c = torch.tensor(z["raw_rotation"], device=DEV, requires_grad=True)
+    o, s, r = activate(a, b, c)
+    (o.sum() * 2.0).backward()
+    assert c.grad is None or float(c.grad.abs().max()) == 0.0
+    assert rel_err(a.grad.cpu().numpy(), (2.0 * z["opacity"] * (1 - z["opacity"]))) < 1e-6
+    # at size, against ATen on the same device
+    g = torch.Generator(device=DEV).manual_seed(5)
+    P = 2_000_000
+    ro = torch.randn(P, 1, device=DEV, generator=g) * 3
+    rs = torch.randn(P, 3, device=DEV, generator=g) * 2 - 3
+    rq = torch.randn(P, 4, device=DEV, generator=g)
+    gs = [torch.randn(P, n, device=DEV, generator=g) for n in (1, 3, 4)]
+    x1 = [t.clone().requires_grad_(True) for t in (ro, rs, rq)]
+    x2 = [t.clone().requires_grad_(True) for t in (ro, rs, rq)]
+    y1 = activate(*x1)
+    y2 = (torch.sigmoid(x2[0]), torch.exp(x2[1]), F.normalize(x2[2]))
+    torch.autograd.backward(list(y1), gs)
+    torch.autograd.backward(list(y2), gs)
+    for u, v in zip(y1, y2):
+        assert float((u - v).detach().abs().max()) <= 3e-7 * max(1.0, float(v.detach().abs().max()))
+    for name, u, v in zip(("opacity", "scaling"), x1[:2], x2[:2]):
+        worst = float(((u.grad - v.grad).abs() / (v.grad.abs() + 1e-30)).max())
+        assert worst < 2e-6, (name, worst)
+    # quaternion: (g - y <y,g>) / |x| cancels when g is nearly parallel to x, so fp32 results agree to a few ulp of the
+    # TERMS (|g| / |x|), not of the result; measured against float64: this kernel must be as close as ATen's fp32 is
+    x64 = rq.double().requires_grad_(True)
+    F.normalize(x64).backward(gs[2].double())
+    scale = gs[2].abs().amax(dim=-1, keepdim=True).double() / rq.double().norm(dim=-1, keepdim=True)
+    e_mine = float(((x1[2].grad.double() - x64.grad).abs() / scale).max())
+    e_aten = float(((x2[2].grad.double() - x64.grad).abs() / scale).max())
+    assert e_mine < 1e-6 and e_mine < 2.0 * e_aten + 2e-7, (e_mine, e_aten)
+
+
+def test_activation_argument_checks():
+    from vegs_amd.instances import activate
+    o, s, q = torch.zeros(5, 1, device=DEV), torch.zeros(5, 3, device=DEV), torch.ones(5, 4, device=DEV)
+    with pytest.raises(ValueError):
+        activate(o, s, q[:, :3])
+    with pytest.raises(ValueError):
+        activate(o[:4], s, q)
+    with pytest.raises(ValueError):
+        activate(o.cpu(), s.cpu(), q.cpu())
+    e = activate(o[:0], s[:0], q[:0])
+    assert e[0].shape == (0, 1) and e[2].shape == (0, 4)

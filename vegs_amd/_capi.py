@@ -25,7 +25,7 @@ EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_b
            "vr_knn3_mean_dist2", "vr_photometric_forward", "vr_photometric_backward",
            "vr_normal_guidance_forward", "vr_normal_guidance_backward", "vr_adam_step", "vr_densify_stats",
            "vr_sh_grad_from_factors", "vr_sh_adam_step",
-           "vr_instances_forward", "vr_instances_backward"]
+           "vr_instances_forward", "vr_instances_backward", "vr_activations_forward", "vr_activations_backward"]
 STAGES = ["preprocess", "compact", "depth_sort", "emit", "tile_sort", "ranges", "render_fwd", "bwd_zero",
           "render_bwd", "preprocess_bwd", "k_seg_bwd"]
 
@@ -164,6 +164,10 @@ def load():
     lib.vr_instances_forward.argtypes = [C.POINTER(VrInstance), i32, vp, vp, vp, vp]
     lib.vr_instances_backward.restype = C.c_int
     lib.vr_instances_backward.argtypes = [C.POINTER(VrInstance), C.POINTER(VrInstanceGrads), i32, vp, vp, vp, VrAllocFn, vp, vp]
+    lib.vr_activations_forward.restype = C.c_int
+    lib.vr_activations_forward.argtypes = [vp, vp, vp, C.c_int64, vp, vp, vp, vp]
+    lib.vr_activations_backward.restype = C.c_int
+    lib.vr_activations_backward.argtypes = [vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
     lib.vr_profile_level.restype = C.c_int
     lib.vr_profile_level.argtypes = [C.c_int]
     lib.vr_profile_collect.restype = C.c_int

@@ -106,3 +106,49 @@ def prepare_and_merge(static, boxes, box2worlds):
     means, scales, rotations = _TransformConcat.apply(*flat)
     cat = (lambda k: models[0][0][k]) if len(models) == 1 else (lambda k: torch.cat([t[k] for t, _ in models], 0))
     return {"means3D": means, "shs": cat("shs"), "opacities": cat("opacities"), "scales": scales, "rotations": rotations}
+
+
+class _Activate(torch.autograd.Function):
+    """(_opacity [P,1], _scaling [P,3], _rotation [P,4]) -> (sigmoid, exp, F.normalize) in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, raw_opacity, raw_scaling, raw_rotation):
+        lib = _capi.load()
+        device = raw_rotation.device
+        P = raw_rotation.shape[0]
+        _check("_scaling", raw_scaling, 3, device); _check("_rotation", raw_rotation, 4, device)
+        if not raw_opacity.is_cuda or raw_opacity.dtype != torch.float32 or raw_opacity.numel() != P or raw_scaling.shape[0] != P:
+            raise ValueError("_opacity must be a float32 GPU tensor with one value per Gaussian, like _scaling and _rotation")
+        ro, rs, rr = raw_opacity.contiguous(), raw_scaling.contiguous(), raw_rotation.contiguous()
+        opacity, scales, rot = torch.empty_like(ro), torch.empty_like(rs), torch.empty_like(rr)
+        with torch.cuda.device(device):
+            rc = lib.vr_activations_forward(_capi.ptr(ro), _capi.ptr(rs), _capi.ptr(rr), P, _capi.ptr(opacity),
+                                            _capi.ptr(scales), _capi.ptr(rot), torch.cuda.current_stream(device).cuda_stream)
+        _capi.check(rc)
+        ctx.save_for_backward(opacity, scales, rr)
+        ctx.set_materialize_grads(False)
+        return opacity, scales, rot
+
+    @staticmethod
+    def backward(ctx, g_o, g_s, g_r):
+        lib = _capi.load()
+        opacity, scales, rr = ctx.saved_tensors
+        device = rr.device
+        need = ctx.needs_input_grad
+        g_o, g_s, g_r = (None if g is None else g.contiguous() for g in (g_o, g_s, g_r))
+        d_o = torch.empty_like(opacity) if need[0] else None
+        d_s = torch.empty_like(scales) if need[1] else None
+        d_r = torch.empty_like(rr) if need[2] else None
+        with torch.cuda.device(device):
+            rc = lib.vr_activations_backward(_capi.ptr(opacity), _capi.ptr(scales), _capi.ptr(rr), rr.shape[0],
+                                             _capi.ptr(g_o), _capi.ptr(g_s), _capi.ptr(g_r), _capi.ptr(d_o), _capi.ptr(d_s),
+                                             _capi.ptr(d_r), torch.cuda.current_stream(device).cuda_stream)
+        _capi.check(rc)
+        return d_o, d_s, d_r
+
+
+def activate(raw_opacity, raw_scaling, raw_rotation):
+    """The model's three activations (scene/gaussian_model.py:98-120: get_opacity, get_scaling, get_rotation) for
+    every Gaussian in one launch; gradients to the raw parameters in one launch.  Returns (opacity, scales, rotations)
+    shaped like the inputs."""
+    return _Activate.apply(raw_opacity, raw_scaling, raw_rotation)

@@ -65,8 +65,13 @@ def ssim_window(device):
 
 
 def render_model(p, boxes, cam, cam_t, deg, bg, fused, sh_sink=None):
-    t = {"means3D": p["xyz"], "opacities": torch.sigmoid(p["opacity"]), "scales": torch.exp(p["scaling"]),
-         "rotations": F.normalize(p["rotation"])}
+    if fused:
+        from . import instances
+        opac, scal, rot = instances.activate(p["opacity"], p["scaling"], p["rotation"])
+        t = {"means3D": p["xyz"], "opacities": opac, "scales": scal, "rotations": rot}
+    else:
+        t = {"means3D": p["xyz"], "opacities": torch.sigmoid(p["opacity"]), "scales": torch.exp(p["scaling"]),
+             "rotations": F.normalize(p["rotation"])}
     if not boxes:
         # fused: the model's two SH tensors as they are (no torch.cat, no slicing copies in the backward)
         t["shs"] = (p["f_dc"], p["f_rest"]) if fused else torch.cat((p["f_dc"], p["f_rest"]), dim=1)

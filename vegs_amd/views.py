@@ -30,12 +30,16 @@ class ViewStreams:
     batch runs is not waited for -- autograd puts the gradient accumulation of view k there, and view k+2 waiting for it
     would wait for view k+1, i.e. serialise the batch (measured: no gain at all).
     join() makes the caller's stream wait for all side streams -- call it before touching what the views produced
-    (accumulated gradients, images) from the caller's stream.  n = 1 runs everything on the caller's stream."""
+    (accumulated gradients, images) from the caller's stream.  n = 1 runs everything on the caller's stream.
+    The side streams are HIGH-PRIORITY streams, not for the priority: HIP multiplexes streams onto a few hardware queues,
+    and a normal-priority side stream that lands on the caller's queue sits behind the barrier packets autograd's
+    accumulation puts there (they wait for the other side stream) -- one ViewStreams in eight serialised completely;
+    high-priority streams get queues of their own (profiles/tools/stream_queues.py)."""
 
-    def __init__(self, device, n=2):
+    def __init__(self, device, n=2, priority=-1):
         self.device = torch.device(device)
         self.n = max(1, int(n))
-        self.side = [torch.cuda.Stream(self.device) for _ in range(self.n)] if self.n > 1 else []
+        self.side = [torch.cuda.Stream(self.device, priority=priority) for _ in range(self.n)] if self.n > 1 else []
         self._next = 0
         self._fresh = set(range(len(self.side)))
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VR_ABI_VERSION 5
+#define VR_ABI_VERSION 6
 
 typedef enum VrStatus {
     VR_OK = 0,
@@ -122,6 +122,14 @@ typedef struct VrInputs {
                                     model keeps _features_dc / _features_rest apart and concatenates them on every
                                     call (get_features, scene/gaussian_model.py:112-116); passing the two tensors as
                                     they are saves that 2 x 384 MB copy per view at 2 M Gaussians.  NULL = shs is whole. */
+    const float* shs_tail;       /* optional (ABI v6), SH TAIL: the SH rows of Gaussians tail_start .. P-1 live in this
+                                    second, whole [P - tail_start, M, 3] tensor; shs (/ shs_rest) then hold only the
+                                    first tail_start rows.  render_all / render_dyn put the dynamic instances' Gaussians
+                                    behind the static model's (merge_kwargs, gaussian_renderer/__init__.py:182-186): with
+                                    a tail the static model's SH tensors are read where they are instead of being
+                                    concatenated with a few thousand instance rows (2 x 0.96 GB of copies per view at
+                                    5 M Gaussians).  Needs M*3 % 4 == 0 and 16-byte aligned SH arrays.  NULL = no tail. */
+    int64_t tail_start;          /* first Gaussian whose SH row is in shs_tail (0 <= tail_start <= P); ignored without */
 } VrInputs;
 
 typedef struct VrOutputs {
@@ -185,7 +193,7 @@ typedef struct VrInGrads {
     float* dL_dscales;         /* [P,3] or NULL */
     float* dL_drotations;      /* [P,4] or NULL */
     float* dL_dcov3D_precomp;  /* [P,6] or NULL */
-    float* dL_dshs_rest;       /* [P,M-1,3], required when VrInputs.shs_rest is given */
+    float* dL_dshs_rest;       /* [P,M-1,3], required when VrInputs.shs_rest is given ([tail_start,M-1,3] with a tail) */
     float* dL_dcolors_sh;      /* optional (SH mode, ABI v4): FACTORED SH gradient.  dL/dshs of one view is a rank-1
                                   product per Gaussian, dL_dshs[i][k][c] = basis_k(dir_i) * g[i][c] with g = dL/d(colour)
                                   zeroed where the colour was clamped.  When this [P,3] array is given the library
@@ -193,6 +201,8 @@ typedef struct VrInGrads {
                                   dL_dshs_rest (they may be NULL): 12 instead of 192 bytes per Gaussian leave the
                                   kernel, and a multi-GPU job exchanges 3 instead of 48 floats per Gaussian and view
                                   (vegs_optim.h: vr_sh_grad_from_factors / vr_sh_adam_step rebuild or consume it). */
+    float* dL_dshs_tail;       /* [P - tail_start, M, 3], required when VrInputs.shs_tail is given (unless the factored
+                                  gradient is requested); dL_dshs / dL_dshs_rest then have tail_start rows */
 } VrInGrads;
 
 /* Work counters of the most recent vr_forward on this thread (roofline accounting). */

@@ -6,7 +6,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-PYTHONPATH=$root timeout 800 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python $root/profiles/tools/iteration_bench.py --iters 16 --only ${2:-C} > $root/gpurun_out/${tag}_iter.json 2> $out/err.log
+PYTHONPATH=$root timeout 800 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python $root/profiles/tools/iteration_bench.py --iters 16 --only ${2:-C} ${3:-} ${4:-} ${5:-} ${6:-} > $root/gpurun_out/${tag}_iter.json 2> $out/err.log
 cp $out/*/*kernel_stats.csv $root/gpurun_out/${tag}_kernel_stats.csv
 python - "$root/gpurun_out/${tag}_kernel_stats.csv" <<'PY'
 import csv, sys

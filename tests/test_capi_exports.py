@@ -35,11 +35,11 @@ def test_struct_layouts_match_header_sizes():
     from vegs_amd import _capi
     p = ctypes.sizeof(ctypes.c_void_p)
     assert ctypes.sizeof(_capi.VrSettings) == 8 * 4 + 4 * p + 8          # + uint32 flags, padded to pointer alignment
-    assert ctypes.sizeof(_capi.VrInputs) == 2 * 4 + 8 * p
+    assert ctypes.sizeof(_capi.VrInputs) == 2 * 4 + 9 * p + 8      # + shs_tail, tail_start (ABI v6)
     assert ctypes.sizeof(_capi.VrOutputs) == 6 * p
     assert ctypes.sizeof(_capi.VrSaved) == 4 * p + 3 * 8 + 8        # + uint64 ticket (ABI v5)
     assert ctypes.sizeof(_capi.VrOutGrads) == 5 * p
-    assert ctypes.sizeof(_capi.VrInGrads) == 10 * p
+    assert ctypes.sizeof(_capi.VrInGrads) == 11 * p               # + dL_dshs_tail (ABI v6)
     assert ctypes.sizeof(_capi.VrCounters) == 5 * 8
 
 

@@ -539,6 +539,99 @@ def test_split_sh_storage_equals_concatenated(P, M, deg, dev):
     assert not dc.grad.cpu().numpy()[culled].any() and not rest.grad.cpu().numpy()[culled].any()
 
 
+@pytest.mark.parametrize("P,P0,M,deg,split", [(3000, 2000, 16, 3, True), (3000, 1985, 16, 3, True), (3000, 1985, 16, 2, False),
+                                              (1000, 64, 4, 1, True), (1000, 937, 8, 1, False), (700, 1, 16, 3, True),
+                                              (700, 699, 16, 3, False), (700, 0, 16, 3, True), (700, 700, 16, 3, True)])
+def test_sh_tail_equals_concatenated(P, P0, M, deg, split, dev):
+    """ABI v6, `shs=(features_dc | whole, features_rest | None, tail)`: the SH rows of the Gaussians behind the first P0
+    come from a second whole tensor (the dynamic instances behind the static model, merge_kwargs
+    gaussian_renderer/__init__.py:182-186) -- with the boundary on a wave boundary, inside a wave, at the first / last row
+    and with an empty head / tail.  Images bit-identical to the concatenated call, every SH gradient equal to the slice of
+    its dL_dshs, exact zero rows for culled Gaussians; also with the factored SH gradient."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from vegs_amd import scenes
+    sc, _ = scenes.scene_random(P=P, sh_degree=3, seed=P + P0, scale=0.05)
+    cam = scenes.camera_c1(120, 72)
+    st = _settings(cam, [0.1, 0.2, 0.3], deg, 1.0, dev)
+    rng = np.random.default_rng(P0)
+    gouts = [torch.tensor(rng.normal(size=s).astype(np.float32), device=dev) for s in [(3, 72, 120), (4, 72, 120), (3, 72, 120)]]
+    shs = np.ascontiguousarray(sc["shs"][:, :M])
+
+    def run(parts, sink=False):
+        t = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in sc.items() if k != "shs"}
+        if parts:
+            tail = torch.tensor(shs[P0:].copy(), device=dev, requires_grad=True)
+            if split:
+                dc = torch.tensor(shs[:P0, :1].copy(), device=dev, requires_grad=True)
+                rest = torch.tensor(shs[:P0, 1:].copy(), device=dev, requires_grad=True)
+                sh_arg, leaves = (dc, rest, tail), (dc, rest, tail)
+            else:
+                whole = torch.tensor(shs[:P0].copy(), device=dev, requires_grad=True)
+                sh_arg, leaves = (whole, None, tail), (whole, tail)
+        else:
+            full = torch.tensor(shs, device=dev, requires_grad=True)
+            sh_arg, leaves = full, (full,)
+        m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
+        snk = torch.zeros(P, 3, device=dev, requires_grad=True) if sink else None
+        res = GaussianRasterizer(raster_settings=st)(means3D=t["means3D"], means2D=m2d, shs=sh_arg, opacities=t["opacities"],
+                                                    scales=t["scales"], rotations=t["rotations"],
+                                                    **({"sh_color_grad": snk} if sink else {}))
+        torch.autograd.backward([res[0], res[2], res[3]], gouts)
+        return res, t, leaves, snk
+
+    ra, ta, (full,), _ = run(False)
+    rb, tb, leaves, _ = run(True)
+    for a, b in zip(ra, rb):
+        assert torch.equal(a, b)
+    fg = full.grad.cpu().numpy()
+    culled = (rb[5] == 0).cpu().numpy()
+
+    def same(leaf, want, rows):
+        if want.size == 0:
+            assert leaf.grad is None or leaf.grad.numel() == 0
+            return
+        got = leaf.grad.cpu().numpy()
+        assert got.shape == want.shape
+        assert rel_err(got, want) < 1e-5
+        assert not got[culled[rows]].any()
+    if split:
+        same(leaves[0], fg[:P0, :1], slice(0, P0)); same(leaves[1], fg[:P0, 1:], slice(0, P0)); same(leaves[2], fg[P0:], slice(P0, P))
+    else:
+        same(leaves[0], fg[:P0], slice(0, P0)); same(leaves[1], fg[P0:], slice(P0, P))
+    for k in ("means3D", "opacities", "scales", "rotations"):
+        assert rel_err(tb[k].grad.cpu().numpy(), ta[k].grad.cpu().numpy()) < 1e-4, k
+    # factored SH gradient with a tail: the factor does not care where the rows live
+    _, _, _, s1 = run(False, sink=True)
+    rc, _, lv, s2 = run(True, sink=True)
+    assert torch.equal(rc[0], ra[0])
+    assert rel_err(s2.grad.cpu().numpy(), s1.grad.cpu().numpy()) < 1e-5
+    assert all(x.grad is None for x in lv)
+
+
+def test_sh_tail_argument_checks(dev):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from vegs_amd import scenes
+    sc, _ = scenes.scene_random(P=100, sh_degree=3, seed=3, scale=0.05)
+    st = _settings(scenes.camera_c1(64, 48), [0, 0, 0], 1, 1.0, dev)
+    t = {k: torch.tensor(v, device=dev) for k, v in sc.items()}
+    m2d = torch.zeros(100, 3, device=dev)
+
+    def call(shs):
+        return GaussianRasterizer(raster_settings=st)(means3D=t["means3D"], means2D=m2d, shs=shs, opacities=t["opacities"],
+                                                     scales=t["scales"], rotations=t["rotations"])
+    full = t["shs"]
+    with pytest.raises(ValueError):
+        call((full[:60], None, full[60:90]))                 # rows do not add up to P
+    with pytest.raises(ValueError):
+        call((full[:60], None, full[60:, :9].contiguous()))  # the tail holds fewer coefficients
+    with pytest.raises(ValueError):
+        call((full[:60, :9].contiguous(), None, full[60:, :9].contiguous()))   # 27 floats per row: not whole float4s
+    with pytest.raises(Exception):
+        call((full[:60], None, full[60:], full))             # four parts
+    ok = call((full[:60].contiguous(), None, full[60:].contiguous()))
+    assert torch.equal(ok[0], call(full)[0])
+
+
 def test_non_finite_inputs_do_not_crash_or_poison_the_frame(dev):
     """NaN / Inf / absurd values in 1 % of the Gaussians: the call returns, the list sizes stay sane and the other
     Gaussians still render (such splats are culled or clamped, as NaN comparisons fail)."""

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libvegsrast.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # VrSettings.flags (include/vegs_rast.h, VrFlags)
 FLAG_SCALE_MODIFIED, FLAG_DEPTH_NORMALIZED, FLAG_EXTRA_NO_ALPHA_GRAD, FLAG_FILL_EMPTY, FLAG_DETERMINISTIC = 1, 2, 4, 8, 256
@@ -40,7 +40,8 @@ class VrSettings(C.Structure):
 class VrInputs(C.Structure):
     _fields_ = [("P", C.c_int32), ("M", C.c_int32), ("means3D", C.c_void_p), ("shs", C.c_void_p),
                 ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
-                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("shs_rest", C.c_void_p)]
+                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("shs_rest", C.c_void_p),
+                ("shs_tail", C.c_void_p), ("tail_start", C.c_int64)]
 
 
 class VrOutputs(C.Structure):
@@ -63,7 +64,7 @@ class VrInGrads(C.Structure):
     _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
                 ("dL_dcolors_precomp", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
                 ("dL_drotations", C.c_void_p), ("dL_dcov3D_precomp", C.c_void_p), ("dL_dshs_rest", C.c_void_p),
-                ("dL_dcolors_sh", C.c_void_p)]
+                ("dL_dcolors_sh", C.c_void_p), ("dL_dshs_tail", C.c_void_p)]
 
 
 class VrAdamTensor(C.Structure):

@@ -234,8 +234,18 @@ static int check_inputs(const VrSettings* st, const VrInputs* in)
                             st->sh_degree, K);
             if (in->shs_rest && (in->M < 2 || in->M > 16))
                 return fail(VR_ERR_INVALID_ARGUMENT, "split SH storage needs 2..16 coefficients in total (got %d)", in->M);
-        } else if (in->shs_rest) {
-            return fail(VR_ERR_INVALID_ARGUMENT, "shs_rest given without shs (the DC coefficients)");
+            if (in->shs_tail) {
+                if (in->tail_start < 0 || in->tail_start > in->P)
+                    return fail(VR_ERR_INVALID_ARGUMENT, "tail_start must lie in [0, P] (got %lld, P = %d)",
+                                (long long)in->tail_start, in->P);
+                if ((in->M * 3) % 4 != 0 || in->M > 16 ||
+                    ((reinterpret_cast<uintptr_t>(in->shs) | reinterpret_cast<uintptr_t>(in->shs_rest) |
+                      reinterpret_cast<uintptr_t>(in->shs_tail)) & 15u))
+                    return fail(VR_ERR_INVALID_ARGUMENT,
+                                "an SH tail needs 4 | 3 M (M <= 16) and 16-byte aligned SH arrays (M = %d)", in->M);
+            }
+        } else if (in->shs_rest || in->shs_tail) {
+            return fail(VR_ERR_INVALID_ARGUMENT, "shs_rest / shs_tail given without shs");
         }
     }
     return 0;
@@ -350,7 +360,8 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     }
     if (P > 0) {
         prof_begin(VR_STAGE_PREPROCESS, s);
-        rc = launch_preprocess(cam, P, in->means3D, in->shs, in->shs_rest, in->colors_precomp, in->opacities, in->scales,
+        rc = launch_preprocess(cam, P, in->means3D, in->shs, in->shs_rest, in->shs_tail,
+                               in->shs_tail ? (int)in->tail_start : P, in->colors_precomp, in->opacities, in->scales,
                                in->rotations, in->cov3D_precomp, rec, out->radii, rect, depth_key,
                                (uint8_t*)geom + geom_clamp, (float*)((char*)geom + geom_shd), s, debug);
         prof_end(VR_STAGE_PREPROCESS, s);
@@ -450,6 +461,12 @@ static int backward_checks(const VrSettings* st, const VrInputs* in, const int32
         return fail(VR_ERR_INVALID_ARGUMENT, "a gradient array is missing for a provided input");
     if (!*sh_factored && in->shs_rest && (!gin->dL_dshs || !gin->dL_dshs_rest))
         return fail(VR_ERR_INVALID_ARGUMENT, "split SH storage needs both dL_dshs and dL_dshs_rest");
+    if (!*sh_factored && in->shs_tail) {
+        if (!gin->dL_dshs_tail) return fail(VR_ERR_INVALID_ARGUMENT, "an SH tail needs dL_dshs_tail");
+        if ((reinterpret_cast<uintptr_t>(gin->dL_dshs) | reinterpret_cast<uintptr_t>(gin->dL_dshs_rest) |
+             reinterpret_cast<uintptr_t>(gin->dL_dshs_tail)) & 15u)
+            return fail(VR_ERR_INVALID_ARGUMENT, "with an SH tail the SH gradient arrays must be 16-byte aligned");
+    }
     return VR_OK;
 }
 
@@ -479,6 +496,8 @@ static int backward_first(const Camera& cam, const VrSettings* st, const VrInput
         // nothing to clear: every row of the [P,3] factor array is written
     } else if (in->shs_rest) {
         // split SH storage: the kernel writes every row of both gradient arrays
+    } else if (in->shs_tail) {
+        // SH tail: validated for the staged paths, which write every row of all the SH gradient arrays
     } else if (gin->dL_dshs && !preprocess_bwd_writes_all_sh(in->M, in->shs, gin->dL_dshs)) {
         VR_HIP(hipMemsetAsync(gin->dL_dshs, 0, (size_t)P * in->M * 3 * sizeof(float), s));
     }
@@ -516,12 +535,12 @@ static int backward_second(const Camera& cam, const VrSettings* st, const VrInpu
 {
     const int P = in->P;
     ProfScope ps2(VR_STAGE_PREPROCESS_BWD, s);
-    return launch_preprocess_bwd(cam, P, in->means3D, in->shs, in->shs_rest, in->colors_precomp, in->scales, in->rotations,
-                                 in->cov3D_precomp, radii,
+    return launch_preprocess_bwd(cam, P, in->means3D, in->shs, in->shs_rest, in->shs_tail ? (int)in->tail_start : P,
+                                 in->colors_precomp, in->scales, in->rotations, in->cov3D_precomp, radii,
                                  (const uint8_t*)saved->geom + align_up((size_t)P * sizeof(Splat), 256),
                                  (const float*)((const char*)saved->geom + align_up((size_t)P * sizeof(Splat), 256) + align_up((size_t)P, 256)),
                                  gacc, gin->dL_dmeans2D, gin->dL_dmeans3D, gin->dL_dshs, gin->dL_dshs_rest,
-                                 gin->dL_dcolors_precomp, gin->dL_dopacities, gin->dL_dscales, gin->dL_drotations,
+                                 (in->shs_tail && !sh_factored) ? gin->dL_dshs_tail : nullptr, gin->dL_dcolors_precomp, gin->dL_dopacities, gin->dL_dscales, gin->dL_drotations,
                                  gin->dL_dcov3D_precomp, sh_factored ? gin->dL_dcolors_sh : nullptr, store_factor, s,
                                  st->debug != 0);
 }

@@ -39,7 +39,8 @@ __device__ __forceinline__ void sh_dot(const float* bas, int K, const float* sh,
 
 __global__ void __launch_bounds__(256)
 k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
-             const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+             const float* __restrict__ shs_rest, const float* __restrict__ shs_tail, int tail_start,
+             const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
              const float* __restrict__ scales, const float* __restrict__ rotations,
              const float* __restrict__ cov3D_precomp, Splat* __restrict__ rec, int* __restrict__ radii,
              uint2* __restrict__ rect, uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clampb,
@@ -112,8 +113,16 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
     } else if (__ballot(vis) != 0ull) {
         // stage this wave's 64 SH rows (contiguous in memory) through LDS, coalesced
         const int row = cam.M * 3;                             // floats per Gaussian
-        const bool staged = row <= SH_ROW_MAX && (row & 3) == 0 && (reinterpret_cast<size_t>(shs) & 15) == 0;
         const size_t wave_first = (size_t)(blockIdx.x * blockDim.x + w * 64);
+        // SH TAIL (VrInputs.shs_tail): rows tail_start.. live in a second, whole tensor.  A wave lies in the static part
+        // (paths as without a tail, its rows ending at tail_start), in the tail (the whole-tensor path on the tail), or --
+        // one wave of the launch at most -- across the boundary (every lane fetches its own row).
+        const bool in_tail = shs_tail && (long)wave_first >= (long)tail_start;
+        const bool straddle = shs_tail && !in_tail && (long)wave_first + 64 > (long)tail_start;
+        const int seg_end = in_tail || !shs_tail ? P : tail_start;     // end of the rows this wave's SH source holds
+        // whole-row source indexed by the Gaussian id (NULL: split storage)
+        const float* const whole = in_tail ? shs_tail - (size_t)tail_start * row : (shs_rest ? nullptr : shs);
+        const bool staged = row <= SH_ROW_MAX && (row & 3) == 0 && (reinterpret_cast<size_t>(whole) & 15) == 0;
         float acc[3] = {0.f, 0.f, 0.f};
         float bas[16], bx[16], by[16], bz[16];
         float D[9];            // d colour / d direction, kept for the backward (see sh_ddir9)
@@ -125,12 +134,28 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
             sh_basis(cam.deg, dx, dy, dz, bas);
             sh_basis_grad(cam.deg, dx, dy, dz, bx, by, bz);
         }
-        if (shs_rest) {
+        if (straddle) {
+            if (vis) {
+                float srow[SH_ROW_MAX];
+                // (constant trip counts + guards: srow must stay a register array)
+                const bool mine_tail = i >= tail_start;
+                const float* head = mine_tail ? shs_tail + (size_t)(i - tail_start) * row
+                                              : (shs_rest ? shs + 3 * (size_t)i : shs + (size_t)i * row);
+                const float* rest = (!mine_tail && shs_rest) ? shs_rest + (size_t)i * (row - 3) : head + 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) srow[c] = head[c];
+#pragma unroll
+                for (int k = 0; k < SH_ROW_MAX - 3; ++k)
+                    if (k < row - 3) srow[3 + k] = rest[k];
+                sh_dot(bas, K, srow, acc);
+                sh_ddir9(bx, by, bz, K, srow, D);
+            }
+        } else if (!whole) {
             // split storage (the model's own two tensors, no torch.cat): shs = [P,1,3] DC rows, shs_rest = [P,M-1,3].
             // The wave's 64 rest rows are one contiguous block: copied linearly into LDS, where the row stride is
             // the memory's own (45 floats at M = 16: odd, so the per-lane row reads are bank-conflict free).
             const int rowr = row - 3;
-            const int rows_here = min(64, P - (int)wave_first);
+            const int rows_here = min(64, seg_end - (int)wave_first);
             float srow[SH_ROW_MAX];
             if (vis) {      // DC row first: its loads are in flight together with the staging loads below
 #pragma unroll
@@ -148,8 +173,8 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
                 sh_ddir9(bx, by, bz, K, srow, D);
             }
         } else if (staged) {
-            const float* src = shs + wave_first * row;
-            const int rows_here = min(64, P - (int)wave_first);
+            const float* src = whole + wave_first * row;
+            const int rows_here = min(64, seg_end - (int)wave_first);
             const int nvec = rows_here * row / 4;               // float4s to move
             float4* dst4 = reinterpret_cast<float4*>(sh_lds[w]);
             const float4* src4 = reinterpret_cast<const float4*>(src);
@@ -185,8 +210,8 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
                 sh_ddir9(bx, by, bz, K, srow, D);
             }
         } else if (vis) {
-            sh_dot(bas, K, shs + (size_t)i * row, acc);        // unusual M / alignment: direct row reads
-            sh_ddir9(bx, by, bz, K, shs + (size_t)i * row, D);
+            sh_dot(bas, K, whole + (size_t)i * row, acc);      // unusual M / alignment: direct row reads
+            sh_ddir9(bx, by, bz, K, whole + (size_t)i * row, D);
         }
         {   // the wave's 64 D rows are one contiguous 2304-byte block: through LDS (row stride 9, odd), out as float4s
             const int rows_here = min(64, P - (int)wave_first);
@@ -240,14 +265,14 @@ k_mark_visible(const float* __restrict__ xyz, int P, const float* __restrict__ v
 }
 
 int launch_preprocess(const Camera& cam, int P, const float* means3D, const float* shs, const float* shs_rest,
-                      const float* colors_precomp,
+                      const float* shs_tail, int tail_start, const float* colors_precomp,
                       const float* opacities, const float* scales, const float* rotations,
                       const float* cov3D_precomp, Splat* rec, int* radii, uint2* rect,
                       uint32_t* depth_key, uint8_t* clampb, float* shd, hipStream_t s, bool debug)
 {
     if (P == 0) return 0;
-    hipLaunchKernelGGL(k_preprocess, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, means3D, shs, shs_rest,
-                       colors_precomp, opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, clampb, shd);
+    hipLaunchKernelGGL(k_preprocess, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, means3D, shs, shs_rest, shs_tail,
+                       tail_start, colors_precomp, opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, clampb, shd);
     VR_KERNEL_CHECK("preprocess", s, debug);
     return 0;
 }

@@ -72,8 +72,8 @@ __device__ __forceinline__ void sh_backward_factor(const Camera& cam, float px3,
 
 __global__ void __launch_bounds__(256)
 k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ means3D, const float* __restrict__ shs,
-                 const float* __restrict__ shs_rest, float* __restrict__ dL_dshs_rest,
-                 const float* __restrict__ colors_precomp, const float* __restrict__ scales,
+                 const float* __restrict__ shs_rest, float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dshs_tail,
+                 int tail_start, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
                  const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
                  const int* __restrict__ radii, const uint8_t* __restrict__ clampb, const float* __restrict__ shd,
                  const float* __restrict__ gacc,
@@ -110,14 +110,41 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
 #pragma unroll
             for (int c = 0; c < 3; ++c) dL_dcolors_sh[3 * (size_t)i + c] = gc[c];
         }
-    } else if (shs && shs_rest) {
+    } else if (shs && dL_dshs_tail && (long)(blockIdx.x * blockDim.x + w * 64) < (long)tail_start &&
+               (long)(blockIdx.x * blockDim.x + w * 64) + 64 > (long)tail_start) {
+        // SH TAIL (VrInputs.shs_tail), the one wave across the boundary: every lane writes its own row (zeros when
+        // culled) to wherever it lives -- the static model's dL_dshs (/ dL_dshs_rest) or the tail's gradient
+        if (in_range) {
+            const int row = cam.M * 3;
+            float srow[SH_ROW_MAX];
+#pragma unroll
+            for (int k = 0; k < SH_ROW_MAX; ++k) srow[k] = 0.0f;
+            if (vis) {
+                const float4 a1 = reinterpret_cast<const float4*>(gacc + (size_t)i * 16)[1];
+                const float px3 = means3D[3 * (size_t)i], py3 = means3D[3 * (size_t)i + 1], pz3 = means3D[3 * (size_t)i + 2];
+                float D[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) D[q] = shd[9 * (size_t)i + q];
+                sh_backward_row(cam, px3, py3, pz3, (uint32_t)clampb[i], a1.x, a1.y, a1.z, D, srow, dmean);
+            }
+            const bool mine_tail = i >= tail_start;
+            float* head = mine_tail ? dL_dshs_tail + (size_t)(i - tail_start) * row
+                                    : (shs_rest ? dL_dshs + 3 * (size_t)i : dL_dshs + (size_t)i * row);
+            float* rest = (!mine_tail && shs_rest) ? dL_dshs_rest + (size_t)i * (row - 3) : head + 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) head[c] = srow[c];
+#pragma unroll
+            for (int k = 0; k < SH_ROW_MAX - 3; ++k)
+                if (k < row - 3) rest[k] = srow[3 + k];
+        }
+    } else if (shs && shs_rest && !(dL_dshs_tail && (long)(blockIdx.x * blockDim.x + w * 64) >= (long)tail_start)) {
         // split storage: dL_dshs = [P,1,3] DC rows (written by their own lane: 12 contiguous bytes per lane),
         // dL_dshs_rest = [P,M-1,3]: every lane builds its gradient row in LDS (row stride = the memory's own, 45
         // floats at M = 16: odd, conflict-free) and the wave's 64 rows, one contiguous block, are copied out
         // linearly.  Every row of both gradients is written.
         const int rowr = cam.M * 3 - 3;
         const size_t wave_first = (size_t)(blockIdx.x * blockDim.x + w * 64);
-        const int rows_here = max(0, min(64, P - (int)wave_first));
+        const int rows_here = max(0, min(64, (dL_dshs_tail ? tail_start : P) - (int)wave_first));
         const bool any = __ballot(vis) != 0ull;
         float dc[3] = {0.f, 0.f, 0.f};
         if (any) {
@@ -144,10 +171,13 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
             for (int c = 0; c < 3; ++c) dL_dshs[3 * (size_t)i + c] = dc[c];
         }
         wave_copy_from_lds<SH_ROW_MAX / 4>(dL_dshs_rest + wave_first * rowr, sh_lds[w], rows_here * rowr, lane, !any);
-    } else if (shs && sh_staged) {
+    } else if (shs && (sh_staged || dL_dshs_tail)) {
+        // whole rows: the only SH tensor, the static part in front of a tail, or the tail itself (indexed by Gaussian id)
         const int row = cam.M * 3;
         const size_t wave_first = (size_t)(blockIdx.x * blockDim.x + w * 64);
-        const int rows_here = max(0, min(64, P - (int)wave_first));
+        const bool in_tail = dL_dshs_tail && (long)wave_first >= (long)tail_start;
+        float* const whole_out = in_tail ? dL_dshs_tail - (size_t)tail_start * row : dL_dshs;
+        const int rows_here = max(0, min(64, (in_tail || !dL_dshs_tail ? P : tail_start) - (int)wave_first));
         const int nvec = rows_here * row / 4;
         const int row4 = row >> 2;
         float4* lds4 = reinterpret_cast<float4*>(sh_lds[w]);
@@ -169,7 +199,7 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
             }
             __builtin_amdgcn_wave_barrier();
         }
-        float4* dst4 = reinterpret_cast<float4*>(dL_dshs + wave_first * row);
+        float4* dst4 = reinterpret_cast<float4*>(whole_out + wave_first * row);
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < SH_ROW_MAX / 4; ++j) {
@@ -340,16 +370,17 @@ bool preprocess_bwd_writes_all_sh(int M, const float* shs, const float* dL_dshs)
 }
 
 int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const float* shs, const float* shs_rest,
-                          const float* colors_precomp, const float* scales, const float* rotations,
+                          int tail_start, const float* colors_precomp, const float* scales, const float* rotations,
                           const float* cov3D_precomp, const int* radii, const uint8_t* clampb, const float* shd, const float* gacc,
-                          const float* gmean2D, float* dL_dmeans3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dcolors,
+                          const float* gmean2D, float* dL_dmeans3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dshs_tail,
+                          float* dL_dcolors,
                           float* dL_dopacities, float* dL_dscales, float* dL_drots, float* dL_dcov3D,
                           float* dL_dcolors_sh, bool store_factor, hipStream_t s, bool debug)
 {
     if (P == 0) return 0;
     const int sh_staged = preprocess_bwd_writes_all_sh(cam.M, shs, dL_dshs) ? 1 : 0;
     hipLaunchKernelGGL(k_preprocess_bwd, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, sh_staged, means3D, shs, shs_rest,
-                       dL_dshs_rest, colors_precomp, scales, rotations, cov3D_precomp, radii, clampb, shd, gacc, gmean2D, dL_dmeans3D,
+                       dL_dshs_rest, dL_dshs_tail, tail_start, colors_precomp, scales, rotations, cov3D_precomp, radii, clampb, shd, gacc, gmean2D, dL_dmeans3D,
                        dL_dshs, dL_dcolors,
                        dL_dopacities, dL_dscales, dL_drots, dL_dcov3D, dL_dcolors_sh, store_factor ? 1 : 0);
     VR_KERNEL_CHECK("preprocess_bwd", s, debug);

@@ -44,7 +44,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 // ---- preprocess.hip
 int launch_preprocess(const Camera& cam, int P, const float* means3D, const float* shs, const float* shs_rest,
-                      const float* colors_precomp,
+                      const float* shs_tail, int tail_start, const float* colors_precomp,
                       const float* opacities, const float* scales, const float* rotations,
                       const float* cov3D_precomp, Splat* rec, int* radii, uint2* rect,
                       uint32_t* depth_key, uint8_t* clampb, float* shd, hipStream_t s, bool debug);
@@ -129,9 +129,10 @@ int launch_count_blended(const Camera& cam, const int2* ranges, const uint32_t* 
 // ---- preprocess_bwd.hip
 bool preprocess_bwd_writes_all_sh(int M, const float* shs, const float* dL_dshs);
 int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const float* shs, const float* shs_rest,
-                          const float* colors_precomp, const float* scales, const float* rotations,
+                          int tail_start, const float* colors_precomp, const float* scales, const float* rotations,
                           const float* cov3D_precomp, const int* radii, const uint8_t* clampb, const float* shd, const float* gacc,
-                          const float* gmean2D, float* dL_dmeans3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dcolors,
+                          const float* gmean2D, float* dL_dmeans3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dshs_tail,
+                          float* dL_dcolors,
                           float* dL_dopacities, float* dL_dscales, float* dL_drots, float* dL_dcov3D,
                           float* dL_dcolors_sh, bool store_factor, hipStream_t s, bool debug);
 int launch_sh_factor(int P, const int* radii, const uint8_t* clampb, const float* gacc, float* dL_dcolors_sh,

@@ -105,7 +105,24 @@ def prepare_and_merge(static, boxes, box2worlds):
         flat += [t["means3D"], t["scales"], t["rotations"], b]
     means, scales, rotations = _TransformConcat.apply(*flat)
     cat = (lambda k: models[0][0][k]) if len(models) == 1 else (lambda k: torch.cat([t[k] for t, _ in models], 0))
-    return {"means3D": means, "shs": cat("shs"), "opacities": cat("opacities"), "scales": scales, "rotations": rotations}
+    # SH: the instances' rows go behind the static model's as an SH TAIL (the rasterizer reads the static model's tensor(s)
+    # where they are: whole [P0,M,3] or the pair (features_dc, features_rest)); merge_kwargs' torch.cat would copy the whole
+    # static model to append a few thousand rows -- 2 x 0.96 GB per view at 5 M Gaussians, forward and backward
+    if static is not None and boxes:
+        head = static["shs"]
+        dc, rest = head if isinstance(head, (tuple, list)) else (head, None)
+        M = dc.shape[1] + (rest.shape[1] if rest is not None else 0)
+        tail = torch.cat([b["shs"] for b in boxes], 0) if len(boxes) > 1 else boxes[0]["shs"]
+        if (3 * M) % 4 == 0 and M <= 16 and tail.shape[1] == M:
+            shs = (dc, rest, tail)
+        else:   # the kernels' tail path needs whole float4 rows: fall back to one concatenated tensor
+            whole = dc if rest is None else torch.cat((dc, rest), 1)
+            shs = torch.cat((whole, tail), 0)
+    else:
+        shs = cat("shs")
+        if isinstance(models[0][0]["shs"], (tuple, list)) and len(models) > 1:
+            raise ValueError("split SH storage is supported for the static model only")
+    return {"means3D": means, "shs": shs, "opacities": cat("opacities"), "scales": scales, "rotations": rotations}
 
 
 class _Activate(torch.autograd.Function):

@@ -76,7 +76,8 @@ def render_model(p, boxes, cam, cam_t, deg, bg, fused, sh_sink=None):
         # fused: the model's two SH tensors as they are (no torch.cat, no slicing copies in the backward)
         t["shs"] = (p["f_dc"], p["f_rest"]) if fused else torch.cat((p["f_dc"], p["f_rest"]), dim=1)
         return harness.render(cam, t, deg, bg, cam_t=cam_t, sh_color_grad=sh_sink)
-    t["shs"] = torch.cat((p["f_dc"], p["f_rest"]), dim=1)
+    # fused: the model's two SH tensors as they are; prepare_and_merge hands the instances' rows over as an SH tail
+    t["shs"] = (p["f_dc"], p["f_rest"]) if fused else torch.cat((p["f_dc"], p["f_rest"]), dim=1)
     return harness.render_all(cam, t, [b for b, _ in boxes], [w for _, w in boxes], deg, bg, cam_t=cam_t, fused=fused)
 
 

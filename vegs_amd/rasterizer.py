@@ -102,11 +102,12 @@ def _settings_struct(rs, device, keep, flag_bits=0):
                             int(flag_bits))
 
 
-def _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, sh_rest=None):
+def _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, sh_rest=None, sh_tail=None):
     P = means3D.shape[0]
     M = (sh.shape[1] if sh is not None else 0) + (sh_rest.shape[1] if sh_rest is not None else 0)
     return _capi.VrInputs(P, M, _capi.ptr(means3D), _capi.ptr(sh), _capi.ptr(colors_precomp), _capi.ptr(opacities),
-                          _capi.ptr(scales), _capi.ptr(rotations), _capi.ptr(cov3Ds_precomp), _capi.ptr(sh_rest))
+                          _capi.ptr(scales), _capi.ptr(rotations), _capi.ptr(cov3Ds_precomp), _capi.ptr(sh_rest),
+                          _capi.ptr(sh_tail), sh.shape[0] if sh_tail is not None else 0)
 
 
 def _cpu_args_copy(args):
@@ -156,7 +157,7 @@ def set_backward_split_hook(fn):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, sh_rest=None, sh_color_grad=None):
+                raster_settings, sh_rest=None, sh_color_grad=None, sh_tail=None):
         lib = _capi.load()
         rs = raster_settings
         if means3D.dim() != 2 or means3D.shape[1] != 3:
@@ -173,12 +174,26 @@ class _RasterizeGaussians(torch.autograd.Function):
         rotations = _prep(rotations, "rotations", device)
         cov3Ds_precomp = _prep(cov3Ds_precomp, "cov3D_precomp", device)
         sh_rest = _prep(sh_rest, "shs[1] (features_rest)", device)
+        sh_tail = _prep(sh_tail, "shs[2] (SH tail)", device)
+        # SH tail: the rows of the last Gaussians live in a second whole tensor (the instances behind the static model)
+        P0 = P
+        ctx.tail_is_whole = False
+        if sh_tail is not None and sh is None:       # nothing in front of the tail (an empty head was dropped by _prep):
+            sh, sh_rest, sh_tail = sh_tail, None, None   # it is simply the whole tensor; its gradient goes back as the tail's
+            ctx.tail_is_whole = True
+        if sh_tail is not None:                      # (an empty tail was dropped by _prep as well)
+            if sh.dim() != 3 or sh_tail.dim() != 3 or sh_tail.shape[2] != 3 or sh.shape[0] + sh_tail.shape[0] != P:
+                raise ValueError("an SH tail needs shs [P0,.,3] and the tail [P - P0, M, 3]")
+            P0 = sh.shape[0]
+            M_all = sh.shape[1] + (sh_rest.shape[1] if sh_rest is not None else 0)
+            if sh_tail.shape[1] != M_all or (3 * M_all) % 4 != 0 or M_all > 16:
+                raise ValueError("the SH tail must hold the same number of coefficients (a multiple of 4, at most 16)")
         if sh_rest is not None:
             # split SH storage: shs = (features_dc [P,1,3], features_rest [P,M-1,3]) as the model keeps them
-            if sh is None or sh.dim() != 3 or sh.shape[1] != 1 or sh_rest.dim() != 3 or sh_rest.shape[0] != P \
+            if sh is None or sh.dim() != 3 or sh.shape[1] != 1 or sh_rest.dim() != 3 or sh_rest.shape[0] != P0 \
                     or sh_rest.shape[2] != 3:
                 raise ValueError("split shs must be (features_dc [P,1,3], features_rest [P,M-1,3])")
-        for t, name, shape in ((sh, "shs", (P, None, 3)), (colors_precomp, "colors_precomp", (P, 3)),
+        for t, name, shape in ((sh, "shs", (P0, None, 3)), (colors_precomp, "colors_precomp", (P, 3)),
                                (opacities, "opacities", None), (scales, "scales", (P, 3)),
                                (rotations, "rotations", (P, 4)), (cov3Ds_precomp, "cov3D_precomp", (P, 6))):
             if t is None:
@@ -193,7 +208,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         flag_bits = _flags
         with torch.cuda.device(device):
             st = _settings_struct(rs, device, keep, flag_bits)
-            inp = _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, sh_rest)
+            inp = _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, sh_rest, sh_tail)
             # one [12,H,W] block: colour(3) depth(1) quat(4) scale(3) alpha(1) -- sliced into the 5 outputs
             img = torch.empty((12, H, W), dtype=torch.float32, device=device)
             color, depth, cov_quat, cov_scale, alpha = img[0:3], img[3:4], img[4:8], img[8:11], img[11:12]
@@ -248,7 +263,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         if sh_color_grad is not None and (sh is None or tuple(sh_color_grad.shape) != (P, 3)):
             raise ValueError("sh_color_grad needs shs and must be a [P,3] tensor")
         ctx.sh_factored = sh_color_grad is not None
-        ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, sh_rest)
+        ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, sh_rest,
+                              sh_tail)
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)   # unused outputs arrive as None -> NULL, no zero tensors
         return color, depth, cov_quat, cov_scale, alpha, radii
@@ -257,7 +273,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, g_color, g_depth, g_quat, g_scale, g_alpha, _g_radii):
         lib = _capi.load()
         rs = ctx.raster_settings
-        means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, sh_rest = ctx.saved_tensors
+        means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, sh_rest, sh_tail = ctx.saved_tensors
         geom, binning, image = ctx.buffers
         device = means3D.device
         P = means3D.shape[0]
@@ -268,7 +284,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         g_color, g_depth, g_quat, g_scale, g_alpha = g(g_color), g(g_depth), g(g_quat), g(g_scale), g(g_alpha)
         with torch.cuda.device(device):
             st = _settings_struct(rs, device, keep, ctx.flag_bits)
-            inp = _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, sh_rest)
+            inp = _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, sh_rest, sh_tail)
             d_means3D = torch.empty_like(means3D)
             d_means2D = torch.empty((P, 3), dtype=torch.float32, device=device)
             d_opac = torch.empty_like(opacities) if opacities is not None else None
@@ -278,6 +294,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_sink = torch.empty((P, 3), dtype=torch.float32, device=device) if factored else None
             d_sh = torch.empty_like(sh) if sh is not None and not factored else None
             d_sh_rest = torch.empty_like(sh_rest) if sh_rest is not None and not factored else None
+            d_sh_tail = torch.empty_like(sh_tail) if sh_tail is not None and not factored else None
             d_col = torch.empty_like(colors_precomp) if colors_precomp is not None else None
             d_scales = torch.empty_like(scales) if scales is not None else None
             d_rot = torch.empty_like(rotations) if rotations is not None else None
@@ -286,7 +303,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                     _capi.ptr(g_alpha))
             gin = _capi.VrInGrads(_capi.ptr(d_means3D), _capi.ptr(d_means2D), _capi.ptr(d_sh), _capi.ptr(d_col),
                                   _capi.ptr(d_opac), _capi.ptr(d_scales), _capi.ptr(d_rot), _capi.ptr(d_cov),
-                                  _capi.ptr(d_sh_rest), _capi.ptr(d_sink))
+                                  _capi.ptr(d_sh_rest), _capi.ptr(d_sink), _capi.ptr(d_sh_tail))
             saved = _capi.VrSaved(geom.data_ptr(), binning.data_ptr(), image.data_ptr(), ctx.num_rendered,
                                   ctx.num_visible, ctx.binning_capacity, None, ctx.ticket)
             arena = _capi.Arena(device)
@@ -316,13 +333,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                     raise arena.error
                 _capi.check(rc)
         # input order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings
-        return d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, d_sh_rest, d_sink
+        if ctx.tail_is_whole:        # the tail stood in for the whole tensor (empty head): its gradient goes back as the tail's
+            d_sh, d_sh_tail = None, d_sh
+        return d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, d_sh_rest, d_sink, d_sh_tail
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, sh_rest=None, sh_color_grad=None):
+                        raster_settings, sh_rest=None, sh_color_grad=None, sh_tail=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, sh_rest, sh_color_grad)
+                                     cov3Ds_precomp, raster_settings, sh_rest, sh_color_grad, sh_tail)
 
 
 class GaussianRasterizer(nn.Module):
@@ -365,11 +384,18 @@ class GaussianRasterizer(nn.Module):
         # Extension: shs may be the PAIR (features_dc [P,1,3], features_rest [P,M-1,3]) the reference's model stores
         # (scene/gaussian_model.py:112-116 concatenates them on every call); the kernels then read the two tensors
         # in place and return their gradients separately -- no torch.cat, no slicing copies.
-        sh_rest = None
+        # A THIRD element is the SH TAIL: the whole [P - P0, M, 3] tensor of the Gaussians behind the first P0 (the
+        # dynamic instances that render_all / render_dyn put behind the static model, merge_kwargs :182-186) -- the static
+        # model's tensors are then read where they are instead of being concatenated with a few thousand instance rows;
+        # (whole [P0,M,3], None, tail) is accepted as well.
+        sh_rest, sh_tail = None, None
         if isinstance(shs, (tuple, list)):
-            if len(shs) != 2:
-                raise Exception("split shs must be the pair (features_dc, features_rest)")
-            shs, sh_rest = shs
+            if len(shs) == 3:
+                shs, sh_rest, sh_tail = shs
+            elif len(shs) == 2:
+                shs, sh_rest = shs
+            else:
+                raise Exception("split shs must be (features_dc, features_rest) or (features_dc, features_rest, tail)")
             if sh_rest is not None and sh_rest.shape[1] == 0:
                 sh_rest = None
         empty = torch.Tensor([])
@@ -379,4 +405,4 @@ class GaussianRasterizer(nn.Module):
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, rs, sh_rest, sh_color_grad)
+                                   cov3D_precomp, rs, sh_rest, sh_color_grad, sh_tail)

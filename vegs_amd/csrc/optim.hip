@@ -55,10 +55,10 @@ __global__ void __launch_bounds__(256) k_adam(AdamArgs a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const long o = base / 4 + j * 256 + threadIdx.x;
-            p[j] = reinterpret_cast<const float4*>(s.p)[o];
+            p[j] = nt_load4(reinterpret_cast<const float4*>(s.p) + o);
             g[j] = nt_load4(reinterpret_cast<const float4*>(s.g) + o);
-            m[j] = reinterpret_cast<const float4*>(s.m)[o];
-            v[j] = reinterpret_cast<const float4*>(s.v)[o];
+            m[j] = nt_load4(reinterpret_cast<const float4*>(s.m) + o);
+            v[j] = nt_load4(reinterpret_cast<const float4*>(s.v) + o);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -67,9 +67,9 @@ __global__ void __launch_bounds__(256) k_adam(AdamArgs a)
             adam_elem(p[j].z, g[j].z, m[j].z, v[j].z, s, a);
             adam_elem(p[j].w, g[j].w, m[j].w, v[j].w, s, a);
             const long o = base / 4 + j * 256 + threadIdx.x;
-            reinterpret_cast<float4*>(s.p)[o] = p[j];
-            reinterpret_cast<float4*>(s.m)[o] = m[j];
-            reinterpret_cast<float4*>(s.v)[o] = v[j];
+            nt_store4(p[j], reinterpret_cast<float4*>(s.p) + o);
+            nt_store4(m[j], reinterpret_cast<float4*>(s.m) + o);
+            nt_store4(v[j], reinterpret_cast<float4*>(s.v) + o);
         }
     } else {
         for (long o = base + threadIdx.x; o < base + ADAM_EPB && o < s.n; o += 256) {
@@ -153,7 +153,7 @@ __device__ __forceinline__ void sh_walk(const ShFactorArgs& a, const ShAdamSeg& 
                 float4* pp = reinterpret_cast<float4*>(s.p + base) + q;
                 float4* pm = reinterpret_cast<float4*>(s.m + base) + q;
                 float4* pv = reinterpret_cast<float4*>(s.v + base) + q;
-                const float4 p4 = *pp, m4 = *pm, v4 = *pv;
+                const float4 p4 = nt_load4(pp), m4 = nt_load4(pm), v4 = nt_load4(pv);   // streamed once per step
                 float p[4] = {p4.x, p4.y, p4.z, p4.w}, m[4] = {m4.x, m4.y, m4.z, m4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -162,9 +162,9 @@ __device__ __forceinline__ void sh_walk(const ShFactorArgs& a, const ShAdamSeg& 
                     const float denom = sqrtf(v[c]) * s.inv_bc2_sqrt + a.eps;
                     p[c] = p[c] - s.step_size * (m[c] / denom);
                 }
-                *pp = make_float4(p[0], p[1], p[2], p[3]);
-                *pm = make_float4(m[0], m[1], m[2], m[3]);
-                *pv = make_float4(v[0], v[1], v[2], v[3]);
+                nt_store4(make_float4(p[0], p[1], p[2], p[3]), pp);
+                nt_store4(make_float4(m[0], m[1], m[2], m[3]), pm);
+                nt_store4(make_float4(v[0], v[1], v[2], v[3]), pv);
             } else {
                 reinterpret_cast<float4*>(s.out + base)[q] = make_float4(g[0], g[1], g[2], g[3]);
             }

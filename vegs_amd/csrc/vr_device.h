@@ -233,28 +233,6 @@ __device__ __forceinline__ uint32_t strips_relevant_exact(float sx, float sy, fl
     return bits;
 }
 
-// The same one level down: relevance for the four 4x4-pixel QUADRANTS of an 8x8 region whose first pixel centre is
-// (x0, y0) (bit q = quadrant q: x half = q & 1, y half = q >> 1).  An entry that passed the region test may still
-// fail all four (its ellipse slips between pixel centres): it then contributes nothing to the region.
-constexpr int QUAD = 4;
-__device__ __forceinline__ uint32_t quads_relevant(float sx, float sy, float A, float B, float C, float thr, float x0,
-                                                   float y0)
-{
-    const float k = -2.0f * thr;
-    if (!(k > 0.0f)) return 0u;
-    if (!(A > 0.0f) || !(C > 0.0f) || !(A * C - B * B > 0.0f)) return 0xFu;
-    const float lim = k * 1.001f + 0.001f;
-    const float inv_A = __builtin_amdgcn_rcpf(A), inv_C = __builtin_amdgcn_rcpf(C);
-    uint32_t bits = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float xl = x0 + (float)((q & 1) * QUAD) - sx, xh = xl + (float)(QUAD - 1);
-        const float yl = y0 + (float)((q >> 1) * QUAD) - sy, yh = yl + (float)(QUAD - 1);
-        bits |= rect_relevant(A, inv_A, B, C, inv_C, lim, xl, xh, yl, yh) ? (1u << q) : 0u;
-    }
-    return bits;
-}
-
 // The Gaussian exponent at a pixel in units of log2 e:  power2 = log2(e) (-1/2 (A dx^2 + C dy^2) - B dx dy)
 //   = ((kA dx) dx + (kC dy) dy) + (kB dx) dy,   kA = (-1/2 log2 e) A, kB = -(log2 e) B, kC = (-1/2 log2 e) C
 // (splat_k2: rounded once per splat, where the record is staged; thr2 = thr log2 e is the pre-filter threshold in the

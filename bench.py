@@ -38,6 +38,8 @@ def build_workload(args):
     else:  # c2
         P, length, seed = args.gaussians or 500_000, 120.0, 1
     sc, deg = scenes.scene_street(P=P, length=length, sh_degree=3, seed=seed)
+    if getattr(args, "disc_scale", 1.0) != 1.0:      # (profiling aid: the "dense" variant's scene as the main workload)
+        sc["scales"] = (sc["scales"] * args.disc_scale).astype(np.float32)
     cams = []
     n_stations = 8
     for s in range(n_stations):               # stations every 10 m, stereo pair (baseline 0.6 m)
@@ -377,6 +379,8 @@ def main():
                     help="per-camera needed-segment hints in the HEADLINE: off (default: every view costs what a camera's "
                          "first visit costs -- a number any training loop meets) or warm (zero model drift: the best case)")
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--disc-scale", type=float, default=1.0,
+                    help="multiply every Gaussian's scales (3.0 = the 'dense' variant's scene); a profiling aid, changes the workload")
     ap.add_argument("--streams", type=int, default=1,
                     help="with --views-per-step > 1: HIP streams the views of a step alternate between (2 = two views in flight)")
     ap.add_argument("--views-per-step", type=int, default=1,
@@ -479,6 +483,7 @@ def main():
         "exchange": exchange,
         "config": {"workload": f"{args.workload}: {P} street Gaussians (VEGS disc init), SH deg {deg}, {W}x{H} "
                                f"KITTI-360 intrinsics, {n_views} views cycled, 12 output channels + colour/quat/scale grads; "
+                               + (f"EVERY DISC x{args.disc_scale} (--disc-scale: not the headline workload); " if args.disc_scale != 1.0 else "")
                                + ("per-camera needed-segment hints OFF: every view is rendered as a camera's first visit"
                                   if args.hints == "off" else
                                   "per-camera needed-segment hints WARM with zero model drift (best case; see variants)"),

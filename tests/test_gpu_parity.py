@@ -539,6 +539,57 @@ def test_split_sh_storage_equals_concatenated(P, M, deg, dev):
     assert not dc.grad.cpu().numpy()[culled].any() and not rest.grad.cpu().numpy()[culled].any()
 
 
+def test_segment_rounds_never_change_results(dev):
+    """VR_FLAG_ROUNDS_ON / _OFF and the default (chosen from the list density): the forward evaluates a tile's list
+    segments all at once or in three rounds (6, then 18 more for tiles with a live pixel left, then the rest).  A dense,
+    fairly opaque scene (the default picks rounds) and a sparse one (it does not): images, lists and needed-segment
+    counts bit-identical to the oracle and to each other in all three settings, and so are the gradients of the
+    deterministic backward."""
+    from oracle import oracle as orc
+    from vegs_amd import rasterizer, scenes
+    cam = scenes.kitti_camera(0.0, 0.0, 688, 188)
+    H, W = 188, 688
+    rng = np.random.default_rng(8)
+    gouts = [rng.normal(size=s).astype(np.float32) for s in [(3, H, W), (1, H, W), (4, H, W), (3, H, W), (1, H, W)]]
+    for P, opac, disc, expect_rounds in ((500000, 3.0, 2.5, True), (20000, 1.0, 1.0, False)):
+        sc, deg = scenes.scene_street(P=P, length=25.0, sh_degree=1, seed=23)
+        sc["opacities"] = np.clip(sc["opacities"] * opac, 0.0, 0.95).astype(np.float32)
+        sc["scales"] = (sc["scales"] * disc).astype(np.float32)
+        inputs = dict(means3D=sc["means3D"], shs=sc["shs"], colors_precomp=None, opacities=sc["opacities"], scales=sc["scales"],
+                      rotations=sc["rotations"], cov3D_precomp=None)
+        st = _settings(cam, [0, 0, 0], deg, 1.0, dev)
+        o_out, ost = orc.forward(oracle_cam(cam, [0, 0, 0], deg), **inputs)
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        assert (ost["R"] // 256 >= 12 * T) == expect_rounds, (ost["R"], T)   # which side of the default's threshold the scene is on
+        runs = {}
+        for name, fl in (("default", 0), ("on", rasterizer.FLAG_ROUNDS_ON), ("off", rasterizer.FLAG_ROUNDS_OFF)):
+            old = rasterizer.needed_hints(False)         # (a hint implies rounds: keep the operator's hint cache out of this)
+            try:
+                h_out, h_grads, res = _run_hip(st, inputs, dev, gouts, flags=fl | rasterizer.FLAG_DETERMINISTIC)
+            finally:
+                rasterizer.needed_hints(old)
+            pl, rg = _export_binning(res, H, W, dev)
+            need = torch.zeros(T, dtype=torch.int32, device=dev)
+            saved = _capi_saved(res)
+            from vegs_amd import _capi
+            _capi.check(_capi.load().vr_export_needed(C.byref(saved), H, W, need.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+            runs[name] = (h_out, h_grads, pl, rg, need.cpu().numpy())
+            assert np.array_equal(pl, ost["point_list"]) and np.array_equal(rg, ost["ranges"])
+            for n in OUT_NAMES:
+                assert np.array_equal(h_out[n], o_out[n]), (name, n)
+        for name in ("on", "off"):
+            assert np.array_equal(runs[name][4], runs["default"][4]), name      # needed segments per tile
+            for k, g in runs[name][1].items():        # deterministic backward: the same fragments in the same order
+                if g is not None:
+                    assert np.array_equal(g, runs["default"][1][k]), (name, k)
+        assert int(runs["default"][4].max()) >= (7 if expect_rounds else 1)
+
+
+def _capi_saved(res):
+    from vegs_amd import _capi
+    return _capi.saved_of(res[0].grad_fn)
+
+
 @pytest.mark.parametrize("P,P0,M,deg,split", [(3000, 2000, 16, 3, True), (3000, 1985, 16, 3, True), (3000, 1985, 16, 2, False),
                                               (1000, 64, 4, 1, True), (1000, 937, 8, 1, False), (700, 1, 16, 3, True),
                                               (700, 699, 16, 3, False), (700, 0, 16, 3, True), (700, 700, 16, 3, True)])

@@ -17,9 +17,10 @@ namespace vr {
 
 static_assert(FLAG_SCALE_MODIFIED == VR_FLAG_SCALE_MODIFIED && FLAG_DEPTH_NORMALIZED == VR_FLAG_DEPTH_NORMALIZED &&
               FLAG_EXTRA_NO_ALPHA_GRAD == VR_FLAG_EXTRA_NO_ALPHA_GRAD && FLAG_FILL_EMPTY == VR_FLAG_FILL_EMPTY &&
-              FLAG_DETERMINISTIC == VR_FLAG_DETERMINISTIC && FLAG_SCAN_BINNING == VR_FLAG_SCAN_BINNING, "device-side flag constants must match include/vegs_rast.h");
+              FLAG_DETERMINISTIC == VR_FLAG_DETERMINISTIC && FLAG_SCAN_BINNING == VR_FLAG_SCAN_BINNING &&
+              FLAG_ROUNDS_OFF == VR_FLAG_ROUNDS_OFF && FLAG_ROUNDS_ON == VR_FLAG_ROUNDS_ON, "device-side flag constants must match include/vegs_rast.h");
 constexpr uint32_t KNOWN_FLAGS = FLAG_SCALE_MODIFIED | FLAG_DEPTH_NORMALIZED | FLAG_EXTRA_NO_ALPHA_GRAD | FLAG_FILL_EMPTY |
-                                 FLAG_DETERMINISTIC | FLAG_SCAN_BINNING;
+                                 FLAG_DETERMINISTIC | FLAG_SCAN_BINNING | FLAG_ROUNDS_OFF | FLAG_ROUNDS_ON;
 
 static thread_local char g_err[512] = "";
 static thread_local VrCounters g_counters = {0, 0, 0, 0, 0};
@@ -272,7 +273,7 @@ static BinLayout bin_layout(size_t T, size_t R)
     BinLayout L;
     L.ranges = 0;
     L.seg_off = align_up(T * 8, 256);
-    L.seg_needed = L.seg_off + align_up(((size_t)seg_tile_offset((int)T) + 4 * seg_capacity((long)R, (int)T)) * 4, 256);
+    L.seg_needed = L.seg_off + align_up(seg_table_words((int)T, seg_capacity((long)R, (int)T)) * 4, 256);
     L.point_list = L.seg_needed + align_up(T * 4, 256);
     L.tbuf = L.point_list + align_up((R > 0 ? R : 1) * 4, 256);
     L.part = L.tbuf + align_up(seg_capacity((long)R, (int)T) * 256 * sizeof(float), 256);

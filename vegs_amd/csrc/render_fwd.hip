@@ -28,6 +28,8 @@
 namespace vr {
 
 __device__ __forceinline__ uint32_t hinted_limit(uint32_t h) { return h + 2u + (h >> 3); }
+constexpr uint32_t AUTO_FIRST = 6u;    // segments of every tile computed in round 0 of a forward with automatic rounds
+constexpr uint32_t AUTO_DENSITY = 12u; // ... which are used from this many list segments per tile on (launch_render_fwd)
 
 // seg_off[t] = first global segment id of tile t; seg_off[T] = total.  Single workgroup.  (k_seg_tiles then
 // fills seg_tile[s] = tile of segment s, 0xFFFFFFFF beyond the total: the launch grids cover `cap` segments.)
@@ -38,39 +40,50 @@ __device__ __forceinline__ uint32_t hinted_limit(uint32_t h) { return h + 2u + (
 constexpr int SEGOFF_THREADS = 1024;
 __global__ void __launch_bounds__(SEGOFF_THREADS)
 k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict__ seg_off,
-              const uint32_t* __restrict__ hint, uint32_t* __restrict__ limit)
+              const uint32_t* __restrict__ hint, uint32_t* __restrict__ limit, uint32_t cap, uint32_t auto_first)
 {
     constexpr int NW = SEGOFF_THREADS / 64;
-    __shared__ uint32_t wsum[NW];
-    __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
+    __shared__ uint32_t wsum[NW], wsum_a[NW];
+    __shared__ uint32_t carry_s, carry_a;
+    uint32_t* const counts = seg_off + seg_counts_offset(ntiles, cap);
+    uint32_t* const act_off = seg_off + seg_actoff_offset(ntiles, cap);
+    if (threadIdx.x == 0) { carry_s = 0; carry_a = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int base = 0; base < ntiles; base += SEGOFF_THREADS) {
         const int t = base + threadIdx.x;
-        uint32_t n = 0;
+        uint32_t n = 0, a = 0;
         if (t < ntiles) {
             const int2 r = ranges[t];
             n = (uint32_t)((r.y - r.x + SEG - 1) / SEG);
-            limit[t] = hint ? min(n, hinted_limit(min(hint[t], 0x3FFFFFFFu))) : n;
+            // no hint: the first AUTO_FIRST segments of every tile up front, the rest in the catch-up rounds if any pixel
+            // is still alive behind them (k_seg_scan) -- most tiles never need more
+            a = hint ? min(n, hinted_limit(min(hint[t], 0x3FFFFFFFu))) : min(n, auto_first);
+            limit[t] = a;
         }
-        uint32_t incl = n;
+        uint32_t incl = n, incl_a = a;      // two scans: all segments (global ids), round-0 segments (list positions)
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            uint32_t o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
+            const uint32_t o = __shfl_up(incl, d, 64), oa = __shfl_up(incl_a, d, 64);
+            if (lane >= d) { incl += o; incl_a += oa; }
         }
-        if (lane == 63) wsum[w] = incl;
+        if (lane == 63) { wsum[w] = incl; wsum_a[w] = incl_a; }
         __syncthreads();
-        uint32_t woff = 0;
-        for (int k = 0; k < w; ++k) woff += wsum[k];
-        const uint32_t carry = carry_s;
-        if (t < ntiles) seg_off[t] = carry + woff + incl - n;
+        uint32_t woff = 0, woff_a = 0;
+        for (int k = 0; k < w; ++k) { woff += wsum[k]; woff_a += wsum_a[k]; }
+        const uint32_t carry = carry_s, ca = carry_a;
+        if (t < ntiles) { seg_off[t] = carry + woff + incl - n; act_off[t] = ca + woff_a + incl_a - a; }
         __syncthreads();
-        if (threadIdx.x == SEGOFF_THREADS - 1) carry_s = carry + woff + incl;
+        if (threadIdx.x == SEGOFF_THREADS - 1) { carry_s = carry + woff + incl; carry_a = ca + woff_a + incl_a; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) seg_off[ntiles] = carry_s;
+    if (threadIdx.x == 0) {
+        seg_off[ntiles] = carry_s;
+        act_off[ntiles] = carry_a;
+        counts[0] = carry_a;          // entries of the round-0 list; the catch-up lists start empty
+        counts[1] = 0;
+        counts[2] = 0;
+    }
 }
 
 // segment table entries (vr_segment.h): one thread per segment of the launch grid
@@ -90,8 +103,10 @@ k_seg_tiles(int ntiles, const int2* __restrict__ ranges, uint32_t* __restrict__ 
     const int sl = (int)(b - seg_off[lo]);
     const int2 r = ranges[lo];
     const int first = r.x + sl * SEG;
-    // flag 3 = behind the hinted prefix of its tile: k_seg_alpha skips it, k_seg_scan decides (and rewrites the flag)
-    seg_info[b] = make_int4(lo, first, min(SEG, r.y - first), sl | ((uint32_t)sl >= limit[lo] ? (int)(3u << 30) : 0));
+    // flag 3 = behind the round-0 prefix of its tile: not in the round-0 list, k_seg_scan decides (and rewrites the flag)
+    const bool up_front = (uint32_t)sl < limit[lo];
+    seg_info[b] = make_int4(lo, first, min(SEG, r.y - first), sl | (up_front ? 0 : (int)(3u << 30)));
+    if (up_front) seg_off[seg_list_offset(ntiles, cap, 0) + seg_off[seg_actoff_offset(ntiles, cap) + lo] + sl] = b;
 }
 
 // ---- NEEDED-SEGMENT HINT.  Half of the segments lie behind the point where every pixel of their tile has stopped
@@ -179,7 +194,7 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
 constexpr uint32_t TILE_SHORT = 0x80000000u;
 __device__ __forceinline__ uint32_t catchup_end(int round, uint32_t lo, uint32_t nseg)
 {
-    return round == 1 ? min(nseg, lo + 8u + (lo >> 1)) : nseg;
+    return round == 1 ? min(nseg, lo + max(8u + (lo >> 1), 3u * AUTO_FIRST)) : nseg;
 }
 
 // ---- A: per (tile, segment, pixel) product of (1 - alpha).  ROUND 0 = the segments inside the hinted prefix of their
@@ -187,23 +202,26 @@ __device__ __forceinline__ uint32_t catchup_end(int round, uint32_t lo, uint32_t
 // k_seg_scan): the segments still flagged 3 that fall into the round's window.
 template <int ROUND>
 __global__ void __launch_bounds__(256)
-k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
-            const uint32_t* __restrict__ seg_needed, const uint32_t* __restrict__ point_list,
-            const Splat* __restrict__ rec, float* __restrict__ Pbuf, unsigned long long* __restrict__ segmask)
+k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off, uint32_t cap,
+            const uint32_t* __restrict__ point_list, const Splat* __restrict__ rec, float* __restrict__ Pbuf,
+            unsigned long long* __restrict__ segmask)
 {
     __shared__ float4 lds[2][SEG];
     __shared__ unsigned long long masks[16];
-    SegCtx c;
-    if (!seg_setup(cam, ranges, seg_off, c)) return;
-    if ((c.flag == 3u) != (ROUND > 0)) return;   // flag 3 = behind the hinted prefix of its tile (k_seg_tiles)
-    if (ROUND > 0) {
-        const uint32_t word = seg_needed[c.tile];
-        if (!(word & TILE_SHORT)) return;
-        const uint32_t lo = word & ~TILE_SHORT, nseg = seg_off[c.tile + 1] - seg_off[c.tile];
-        if ((uint32_t)c.sl < lo || (uint32_t)c.sl >= catchup_end(ROUND, lo, nseg)) return;
+    // the round's work list: round 0 one workgroup per entry (the grid is sized for it: AUTO_FIRST segments per tile
+    // without a hint); the catch-up rounds a fixed grid striding over a list whose length only the device knows
+    const int ntiles = cam.gx * cam.gy;
+    const uint32_t count = seg_off[seg_counts_offset(ntiles, cap) + ROUND];
+    const uint32_t* const list = seg_off + seg_list_offset(ntiles, cap, ROUND);
+    for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+        SegCtx c;
+        if (seg_setup_at(cam, ranges, seg_off, list[item], threadIdx.x >> 6, c)) {
+            const float p = seg_alpha_body(c, point_list, rec, lds, masks, segmask);
+            Pbuf[(size_t)c.seg * SEG + threadIdx.x] = p;
+        }
+        if (ROUND == 0) break;       // (grid >= count in round 0)
+        __syncthreads();             // the staging buffers are reused by the next entry
     }
-    const float p = seg_alpha_body(c, point_list, rec, lds, masks, segmask);
-    Pbuf[(size_t)c.seg * SEG + threadIdx.x] = p;
 }
 
 // ---- B: per tile, boundary transmittances.  Tbuf[seg][pix] = Tb at the segment start, or -1 when
@@ -221,12 +239,13 @@ k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
 // depends on the hint either way.
 template <int ROUND>
 __global__ void __launch_bounds__(256)
-k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, const float* __restrict__ Pbuf,
+k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, uint32_t cap, const float* __restrict__ Pbuf,
            float* __restrict__ Tbuf, uint32_t* __restrict__ seg_needed, uint32_t* __restrict__ hint)
 {
     constexpr bool PASS2 = ROUND > 0;
     __shared__ uint32_t wneed[4];
     __shared__ uint32_t walive[4];
+    __shared__ uint32_t wbase;
     const int tile = blockIdx.x;
     const uint32_t lim_word = seg_needed[tile];   // k_seg_offsets' snapshot (ROUND > 0: what the previous round left)
     if (PASS2 && !(lim_word & TILE_SHORT)) return;
@@ -273,8 +292,17 @@ k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, const float* __restrict__
         // SHORT tile: rows [mine, last) of the waves that finished earlier, then every pixel's state in row `last`
         for (uint32_t s = s0 + mine; s < s0 + last; ++s) Tbuf[(size_t)s * SEG + threadIdx.x] = -1.0f;
         Tbuf[(size_t)(s0 + last) * SEG + threadIdx.x] = alive ? Tb : -1.0f;
-        if (threadIdx.x == 0) seg_needed[tile] = last | TILE_SHORT;
-        return;   // the segment flags of this tile stay as they are (3 behind the prefix: the second round's work list)
+        // the next round's window of this tile goes onto that round's work list (order among tiles: whoever comes first)
+        const uint32_t wend = catchup_end(ROUND + 1, last, s1 - s0);
+        const int ntiles = cam.gx * cam.gy;
+        if (threadIdx.x == 0) {
+            seg_needed[tile] = last | TILE_SHORT;
+            wbase = atomicAdd(&seg_off[seg_counts_offset(ntiles, cap) + ROUND + 1], wend - last);
+        }
+        __syncthreads();
+        uint32_t* const next_list = seg_off + seg_list_offset(ntiles, cap, ROUND + 1) + wbase;
+        for (uint32_t k = threadIdx.x; k < wend - last; k += 256) next_list[k] = s0 + last + k;
+        return;   // the segment flags of this tile stay as they are (3 behind the prefix)
     }
     const uint32_t needed = max(max(wneed[0], wneed[1]), max(wneed[2], wneed[3]));
     for (uint32_t s = s0 + mine; s < s0 + needed; ++s) Tbuf[(size_t)s * SEG + threadIdx.x] = -1.0f;
@@ -607,30 +635,38 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     if (ntiles == 0) return 0;
     const size_t nseg = seg_capacity(R, ntiles);
     float* Pbuf = (float*)scratch;
+    // Rounds without a hint ("auto"): worth it on dense lists only.  On the headline view (7 segments per tile on
+    // average) the heavy tiles' catch-up rounds run at low parallelism behind everybody else's round 0 and cost 40 us more
+    // than the 22 % fewer segments save; with discs three times larger (25 per tile, 70 % of them never needed) the forward
+    // drops from 0.645 to 0.49 ms.  The host knows R when it gets here; VR_FLAG_ROUNDS_OFF / _ON override.
+    const bool auto_rounds = !needed_hint && R > 0 && !(cam.flags & FLAG_ROUNDS_OFF) &&
+                             ((cam.flags & FLAG_ROUNDS_ON) || (size_t)R / SEG >= (size_t)AUTO_DENSITY * ntiles);
+    const bool rounds = needed_hint || auto_rounds;
     hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(SEGOFF_THREADS), 0, s, ranges, ntiles, seg_off,
-                       (const uint32_t*)needed_hint, seg_needed);
+                       (const uint32_t*)needed_hint, seg_needed, (uint32_t)nseg, auto_rounds ? AUTO_FIRST : 0x3FFFFFFFu);
     hipLaunchKernelGGL(k_seg_tiles, dim3(cdiv((long)nseg, 256)), dim3(256), 0, s, ntiles, ranges, seg_off,
                        (const uint32_t*)seg_needed, (uint32_t)nseg);
     VR_KERNEL_CHECK("seg_offsets", s, debug);
-    if (R > 0) {
-        hipLaunchKernelGGL(k_seg_alpha<0>, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
-                           (const uint32_t*)seg_needed, point_list, rec, Pbuf, segmask);
-        VR_KERNEL_CHECK("seg_alpha", s, debug);
+    // Three rounds over work lists (vr_segment.h).  Round 0: the first AUTO_FIRST segments of every tile (with a hint:
+    // the hinted prefix -- its length is only known on the device, so the grid covers every slot); k_seg_scan walks them
+    // and puts the next window of every tile that still has a live pixel on the next round's list; round 2 takes what is
+    // left of the tiles that are short even then.  The catch-up rounds run a fixed grid over lists whose length only the
+    // device knows.
+    const size_t bound0 = (size_t)AUTO_FIRST * ntiles;      // round 0 of the automatic rounds: at most AUTO_FIRST segments per tile
+    const unsigned grid0 = (unsigned)(!auto_rounds || nseg < bound0 ? nseg : bound0);
+    const unsigned gridc = (unsigned)(nseg < 4096 ? nseg : 4096);
+#define VR_ROUND(RD, GRID)                                                                                                \
+    if (R > 0) hipLaunchKernelGGL(k_seg_alpha<RD>, dim3(GRID), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,     \
+                                  (uint32_t)nseg, point_list, rec, Pbuf, segmask);                                        \
+    if (R > 0 || RD == 0) hipLaunchKernelGGL(k_seg_scan<RD>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (uint32_t)nseg, \
+                                             (const float*)Pbuf, Tbuf, seg_needed, needed_hint)
+    VR_ROUND(0, grid0);
+    if (rounds) {
+        VR_ROUND(1, gridc);
+        VR_ROUND(2, gridc);
     }
-    hipLaunchKernelGGL(k_seg_scan<0>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (const float*)Pbuf, Tbuf,
-                       seg_needed, needed_hint);
-    VR_KERNEL_CHECK("seg_scan", s, debug);
-    if (needed_hint && R > 0) {   // a hinted forward: catch-up rounds for the tiles whose hint was too small (usually none)
-        hipLaunchKernelGGL(k_seg_alpha<1>, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
-                           (const uint32_t*)seg_needed, point_list, rec, Pbuf, segmask);
-        hipLaunchKernelGGL(k_seg_scan<1>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (const float*)Pbuf, Tbuf,
-                           seg_needed, needed_hint);
-        hipLaunchKernelGGL(k_seg_alpha<2>, dim3((unsigned)nseg), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,
-                           (const uint32_t*)seg_needed, point_list, rec, Pbuf, segmask);
-        hipLaunchKernelGGL(k_seg_scan<2>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (const float*)Pbuf, Tbuf,
-                           seg_needed, needed_hint);
-        VR_KERNEL_CHECK("seg_scan (catch-up rounds)", s, debug);
-    }
+#undef VR_ROUND
+    VR_KERNEL_CHECK("seg_alpha / seg_scan rounds", s, debug);
     if (R > 0) {
         hipLaunchKernelGGL(k_seg_blend, dim3((unsigned)nseg * 4), dim3(64), 0, s, cam, ranges, (const uint32_t*)seg_off,
                            (const uint32_t*)seg_needed, point_list, rec, (const float*)Tbuf, part,

@@ -37,6 +37,8 @@ constexpr uint32_t FLAG_EXTRA_NO_ALPHA_GRAD = 1u << 2;  // depth/quat/scale chan
 constexpr uint32_t FLAG_FILL_EMPTY = 1u << 3;           // cov_quat += T_final * (1,0,0,0)
 constexpr uint32_t FLAG_DETERMINISTIC = 1u << 8;        // backward without atomics
 constexpr uint32_t FLAG_SCAN_BINNING = 1u << 9;         // binning with the scan-based (multi-launch) radix passes
+constexpr uint32_t FLAG_ROUNDS_OFF = 1u << 10;          // forward: all list segments at once
+constexpr uint32_t FLAG_ROUNDS_ON = 1u << 11;           // forward: segment rounds whatever the list density
 
 struct Camera {
     int H, W, gx, gy;

@@ -19,6 +19,21 @@ constexpr int SEG = 256;
 // ranges[tile] -> seg_needed[tile].)
 __host__ __device__ inline int seg_tile_offset(int ntiles) { return (ntiles + 1 + 63) & ~63; }
 
+// WORK LISTS of the forward's three alpha rounds, behind the seg_info entries of the `cap` segment slots (all uint32):
+//   counts[64] (counts[r] = entries of list r) | act_off[T+1, padded] (round 0: first list position of every tile) |
+//   list 0 [cap] | list 1 [cap] | list 2 [cap]          -- each entry a global segment id.
+// Round 0's list is written in tile order by k_seg_tiles, the catch-up rounds' lists by the k_seg_scan that leaves a
+// tile short.  A launch over "all segment slots, most of which return at once" costs ~0.5 us of a CU per empty
+// workgroup -- 30 us per round on the headline view, more than the rounds save there; the lists make a round cost what
+// it computes.
+__host__ __device__ inline size_t seg_counts_offset(int ntiles, size_t cap) { return (size_t)seg_tile_offset(ntiles) + 4 * cap; }
+__host__ __device__ inline size_t seg_actoff_offset(int ntiles, size_t cap) { return seg_counts_offset(ntiles, cap) + 64; }
+__host__ __device__ inline size_t seg_list_offset(int ntiles, size_t cap, int r)
+{
+    return seg_actoff_offset(ntiles, cap) + (size_t)seg_tile_offset(ntiles) + (size_t)r * cap;
+}
+__host__ __device__ inline size_t seg_table_words(int ntiles, size_t cap) { return seg_list_offset(ntiles, cap, 3); }
+
 struct SegCtx {
     uint32_t seg;      // global segment id handled by this workgroup
     int tile, sl;      // tile id, segment index inside the tile

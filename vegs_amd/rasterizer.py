@@ -48,6 +48,8 @@ FLAG_EXTRA_NO_ALPHA_GRAD = _capi.FLAG_EXTRA_NO_ALPHA_GRAD  # depth/quat/scale: g
 FLAG_FILL_EMPTY = _capi.FLAG_FILL_EMPTY                    # cov_quat += T_final * (1,0,0,0)
 FLAG_DETERMINISTIC = _capi.FLAG_DETERMINISTIC              # backward without atomics (bit-reproducible gradients)
 FLAG_SCAN_BINNING = _capi.FLAG_SCAN_BINNING                # binning without inter-workgroup waits (multi-launch passes)
+FLAG_ROUNDS_OFF = _capi.FLAG_ROUNDS_OFF                    # forward: every list segment at once, whatever the list density
+FLAG_ROUNDS_ON = _capi.FLAG_ROUNDS_ON                      # forward: segment rounds, whatever the list density (default: by density)
 _flags = int(os.environ.get("VEGS_RAST_FLAGS", "0"), 0)
 
 

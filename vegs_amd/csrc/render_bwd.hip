@@ -166,7 +166,7 @@ k_seg_suffix(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ 
 // neither their branches nor their registers (round 2 added them as run-time tests: 360 -> 373 us).
 template <bool NO_EXTRA, bool DET>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
+k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off, uint32_t cap,
           const uint32_t* __restrict__ seg_needed, const uint32_t* __restrict__ point_list,
           const Splat* __restrict__ rec, const float* __restrict__ Tbuf, const float* __restrict__ Ubuf,
           const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -181,8 +181,9 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     __shared__ float4 pixrec[32][8];              // per PIXEL PAIR: coords, bg term, 11 upstream grads, carries
     SegCtx c;
     const int w = (int)(blockIdx.x & 3u);
-    if (!seg_setup_at(cam, ranges, seg_off, blockIdx.x >> 2, w, c)) return;
-    if (c.flag == 0u) return;
+    const int ntiles = cam.gx * cam.gy;
+    if ((blockIdx.x >> 2) >= seg_off[seg_counts_offset(ntiles, cap) + SEG_LIST_NEEDED]) return;    // beyond the needed list (vr_segment.h)
+    if (!seg_setup_at(cam, ranges, seg_off, seg_off[seg_list_offset(ntiles, cap, SEG_LIST_NEEDED) + (blockIdx.x >> 2)], w, c)) return;
     const int lane = threadIdx.x;
     const int pixslot = w * 64 + lane;            // this pixel's slot in the [segment][256] buffers
 
@@ -489,7 +490,7 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
     prof_begin(VR_STAGE_K_SEG_BWD, s);
 #define VR_BWD(NOX, DETM)                                                                                              \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_bwd<NOX, DETM>), dim3(nseg * 4), dim3(64), 0, s, cam, ranges, seg_off,    \
-                       seg_needed, point_list, rec, Tbuf, (const float*)Ubuf, final_T, n_contrib, dL_dcolor, dL_ddepth, \
+                       (uint32_t)nseg, seg_needed, point_list, rec, Tbuf, (const float*)Ubuf, final_T, n_contrib, dL_dcolor, dL_ddepth, \
                        dL_dquat, dL_dscale, dL_dalpha, gacc, gmean2D, segmask, dsum, gpart)
     {
         const bool nox = (cam.flags & FLAG_EXTRA_NO_ALPHA_GRAD) != 0u;

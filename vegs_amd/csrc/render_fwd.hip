@@ -83,6 +83,8 @@ k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict_
         counts[0] = carry_a;          // entries of the round-0 list; the catch-up lists start empty
         counts[1] = 0;
         counts[2] = 0;
+        counts[SEG_LIST_NEEDED] = 0;
+        for (int q = 0; q < SEG_QUEUES; ++q) seg_off[seg_qcount_offset(ntiles, cap, q)] = 0;
     }
 }
 
@@ -306,9 +308,17 @@ k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, uint32_t cap, const float
     }
     const uint32_t needed = max(max(wneed[0], wneed[1]), max(wneed[2], wneed[3]));
     for (uint32_t s = s0 + mine; s < s0 + needed; ++s) Tbuf[(size_t)s * SEG + threadIdx.x] = -1.0f;
+    // the tile's needed segments go onto the list of its dispatch queue, in the order in which tiles finish (vr_segment.h)
+    const int ntiles_all = cam.gx * cam.gy, queue = (int)(blockIdx.x % SEG_QUEUES);
     if (threadIdx.x == 0) {
         seg_needed[tile] = needed;
         if (hint) hint[tile] = needed;     // in/out: what this forward needed is the hint of the camera's next visit
+        wbase = atomicAdd(&seg_off[seg_qcount_offset(ntiles_all, cap, queue)], needed);
+    }
+    __syncthreads();
+    {
+        uint32_t* const ql = seg_off + seg_qlist_offset(ntiles_all, cap, queue) + wbase;
+        for (uint32_t k = threadIdx.x; k < needed; k += 256) ql[k] = s0 + k;
     }
     // per-segment flag for the segment kernels (vr_segment.h): 0 not needed / 1 needed, last / 2 needed, next too
     int4* seg_info = reinterpret_cast<int4*>(seg_off + seg_tile_offset(cam.gx * cam.gy));
@@ -318,12 +328,30 @@ k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, uint32_t cap, const float
     }
 }
 
+// The eight queue lists dealt round-robin into the needed list: entry k of queue q goes behind the entries < k of every
+// queue and the entries k of the queues before q.  One thread per (queue, k) slot.
+__global__ void __launch_bounds__(256)
+k_seg_merge(int ntiles, uint32_t* __restrict__ seg_off, uint32_t cap)
+{
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    const int q = (int)blockIdx.y;
+    uint32_t len[SEG_QUEUES], total = 0;
+#pragma unroll
+    for (int i = 0; i < SEG_QUEUES; ++i) { len[i] = seg_off[seg_qcount_offset(ntiles, cap, i)]; total += len[i]; }
+    if (k == 0 && q == 0) seg_off[seg_counts_offset(ntiles, cap) + SEG_LIST_NEEDED] = total;
+    if (k >= len[q]) return;
+    uint32_t pos = 0;
+#pragma unroll
+    for (int i = 0; i < SEG_QUEUES; ++i) pos += min(len[i], k) + ((i < q && len[i] > k) ? 1u : 0u);
+    seg_off[seg_list_offset(ntiles, cap, SEG_LIST_NEEDED) + pos] = seg_off[seg_qlist_offset(ntiles, cap, q) + k];
+}
+
 // ---- C: blend one segment from its boundary transmittance into segment-local sums.
 // part[seg][k][pix], k = 0..10 channel sums, 11 = local product p, 12 = local last-contributor | done<<31
 constexpr int NPART = 13;
 
 __global__ void __launch_bounds__(64)
-k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
+k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off, uint32_t cap,
             const uint32_t* __restrict__ seg_needed, const uint32_t* __restrict__ point_list,
             const Splat* __restrict__ rec, const float* __restrict__ Tbuf, float* __restrict__ part,
             const unsigned long long* __restrict__ segmask)
@@ -337,8 +365,9 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     __shared__ uint32_t rel_gid[SEG];
     SegCtx c;
     const int w = (int)(blockIdx.x & 3u);
-    if (!seg_setup_at(cam, ranges, seg_off, blockIdx.x >> 2, w, c)) return;
-    if (c.flag == 0u) return;
+    const int ntiles = cam.gx * cam.gy;
+    if ((blockIdx.x >> 2) >= seg_off[seg_counts_offset(ntiles, cap) + SEG_LIST_NEEDED]) return;    // beyond the needed list
+    if (!seg_setup_at(cam, ranges, seg_off, seg_off[seg_list_offset(ntiles, cap, SEG_LIST_NEEDED) + (blockIdx.x >> 2)], w, c)) return;
     const int lane = threadIdx.x;
     const int pixslot = w * 64 + lane;
     // one batch of independent loads right after the segment descriptor (boundary transmittance, relevance masks,
@@ -667,9 +696,10 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     }
 #undef VR_ROUND
     VR_KERNEL_CHECK("seg_alpha / seg_scan rounds", s, debug);
+    hipLaunchKernelGGL(k_seg_merge, dim3(cdiv((long)nseg, 256), SEG_QUEUES), dim3(256), 0, s, ntiles, seg_off, (uint32_t)nseg);
     if (R > 0) {
         hipLaunchKernelGGL(k_seg_blend, dim3((unsigned)nseg * 4), dim3(64), 0, s, cam, ranges, (const uint32_t*)seg_off,
-                           (const uint32_t*)seg_needed, point_list, rec, (const float*)Tbuf, part,
+                           (uint32_t)nseg, (const uint32_t*)seg_needed, point_list, rec, (const float*)Tbuf, part,
                            (const unsigned long long*)segmask);
         VR_KERNEL_CHECK("seg_blend", s, debug);
     }

@@ -19,20 +19,35 @@ constexpr int SEG = 256;
 // ranges[tile] -> seg_needed[tile].)
 __host__ __device__ inline int seg_tile_offset(int ntiles) { return (ntiles + 1 + 63) & ~63; }
 
-// WORK LISTS of the forward's three alpha rounds, behind the seg_info entries of the `cap` segment slots (all uint32):
-//   counts[64] (counts[r] = entries of list r) | act_off[T+1, padded] (round 0: first list position of every tile) |
-//   list 0 [cap] | list 1 [cap] | list 2 [cap]          -- each entry a global segment id.
+// WORK LISTS behind the seg_info entries of the `cap` segment slots (all uint32; each list entry a global segment id):
+//   counts[64] (counts[r] = entries of list r) | 8 queue counters, one 128-byte line each | act_off[T+1, padded]
+//   (round 0: first list position of every tile) | lists 0, 1, 2 [cap each]: the forward's three alpha rounds |
+//   list 3 [cap]: the NEEDED segments | 8 queue lists [cap each].
 // Round 0's list is written in tile order by k_seg_tiles, the catch-up rounds' lists by the k_seg_scan that leaves a
 // tile short.  A launch over "all segment slots, most of which return at once" costs ~0.5 us of a CU per empty
-// workgroup -- 30 us per round on the headline view, more than the rounds save there; the lists make a round cost what
-// it computes.
+// 256-thread workgroup -- 30 us per round on the headline view; the lists make a round cost what it computes.
+//
+// NEEDED list: what k_seg_blend and k_seg_bwd run over (workgroup b takes entry b >> 2, region b & 3).  Its ORDER is
+// worth 8 % of k_seg_bwd and 5 % of k_seg_blend: in the COMPLETION order of the k_seg_scan workgroups (the tile that
+// finishes its chain appends its run) they take 320 / 127 us, in tile order 350 / 134 -- same instructions, same wave
+// cycles, 8 % more waves in flight on average (PMC); ten deterministic orders (sorted by length either way, permuted,
+// grouped by dispatch queue, heavy tiles last, window shuffles, ...) do not reproduce it
+// (profiles/experiments/README.md).  So the list is built the way that works: a finishing tile appends to the list of
+// its dispatch queue (blockIdx % 8; one atomicAdd on that queue's own cache line -- 2064 appends to ONE counter cost
+// the scan 16 us), and k_seg_merge deals the eight queue lists round-robin into the needed list.  The order varies
+// from run to run; no result depends on it (the images are per-segment sums added in segment order by k_seg_combine,
+// the gradient sums are atomic -- or, in deterministic mode, written to per-(entry, region) slots).
+constexpr int SEG_LIST_NEEDED = 3;
+constexpr int SEG_QUEUES = 8;
 __host__ __device__ inline size_t seg_counts_offset(int ntiles, size_t cap) { return (size_t)seg_tile_offset(ntiles) + 4 * cap; }
-__host__ __device__ inline size_t seg_actoff_offset(int ntiles, size_t cap) { return seg_counts_offset(ntiles, cap) + 64; }
+__host__ __device__ inline size_t seg_qcount_offset(int ntiles, size_t cap, int q) { return seg_counts_offset(ntiles, cap) + 64 + 32 * (size_t)q; }
+__host__ __device__ inline size_t seg_actoff_offset(int ntiles, size_t cap) { return seg_counts_offset(ntiles, cap) + 64 + 32 * SEG_QUEUES; }
 __host__ __device__ inline size_t seg_list_offset(int ntiles, size_t cap, int r)
 {
     return seg_actoff_offset(ntiles, cap) + (size_t)seg_tile_offset(ntiles) + (size_t)r * cap;
 }
-__host__ __device__ inline size_t seg_table_words(int ntiles, size_t cap) { return seg_list_offset(ntiles, cap, 3); }
+__host__ __device__ inline size_t seg_qlist_offset(int ntiles, size_t cap, int q) { return seg_list_offset(ntiles, cap, 4 + q); }
+__host__ __device__ inline size_t seg_table_words(int ntiles, size_t cap) { return seg_list_offset(ntiles, cap, 4 + SEG_QUEUES); }
 
 struct SegCtx {
     uint32_t seg;      // global segment id handled by this workgroup

@@ -108,14 +108,17 @@ __device__ __forceinline__ int alpha_grad_channels(uint32_t flags) { return (fla
 // Fully parallel over (segment, pixel); the sequential part (B') then only touches one float per segment.
 constexpr int NPART_B = 13;
 __global__ void __launch_bounds__(256)
-k_seg_u(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
+k_seg_u(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off, uint32_t cap,
         const uint32_t* __restrict__ seg_needed, const float* __restrict__ part,
         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
         const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dquat, const float* __restrict__ dL_dscale,
         const float* __restrict__ final_T, const float* __restrict__ dsum, float* __restrict__ Ubuf)
 {
     SegCtx c;
-    if (!seg_setup(cam, ranges, seg_off, c)) return;
+    const int ntiles = cam.gx * cam.gy;
+    if (blockIdx.x >= seg_off[seg_counts_offset(ntiles, cap) + SEG_LIST_NEEDED]) return;    // beyond the needed list (vr_segment.h)
+    if (!seg_setup_at(cam, ranges, seg_off, seg_off[seg_list_offset(ntiles, cap, SEG_LIST_NEEDED) + blockIdx.x],
+                      threadIdx.x >> 6, c)) return;
     // U of a tile's FIRST segment is never used: it would only enter the "behind" sums of earlier segments, and there
     // are none (k_seg_suffix overwrites the slot with the suffix before it adds the slot's old content to a running sum
     // nobody reads).  2 k of the ~9.5 k needed segments of the headline view.
@@ -482,7 +485,7 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
         gpart = (float*)det_scratch;
         VR_HIP(hipMemsetAsync(gpart, 0, (size_t)R * 4 * NACC * sizeof(float), s));
     }
-    hipLaunchKernelGGL(k_seg_u, dim3(nseg), dim3(256), 0, s, cam, ranges, seg_off, seg_needed, part, n_contrib,
+    hipLaunchKernelGGL(k_seg_u, dim3(nseg), dim3(256), 0, s, cam, ranges, seg_off, (uint32_t)nseg, seg_needed, part, n_contrib,
                        dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, final_T, dsum, Ubuf);
     VR_KERNEL_CHECK("seg_u", s, debug);
     hipLaunchKernelGGL(k_seg_suffix, dim3(ntiles), dim3(256), 0, s, seg_off, seg_needed, Ubuf);

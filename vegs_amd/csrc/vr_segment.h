@@ -30,9 +30,10 @@ __host__ __device__ inline int seg_tile_offset(int ntiles) { return (ntiles + 1 
 // NEEDED list: what k_seg_blend and k_seg_bwd run over (workgroup b takes entry b >> 2, region b & 3).  Its ORDER is
 // worth 8 % of k_seg_bwd and 5 % of k_seg_blend: in the COMPLETION order of the k_seg_scan workgroups (the tile that
 // finishes its chain appends its run) they take 320 / 127 us, in tile order 350 / 134 -- same instructions, same wave
-// cycles, 8 % more waves in flight on average (PMC); ten deterministic orders (sorted by length either way, permuted,
-// grouped by dispatch queue, heavy tiles last, window shuffles, ...) do not reproduce it
-// (profiles/experiments/README.md).  So the list is built the way that works: a finishing tile appends to the list of
+// cycles, 8 % more waves in flight on average (PMC).  What a good order has (profiles/experiments/README.md): the
+// expensive workgroups -- a tile's FRONT segments, every pixel still alive -- first, the cheap deep ones last, and
+// consecutive workgroups on different tiles; a constructed depth-index-major list gets 325 / 129 us, orders that sort or
+// permute TILES get nothing.  The completion order has both properties by itself and is cheaper to produce: a finishing tile appends to the list of
 // its dispatch queue (blockIdx % 8; one atomicAdd on that queue's own cache line -- 2064 appends to ONE counter cost
 // the scan 16 us), and k_seg_merge deals the eight queue lists round-robin into the needed list.  The order varies
 // from run to run; no result depends on it (the images are per-segment sums added in segment order by k_seg_combine,

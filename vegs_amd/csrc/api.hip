@@ -491,8 +491,12 @@ static int backward_first(const Camera& cam, const VrSettings* st, const VrInput
     const uint32_t* point_list = (const uint32_t*)((const char*)saved->binning + BL.point_list);
 
     prof_begin(VR_STAGE_BWD_ZERO, s);
-    VR_HIP(hipMemsetAsync(gacc, 0, (size_t)P * 16 * sizeof(float), s));
-    VR_HIP(hipMemsetAsync(gin->dL_dmeans2D, 0, (size_t)P * 3 * sizeof(float), s));
+    // the accumulators of the render backward are cleared by its first kernel (k_seg_u) when there is one
+    const bool zero_in_kernel = saved->num_rendered > 0 && cam.gx * cam.gy > 0;
+    if (!zero_in_kernel) {
+        VR_HIP(hipMemsetAsync(gacc, 0, (size_t)P * 16 * sizeof(float), s));
+        VR_HIP(hipMemsetAsync(gin->dL_dmeans2D, 0, (size_t)P * 3 * sizeof(float), s));
+    }
     if (sh_factored) {
         // nothing to clear: every row of the [P,3] factor array is written
     } else if (in->shs_rest) {
@@ -521,7 +525,7 @@ static int backward_first(const Camera& cam, const VrSettings* st, const VrInput
                                n_contrib,
                                gout->dL_dcolor, gout->dL_ddepth, gout->dL_dcov_quat, gout->dL_dcov_scale,
                                gout->dL_dalpha, gacc, gin->dL_dmeans2D,
-                               (const float*)((const char*)saved->image + IL.dsum), det_scr, P, s, debug);
+                               (const float*)((const char*)saved->image + IL.dsum), det_scr, P, zero_in_kernel, s, debug);
         if (rc) return rc;
     }
     if (sh_factored && factor_now)

@@ -112,8 +112,24 @@ k_seg_u(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict_
         const uint32_t* __restrict__ seg_needed, const float* __restrict__ part,
         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
         const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dquat, const float* __restrict__ dL_dscale,
-        const float* __restrict__ final_T, const float* __restrict__ dsum, float* __restrict__ Ubuf)
+        const float* __restrict__ final_T, const float* __restrict__ dsum, float* __restrict__ Ubuf,
+        float* __restrict__ zero_a, size_t n_a, float* __restrict__ zero_b, size_t n_b)
 {
+    // The backward's accumulators (gacc [P][16] and dL/dmeans2D [P][3], contiguous quads) are cleared HERE, by every
+    // workgroup of the launch before it looks at its segment: this kernel waits for gathers most of its life, the
+    // stores ride along (two fill launches of 25 us per view are gone).  k_seg_bwd, the first to add to them, is the
+    // next launch but one.
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        float* const z = which ? zero_b : zero_a;
+        const size_t n = which ? n_b : n_a;
+        if (!z) continue;
+        const size_t head = (reinterpret_cast<size_t>(z) & 15) ? n : 0;         // unaligned array: all of it by dwords
+        const size_t nq = (n - head) >> 2;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nq; i += (size_t)gridDim.x * 256)
+            nt_store4(make_float4(0.f, 0.f, 0.f, 0.f), reinterpret_cast<float4*>(z) + i);
+        for (size_t i = (nq << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) z[i] = 0.0f;
+    }
     SegCtx c;
     const int ntiles = cam.gx * cam.gy;
     if (blockIdx.x >= seg_off[seg_counts_offset(ntiles, cap) + SEG_LIST_NEEDED]) return;    // beyond the needed list (vr_segment.h)
@@ -474,7 +490,7 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
                       const unsigned long long* segmask, void* scratch, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                       const float* dL_ddepth, const float* dL_dquat, const float* dL_dscale,
                       const float* dL_dalpha, float* gacc, float* gmean2D, const float* dsum, void* det_scratch, int P,
-                      hipStream_t s, bool debug)
+                      bool zero_accumulators, hipStream_t s, bool debug)
 {
     const int ntiles = cam.gx * cam.gy;
     if (ntiles == 0 || R == 0) return 0;
@@ -486,7 +502,8 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
         VR_HIP(hipMemsetAsync(gpart, 0, (size_t)R * 4 * NACC * sizeof(float), s));
     }
     hipLaunchKernelGGL(k_seg_u, dim3(nseg), dim3(256), 0, s, cam, ranges, seg_off, (uint32_t)nseg, seg_needed, part, n_contrib,
-                       dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, final_T, dsum, Ubuf);
+                       dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, final_T, dsum, Ubuf,
+                       zero_accumulators ? gacc : nullptr, (size_t)P * 16, zero_accumulators ? gmean2D : nullptr, (size_t)P * 3);
     VR_KERNEL_CHECK("seg_u", s, debug);
     hipLaunchKernelGGL(k_seg_suffix, dim3(ntiles), dim3(256), 0, s, seg_off, seg_needed, Ubuf);
     VR_KERNEL_CHECK("seg_suffix", s, debug);

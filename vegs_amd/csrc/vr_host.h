@@ -119,7 +119,7 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
                       const unsigned long long* segmask, void* scratch, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                       const float* dL_ddepth, const float* dL_dquat, const float* dL_dscale,
                       const float* dL_dalpha, float* gacc, float* gmean2D, const float* dsum, void* det_scratch, int P,
-                      hipStream_t s, bool debug);
+                      bool zero_accumulators, hipStream_t s, bool debug);
 // scratch of the deterministic backward mode (VR_FLAG_DETERMINISTIC): per-(entry, region) slots + the id sort
 size_t render_bwd_det_bytes(long R, int P);
 // B = blended (pixel, splat) pairs of a finished forward (one thread per pixel walks its list; bookkeeping only)

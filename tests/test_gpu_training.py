@@ -77,3 +77,46 @@ def test_iteration_with_factored_sh_equals_dense_iteration():
         # Adam's first steps move by ~lr * sign(g): differences come from noise-level gradients changing sign
         tol = 1e-4 * np.abs(pa[k]).max()
         assert float((np.abs(pa[k] - pb[k]) > tol).mean()) < 5e-3, k
+
+
+def test_factored_sh_with_box_instances_equals_the_dense_step():
+    """Trainer(n_boxes > 0, factored_sh=True): the op's 3-float factor covers the concatenated op inputs (static model +
+    instances, SH rows read through the SH tail); the static model's rows feed Adam directly, the instances' SH gradients
+    are rebuilt densely from their rows of the factor and their world-space means.  Against the same step with the dense
+    gradient: losses, parameters after three iterations, and every instance's SH / means / box2world gradient."""
+    from helpers import assert_grad_close
+    from vegs_amd import harness, iteration, scenes
+    dev = torch.device("cuda:0")
+    sc, deg = scenes.scene_street(P=60000, length=60.0, sh_degree=3, seed=33)
+    cams = [scenes.kitti_camera(2.0 * i, 0.3, 688, 188) for i in range(3)]
+    rng = np.random.default_rng(1)
+    gt = torch.tensor(rng.uniform(0, 1, (3, 188, 688)).astype(np.float32), device=dev)
+    normal = torch.tensor(rng.normal(size=(3, 188, 688)).astype(np.float32), device=dev)
+    bg = torch.zeros(3, device=dev)
+    out = []
+    for factored in (False, True):
+        tr = iteration.Trainer(sc, dev, n_boxes=3, fused=True, box_points=2000, factored_sh=factored)
+        assert tr.factored_sh == factored
+        losses, box_grads = [], None
+        for it in range(3):
+            cam = cams[it % 3]
+            loss, pkg, _ = tr.step(cam, harness.cam_tensors(cam, dev), deg, bg, gt, normal, keep_grads=True)
+            losses.append(float(loss))
+            if it == 0:
+                box_grads = [({k: v.grad.detach().cpu().numpy() for k, v in b.items() if v.grad is not None}, w.grad.cpu().numpy())
+                             for b, w in tr.boxes]
+            for b, w in tr.boxes:
+                w.grad = None
+                for t in b.values():
+                    t.grad = None
+        out.append((losses, {k: v.detach().cpu().numpy() for k, v in tr.p.items()}, box_grads))
+    (la, pa, ga), (lb, pb, gb) = out
+    assert np.allclose(la, lb, rtol=2e-5)
+    for k in pa:
+        tol = 1e-4 * np.abs(pa[k]).max()
+        assert float((np.abs(pa[k] - pb[k]) > tol).mean()) < 5e-3, k
+    for (da, wa), (db, wb) in zip(ga, gb):
+        assert set(da) == set(db) and "shs" in db
+        for k in da:
+            assert_grad_close(f"box {k}: factored vs dense", db[k], da[k], rtol=1e-3, floor=2e-6)
+        assert np.abs(wa - wb).max() <= 1e-3 * max(np.abs(wa).max(), 1e-12)

@@ -102,7 +102,8 @@ def merge_kwargs(a, b):
     return {k: torch.cat((a[k], b[k]), 0).contiguous() for k in a}
 
 
-def render_all(cam, static, boxes, box2worlds, sh_degree, bg_color, scaling_modifier=1.0, cam_t=None, fused=False):
+def render_all(cam, static, boxes, box2worlds, sh_degree, bg_color, scaling_modifier=1.0, cam_t=None, fused=False,
+               sh_color_grad=None):
     """fused=False: the reference's op-by-op composition (device-agnostic; what the CPU checks run);
     fused=True: vegs_amd.instances.prepare_and_merge (one HIP launch for all instances, GPU only)."""
     if fused:
@@ -112,6 +113,6 @@ def render_all(cam, static, boxes, box2worlds, sh_degree, bg_color, scaling_modi
         kw = prepare_rasterization(static)
         for t, b2w in zip(boxes, box2worlds):
             kw = merge_kwargs(kw, prepare_rasterization(t, b2w))
-    pkg = render(cam, kw, sh_degree, bg_color, scaling_modifier, cam_t=cam_t)
+    pkg = render(cam, kw, sh_degree, bg_color, scaling_modifier, cam_t=cam_t, sh_color_grad=sh_color_grad)
     pkg["op_inputs"] = kw
     return pkg

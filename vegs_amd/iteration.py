@@ -78,7 +78,8 @@ def render_model(p, boxes, cam, cam_t, deg, bg, fused, sh_sink=None):
         return harness.render(cam, t, deg, bg, cam_t=cam_t, sh_color_grad=sh_sink)
     # fused: the model's two SH tensors as they are; prepare_and_merge hands the instances' rows over as an SH tail
     t["shs"] = (p["f_dc"], p["f_rest"]) if fused else torch.cat((p["f_dc"], p["f_rest"]), dim=1)
-    return harness.render_all(cam, t, [b for b, _ in boxes], [w for _, w in boxes], deg, bg, cam_t=cam_t, fused=fused)
+    return harness.render_all(cam, t, [b for b, _ in boxes], [w for _, w in boxes], deg, bg, cam_t=cam_t, fused=fused,
+                              sh_color_grad=sh_sink)
 
 
 def aten_loss(pkg, gt, normal, win, R_c2w):
@@ -116,11 +117,13 @@ class Trainer:
     """State of one variant: parameters, optimizer, densification statistics."""
 
     def __init__(self, sc, device, n_boxes=0, fused=True, box_points=8196, factored_sh=False, lrs=None):
-        """factored_sh (fused variant without box instances): the op returns the 3-float factor of the SH gradient
-        and Adam consumes it directly (optim.adam_step_sh_factored) -- the dense [P,16,3] gradient is never written."""
+        """factored_sh (fused variant): the op returns the 3-float factor of the SH gradient and Adam consumes it directly
+        (optim.adam_step_sh_factored) -- the static model's dense [P,16,3] gradient is never written.  With box instances
+        in frame the factor covers the concatenated op inputs: the static model's rows feed Adam, the instances' few
+        thousand rows are rebuilt densely (optim.sh_grad_from_factors on their world-space means)."""
         from . import optim
         self.device, self.fused = device, fused
-        self.factored_sh = bool(factored_sh and fused and not n_boxes)
+        self.factored_sh = bool(factored_sh and fused)
         self.p, groups = make_model(sc, device, lrs)
         self.boxes = make_boxes(n_boxes, device, box_points) if n_boxes else []
         self.opt = (optim.Adam if fused else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
@@ -133,7 +136,8 @@ class Trainer:
     def forward_loss(self, cam, cam_t, deg, bg, gt, normal):
         sink = None
         if self.factored_sh and torch.is_grad_enabled():
-            sink = torch.zeros_like(self.p["xyz"], requires_grad=True)
+            rows = self.p["xyz"].shape[0] + sum(b["means3D"].shape[0] for b, _ in self.boxes)
+            sink = torch.zeros((rows, 3), dtype=torch.float32, device=self.device, requires_grad=True)
         pkg = render_model(self.p, self.boxes, cam, cam_t, deg, bg, self.fused, sh_sink=sink)
         pkg["sh_sink"] = sink
         # NaN guard for pixels no Gaussian covers (A-5: exact zeros; the reference's 2/|q|^2 is NaN there) -- same in
@@ -162,8 +166,19 @@ class Trainer:
         grads = {k: v.grad.detach().clone() for k, v in self.p.items() if v.grad is not None} if keep_grads else None
         if pkg.get("sh_sink") is not None:
             ct = cam_t if cam_t is not None else harness.cam_tensors(cam, self.device)
-            optim.adam_step_sh_factored(self.opt, self.p["f_dc"], self.p["f_rest"], self.p["xyz"].detach(),
-                                        ct["campos"].reshape(1, 3), pkg["sh_sink"].grad[None], deg, 1.0)
+            campos = ct["campos"].reshape(1, 3)
+            factors = pkg["sh_sink"].grad
+            P0 = self.p["xyz"].shape[0]
+            optim.adam_step_sh_factored(self.opt, self.p["f_dc"], self.p["f_rest"], self.p["xyz"].detach(), campos,
+                                        factors[:P0][None], deg, 1.0)
+            if self.boxes:      # the instances' SH gradients, densely, from their rows of the factor and their WORLD-space means
+                means = pkg["op_inputs"]["means3D"].detach()
+                g_all = optim.sh_grad_from_factors(means[P0:], campos, factors[P0:][None], deg, self.boxes[0][0]["shs"].shape[1])
+                row = 0
+                for b, _ in self.boxes:       # (one launch for all instances; the gradients are row slices of its result)
+                    n = b["means3D"].shape[0]
+                    b["shs"].grad = g_all[row:row + n]
+                    row += n
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
         if not keep_grads:

@@ -127,10 +127,13 @@ _LAST_R = {}
 # world_view_transform / full_proj_transform tensors for their lifetime, scene/cameras.py:76-87) and the image size.  A hint
 # is never trusted -- a wrong one (a reused address, a scene that changed) only costs time, the kernels redo what it
 # missed -- so no invalidation is needed.  A key's hint array is created on its SECOND sighting (value None until then):
-# a camera has to come back before anything is spent on it.  VEGS_RAST_HINTS=0 (or needed_hints(False)) turns the cache off.
+# a camera has to come back before anything is spent on it.
+# OFF by default: a hint pays only while the model stands still between two visits of a camera (repeated rendering of
+# fixed views: -3 %); in training a camera comes back once per epoch, and hints one epoch old cost 4 % (DESIGN.md section
+# 12).  VEGS_RAST_HINTS=1 (or needed_hints(True)) turns the cache on.
 _NEEDED = {}
 _NEEDED_MAX = 4096
-_use_hints = os.environ.get("VEGS_RAST_HINTS", "1") != "0"
+_use_hints = os.environ.get("VEGS_RAST_HINTS", "0") not in ("0", "")
 
 
 def needed_hints(enabled):

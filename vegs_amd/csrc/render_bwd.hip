@@ -156,9 +156,20 @@ k_seg_u(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict_
 
 // ---- B': per tile, in place: Ubuf[seg][pix] <- sum of U over the LATER segments of the tile
 __global__ void __launch_bounds__(256)
-k_seg_suffix(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_needed, float* __restrict__ Ubuf)
+k_seg_suffix(int ntiles, uint32_t cap, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_needed,
+             float* __restrict__ Ubuf)
 {
-    const int tile = blockIdx.x;
+    // heavy tiles first (vr_segment.h): the first `ntiles` workgroups take the forward's heavy list from its end, the others
+    // their own tile unless it is on that list
+    int tile;
+    if ((int)blockIdx.x < ntiles) {
+        const uint32_t hcount = seg_off[seg_counts_offset(ntiles, cap) + SEG_COUNT_HEAVY];
+        if (blockIdx.x >= hcount) return;
+        tile = (int)seg_off[seg_actoff_offset(ntiles, cap) + (hcount - 1u - blockIdx.x)];
+    } else {
+        tile = (int)blockIdx.x - ntiles;
+        if (seg_needed[tile] >= HEAVY_TILE) return;
+    }
     const uint32_t s0 = seg_off[tile];
     const int needed = (int)seg_needed[tile];
     constexpr int CU = 24;
@@ -505,7 +516,7 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
                        dL_dcolor, dL_ddepth, dL_dquat, dL_dscale, final_T, dsum, Ubuf,
                        zero_accumulators ? gacc : nullptr, (size_t)P * 16, zero_accumulators ? gmean2D : nullptr, (size_t)P * 3);
     VR_KERNEL_CHECK("seg_u", s, debug);
-    hipLaunchKernelGGL(k_seg_suffix, dim3(ntiles), dim3(256), 0, s, seg_off, seg_needed, Ubuf);
+    hipLaunchKernelGGL(k_seg_suffix, dim3(2 * ntiles), dim3(256), 0, s, ntiles, (uint32_t)nseg, seg_off, seg_needed, Ubuf);
     VR_KERNEL_CHECK("seg_suffix", s, debug);
     prof_begin(VR_STAGE_K_SEG_BWD, s);
 #define VR_BWD(NOX, DETM)                                                                                              \

@@ -84,6 +84,7 @@ k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict_
         counts[1] = 0;
         counts[2] = 0;
         counts[SEG_LIST_NEEDED] = 0;
+        counts[SEG_COUNT_HEAVY] = 0;
         for (int q = 0; q < SEG_QUEUES; ++q) seg_off[seg_qcount_offset(ntiles, cap, q)] = 0;
     }
 }
@@ -314,6 +315,10 @@ k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, uint32_t cap, const float
         seg_needed[tile] = needed;
         if (hint) hint[tile] = needed;     // in/out: what this forward needed is the hint of the camera's next visit
         wbase = atomicAdd(&seg_off[seg_qcount_offset(ntiles_all, cap, queue)], needed);
+        if (needed >= HEAVY_TILE) {      // long chains start first in the per-tile kernels that follow (vr_segment.h)
+            const uint32_t hp = atomicAdd(&seg_off[seg_counts_offset(ntiles_all, cap) + SEG_COUNT_HEAVY], 1u);
+            seg_off[seg_actoff_offset(ntiles_all, cap) + hp] = (uint32_t)tile;     // (act_off's space: free after k_seg_tiles)
+        }
     }
     __syncthreads();
     {
@@ -495,7 +500,7 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
 // tile), it is not bound by the longest tile's chain: four waves fetching four runs of a heavy tile's segments at
 // once and adding them in turn (sums handed on through LDS) took 75 us.
 template <int GROUP>
-__device__ __forceinline__ void seg_combine_group(const Camera& cam, const uint32_t* __restrict__ seg_off,
+__device__ __forceinline__ void seg_combine_group(const Camera& cam, uint32_t cap, const uint32_t* __restrict__ seg_off,
                                                   const uint32_t* __restrict__ seg_needed, const float* __restrict__ Tbuf,
                                                   const float* __restrict__ part, float* __restrict__ out_color,
                                                   float* __restrict__ out_depth, float* __restrict__ out_quat,
@@ -510,7 +515,18 @@ __device__ __forceinline__ void seg_combine_group(const Camera& cam, const uint3
     constexpr bool WITH_P = GROUP != 2;
     constexpr int NL = NP + (WITH_P ? 1 : 0) + (GROUP == 0 ? 1 : 0);   // loads per segment besides Tbuf
     constexpr int CU = GROUP == 0 ? 16 : (GROUP == 1 ? 13 : 24);       // segments in flight (~96 registers)
-    const int tile = xcd_tile(blockIdx.x, cam.gx * cam.gy);
+    // the first `ntiles` workgroups of the launch take the tiles of the heavy list (long chains first, vr_segment.h), the
+    // others their own tile unless it is on that list
+    const int ntiles_c = cam.gx * cam.gy;
+    int tile;
+    if ((int)blockIdx.x < ntiles_c) {
+        const uint32_t hcount = seg_off[seg_counts_offset(ntiles_c, cap) + SEG_COUNT_HEAVY];
+        if (blockIdx.x >= hcount) return;
+        tile = (int)seg_off[seg_actoff_offset(ntiles_c, cap) + (hcount - 1u - blockIdx.x)];   // the list is in finishing order: longest last
+    } else {
+        tile = xcd_tile(blockIdx.x - ntiles_c, ntiles_c);
+        if ((seg_needed[tile] & 0x7FFFFFFFu) >= HEAVY_TILE) return;
+    }
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int px = tx * TILE + region_x(w, lane), py = ty * TILE + region_y(w, lane);
@@ -579,20 +595,20 @@ __device__ __forceinline__ void seg_combine_group(const Camera& cam, const uint3
 }
 
 __global__ void __launch_bounds__(256)
-k_seg_combine(Camera cam, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_needed,
+k_seg_combine(Camera cam, uint32_t cap, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_needed,
               const float* __restrict__ Tbuf, const float* __restrict__ part, float* __restrict__ out_color,
               float* __restrict__ out_depth, float* __restrict__ out_quat, float* __restrict__ out_scale,
               float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
               float* __restrict__ dsum)
 {
     if (blockIdx.y == 0)
-        seg_combine_group<0>(cam, seg_off, seg_needed, Tbuf, part, out_color, out_depth, out_quat, out_scale, out_alpha,
+        seg_combine_group<0>(cam, cap, seg_off, seg_needed, Tbuf, part, out_color, out_depth, out_quat, out_scale, out_alpha,
                              final_T, n_contrib, dsum);
     else if (blockIdx.y == 1)
-        seg_combine_group<1>(cam, seg_off, seg_needed, Tbuf, part, out_color, out_depth, out_quat, out_scale, out_alpha,
+        seg_combine_group<1>(cam, cap, seg_off, seg_needed, Tbuf, part, out_color, out_depth, out_quat, out_scale, out_alpha,
                              final_T, n_contrib, dsum);
     else
-        seg_combine_group<2>(cam, seg_off, seg_needed, Tbuf, part, out_color, out_depth, out_quat, out_scale, out_alpha,
+        seg_combine_group<2>(cam, cap, seg_off, seg_needed, Tbuf, part, out_color, out_depth, out_quat, out_scale, out_alpha,
                              final_T, n_contrib, dsum);
 }
 
@@ -703,7 +719,7 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
                            (const unsigned long long*)segmask);
         VR_KERNEL_CHECK("seg_blend", s, debug);
     }
-    hipLaunchKernelGGL(k_seg_combine, dim3(ntiles, 3), dim3(256), 0, s, cam, (const uint32_t*)seg_off,
+    hipLaunchKernelGGL(k_seg_combine, dim3(2 * ntiles, 3), dim3(256), 0, s, cam, (uint32_t)nseg, (const uint32_t*)seg_off,
                        (const uint32_t*)seg_needed, (const float*)Tbuf, (const float*)part, out_color, out_depth,
                        out_quat, out_scale, out_alpha, final_T, n_contrib, dsum);
     VR_KERNEL_CHECK("seg_combine", s, debug);

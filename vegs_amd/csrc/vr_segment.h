@@ -40,6 +40,14 @@ __host__ __device__ inline int seg_tile_offset(int ntiles) { return (ntiles + 1 
 // the gradient sums are atomic -- or, in deterministic mode, written to per-(entry, region) slots).
 constexpr int SEG_LIST_NEEDED = 3;
 constexpr int SEG_QUEUES = 8;
+// HEAVY tiles (>= HEAVY_TILE needed segments: the vanishing-point tiles of a street view need up to ~200): the per-tile
+// chain kernels behind k_seg_scan (k_seg_combine, k_seg_suffix) start them FIRST -- a chain of 200 segments takes ~20 us
+// whoever else is running, so it had better not start in the middle of the launch (k_seg_combine 63.5 -> 54 us).  The
+// finishing k_seg_scan workgroup appends the tile id (counts[SEG_COUNT_HEAVY]; list in act_off's space, which is free once
+// k_seg_tiles has run); the first `ntiles` workgroups of those launches take the list from its END (finishing order =
+// shortest first), the others their own tile unless it is on the list.
+constexpr uint32_t HEAVY_TILE = 64u;
+constexpr int SEG_COUNT_HEAVY = 16;
 __host__ __device__ inline size_t seg_counts_offset(int ntiles, size_t cap) { return (size_t)seg_tile_offset(ntiles) + 4 * cap; }
 __host__ __device__ inline size_t seg_qcount_offset(int ntiles, size_t cap, int q) { return seg_counts_offset(ntiles, cap) + 64 + 32 * (size_t)q; }
 __host__ __device__ inline size_t seg_actoff_offset(int ntiles, size_t cap) { return seg_counts_offset(ntiles, cap) + 64 + 32 * SEG_QUEUES; }

@@ -29,6 +29,8 @@ namespace vr {
 
 __device__ __forceinline__ uint32_t hinted_limit(uint32_t h) { return h + 2u + (h >> 3); }
 constexpr uint32_t AUTO_FIRST = 6u;    // segments of every tile computed in round 0 of a forward with automatic rounds
+constexpr uint32_t AUTO_SECOND = 30u;  // ... and at least this many more in round 1 (swept 12 ... 48 at 13 and 24 segments per tile:
+                                       // the sparser of the two wants 48, the denser 12 ... 30)
 constexpr uint32_t AUTO_DENSITY = 12u; // ... which are used from this many list segments per tile on (launch_render_fwd)
 
 // seg_off[t] = first global segment id of tile t; seg_off[T] = total.  Single workgroup.  (k_seg_tiles then
@@ -197,7 +199,7 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
 constexpr uint32_t TILE_SHORT = 0x80000000u;
 __device__ __forceinline__ uint32_t catchup_end(int round, uint32_t lo, uint32_t nseg)
 {
-    return round == 1 ? min(nseg, lo + max(8u + (lo >> 1), 3u * AUTO_FIRST)) : nseg;
+    return round == 1 ? min(nseg, lo + max(8u + (lo >> 1), AUTO_SECOND)) : nseg;
 }
 
 // ---- A: per (tile, segment, pixel) product of (1 - alpha).  ROUND 0 = the segments inside the hinted prefix of their

@@ -105,7 +105,7 @@ typedef enum VrFlags {
     VR_FLAG_SCAN_BINNING = 1u << 9,
     /* The forward's segment rounds (ABI v6).  A tile's list is cut into 256-entry segments; most of them lie behind
      * the point where every pixel of the tile has stopped.  With ROUNDS the forward evaluates the first 6 segments of
-     * every tile, then -- only for tiles that still have a live pixel -- the next 30, then whatever is left; without,
+     * every tile, then -- only for tiles that still have a live pixel -- the next 24 ... 48 (by list density), then whatever is left; without,
      * every segment at once.  Results are identical bit for bit either way; the time is not: rounds win when lists
      * are long (discs three times larger than the street scene's: forward 0.65 -> 0.48 ms) and lose on short ones (the
      * heavy tiles' later rounds run at low parallelism: +0.04 ms on the headline view).  Default: chosen per call from

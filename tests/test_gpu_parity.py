@@ -541,7 +541,7 @@ def test_split_sh_storage_equals_concatenated(P, M, deg, dev):
 
 def test_segment_rounds_never_change_results(dev):
     """VR_FLAG_ROUNDS_ON / _OFF and the default (chosen from the list density): the forward evaluates a tile's list
-    segments all at once or in three rounds (6, then 30 more for tiles with a live pixel left, then the rest).  A dense,
+    segments all at once or in three rounds (6, then 24 ... 48 more for tiles with a live pixel left, then the rest).  A dense,
     fairly opaque scene (the default picks rounds) and a sparse one (it does not): images, lists and needed-segment
     counts bit-identical to the oracle and to each other in all three settings, and so are the gradients of the
     deterministic backward."""

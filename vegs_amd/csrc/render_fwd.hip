@@ -29,8 +29,10 @@ namespace vr {
 
 __device__ __forceinline__ uint32_t hinted_limit(uint32_t h) { return h + 2u + (h >> 3); }
 constexpr uint32_t AUTO_FIRST = 6u;    // segments of every tile computed in round 0 of a forward with automatic rounds
-constexpr uint32_t AUTO_SECOND = 30u;  // ... and at least this many more in round 1 (swept 12 ... 48 at 13 and 24 segments per tile:
-                                       // the sparser of the two wants 48, the denser 12 ... 30)
+// ... and at least this many more in round 1.  Swept 12 ... 48 at 13 and at 24 list segments per tile: the sparser scene wants
+// 48 (forward 0.44 -> 0.39 ms), the denser 12 ... 30 (its pixels saturate sooner although its lists are longer) -- the host
+// knows the density when it launches (launch_render_fwd)
+constexpr uint32_t AUTO_SECOND_SPARSE = 48u, AUTO_SECOND_DENSE = 24u, AUTO_SECOND_SPLIT = 18u;
 constexpr uint32_t AUTO_DENSITY = 12u; // ... which are used from this many list segments per tile on (launch_render_fwd)
 
 // seg_off[t] = first global segment id of tile t; seg_off[T] = total.  Single workgroup.  (k_seg_tiles then
@@ -197,9 +199,9 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
 // after an epoch of training the heavy tiles' counts have moved by up to +-50 % (profiles/tools/epoch_drift.py: 55 short
 // tiles per view, 429 segments beyond their limits, out of ~10 k needed) --, round 2 takes whatever is left.
 constexpr uint32_t TILE_SHORT = 0x80000000u;
-__device__ __forceinline__ uint32_t catchup_end(int round, uint32_t lo, uint32_t nseg)
+__device__ __forceinline__ uint32_t catchup_end(int round, uint32_t lo, uint32_t nseg, uint32_t second)
 {
-    return round == 1 ? min(nseg, lo + max(8u + (lo >> 1), AUTO_SECOND)) : nseg;
+    return round == 1 ? min(nseg, lo + max(8u + (lo >> 1), second)) : nseg;
 }
 
 // ---- A: per (tile, segment, pixel) product of (1 - alpha).  ROUND 0 = the segments inside the hinted prefix of their
@@ -244,7 +246,7 @@ k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
 // depends on the hint either way.
 template <int ROUND>
 __global__ void __launch_bounds__(256)
-k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, uint32_t cap, const float* __restrict__ Pbuf,
+k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, uint32_t cap, uint32_t second, const float* __restrict__ Pbuf,
            float* __restrict__ Tbuf, uint32_t* __restrict__ seg_needed, uint32_t* __restrict__ hint)
 {
     constexpr bool PASS2 = ROUND > 0;
@@ -260,7 +262,7 @@ k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, uint32_t cap, const float
     const uint32_t s0 = seg_off[tile], s1 = seg_off[tile + 1];
     // segments [first, last) of the tile are walked by this launch
     const uint32_t first = PASS2 ? (lim_word & ~TILE_SHORT) : 0u;
-    const uint32_t last = PASS2 ? catchup_end(ROUND, first, s1 - s0) : min(s1 - s0, lim_word);
+    const uint32_t last = PASS2 ? catchup_end(ROUND, first, s1 - s0, second) : min(s1 - s0, lim_word);
     bool alive = px < cam.W && py < cam.H;
     float Tb = 1.0f;
     if (PASS2) {   // the state parked by the first pass
@@ -298,7 +300,7 @@ k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, uint32_t cap, const float
         for (uint32_t s = s0 + mine; s < s0 + last; ++s) Tbuf[(size_t)s * SEG + threadIdx.x] = -1.0f;
         Tbuf[(size_t)(s0 + last) * SEG + threadIdx.x] = alive ? Tb : -1.0f;
         // the next round's window of this tile goes onto that round's work list (order among tiles: whoever comes first)
-        const uint32_t wend = catchup_end(ROUND + 1, last, s1 - s0);
+        const uint32_t wend = catchup_end(ROUND + 1, last, s1 - s0, second);
         const int ntiles = cam.gx * cam.gy;
         if (threadIdx.x == 0) {
             seg_needed[tile] = last | TILE_SHORT;
@@ -689,6 +691,7 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     const bool auto_rounds = !needed_hint && R > 0 && !(cam.flags & FLAG_ROUNDS_OFF) &&
                              ((cam.flags & FLAG_ROUNDS_ON) || (size_t)R / SEG >= (size_t)AUTO_DENSITY * ntiles);
     const bool rounds = needed_hint || auto_rounds;
+    const uint32_t second = (size_t)R / SEG >= (size_t)AUTO_SECOND_SPLIT * ntiles ? AUTO_SECOND_DENSE : AUTO_SECOND_SPARSE;
     hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(SEGOFF_THREADS), 0, s, ranges, ntiles, seg_off,
                        (const uint32_t*)needed_hint, seg_needed, (uint32_t)nseg, auto_rounds ? AUTO_FIRST : 0x3FFFFFFFu);
     hipLaunchKernelGGL(k_seg_tiles, dim3(cdiv((long)nseg, 256)), dim3(256), 0, s, ntiles, ranges, seg_off,
@@ -705,7 +708,7 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
 #define VR_ROUND(RD, GRID)                                                                                                \
     if (R > 0) hipLaunchKernelGGL(k_seg_alpha<RD>, dim3(GRID), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,     \
                                   (uint32_t)nseg, point_list, rec, Pbuf, segmask);                                        \
-    if (R > 0 || RD == 0) hipLaunchKernelGGL(k_seg_scan<RD>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (uint32_t)nseg, \
+    if (R > 0 || RD == 0) hipLaunchKernelGGL(k_seg_scan<RD>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (uint32_t)nseg, second, \
                                              (const float*)Pbuf, Tbuf, seg_needed, needed_hint)
     VR_ROUND(0, grid0);
     if (rounds) {

@@ -5,6 +5,8 @@
  *   torch.optim.Adam(l, lr=0.0, eps=1e-15).step()   scene/gaussian_model.py:159-168 (groups xyz, f_dc, f_rest,
  *                                                   opacity, scaling, rotation), stepped at train.py:319
  *   add_densification_stats + max_radii2D update    scene/gaussian_model.py:411-413, train.py:299-300
+ *   densify_and_prune (clone + split + prune, with   scene/gaussian_model.py:278-403, called at train.py:312
+ *     the optimizer-state surgery), reset_opacity    scene/gaussian_model.py:215-218, called at train.py:315
  */
 #ifndef VEGS_OPTIM_H
 #define VEGS_OPTIM_H
@@ -36,6 +38,53 @@ int vr_adam_step(const VrAdamTensor* tensors, int32_t count, double beta1, doubl
  * max_radii2D = max(max_radii2D, radii).  means2D_grad [P,3], radii int32 [P], the three statistics fp32 [P]. */
 int vr_densify_stats(const float* means2D_grad, const int32_t* radii, int32_t P, float* xyz_gradient_accum,
                      float* denom, float* max_radii2D, void* stream);
+
+/* ---- densification (scene/gaussian_model.py:384-403 densify_and_prune).  The reference's sequence of concatenations and
+ * mask gathers amounts to one gather: every output row copies one input row.  In output order:
+ *   A  the originals that are neither split nor pruned          parameters and Adam moments carried along
+ *   B  one clone of every original with |g| >= max_grad whose largest scale <= percent_dense * extent      moments 0
+ *   C1, C2  the two samples of every original with g >= max_grad and a larger scale (copy-major):
+ *           xyz = R(rotation) (noise * exp(scaling)) + xyz,  scaling = log(exp(scaling) / 1.6),  moments 0
+ * g = xyz_gradient_accum / denom with NaN -> 0.  Pruned (all rows, after the above): sigmoid(opacity) < min_opacity and,
+ * if prune_big, largest scale > 0.1 * extent.  (prune_big = the reference's `max_screen_size` being truthy; its
+ * screen-size test max_radii2D > max_screen_size can never fire, because densification_postfix, :349-351, has reset
+ * max_radii2D to zeros by then.)  The caller zeroes xyz_gradient_accum / denom / max_radii2D at the new length. */
+typedef struct VrDensifySettings {
+    double max_grad;       /* densify_grad_threshold (train.py:305-312) */
+    double min_opacity;    /* 0.005 at train.py:312 */
+    double extent;         /* scene.cameras_extent */
+    double percent_dense;  /* training_args.percent_dense (scene/gaussian_model.py:155) */
+    int32_t prune_big;
+} VrDensifySettings;
+
+/* int32 words of the `plan` buffer for P Gaussians */
+int64_t vr_densify_plan_words(int32_t P);
+
+/* Classify and lay out.  opacity [P], scaling [P,3] raw parameters; the statistics [P].  plan: device buffer of
+ * vr_densify_plan_words(P) int32.  counts: device int32[5] = { rows out, A, B, C, S } with S = number of split originals =
+ * rows per copy of the caller's unit-normal draw `noise` [2 S, 3] (torch.normal's, :367). */
+int vr_densify_plan(const float* opacity, const float* scaling, const float* xyz_gradient_accum, const float* denom,
+                    int32_t P, const VrDensifySettings* settings, int32_t* plan, int32_t* counts, void* stream);
+
+/* One model tensor [P, width] -> [rows out, width], with its Adam moments (all four pointers or none).
+ * role: 0 copied columns, 1 the position tensor, 2 the scaling tensor (the computed columns of the split samples). */
+typedef struct VrDensifyTensor {
+    const float* src;   float* dst;
+    const float* m_src; float* m_dst;   /* exp_avg */
+    const float* v_src; float* v_dst;   /* exp_avg_sq */
+    int32_t width;
+    int32_t role;
+} VrDensifyTensor;
+
+/* Gather: n_out = counts[0], n_split = counts[4] (the caller has read them back to size the outputs).  scaling [P,3],
+ * rotation [P,4] (16-byte aligned) = the INPUT model's raw parameters, noise [2 n_split, 3].  `tensors` is a HOST array;
+ * one launch per tensor moves the parameter and both moments. */
+int vr_densify_apply(const int32_t* plan, int32_t n_out, int32_t n_split, const VrDensifyTensor* tensors, int32_t count,
+                     const float* scaling, const float* rotation, const float* noise, void* stream);
+
+/* reset_opacity (scene/gaussian_model.py:215-218): opacity = logit(min(sigmoid(opacity), cap)) in place, cap = 0.01 in the
+ * reference; the moments (both or none) are zeroed as replace_tensor_to_optimizer does. */
+int vr_reset_opacity(float* opacity, float* exp_avg, float* exp_avg_sq, int64_t P, float cap, void* stream);
 
 /* ---- factored SH gradients (VrInGrads.dL_dcolors_sh of vegs_rast.h).
  * Dense gradient from the factors of n_views views (what a view-sharded job all-gathers: 3 floats per Gaussian and

@@ -305,7 +305,125 @@ def part_c():
                         d_scaling=ts.grad.numpy(), d_rotation=tq.grad.numpy())
 
 
+def part_d():
+    """ref_densify.npz: scene/gaussian_model.py:263-413 (densify_and_prune with its clone / split / prune and the
+    optimizer-state surgery, reset_opacity) run by the reference's OWN GaussianModel methods on the CPU.  What had to be
+    arranged for that (none of it arithmetic): the module's imports that are absent here (plyfile, the decoder package)
+    are empty stand-ins, torch.zeros ignores device="cuda", and torch.normal -- the split's random draw,
+    scene/gaussian_model.py:367 -- returns mean + std * noise with the unit-normal `noise` of the fixture, so that the
+    draw is an INPUT of the case (torch.normal(mean, std) is defined as that with noise ~ N(0, 1))."""
+    import types
+    sys.path.insert(0, REF)
+    for name, attrs in (("plyfile", ("PlyData", "PlyElement")), ("model", ("GaussianDecoder",))):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for a in attrs:
+                setattr(m, a, type(a, (), {}))
+            sys.modules[name] = m
+    if "torchvision" not in sys.modules:
+        tv, tvt = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+        tvt.functional = types.ModuleType("torchvision.transforms.functional")
+        tv.transforms = tvt
+        sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt,
+                            "torchvision.transforms.functional": tvt.functional})
+    knn = types.ModuleType("simple_knn._C")
+    knn.distCUDA2 = None
+    saved_knn = {k: sys.modules.get(k) for k in ("simple_knn", "simple_knn._C")}
+    sys.modules["simple_knn"] = types.ModuleType("simple_knn")
+    sys.modules["simple_knn._C"] = knn
+    try:
+        # the file itself, not the `scene` package (whose __init__ pulls in the dataset readers and their dependencies)
+        spec = importlib.util.spec_from_file_location("ref_gaussian_model", os.path.join(REF, "scene", "gaussian_model.py"))
+        gm = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(gm)
+        GaussianModel = gm.GaussianModel
+    finally:
+        for k, v in saved_knn.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    real_zeros, real_normal = torch.zeros, torch.normal
+
+    def zeros_cpu(*a, **k):
+        k.pop("device", None)
+        return real_zeros(*a, **k)
+
+    blob = {}
+    cases = {"a": dict(P=1200, seed=5, max_grad=0.0002, min_opacity=0.005, extent=5.0, size_threshold=20, deg=3),
+             "b": dict(P=700, seed=6, max_grad=0.0004, min_opacity=0.02, extent=3.0, size_threshold=None, deg=2),
+             "c": dict(P=300, seed=7, max_grad=1e9, min_opacity=0.005, extent=4.0, size_threshold=20, deg=1)}  # nothing selected
+    for tag, c in cases.items():
+        rng = np.random.default_rng(c["seed"])
+        P, M = c["P"], (c["deg"] + 1) ** 2
+        g = GaussianModel(c["deg"])
+        par = {"xyz": rng.normal(0, 2, (P, 3)), "f_dc": rng.normal(0, 1, (P, 1, 3)), "f_rest": rng.normal(0, .2, (P, M - 1, 3)),
+               "opacity": rng.normal(-1.0, 3.0, (P, 1)),
+               "scaling": np.log(np.exp(rng.normal(np.log(0.03), 1.2, (P, 3)))), "rotation": rng.normal(size=(P, 4))}
+        par = {k: v.astype(np.float32) for k, v in par.items()}
+        g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation = (
+            torch.nn.Parameter(torch.tensor(par[k])) for k in ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"))
+        args = types.SimpleNamespace(percent_dense=0.01, position_lr_init=1.6e-4, position_lr_final=1.6e-6,
+                                     position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=2.5e-3,
+                                     opacity_lr=0.05, scaling_lr=5e-3, rotation_lr=1e-3)
+        g.spatial_lr_scale = 1.0
+        noise_used = []
+
+        def normal_from_noise(mean=None, std=None, **k):
+            n = torch.tensor(rng.normal(size=tuple(std.shape)).astype(np.float32))
+            noise_used.append(n.numpy().copy())
+            return mean + std * n
+        torch.zeros = zeros_cpu
+        torch.normal = normal_from_noise
+        try:
+            g.training_setup(args)
+            for _ in range(3):                     # the moments the surgery has to carry along
+                for grp in g.optimizer.param_groups:
+                    q = grp["params"][0]
+                    q.grad = torch.tensor(rng.normal(0, 1e-3, tuple(q.shape)).astype(np.float32))
+                g.optimizer.step()
+            names = [grp["name"] for grp in g.optimizer.param_groups]
+            for grp in g.optimizer.param_groups:
+                st = g.optimizer.state[grp["params"][0]]
+                blob[f"{tag}_in_{grp['name']}"] = grp["params"][0].detach().numpy().copy()
+                blob[f"{tag}_in_m_{grp['name']}"] = st["exp_avg"].numpy().copy()
+                blob[f"{tag}_in_v_{grp['name']}"] = st["exp_avg_sq"].numpy().copy()
+            den = rng.integers(0, 40, (P, 1)).astype(np.float32)
+            den[rng.random(P) < 0.1] = 0.0        # never visible: 0 / 0 = NaN -> 0 (scene/gaussian_model.py:391-392)
+            acc = (den * np.exp(rng.normal(np.log(c["max_grad"] if c["max_grad"] < 1 else 2e-4), 1.0, (P, 1)))).astype(np.float32)
+            g.xyz_gradient_accum, g.denom = torch.tensor(acc), torch.tensor(den)
+            g.max_radii2D = torch.tensor(rng.uniform(0, 60, P).astype(np.float32))
+            blob[f"{tag}_in_accum"], blob[f"{tag}_in_denom"], blob[f"{tag}_in_max_radii2D"] = acc, den, g.max_radii2D.numpy().copy()
+            g.densify_and_prune(c["max_grad"], c["min_opacity"], c["extent"], c["size_threshold"])
+            for grp in g.optimizer.param_groups:
+                st = g.optimizer.state[grp["params"][0]]
+                assert grp["params"][0] is {"xyz": g._xyz, "f_dc": g._features_dc, "f_rest": g._features_rest,
+                                             "opacity": g._opacity, "scaling": g._scaling, "rotation": g._rotation}[grp["name"]]
+                blob[f"{tag}_out_{grp['name']}"] = grp["params"][0].detach().numpy().copy()
+                blob[f"{tag}_out_m_{grp['name']}"] = st["exp_avg"].numpy().copy()
+                blob[f"{tag}_out_v_{grp['name']}"] = st["exp_avg_sq"].numpy().copy()
+                blob[f"{tag}_out_step_{grp['name']}"] = np.float32(float(st["step"]))
+            blob[f"{tag}_out_accum"], blob[f"{tag}_out_denom"] = g.xyz_gradient_accum.numpy().copy(), g.denom.numpy().copy()
+            blob[f"{tag}_out_max_radii2D"] = g.max_radii2D.numpy().copy()
+            assert len(noise_used) == 1
+            blob[f"{tag}_noise"] = noise_used[0]
+            blob[f"{tag}_settings"] = np.array([c["max_grad"], c["min_opacity"], c["extent"], 0.01,
+                                                1.0 if c["size_threshold"] else 0.0], dtype=np.float64)
+            # reset_opacity on the densified model (scene/gaussian_model.py:215-218)
+            g.reset_opacity()
+            st = g.optimizer.state[g._opacity]
+            blob[f"{tag}_reset_opacity"] = g._opacity.detach().numpy().copy()
+            assert float(st["exp_avg"].abs().max()) == 0.0 and float(st["exp_avg_sq"].abs().max()) == 0.0
+            print(tag, "P", P, "->", g._xyz.shape[0], "split draws", noise_used[0].shape[0])
+        finally:
+            torch.zeros, torch.normal = real_zeros, real_normal
+    np.savez_compressed(os.path.join(HERE, "ref_densify.npz"), **blob)
+
+
 if __name__ == "__main__":
+    if "--densify" in sys.argv:
+        part_d()
+        sys.exit(0)
     if "--activations" in sys.argv:
         part_c()
         sys.exit(0)
@@ -316,3 +434,5 @@ if __name__ == "__main__":
     part_b(only_new=new)
     if not new or not os.path.exists(os.path.join(HERE, "ref_activations.npz")):
         part_c()
+    if not new or not os.path.exists(os.path.join(HERE, "ref_densify.npz")):
+        part_d()

@@ -25,6 +25,7 @@ EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_b
            "vr_count_fragments", "vr_count_blended", "vr_export_needed", "vr_debug_export_binning", "vr_debug_set_guard", "vr_debug_raise_guard", "vr_profile_level", "vr_profile_collect",
            "vr_knn3_mean_dist2", "vr_photometric_forward", "vr_photometric_backward",
            "vr_normal_guidance_forward", "vr_normal_guidance_backward", "vr_adam_step", "vr_densify_stats",
+           "vr_densify_plan_words", "vr_densify_plan", "vr_densify_apply", "vr_reset_opacity",
            "vr_sh_grad_from_factors", "vr_sh_adam_step",
            "vr_instances_forward", "vr_instances_backward", "vr_activations_forward", "vr_activations_backward"]
 STAGES = ["preprocess", "compact", "depth_sort", "emit", "tile_sort", "ranges", "render_fwd", "bwd_zero",
@@ -71,6 +72,16 @@ class VrInGrads(C.Structure):
 class VrAdamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("n", C.c_int64), ("lr", C.c_double), ("step", C.c_int64)]
+
+
+class VrDensifySettings(C.Structure):
+    _fields_ = [("max_grad", C.c_double), ("min_opacity", C.c_double), ("extent", C.c_double),
+                ("percent_dense", C.c_double), ("prune_big", C.c_int32)]
+
+
+class VrDensifyTensor(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("m_src", C.c_void_p), ("m_dst", C.c_void_p),
+                ("v_src", C.c_void_p), ("v_dst", C.c_void_p), ("width", C.c_int32), ("role", C.c_int32)]
 
 
 class VrShAdamTensor(C.Structure):
@@ -157,6 +168,14 @@ def load():
     lib.vr_adam_step.argtypes = [C.POINTER(VrAdamTensor), i32, C.c_double, C.c_double, C.c_double, vp]
     lib.vr_densify_stats.restype = C.c_int
     lib.vr_densify_stats.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    lib.vr_densify_plan_words.restype = C.c_int64
+    lib.vr_densify_plan_words.argtypes = [i32]
+    lib.vr_densify_plan.restype = C.c_int
+    lib.vr_densify_plan.argtypes = [vp, vp, vp, vp, i32, C.POINTER(VrDensifySettings), vp, vp, vp]
+    lib.vr_densify_apply.restype = C.c_int
+    lib.vr_densify_apply.argtypes = [vp, i32, i32, C.POINTER(VrDensifyTensor), i32, vp, vp, vp, vp]
+    lib.vr_reset_opacity.restype = C.c_int
+    lib.vr_reset_opacity.argtypes = [vp, vp, vp, C.c_int64, C.c_float, vp]
     lib.vr_sh_grad_from_factors.restype = C.c_int
     lib.vr_sh_grad_from_factors.argtypes = [vp, i32, vp, vp, i32, i32, i32, C.c_float, vp, vp, vp]
     lib.vr_sh_adam_step.restype = C.c_int

@@ -133,6 +133,25 @@ class Trainer:
         self.max_radii = torch.zeros(P, device=device)
         self.win = ssim_window(device)
 
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, percent_dense=0.01, noise=None):
+        """train.py:303-312 for the static model (fused variant): optim.densify_and_prune on the optimizer's tensors, the
+        statistics restarted at the new length.  Returns the number of Gaussians after the step."""
+        from . import optim
+        if not self.fused:
+            raise NotImplementedError("the ATen variant exists for timing comparisons of the iteration only")
+        P0 = self.p["xyz"].shape[0]
+        rows_boxes = self.accum.shape[0] - P0
+        new, (accum, denom, max_radii) = optim.densify_and_prune(
+            self.opt, self.accum[:P0].contiguous(), self.denom[:P0].contiguous(), max_grad, min_opacity, extent,
+            max_screen_size, percent_dense, noise=noise)
+        self.p = new
+        if rows_boxes:                        # the instances' rows of the statistics follow the static model's
+            pad = torch.zeros(rows_boxes, 1, device=self.device)
+            accum, denom = torch.cat((accum, pad)), torch.cat((denom, pad))
+            max_radii = torch.cat((max_radii, pad[:, 0]))
+        self.accum, self.denom, self.max_radii = accum, denom, max_radii
+        return new["xyz"].shape[0]
+
     def forward_loss(self, cam, cam_t, deg, bg, gt, normal):
         sink = None
         if self.factored_sh and torch.is_grad_enabled():

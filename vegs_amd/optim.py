@@ -4,6 +4,9 @@ by fused HIP kernels (vegs_amd/csrc/optim.hip, C ABI include/vegs_optim.h):
   Adam(params, lr, betas, eps)          drop-in for torch.optim.Adam as scene/gaussian_model.py:159-168 builds it
                                         (six named groups, eps=1e-15) and train.py:319-320 steps it
   add_densification_stats(...)          scene/gaussian_model.py:411-413 + the max_radii2D line of train.py:299
+  densify_and_prune(optimizer, ...)     scene/gaussian_model.py:384-403 with its clone / split / prune and the
+                                        optimizer-state surgery (:278-351), as one planned gather
+  reset_opacity(optimizer)              scene/gaussian_model.py:215-218
 
 `Adam` is a torch.optim.Optimizer: param_groups (with the reference's extra "name" keys) and the per-parameter
 state dict {"step", "exp_avg", "exp_avg_sq"} have torch's layout, because the reference's densification code
@@ -12,6 +15,7 @@ replace_tensor_to_optimizer) and checkpoints them with state_dict().  One kernel
 GPU tensors only; there is no CPU path.
 """
 import ctypes as C
+import math
 
 import torch
 
@@ -87,6 +91,139 @@ def add_densification_stats(viewspace_point_grad, radii, xyz_gradient_accum, den
                                   _capi.ptr(denom), _capi.ptr(max_radii2D),
                                   torch.cuda.current_stream(radii.device).cuda_stream)
     _capi.check(rc)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Densification (csrc/densify.hip).  The model's tensors are found the way the reference finds them: by the "name" of their
+# optimizer group (scene/gaussian_model.py:159-166: xyz, f_dc, f_rest, opacity, scaling, rotation; one tensor per group).
+DENSIFY_NAMES = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+_ROLES = {"xyz": 1, "scaling": 2}
+
+
+def _named_groups(optimizer):
+    groups = {}
+    for group in optimizer.param_groups:
+        if len(group["params"]) != 1:
+            raise ValueError("densification expects one tensor per optimizer group (scene/gaussian_model.py:313)")
+        groups[group.get("name")] = group
+    missing = [n for n in DENSIFY_NAMES if n not in groups]
+    if missing:
+        raise ValueError(f"optimizer groups named {missing} are missing (scene/gaussian_model.py:159-166)")
+    return groups
+
+
+def _model_tensor(name, p, P, width=None):
+    if not p.is_cuda:
+        raise ValueError(f"{name} must be a GPU tensor (there is no CPU path)")
+    if p.dtype != torch.float32 or p.dim() < 2 or p.shape[0] != P or not p.is_contiguous():
+        raise ValueError(f"{name} must be contiguous float32 [{P}, ...] (got {p.dtype} {tuple(p.shape)})")
+    if width is not None and math.prod(p.shape[1:]) != width:
+        raise ValueError(f"{name} must have {width} values per Gaussian (got {tuple(p.shape)})")
+
+
+def densify_and_prune(optimizer, xyz_gradient_accum, denom, max_grad, min_opacity, extent, max_screen_size,
+                      percent_dense, noise=None, generator=None):
+    """GaussianModel.densify_and_prune (scene/gaussian_model.py:384-403) on the tensors of `optimizer`'s six named groups:
+    clone the small Gaussians whose mean screen-space gradient `xyz_gradient_accum / denom` reaches `max_grad`, replace
+    the large ones by two samples, prune by opacity (and, if `max_screen_size` is truthy, by world size -- the
+    reference's screen-size test never fires, see include/vegs_optim.h), carrying the Adam moments of the survivors
+    along and starting the new rows' at zero.  As in the reference the optimizer ends up with NEW nn.Parameter objects
+    (state re-keyed, "step" untouched); they are returned as {name: parameter} like its `optimizable_tensors`, together
+    with the fresh statistics (xyz_gradient_accum, denom, max_radii2D) = zeros of the new length (:349-351).
+
+    One planned gather instead of the reference's two concatenations and two mask passes per tensor: the result has
+    the same rows in the same order.  `noise` [2 S, 3] is the unit-normal draw behind torch.normal (:367), S = number
+    of split Gaussians; drawn here with `generator` when not given -- pass it to make the step reproducible."""
+    groups = _named_groups(optimizer)
+    par = {n: groups[n]["params"][0] for n in DENSIFY_NAMES}
+    P = par["xyz"].shape[0]
+    dev = par["xyz"].device
+    for n, w in (("xyz", 3), ("opacity", 1), ("scaling", 3), ("rotation", 4), ("f_dc", None), ("f_rest", None)):
+        _model_tensor(n, par[n], P, w)
+    for n, t in (("xyz_gradient_accum", xyz_gradient_accum), ("denom", denom)):
+        if not t.is_cuda or t.dtype != torch.float32 or t.numel() != P or not t.is_contiguous():
+            raise ValueError(f"{n} must be a contiguous float32 GPU tensor with one value per Gaussian")
+    lib = _capi.load()
+    settings = _capi.VrDensifySettings(float(max_grad), float(min_opacity), float(extent), float(percent_dense),
+                                       1 if max_screen_size else 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    with torch.cuda.device(dev), torch.no_grad():
+        plan = torch.empty(max(int(lib.vr_densify_plan_words(P)), 1), dtype=torch.int32, device=dev)
+        counts = torch.empty(8, dtype=torch.int32, device=dev)
+        _capi.check(lib.vr_densify_plan(_capi.ptr(par["opacity"]), _capi.ptr(par["scaling"]), _capi.ptr(xyz_gradient_accum),
+                                        _capi.ptr(denom), P, C.byref(settings), plan.data_ptr(), counts.data_ptr(), stream))
+        n_out, _, _, _, n_split = (int(c) for c in counts[:5].tolist())       # the one host round trip of the step
+        if noise is None:
+            noise = torch.randn((2 * n_split, 3), dtype=torch.float32, device=dev, generator=generator)
+        if not noise.is_cuda or noise.dtype != torch.float32 or tuple(noise.shape) != (2 * n_split, 3):
+            raise ValueError(f"noise must be a float32 GPU tensor [{2 * n_split}, 3] (two samples per split Gaussian)")
+        noise = noise.contiguous()
+        new, moments, items = {}, {}, []
+        for n in DENSIFY_NAMES:
+            p = par[n]
+            st = optimizer.state.get(p, None)
+            have = st is not None and "exp_avg" in st
+            new[n] = torch.empty((n_out,) + tuple(p.shape[1:]), dtype=torch.float32, device=dev)
+            m_src = v_src = m_dst = v_dst = None
+            if have:
+                m_src, v_src = st["exp_avg"], st["exp_avg_sq"]
+                if m_src.shape != p.shape or v_src.shape != p.shape or not m_src.is_contiguous() or not v_src.is_contiguous():
+                    raise ValueError(f"optimizer state of {n} does not match its parameter")
+                m_dst, v_dst = torch.empty_like(new[n]), torch.empty_like(new[n])
+                moments[n] = (m_dst, v_dst)
+            items.append(_capi.VrDensifyTensor(_capi.ptr(p), _capi.ptr(new[n]), _capi.ptr(m_src), _capi.ptr(m_dst),
+                                               _capi.ptr(v_src), _capi.ptr(v_dst), math.prod(p.shape[1:]), _ROLES.get(n, 0)))
+        if n_out > 0:
+            arr = (_capi.VrDensifyTensor * len(items))(*items)
+            _capi.check(lib.vr_densify_apply(plan.data_ptr(), n_out, n_split, arr, len(items), _capi.ptr(par["scaling"]),
+                                             _capi.ptr(par["rotation"]), _capi.ptr(noise), stream))
+    out = {}
+    for n in DENSIFY_NAMES:                      # _prune_optimizer / cat_tensors_to_optimizer's re-keying (:278-331)
+        group, old = groups[n], par[n]
+        stored = optimizer.state.get(old, None)
+        param = torch.nn.Parameter(new[n].requires_grad_(True))
+        if stored is not None:
+            if n in moments:
+                stored["exp_avg"], stored["exp_avg_sq"] = moments[n]
+            del optimizer.state[old]
+            optimizer.state[param] = stored
+        group["params"][0] = param
+        out[n] = param
+    stats = (torch.zeros((n_out, 1), dtype=torch.float32, device=dev), torch.zeros((n_out, 1), dtype=torch.float32, device=dev),
+             torch.zeros((n_out,), dtype=torch.float32, device=dev))
+    return out, stats
+
+
+def reset_opacity(optimizer, cap=0.01):
+    """GaussianModel.reset_opacity (scene/gaussian_model.py:215-218): opacity = inverse_sigmoid(min(sigmoid(opacity), 0.01))
+    as a NEW nn.Parameter of the "opacity" group with zeroed Adam moments (replace_tensor_to_optimizer, :263-276); one
+    launch.  Returns the parameter."""
+    group = None
+    for g in optimizer.param_groups:
+        if g.get("name") == "opacity":
+            group = g
+    if group is None or len(group["params"]) != 1:
+        raise ValueError('the optimizer has no single-tensor group named "opacity"')
+    old = group["params"][0]
+    if not old.is_cuda or old.dtype != torch.float32 or not old.is_contiguous():
+        raise ValueError("opacity must be a contiguous float32 GPU tensor (there is no CPU path)")
+    stored = optimizer.state.get(old, None)
+    with torch.no_grad():
+        new = old.detach().clone()
+        m = v = None
+        if stored is not None and "exp_avg" in stored:
+            m, v = torch.empty_like(new), torch.empty_like(new)
+        with torch.cuda.device(old.device):
+            _capi.check(_capi.load().vr_reset_opacity(_capi.ptr(new), _capi.ptr(m), _capi.ptr(v), new.numel(), float(cap),
+                                                      torch.cuda.current_stream(old.device).cuda_stream))
+    param = torch.nn.Parameter(new.requires_grad_(True))
+    if stored is not None:
+        if m is not None:
+            stored["exp_avg"], stored["exp_avg_sq"] = m, v
+        del optimizer.state[old]
+        optimizer.state[param] = stored
+    group["params"][0] = param
+    return param
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -40,6 +40,25 @@ int vr_normal_guidance_backward(const float* cov_quat, const float* cov_scale, c
                                 const float* R_cam2world, int32_t H, int32_t W, const float* g, float* dL_dquat,
                                 float* dL_dscale, void* stream);
 
+/* The whole loss block of an iteration (train.py:162-168) in one call each way:
+ *   Ll1 = l1_loss(image, gt);  loss = (1 - lambda_dssim) * Ll1 + lambda_dssim * (1 - ssim(image, gt));
+ *   loss += lambda_dnormal * loss_normal_guidance(cam, cov_quat, cov_scale)
+ * Three launches forward (the two losses' partial sums, one combining reduction), two backward, no scalar glue kernels
+ * in between.  loss: device scalar; aux: device float[3] = { Ll1, mean SSIM, Lng } (train.py logs Ll1); dmaps as for
+ * vr_photometric_forward (NULL when no gradient is wanted).  guard_empty: pixels no Gaussian covers (cov_quat == 0, where
+ * the reference's quaternion_to_matrix returns NaN, utils/graphics_utils.py:217) are evaluated with q = (1,1,1,1) and get
+ * no quaternion gradient -- what `torch.where(|q|^2 > 0, q, 1)` in front of the loss does. */
+int vr_training_loss_forward(const float* image, const float* gt, int32_t C, int32_t H, int32_t W, const float* cov_quat,
+                             const float* cov_scale, const float* normal, const float* R_cam2world, float lambda_dssim,
+                             float lambda_dnormal, int32_t guard_empty, float* loss, float* aux, float* dmaps,
+                             VrAllocFn alloc, void* alloc_user, void* stream);
+
+/* g: device scalar dL/dloss.  dL_dimage [C,H,W], dL_dquat [4,H,W], dL_dscale [3,H,W]. */
+int vr_training_loss_backward(const float* image, const float* gt, int32_t C, int32_t H, int32_t W, const float* dmaps,
+                              const float* cov_quat, const float* cov_scale, const float* normal, const float* R_cam2world,
+                              float lambda_dssim, float lambda_dnormal, int32_t guard_empty, const float* g,
+                              float* dL_dimage, float* dL_dquat, float* dL_dscale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -209,6 +209,6 @@ def test_training_continues_after_densification(dev):
         loss, pkg, _ = tr.step(cams[it % 4], cam_ts[it % 4], deg, bg, gts[it % 4], normal)
         assert torch.isfinite(loss) and pkg["radii"].shape[0] == P1
     tr.p["opacity"] = optim.reset_opacity(tr.opt)
-    assert float(torch.sigmoid(tr.p["opacity"]).max()) <= 0.0100001
+    assert float(torch.sigmoid(tr.p["opacity"].detach()).max()) <= 0.0100001
     loss, _, _ = tr.step(cams[0], cam_ts[0], deg, bg, gts[0], normal)
     assert torch.isfinite(loss) and int((tr.denom > 0).sum()) > 500

@@ -105,6 +105,72 @@ def test_normal_guidance_full_frame_against_oracle_and_nan_propagation():
     assert torch.isnan(bad).item()
 
 
+@pytest.mark.parametrize("guard", [False, True])
+def test_training_loss_block_equals_its_parts(guard):
+    """losses.training_loss (train.py:162-168 as one node: 3 launches forward, 2 backward) against the reference outputs the
+    individual losses are pinned by (ref_photometric / ref_normal_guidance goldens) and, at the full frame, against the
+    composition of the separately tested losses -- with the uncovered-pixel guard against torch.where in front of them."""
+    from vegs_amd import losses, scenes
+    zp = np.load(os.path.join(GOLDEN, "ref_photometric.npz"))
+    zn = np.load(os.path.join(GOLDEN, "ref_normal_guidance.npz"))
+    lam, lam_n = 0.2, 0.03
+    if not guard:
+        # the goldens' own sizes differ between the two files: check the terms of each at its size through the block
+        x, y = zp["img_a"], zp["gt_a"]
+        C, H, W = x.shape
+        rng = np.random.default_rng(1)
+        q = rng.normal(size=(4, H, W)).astype(np.float32)
+        sc = rng.uniform(1e-3, 0.3, (3, H, W)).astype(np.float32)
+        n = rng.normal(size=(3, H, W)).astype(np.float32)
+        loss, aux = losses.training_loss(torch.tensor(x, device=DEV), torch.tensor(y, device=DEV),
+                                         _cam(torch.tensor(n, device=DEV), scenes.R_KITTI), torch.tensor(q, device=DEV),
+                                         torch.tensor(sc, device=DEV), lam, lam_n)
+        assert abs(aux[0].item() - float(zp["l1_a"])) < 1e-6 and abs(aux[1].item() - float(zp["ssim_a"])) < 1e-6
+        cq, cs = torch.tensor(zn["cov_quat"], device=DEV), torch.tensor(zn["cov_scale"], device=DEV)
+        Hn, Wn = cq.shape[1:]
+        img = torch.rand(3, Hn, Wn, device=DEV)
+        _, aux_n = losses.training_loss(img, img.clone(), _cam(torch.tensor(zn["normal"], device=DEV), zn["R"]), cq, cs, lam, lam_n)
+        assert abs(aux_n[2].item() - float(zn["loss"])) < 1e-6 and abs(aux_n[0].item()) == 0.0
+    rng = np.random.default_rng(8)
+    H, W = 376, 1408
+    x = rng.uniform(0, 1, (3, H, W)).astype(np.float32)
+    y = np.clip(x + rng.normal(0, 0.1, x.shape), 0, 1).astype(np.float32)
+    q = rng.normal(size=(4, H, W)).astype(np.float32)
+    sc = rng.uniform(1e-4, 0.3, (3, H, W)).astype(np.float32)
+    n = rng.normal(size=(3, H, W)).astype(np.float32)
+    n /= np.linalg.norm(n, axis=0, keepdims=True)
+    if guard:
+        hole = rng.random((H, W)) < 0.15                      # sky: no Gaussian covers these pixels
+        q[:, hole] = 0.0
+        sc[:, hole] = 0.0
+    cam = _cam(torch.tensor(n, device=DEV), scenes.R_KITTI)
+    yt = torch.tensor(y, device=DEV)
+
+    def leaves():
+        return [torch.tensor(a, device=DEV, requires_grad=True) for a in (x, q, sc)]
+    xt, qt, st = leaves()
+    qq = torch.where((qt.detach() * qt.detach()).sum(0, keepdim=True) > 0, qt, torch.ones_like(qt)) if guard else qt
+    want = losses.photometric_loss(xt, yt, lam)[0] + lam_n * losses.loss_normal_guidance(cam, qq, st)
+    (2.5 * want).backward()
+    x2, q2, s2 = leaves()
+    got, aux = losses.training_loss(x2, yt, cam, q2, s2, lam, lam_n, guard_empty=guard)
+    assert not aux.requires_grad and got.requires_grad
+    (2.5 * got).backward()
+    assert torch.isfinite(got).item() and abs(got.item() - want.item()) < 2e-6 * max(1.0, abs(want.item()))
+    for a, b, name in ((x2, xt, "image"), (q2, qt, "cov_quat"), (s2, st, "cov_scale")):
+        ga, gb = a.grad.cpu().numpy(), b.grad.cpu().numpy()
+        assert np.isfinite(ga).all(), name
+        assert np.abs(ga - gb).max() <= 2e-6 * np.abs(gb).max() + 1e-12, name      # (weights rounded in a different order)
+    if guard:
+        assert float(q2.grad[:, torch.tensor(hole, device=DEV)].abs().max()) == 0.0
+    with torch.no_grad():                                       # evaluation: no derivative maps, same value
+        assert abs(losses.training_loss(x2, yt, cam, q2, s2, lam, lam_n, guard_empty=guard)[0].item() - got.item()) == 0.0
+    with pytest.raises(ValueError, match="GPU"):
+        losses.training_loss(x2.cpu(), yt.cpu(), cam, q2, s2, lam, lam_n)
+    with pytest.raises(ValueError, match="cov_quat"):
+        losses.training_loss(x2, yt, cam, q2[:3], s2, lam, lam_n)
+
+
 def test_losses_feed_the_rasterizer_backward():
     """The whole loss block of train.py:162-168 on a rendered frame: gradients reach the Gaussians."""
     from vegs_amd import harness, losses, scenes

@@ -24,7 +24,7 @@ VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH, VR_BUF_BACKWARD = 0, 
 EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_backward_render", "vr_backward_preprocess", "vr_mark_visible", "vr_get_counters",
            "vr_count_fragments", "vr_count_blended", "vr_export_needed", "vr_debug_export_binning", "vr_debug_set_guard", "vr_debug_raise_guard", "vr_profile_level", "vr_profile_collect",
            "vr_knn3_mean_dist2", "vr_photometric_forward", "vr_photometric_backward",
-           "vr_normal_guidance_forward", "vr_normal_guidance_backward", "vr_adam_step", "vr_densify_stats",
+           "vr_normal_guidance_forward", "vr_normal_guidance_backward", "vr_training_loss_forward", "vr_training_loss_backward", "vr_adam_step", "vr_densify_stats",
            "vr_densify_plan_words", "vr_densify_plan", "vr_densify_apply", "vr_reset_opacity",
            "vr_sh_grad_from_factors", "vr_sh_adam_step",
            "vr_instances_forward", "vr_instances_backward", "vr_activations_forward", "vr_activations_backward"]
@@ -164,6 +164,12 @@ def load():
     lib.vr_normal_guidance_forward.argtypes = [vp, vp, vp, C.POINTER(C.c_float), i32, i32, vp, VrAllocFn, vp, vp]
     lib.vr_normal_guidance_backward.restype = C.c_int
     lib.vr_normal_guidance_backward.argtypes = [vp, vp, vp, C.POINTER(C.c_float), i32, i32, vp, vp, vp, vp]
+    lib.vr_training_loss_forward.restype = C.c_int
+    lib.vr_training_loss_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, C.POINTER(C.c_float), C.c_float, C.c_float, i32,
+                                             vp, vp, vp, VrAllocFn, vp, vp]
+    lib.vr_training_loss_backward.restype = C.c_int
+    lib.vr_training_loss_backward.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, C.POINTER(C.c_float), C.c_float, C.c_float,
+                                              i32, vp, vp, vp, vp, vp]
     lib.vr_adam_step.restype = C.c_int
     lib.vr_adam_step.argtypes = [C.POINTER(VrAdamTensor), i32, C.c_double, C.c_double, C.c_double, vp]
     lib.vr_densify_stats.restype = C.c_int

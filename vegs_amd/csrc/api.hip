@@ -686,6 +686,34 @@ int vr_normal_guidance_backward(const float* cov_quat, const float* cov_scale, c
                                       false);
 }
 
+int vr_training_loss_forward(const float* image, const float* gt, int32_t C, int32_t H, int32_t W, const float* cov_quat,
+                             const float* cov_scale, const float* normal, const float* R, float lambda_dssim,
+                             float lambda_dnormal, int32_t guard_empty, float* loss, float* aux, float* dmaps,
+                             VrAllocFn alloc, void* user, void* stream)
+{
+    g_err[0] = 0;
+    if (C <= 0 || H <= 0 || W <= 0) return fail(VR_ERR_INVALID_ARGUMENT, "image must be [C,H,W] with positive sizes");
+    if (!image || !gt || !cov_quat || !cov_scale || !normal || !R || !loss || !aux || !alloc)
+        return fail(VR_ERR_INVALID_ARGUMENT, "training_loss: image, gt, the maps, R_cam2world, loss, aux and alloc are required");
+    void* scr = alloc(user, VR_BUF_SCRATCH, training_loss_scratch_bytes(C, H, W));
+    if (!scr) return fail(VR_ERR_ALLOC, "allocator returned NULL");
+    return launch_training_loss_fwd(image, gt, C, H, W, cov_quat, cov_scale, normal, R, lambda_dssim, lambda_dnormal,
+                                    guard_empty != 0, loss, aux, dmaps, scr, (hipStream_t)stream, false);
+}
+
+int vr_training_loss_backward(const float* image, const float* gt, int32_t C, int32_t H, int32_t W, const float* dmaps,
+                              const float* cov_quat, const float* cov_scale, const float* normal, const float* R,
+                              float lambda_dssim, float lambda_dnormal, int32_t guard_empty, const float* g,
+                              float* dL_dimage, float* dL_dquat, float* dL_dscale, void* stream)
+{
+    g_err[0] = 0;
+    if (C <= 0 || H <= 0 || W <= 0) return fail(VR_ERR_INVALID_ARGUMENT, "image must be [C,H,W] with positive sizes");
+    if (!image || !gt || !dmaps || !cov_quat || !cov_scale || !normal || !R || !g || !dL_dimage || !dL_dquat || !dL_dscale)
+        return fail(VR_ERR_INVALID_ARGUMENT, "training_loss backward: all pointers are required");
+    return launch_training_loss_bwd(image, gt, C, H, W, dmaps, cov_quat, cov_scale, normal, R, lambda_dssim, lambda_dnormal,
+                                    guard_empty != 0, g, dL_dimage, dL_dquat, dL_dscale, (hipStream_t)stream, false);
+}
+
 int vr_count_fragments(const VrSaved* saved, int32_t H, int32_t W, void* stream, int64_t* fragments)
 {
     g_err[0] = 0;

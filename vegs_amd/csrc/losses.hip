@@ -120,13 +120,14 @@ k_reduce_partials(const double* __restrict__ partial, long nblocks, int stride, 
 __global__ void __launch_bounds__(256)
 k_photo_bwd(const float* __restrict__ x, const float* __restrict__ y, int H, int W, SsimWin win,
             const float* __restrict__ dmaps, size_t plane_all, const float* __restrict__ g_l1,
-            const float* __restrict__ g_ssim, float inv_n, float* __restrict__ dx)
+            const float* __restrict__ g_ssim, float w_l1, float w_ssim, float inv_n, float* __restrict__ dx)
 {
     __shared__ float t[3][PIN][PIN + 1];
     __shared__ float hz[3][PIN][PT + 1];
     const int c = blockIdx.z, bx = blockIdx.x * PT, by = blockIdx.y * PT;
     const size_t cbase = (size_t)c * H * W;
-    const float wl1 = (g_l1 ? *g_l1 : 0.0f) * inv_n, wss = (g_ssim ? *g_ssim : 0.0f) * inv_n;
+    // (upstream scalars from device memory, times the host-side weights of the combined training loss)
+    const float wl1 = ((g_l1 ? *g_l1 : 0.0f) * w_l1) * inv_n, wss = ((g_ssim ? *g_ssim : 0.0f) * w_ssim) * inv_n;
     for (int i = threadIdx.x; i < PIN * PIN; i += 256) {
         const int r = i / PIN, q = i - r * PIN;
         const int gy = by + r - SSIM_R, gx = bx + q - SSIM_R;
@@ -170,13 +171,17 @@ struct NgPixel {
     float c[3];      // column j of R(q) . n_world
     float nw[3];
     float q[4], s[3], two_s;
+    bool empty;      // guard: no Gaussian covers the pixel (q == 0), evaluated with q = (1,1,1,1) and no gradient to q
 };
 
 __device__ __forceinline__ void ng_load(const float* __restrict__ cov_quat, const float* __restrict__ cov_scale,
-                                        const float* __restrict__ normal, const Mat3& Rc, size_t p, size_t N, NgPixel& o)
+                                        const float* __restrict__ normal, const Mat3& Rc, size_t p, size_t N, NgPixel& o,
+                                        bool guard = false)
 {
 #pragma unroll
     for (int k = 0; k < 4; ++k) o.q[k] = cov_quat[k * N + p];
+    o.empty = guard && o.q[0] * o.q[0] + o.q[1] * o.q[1] + o.q[2] * o.q[2] + o.q[3] * o.q[3] <= 0.0f;
+    if (o.empty) { o.q[0] = 1.0f; o.q[1] = 1.0f; o.q[2] = 1.0f; o.q[3] = 1.0f; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) o.s[k] = cov_scale[k * N + p];
     const float n0 = normal[p], n1 = normal[N + p], n2 = normal[2 * N + p];
@@ -195,13 +200,13 @@ __device__ __forceinline__ void ng_load(const float* __restrict__ cov_quat, cons
 
 __global__ void __launch_bounds__(256)
 k_ng_fwd(const float* __restrict__ cov_quat, const float* __restrict__ cov_scale, const float* __restrict__ normal,
-         Mat3 Rc, size_t N, double* __restrict__ partial)
+         Mat3 Rc, size_t N, double* __restrict__ partial, bool guard)
 {
     __shared__ double red[4];
     double t1 = 0.0, t2 = 0.0;
     for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < N; p += (size_t)gridDim.x * 256) {
         NgPixel px;
-        ng_load(cov_quat, cov_scale, normal, Rc, p, N, px);
+        ng_load(cov_quat, cov_scale, normal, Rc, p, N, px, guard);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             t1 += (double)fabsf(px.c[j]);
@@ -217,14 +222,14 @@ __device__ __forceinline__ float sgnf(float v) { return v > 0.0f ? 1.0f : (v < 0
 
 __global__ void __launch_bounds__(256)
 k_ng_bwd(const float* __restrict__ cov_quat, const float* __restrict__ cov_scale, const float* __restrict__ normal,
-         Mat3 Rc, size_t N, const float* __restrict__ gup, float inv_3n, float* __restrict__ dquat,
-         float* __restrict__ dscale)
+         Mat3 Rc, size_t N, const float* __restrict__ gup, float weight, float inv_3n, float* __restrict__ dquat,
+         float* __restrict__ dscale, bool guard)
 {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= N) return;
     NgPixel px;
-    ng_load(cov_quat, cov_scale, normal, Rc, p, N, px);
-    const float gl = *gup * inv_3n;
+    ng_load(cov_quat, cov_scale, normal, Rc, p, N, px, guard);
+    const float gl = (*gup * weight) * inv_3n;
     const float k1 = 0.8f * gl, k2 = 0.2f * gl;
     float sg[3];
 #pragma unroll
@@ -247,10 +252,30 @@ k_ng_bwd(const float* __restrict__ cov_quat, const float* __restrict__ cov_scale
     const float dj = -2.0f * j * (G[0][0] + G[2][2]) + i * (G[0][1] + G[1][0]) + r * (G[0][2] - G[2][0]) + k * (G[1][2] + G[2][1]);
     const float dk = -2.0f * k * (G[0][0] + G[1][1]) + r * (G[1][0] - G[0][1]) + i * (G[0][2] + G[2][0]) + j * (G[1][2] + G[2][1]);
     const float tt = t * t * GM;
-    dquat[p] = t * dr - tt * r;
-    dquat[N + p] = t * di - tt * i;
-    dquat[2 * N + p] = t * dj - tt * j;
-    dquat[3 * N + p] = t * dk - tt * k;
+    dquat[p] = px.empty ? 0.0f : t * dr - tt * r;
+    dquat[N + p] = px.empty ? 0.0f : t * di - tt * i;
+    dquat[2 * N + p] = px.empty ? 0.0f : t * dj - tt * j;
+    dquat[3 * N + p] = px.empty ? 0.0f : t * dk - tt * k;
+}
+
+// The combined loss of train.py:162-168 from the two kernels' partial sums, one block, fixed order:
+//   aux = { Ll1, mean SSIM, Lng };  loss = (1 - lambda) Ll1 + lambda (1 - ssim) + lambda_n Lng
+__global__ void __launch_bounds__(256)
+k_loss_terms(const double* __restrict__ photo_partial, long photo_blocks, double photo_scale,
+             const double* __restrict__ ng_partial, long ng_blocks, double ng_scale, float lambda_dssim, float lambda_dnormal,
+             float* __restrict__ loss, float* __restrict__ aux)
+{
+    __shared__ double red[4];
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+    for (long b = threadIdx.x; b < photo_blocks; b += 256) { v0 += photo_partial[2 * b]; v1 += photo_partial[2 * b + 1]; }
+    for (long b = threadIdx.x; b < ng_blocks; b += 256) v2 += ng_partial[b];
+    const double s0 = block_sum_double(v0, red), s1 = block_sum_double(v1, red), s2 = block_sum_double(v2, red);
+    if (threadIdx.x == 0) {
+        const float l1 = (float)(s0 * photo_scale), ss = (float)(s1 * photo_scale), ng = (float)(s2 * ng_scale);
+        aux[0] = l1; aux[1] = ss; aux[2] = ng;
+        // the reference's float32 sequence: (1 - l) * Ll1 + l * (1 - ssim), then += l_n * Lng
+        *loss = ((1.0f - lambda_dssim) * l1 + lambda_dssim * (1.0f - ss)) + lambda_dnormal * ng;
+    }
 }
 
 // ---------------------------------------------------------------- host side
@@ -294,7 +319,7 @@ int launch_photometric_bwd(const float* image, const float* gt, int C, int H, in
 {
     const size_t n = (size_t)C * H * W;
     hipLaunchKernelGGL(k_photo_bwd, photo_grid(C, H, W), dim3(256), 0, s, image, gt, H, W, make_window(), dmaps, n, g_l1,
-                       g_ssim, (float)(1.0 / (double)n), dL_dimage);
+                       g_ssim, 1.0f, 1.0f, (float)(1.0 / (double)n), dL_dimage);
     VR_KERNEL_CHECK("photo_bwd", s, debug);
     return 0;
 }
@@ -310,7 +335,7 @@ int launch_normal_guidance_fwd(const float* cov_quat, const float* cov_scale, co
     for (int i = 0; i < 9; ++i) Rc.m[i] = R9[i];
     const size_t N = (size_t)H * W;
     const int nb = ng_blocks(N);
-    hipLaunchKernelGGL(k_ng_fwd, dim3(nb), dim3(256), 0, s, cov_quat, cov_scale, normal, Rc, N, (double*)scratch);
+    hipLaunchKernelGGL(k_ng_fwd, dim3(nb), dim3(256), 0, s, cov_quat, cov_scale, normal, Rc, N, (double*)scratch, false);
     VR_KERNEL_CHECK("ng_fwd", s, debug);
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s, (const double*)scratch, (long)nb, 1,
                        1.0 / (3.0 * (double)N), loss);
@@ -324,8 +349,53 @@ int launch_normal_guidance_bwd(const float* cov_quat, const float* cov_scale, co
     Mat3 Rc;
     for (int i = 0; i < 9; ++i) Rc.m[i] = R9[i];
     const size_t N = (size_t)H * W;
+    hipLaunchKernelGGL(k_ng_bwd, dim3(cdiv((long)N, 256)), dim3(256), 0, s, cov_quat, cov_scale, normal, Rc, N, g, 1.0f,
+                       (float)(1.0 / (3.0 * (double)N)), dL_dquat, dL_dscale, false);
+    VR_KERNEL_CHECK("ng_bwd", s, debug);
+    return 0;
+}
+
+size_t training_loss_scratch_bytes(int C, int H, int W)
+{
+    return photometric_scratch_bytes(C, H, W) + normal_guidance_scratch_bytes(H, W);
+}
+
+// train.py:162-168 in three launches: both losses' partial sums, then k_loss_terms
+int launch_training_loss_fwd(const float* image, const float* gt, int C, int H, int W, const float* cov_quat,
+                             const float* cov_scale, const float* normal, const float* R9, float lambda_dssim,
+                             float lambda_dnormal, bool guard, float* loss, float* aux, float* dmaps, void* scratch,
+                             hipStream_t s, bool debug)
+{
+    const dim3 g = photo_grid(C, H, W);
+    const size_t n = (size_t)C * H * W, N = (size_t)H * W;
+    double* pp = (double*)scratch;
+    double* np = (double*)((char*)scratch + photometric_scratch_bytes(C, H, W));
+    hipLaunchKernelGGL(k_photo_fwd, g, dim3(256), 0, s, image, gt, H, W, make_window(), dmaps, n, pp);
+    VR_KERNEL_CHECK("photo_fwd", s, debug);
+    Mat3 Rc;
+    for (int i = 0; i < 9; ++i) Rc.m[i] = R9[i];
+    const int nb = ng_blocks(N);
+    hipLaunchKernelGGL(k_ng_fwd, dim3(nb), dim3(256), 0, s, cov_quat, cov_scale, normal, Rc, N, np, guard);
+    VR_KERNEL_CHECK("ng_fwd", s, debug);
+    hipLaunchKernelGGL(k_loss_terms, dim3(1), dim3(256), 0, s, (const double*)pp, (long)g.x * g.y * g.z, 1.0 / (double)n,
+                       (const double*)np, (long)nb, 1.0 / (3.0 * (double)N), lambda_dssim, lambda_dnormal, loss, aux);
+    VR_KERNEL_CHECK("loss_terms", s, debug);
+    return 0;
+}
+
+int launch_training_loss_bwd(const float* image, const float* gt, int C, int H, int W, const float* dmaps,
+                             const float* cov_quat, const float* cov_scale, const float* normal, const float* R9,
+                             float lambda_dssim, float lambda_dnormal, bool guard, const float* g, float* dL_dimage,
+                             float* dL_dquat, float* dL_dscale, hipStream_t s, bool debug)
+{
+    const size_t n = (size_t)C * H * W, N = (size_t)H * W;
+    hipLaunchKernelGGL(k_photo_bwd, photo_grid(C, H, W), dim3(256), 0, s, image, gt, H, W, make_window(), dmaps, n, g, g,
+                       1.0f - lambda_dssim, -lambda_dssim, (float)(1.0 / (double)n), dL_dimage);
+    VR_KERNEL_CHECK("photo_bwd", s, debug);
+    Mat3 Rc;
+    for (int i = 0; i < 9; ++i) Rc.m[i] = R9[i];
     hipLaunchKernelGGL(k_ng_bwd, dim3(cdiv((long)N, 256)), dim3(256), 0, s, cov_quat, cov_scale, normal, Rc, N, g,
-                       (float)(1.0 / (3.0 * (double)N)), dL_dquat, dL_dscale);
+                       lambda_dnormal, (float)(1.0 / (3.0 * (double)N)), dL_dquat, dL_dscale, guard);
     VR_KERNEL_CHECK("ng_bwd", s, debug);
     return 0;
 }

@@ -100,6 +100,15 @@ int launch_normal_guidance_fwd(const float* cov_quat, const float* cov_scale, co
                                int W, float* loss, void* scratch, hipStream_t s, bool debug);
 int launch_normal_guidance_bwd(const float* cov_quat, const float* cov_scale, const float* normal, const float* R9, int H,
                                int W, const float* g, float* dL_dquat, float* dL_dscale, hipStream_t s, bool debug);
+size_t training_loss_scratch_bytes(int C, int H, int W);
+int launch_training_loss_fwd(const float* image, const float* gt, int C, int H, int W, const float* cov_quat,
+                             const float* cov_scale, const float* normal, const float* R9, float lambda_dssim,
+                             float lambda_dnormal, bool guard, float* loss, float* aux, float* dmaps, void* scratch,
+                             hipStream_t s, bool debug);
+int launch_training_loss_bwd(const float* image, const float* gt, int C, int H, int W, const float* dmaps,
+                             const float* cov_quat, const float* cov_scale, const float* normal, const float* R9,
+                             float lambda_dssim, float lambda_dnormal, bool guard, const float* g, float* dL_dimage,
+                             float* dL_dquat, float* dL_dscale, hipStream_t s, bool debug);
 
 // ---- render_fwd.hip / render_bwd.hip (segmented compositing)
 // upper bound on the number of 256-entry segments: sum_t ceil(n_t/256) <= R/256 + T

@@ -99,10 +99,12 @@ def aten_loss(pkg, gt, normal, win, R_c2w):
 
 
 def fused_loss(pkg, gt, normal, R_c2w):
+    """train.py:162-168 as one autograd node (losses.training_loss), the uncovered-pixel guard inside it"""
     from . import losses
-    loss, _ = losses.photometric_loss(pkg["render"], gt, LAMBDA_DSSIM)
     cam = types.SimpleNamespace(original_normal=normal, R=R_c2w)
-    return loss + LAMBDA_NORMAL * losses.loss_normal_guidance(cam, pkg["render_cov_quat"], pkg["render_cov_scale"])
+    loss, _ = losses.training_loss(pkg["render"], gt, cam, pkg["render_cov_quat_raw"], pkg["render_cov_scale"], LAMBDA_DSSIM,
+                                   LAMBDA_NORMAL, guard_empty=True)
+    return loss
 
 
 def op_inputs(p):
@@ -163,10 +165,10 @@ class Trainer:
         # both variants
         q = pkg["render_cov_quat"]
         pkg["render_cov_quat_raw"] = q
-        pkg["render_cov_quat"] = torch.where((q.detach() * q.detach()).sum(0, keepdim=True) > 0, q, torch.ones_like(q))
         if self.fused:
-            loss = fused_loss(pkg, gt, normal, cam.R)
+            loss = fused_loss(pkg, gt, normal, cam.R)        # (the guard is part of the fused loss block)
         else:
+            pkg["render_cov_quat"] = torch.where((q.detach() * q.detach()).sum(0, keepdim=True) > 0, q, torch.ones_like(q))
             loss = aten_loss(pkg, gt, normal, self.win, cam.R)
         return loss, pkg
 

@@ -162,3 +162,64 @@ def loss_normal_guidance(viewpoint_cam, cov_quat, cov_scale):
         raise ValueError("viewpoint_cam.R must be 3x3")
     R9 = (C.c_float * 9)(*Rflat)
     return _NormalGuidance.apply(cov_quat, cov_scale, normal, R9)
+
+
+class _TrainingLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, gt, cov_quat, cov_scale, normal, R9, lambda_dssim, lambda_dnormal, guard_empty):
+        lib = _capi.load()
+        img, ref = image.contiguous(), gt.contiguous()
+        q, s, n = cov_quat.contiguous(), cov_scale.contiguous(), normal.contiguous()
+        Cn, H, W = img.shape[0], img.shape[1], img.shape[2]
+        dev = img.device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        aux = torch.empty(3, dtype=torch.float32, device=dev)
+        need_grad = any(ctx.needs_input_grad[i] for i in (0, 2, 3))
+        dmaps = torch.empty((3,) + tuple(img.shape), dtype=torch.float32, device=dev) if need_grad else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _scratch_call(dev, lambda cb: lib.vr_training_loss_forward(
+            _capi.ptr(img), _capi.ptr(ref), Cn, H, W, _capi.ptr(q), _capi.ptr(s), _capi.ptr(n), R9, lambda_dssim,
+            lambda_dnormal, int(guard_empty), _capi.ptr(loss), _capi.ptr(aux), _capi.ptr(dmaps), cb, None, stream))
+        ctx.save_for_backward(img, ref, dmaps, q, s, n)
+        ctx.cfg = (Cn, H, W, R9, lambda_dssim, lambda_dnormal, int(guard_empty))
+        ctx.mark_non_differentiable(aux)
+        return loss, aux
+
+    @staticmethod
+    def backward(ctx, g, _g_aux):
+        lib = _capi.load()
+        img, ref, dmaps, q, s, n = ctx.saved_tensors
+        Cn, H, W, R9, lam, lam_n, guard = ctx.cfg
+        g = g.to(torch.float32).contiguous()
+        dimg, dq, ds = torch.empty_like(img), torch.empty_like(q), torch.empty_like(s)
+        with torch.cuda.device(img.device):
+            rc = lib.vr_training_loss_backward(_capi.ptr(img), _capi.ptr(ref), Cn, H, W, _capi.ptr(dmaps), _capi.ptr(q),
+                                               _capi.ptr(s), _capi.ptr(n), R9, lam, lam_n, guard, g.data_ptr(), _capi.ptr(dimg),
+                                               _capi.ptr(dq), _capi.ptr(ds), torch.cuda.current_stream(img.device).cuda_stream)
+        _capi.check(rc)
+        return dimg, None, dq, ds, None, None, None, None, None
+
+
+def training_loss(image, gt, viewpoint_cam, cov_quat, cov_scale, lambda_dssim, lambda_dnormal, guard_empty=False):
+    """The loss block of train.py:162-168 as ONE autograd node:
+        Ll1 = l1_loss(image, gt);  loss = (1 - lambda_dssim) * Ll1 + lambda_dssim * (1 - ssim(image, gt))
+        loss += lambda_dnormal * loss_normal_guidance(viewpoint_cam, cov_quat, cov_scale)
+    Returns (loss, aux) with aux = [Ll1, mean SSIM, Lng] (detached; train.py logs Ll1).  Three launches forward, two
+    backward, instead of the three fused losses plus ~15 scalar ATen kernels and their autograd nodes.  guard_empty:
+    uncovered pixels (cov_quat == 0) are evaluated with q = (1,1,1,1) and get no quaternion gradient (see
+    include/vegs_loss.h)."""
+    _check_image_pair(image, gt)
+    if image.dim() != 3:
+        raise ValueError("training_loss expects one [C,H,W] image")
+    normal = viewpoint_cam.original_normal
+    for name, t, k in (("cov_quat", cov_quat, 4), ("cov_scale", cov_scale, 3), ("original_normal", normal, 3)):
+        if not t.is_cuda:
+            raise ValueError(f"{name} must be a GPU tensor (the fused losses have no CPU path)")
+        if t.dim() != 3 or t.shape[0] != k or t.shape[1:] != image.shape[1:] or t.dtype != torch.float32:
+            raise ValueError(f"{name} must be float32 [{k},H,W] like the image (got {tuple(t.shape)}, {t.dtype})")
+    Rflat = [float(v) for row in viewpoint_cam.R for v in row]
+    if len(Rflat) != 9:
+        raise ValueError("viewpoint_cam.R must be 3x3")
+    R9 = (C.c_float * 9)(*Rflat)
+    return _TrainingLoss.apply(image, gt, cov_quat, cov_scale, normal, R9, float(lambda_dssim), float(lambda_dnormal),
+                               bool(guard_empty))

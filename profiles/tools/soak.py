@@ -1,5 +1,6 @@
-"""Soak run: 3000 fused training iterations on a model that grows like a densifying one (P +3 % every 100
-iterations, views of different sizes interleaved); prints time per iteration and allocator statistics per block.
+"""Soak run: 3000 fused training iterations with the real densification schedule of train.py:299-315 (statistics every
+iteration, densify_and_prune every 100 with a threshold that densifies the top 3 %, reset_opacity at 1500; views of
+different sizes interleaved); prints time per iteration and allocator statistics per block.
 PYTHONPATH=. python profiles/tools/soak.py"""
 import time
 import types
@@ -28,6 +29,9 @@ def make(sc):
 p, opt = make(sc)
 gts = {(c.image_height, c.image_width): torch.rand(3, c.image_height, c.image_width, device=dev) for c in cams}
 nrm = {(c.image_height, c.image_width): torch.randn(3, c.image_height, c.image_width, device=dev) for c in cams}
+accum = torch.zeros(P, 1, device=dev)
+denom = torch.zeros(P, 1, device=dev)
+max_radii = torch.zeros(P, device=dev)
 t0 = time.perf_counter()
 for it in range(3000):
     cam = cams[it % len(cams)]
@@ -35,31 +39,26 @@ for it in range(3000):
     t = {"means3D": p["xyz"], "shs": (p["f_dc"], p["f_rest"]), "opacities": torch.sigmoid(p["opacity"]),
          "scales": torch.exp(p["scaling"]), "rotations": torch.nn.functional.normalize(p["rotation"])}
     pkg = harness.render(cam, t, deg, bg)
-    q = pkg["render_cov_quat"]
-    q = torch.where((q.detach() ** 2).sum(0, keepdim=True) > 0, q, torch.ones_like(q))
-    loss, _ = losses.photometric_loss(pkg["render"], gts[key], 0.2)
-    loss = loss + 1e-3 * losses.loss_normal_guidance(types.SimpleNamespace(original_normal=nrm[key], R=scenes.R_KITTI), q, pkg["render_cov_scale"])
+    loss, _ = losses.training_loss(pkg["render"], gts[key], types.SimpleNamespace(original_normal=nrm[key], R=scenes.R_KITTI),
+                                   pkg["render_cov_quat"], pkg["render_cov_scale"], 0.2, 1e-3, guard_empty=True)
     loss.backward()
+    with torch.no_grad():
+        optim.add_densification_stats(pkg["viewspace_points"].grad, pkg["radii"], accum, denom, max_radii)
     opt.step()
     opt.zero_grad(set_to_none=True)
-    if (it + 1) % 100 == 0:                      # "densify": clone 3 % of the Gaussians, rebuild the optimizer state
-        n = p["xyz"].shape[0]
-        idx = torch.randint(0, n, (n * 3 // 100,), device=dev)
-        for group in opt.param_groups:
-            old = group["params"][0]
-            st = opt.state.pop(old)
-            new = torch.nn.Parameter(torch.cat((old.detach(), old.detach()[idx]), 0))
-            st["exp_avg"] = torch.cat((st["exp_avg"], torch.zeros_like(old.detach()[idx])), 0)
-            st["exp_avg_sq"] = torch.cat((st["exp_avg_sq"], torch.zeros_like(old.detach()[idx])), 0)
-            group["params"][0] = new
-            opt.state[new] = st
-            p[group["name"]] = new
+    if (it + 1) % 100 == 0:                      # train.py:303-312
+        g = (accum / denom.clamp_min(1)).flatten()
+        thr = float(g.sort().values[-max(g.numel() * 3 // 100, 1)])
+        new, (accum, denom, max_radii) = optim.densify_and_prune(opt, accum, denom, max(thr, 1e-12), 0.005, 30.0, 20, 0.01)
+        p = new
+    if (it + 1) == 1500:                         # train.py:314-315
+        p["opacity"] = optim.reset_opacity(opt)
     if (it + 1) % 500 == 0:
         torch.cuda.synchronize()
         ms = torch.cuda.memory_stats(dev)
         print(f"it {it + 1}: P={p['xyz'].shape[0]} loss={loss.item():.4f} {1e3 * (time.perf_counter() - t0) / 500:.2f} ms/it "
               f"allocated={ms['allocated_bytes.all.current'] / 2**20:.0f} MiB reserved={ms['reserved_bytes.all.current'] / 2**20:.0f} MiB "
               f"hipMallocs={ms['num_device_alloc']}", flush=True)
-        assert torch.isfinite(loss)
+        assert torch.isfinite(loss) and all(v.shape[0] == p["xyz"].shape[0] for v in p.values())
         t0 = time.perf_counter()
 print("soak ok")

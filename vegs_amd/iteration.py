@@ -158,7 +158,8 @@ class Trainer:
         sink = None
         if self.factored_sh and torch.is_grad_enabled():
             rows = self.p["xyz"].shape[0] + sum(b["means3D"].shape[0] for b, _ in self.boxes)
-            sink = torch.zeros((rows, 3), dtype=torch.float32, device=self.device, requires_grad=True)
+            # (only its .grad is used: no fill)
+            sink = torch.empty((rows, 3), dtype=torch.float32, device=self.device, requires_grad=True)
         pkg = render_model(self.p, self.boxes, cam, cam_t, deg, bg, self.fused, sh_sink=sink)
         pkg["sh_sink"] = sink
         # NaN guard for pixels no Gaussian covers (A-5: exact zeros; the reference's 2/|q|^2 is NaN there) -- same in

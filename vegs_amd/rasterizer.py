@@ -376,7 +376,7 @@ class GaussianRasterizer(nn.Module):
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, sh_color_grad=None):
         """The reference's eight keyword arguments (gaussian_renderer/__init__.py:86-94), plus one extension:
-        `sh_color_grad`, a [P,3] zeros tensor with requires_grad.  When given, the backward deposits on it the
+        `sh_color_grad`, a [P,3] float32 tensor with requires_grad (its contents are never read: `torch.empty` will do).  When given, the backward deposits on it the
         clamp-masked dL/d(colour) -- the 3-float factor of the rank-1 SH gradient dL/dshs[i,k,c] = basis_k(dir_i) *
         factor[i,c] -- and `shs` itself receives NO gradient (vegs_amd.optim.sh_grad_from_factors / Adam.step_sh_factored
         rebuild or consume it; vegs_amd.dist exchanges 3 instead of 48 floats per Gaussian and view)."""

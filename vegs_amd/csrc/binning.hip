@@ -890,23 +890,41 @@ k_compact_apply(const uint2* __restrict__ rect, const uint32_t* __restrict__ dep
     uint32_t acc = 0;
     for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) acc += bsum[j];
     const uint32_t prefix = block_sum(acc, lds4);   // (has the barriers that also publish h)
-    const long base = (long)blockIdx.x * SCAN_BLOCK + (long)threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS], key[SCAN_ITEMS];
-    uint32_t tsum = 0;
+    // Element (k, t) = block start + 256 k + t: every load of a wave is one contiguous run (with SCAN_ITEMS consecutive
+    // elements per thread it touched 64 lines).  The values are FLAGS, so the ordered scan is ballots and popcounts: the
+    // position of a visible element = the visible ones before it in its wave's row + the counts of the (row, wave) pairs
+    // in front, 32 numbers in LDS.
+    __shared__ uint32_t rowcnt[SCAN_ITEMS][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long base = (long)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    uint32_t v[SCAN_ITEMS], key[SCAN_ITEMS], before[SCAN_ITEMS];
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        v[k] = (base + k < n && rect_area(rect[base + k])) ? 1u : 0u;
-        tsum += v[k];
+        const long e = base + (long)k * 256;
+        v[k] = (e < n && rect_area(rect[e])) ? 1u : 0u;
     }
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) key[k] = v[k] ? depth_key[base + k] : 0u;
-    uint32_t total;
-    uint32_t ex = block_excl_scan(tsum, total, lds4) + prefix;
+    for (int k = 0; k < SCAN_ITEMS; ++k) key[k] = v[k] ? depth_key[base + (long)k * 256] : 0u;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        if (v[k]) { vis_key[ex] = key[k]; vis_id[ex] = (uint32_t)(base + k); }
-        ex += v[k];
-        hist_key(h, key[k] - kmin, v[k] != 0u, digit, passes, threadIdx.x & 63);
+        const unsigned long long m = __ballot(v[k] != 0u);
+        before[k] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) rowcnt[k][w] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    uint32_t run = prefix;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            if (ww == w && v[k]) {
+                const uint32_t ex = run + before[k];
+                vis_key[ex] = key[k];
+                vis_id[ex] = (uint32_t)(base + (long)k * 256);
+            }
+            run += rowcnt[k][ww];
+        }
+        hist_key(h, key[k] - kmin, v[k] != 0u, digit, passes, lane);
     }
     __syncthreads();
     for (int d = threadIdx.x; d < words; d += 256) partial[(size_t)blockIdx.x * words + d] = h[d];

@@ -77,14 +77,16 @@ def grad_mismatch(got, want, rtol=1e-3, floor=1e-6):
     return np.nonzero(bad)[0], err / allow
 
 
-def assert_grad_close(name, got, want, rtol=1e-3, floor=1e-6, outliers=1e-4, near=1e-3, cap=10.0, explain=None, ill=None):
+def assert_grad_close(name, got, want, rtol=1e-3, floor=1e-6, outliers=1e-4, near=1e-3, cap=10.0, explain=None, ill=None,
+                      ill_quota=None):
     """Assert the per-row criterion of grad_mismatch.  fp32 atomics are order-dependent and the preprocess backward
     amplifies the noise of rows that are pure cancellation (1e-5-thin discs), so a few rows may leave the allowance:
     at most a fraction `near` of the rows by up to 3x, at most a fraction `outliers` (0.01 %) by more than that, and
     none by `cap` (10x).  The offenders are printed so that a systematic error is visible in the log; `explain(i)`
     (optional) returns a string printed next to offender i (e.g. the conditioning of its conic).  `ill` (optional bool
     per row): rows the caller has shown to be ill-conditioned (helpers.ill_conditioned) are exempt from `cap` -- they
-    still count towards `near` and `outliers`.
+    still count towards `near` and `outliers`, unless `ill_quota` is given: then they are held to that many allowances
+    instead and leave the quotas to the well-conditioned rows.
     Returns the indices of the failing rows."""
     bad, ratio = grad_mismatch(got, want, rtol, floor)
     n = max(int(np.asarray(want).shape[0]) if np.asarray(want).ndim else 1, 1)
@@ -97,12 +99,22 @@ def assert_grad_close(name, got, want, rtol=1e-3, floor=1e-6, outliers=1e-4, nea
             print(f"    row {i}: err/allow {ratio[i]:.2f}  got {g[i][:4]}  want {w[i][:4]}" +
                   (f"  [{explain(int(i))}]" if explain else ""))
         assert np.isfinite(ratio[bad]).all(), f"{name}: non-finite gradient rows"
-        far = int((ratio[bad] > 3.0).sum())
+        if ill is not None and ill_quota:
+            # rows the caller has shown to be ill-conditioned do not use up the quotas of the well-conditioned ones (a
+            # 600-seed fuzz campaign: one screen-filling edge-on disc, conic conditioning 128 against a median of 1.35,
+            # measured summation sensitivity 12 ... 33 allowances, was off by 2 ... 4 -- in both backward modes); they
+            # are held to `ill_quota` allowances instead
+            is_ill = np.asarray(ill, bool)[bad]
+            assert (ratio[bad][is_ill] < ill_quota).all(), f"{name}: ill-conditioned row off by {ratio[bad][is_ill].max():.1f}x"
+            bad_q = bad[~is_ill]
+        else:
+            bad_q = bad
+        far = int((ratio[bad_q] > 3.0).sum())
         assert far <= outliers * n, f"{name}: {far} of {n} rows are off by more than 3x the per-row allowance"
         # (small tensors: ONE row marginally outside -- under 1.5x -- is rounding noise of the atomic sums, not a finding:
         # a 300-row case was seen at 1.01x in one run of 400 with the same inputs; `near * n` would allow 0.3 rows)
-        marginal_ok = len(bad) == 1 and ratio[bad].max() < 1.5
-        assert len(bad) <= near * n or marginal_ok, f"{name}: {len(bad)} of {n} rows fail the per-row gradient check"
+        marginal_ok = len(bad_q) <= 1 and (len(bad_q) == 0 or ratio[bad_q].max() < 1.5)
+        assert len(bad_q) <= near * n or marginal_ok, f"{name}: {len(bad_q)} of {n} rows fail the per-row gradient check"
         capped = bad if ill is None else bad[~np.asarray(ill, bool)[bad]]
         if len(capped):
             assert ratio[capped].max() < cap, f"{name}: outlier row off by {ratio[capped].max():.1f}x the allowance"
@@ -136,7 +148,8 @@ def summation_sensitivity(cam, st, og, names=("means3D", "scales", "rotations"),
 def ill_conditioned(st, factor=20.0):
     """(mask, explain): rows whose conic conditioning is more than `factor` times the median of the visible rows."""
     cond = conic_conditioning(st)
-    typical = float(np.median(cond[np.asarray(st["radii"]) > 0]))
+    vis = np.asarray(st["radii"]) > 0
+    typical = float(np.median(cond[vis])) if vis.any() else 1.0
     return cond > factor * typical, (lambda i: f"conic conditioning {cond[i]:.3g} (median of the visible rows {typical:.3g})")
 
 

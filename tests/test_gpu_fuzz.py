@@ -3,6 +3,8 @@ of the tile, every SH degree / storage width, both colour modes, both covariance
 backgrounds, splats from sub-pixel to screen-filling, opacities including exact 0 and 1, cameras inside the
 cloud, arbitrary subsets of the five upstream gradients.  Same bars as test_gpu_parity.py: radii / tile lists /
 ranges and all five images bit-exact, gradients within the tensor-level tolerance."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -24,7 +26,11 @@ def _cov6(scales, rot, mod):
     return np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).astype(np.float32)
 
 
-@pytest.mark.parametrize("seed", range(28))
+# VEGS_FUZZ_SEEDS=a:b widens the sweep for a campaign (the default 28 seeds are what every round runs)
+_SEEDS = range(*(int(v) for v in os.environ["VEGS_FUZZ_SEEDS"].split(":"))) if os.environ.get("VEGS_FUZZ_SEEDS") else range(28)
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
 def test_random_configuration(seed, dev):  # noqa: F811
     from vegs_amd import scenes
     rng = np.random.default_rng(9000 + seed)

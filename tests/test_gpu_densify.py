@@ -138,6 +138,37 @@ def test_densify_equals_the_restated_sequence(P, M, big, state, dev):
         assert (kind == 1).sum() > 100 and (kind == 2).sum() > 100 and (kind == 0).sum() < P
 
 
+_SEEDS = range(*(int(v) for v in os.environ["VEGS_FUZZ_SEEDS"].split(":"))) if os.environ.get("VEGS_FUZZ_SEEDS") else range(8)
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
+def test_densify_random_settings(seed, dev):
+    """Random model sizes (around the planner's workgroup edges), thresholds, SH widths, with / without optimizer state and
+    world-size prune, against the restated reference sequence (VEGS_FUZZ_SEEDS=a:b widens the sweep)."""
+    from oracle import densify_oracle as do
+    from vegs_amd import optim
+    rng0 = np.random.default_rng(7000 + seed)
+    P = int(rng0.choice([1, 2, 63, 255, 256, 257, 1023, 1024, 1025, 2047, 2049, 3000, 5000, 9000]))
+    M = int(rng0.choice([1, 4, 9, 16]))
+    big, state = bool(rng0.integers(0, 2)), bool(rng0.integers(0, 2))
+    mg = float(rng0.choice([5e-5, 2e-4, 1e-3, 1e9]))
+    mo = float(rng0.choice([0.005, 0.3, 0.9]))
+    ext = float(rng0.choice([0.5, 4.0, 40.0]))
+    pd = float(rng0.choice([0.01, 0.1]))
+    par, m, v, acc, den, rng = _random_model(P, max(M, 2), seed=seed)
+    if M == 1:
+        par["f_rest"] = np.zeros((P, 0, 3), np.float32)
+        m["f_rest"], v["f_rest"] = par["f_rest"].copy(), par["f_rest"].copy()
+    _drop_borderline(par, acc, den, mg, mo, ext, pd)
+    src, kind, draw, S = do.plan(par["opacity"], par["scaling"], acc, den, mg, mo, ext, pd, big)
+    noise = rng.normal(size=(2 * S, 3)).astype(np.float32)
+    want, wm, wv, _, _ = do.densify_and_prune(par, m if state else None, v if state else None, acc, den, noise, mg, mo, ext, pd, big)
+    opt, p = _optimizer(par, m if state else None, v if state else None, dev, fused=bool(seed % 2))
+    new, stats = optim.densify_and_prune(opt, torch.tensor(acc, device=dev), torch.tensor(den, device=dev), mg, mo, ext,
+                                         7 if big else None, pd, noise=torch.tensor(noise, device=dev), empty_cache=False)
+    _compare(opt, new, stats, want, wm, wv)
+
+
 def test_densify_draws_its_own_noise_and_handles_empty_models(dev):
     from oracle import densify_oracle as do
     from vegs_amd import optim

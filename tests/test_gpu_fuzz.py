@@ -59,4 +59,6 @@ def test_random_configuration(seed, dev):  # noqa: F811
     gmask = tuple(int(v) for v in rng.integers(0, 2, 5))
     if not any(gmask):
         gmask = (1, 0, 0, 0, 0)
-    tp._check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=seed, gmask=gmask, M=M)
+    # VEGS_FUZZ_HIP_FLAGS (campaigns): e.g. 256 deterministic backward, 512 scan binning, 2048 segment rounds forced on
+    tp._check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=seed, gmask=gmask, M=M,
+                             hip_flags=int(os.environ.get("VEGS_FUZZ_HIP_FLAGS", "0")))

@@ -87,7 +87,9 @@ def _export_binning(res, H, W, dev):
 
 
 def _check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=0, grad_rtol=GRAD_RTOL, gmask=(1, 1, 1, 1, 1), M=16,
-                          flags=0):
+                          flags=0, hip_flags=0):
+    """hip_flags: VrFlags that change HOW the library computes, never what (deterministic backward, scan binning, segment
+    rounds on / off) -- given to the HIP path only."""
     from oracle import oracle as orc
     oc = oracle_cam(cam, bg, deg, mod, M, flags=flags)
     o_out, st = orc.forward(oc, **inputs)
@@ -95,7 +97,7 @@ def _check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=0, grad_rtol=GRAD
     H, W = cam.image_height, cam.image_width
     shapes = [(3, H, W), (1, H, W), (4, H, W), (3, H, W), (1, H, W)]
     gouts = [rng.normal(size=s).astype(np.float32) if m else None for s, m in zip(shapes, gmask)]
-    h_out, h_grads, res = _run_hip(_settings(cam, bg, deg, mod, dev), inputs, dev, gouts, flags=flags)
+    h_out, h_grads, res = _run_hip(_settings(cam, bg, deg, mod, dev), inputs, dev, gouts, flags=flags | hip_flags)
     # integers: bit exact
     assert np.array_equal(h_out["radii"], o_out["radii"])
     pl, rg = _export_binning(res, H, W, dev)
@@ -547,14 +549,15 @@ def test_split_sh_storage_equals_concatenated(P, M, deg, dev):
     rb, tb, (dc, rest), m2b = run(True)
     for a, b in zip(ra, rb):
         assert torch.equal(a, b)
-    assert dc.grad.shape == (P, 1, 3) and rest.grad.shape == (P, M - 1, 3)
+    # (M = 1: a degree-0 model's features_rest is [P,0,3], scene/gaussian_model.py:143 -- nothing flows back to it)
+    assert dc.grad.shape == (P, 1, 3) and (rest.grad.shape == (P, M - 1, 3) if M > 1 else rest.grad is None or rest.grad.numel() == 0)
     fg = full.grad.cpu().numpy()
-    assert rel_err(dc.grad.cpu().numpy(), fg[:, :1]) < 1e-5 and rel_err(rest.grad.cpu().numpy(), fg[:, 1:]) < 1e-5
+    assert rel_err(dc.grad.cpu().numpy(), fg[:, :1]) < 1e-5 and (M == 1 or rel_err(rest.grad.cpu().numpy(), fg[:, 1:]) < 1e-5)
     for k in ("means3D", "opacities", "scales", "rotations"):
         assert rel_err(tb[k].grad.cpu().numpy(), ta[k].grad.cpu().numpy()) < 1e-4, k
     # culled Gaussians: exact zero rows in both gradient tensors
     culled = (rb[5] == 0).cpu().numpy()
-    assert not dc.grad.cpu().numpy()[culled].any() and not rest.grad.cpu().numpy()[culled].any()
+    assert not dc.grad.cpu().numpy()[culled].any() and (M == 1 or not rest.grad.cpu().numpy()[culled].any())
 
 
 def test_segment_rounds_never_change_results(dev):

@@ -172,9 +172,11 @@ def densify_and_prune(optimizer, xyz_gradient_accum, denom, max_grad, min_opacit
                     raise ValueError(f"optimizer state of {n} does not match its parameter")
                 m_dst, v_dst = torch.empty_like(new[n]), torch.empty_like(new[n])
                 moments[n] = (m_dst, v_dst)
+            if math.prod(p.shape[1:]) == 0:      # f_rest of a degree-0 model is [P,0,3]: nothing to move
+                continue
             items.append(_capi.VrDensifyTensor(_capi.ptr(p), _capi.ptr(new[n]), _capi.ptr(m_src), _capi.ptr(m_dst),
                                                _capi.ptr(v_src), _capi.ptr(v_dst), math.prod(p.shape[1:]), _ROLES.get(n, 0)))
-        if n_out > 0:
+        if n_out > 0 and items:
             arr = (_capi.VrDensifyTensor * len(items))(*items)
             _capi.check(lib.vr_densify_apply(plan.data_ptr(), n_out, n_split, arr, len(items), _capi.ptr(par["scaling"]),
                                              _capi.ptr(par["rotation"]), _capi.ptr(noise), stream))

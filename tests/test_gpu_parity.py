@@ -119,6 +119,7 @@ def _check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=0, grad_rtol=GRAD
         assert g.shape == o_grads[k].shape, k
         per_gaussian = g.shape[0] == len(ill) and k in ("means3D", "scales", "rotations", "cov3D_precomp", "means2D")
         ill_k, explain_k = (ill, explain) if per_gaussian else (None, None)
+        quota = 10.0
         if per_gaussian and len(grad_mismatch(g, o_grads[k], grad_rtol, 1e-6)[0]):
             # offenders: MEASURE what fp32 summation can move each row by (helpers.summation_sensitivity: the oracle's own
             # fp32 chain re-run on its per-Gaussian sums perturbed by 2e-6 of their absolute terms).  A row that moves by
@@ -130,8 +131,11 @@ def _check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=0, grad_rtol=GRAD
             if k in sens:
                 moved = sens[k]
                 ill_k = ill | (moved > 1.0)
+                # ... and such a row may miss by what the perturbation moves it (x8: the largest of three 1-sigma draws
+                # against a 3-sigma reality -- the rule of tests/test_gpu_fullsize.py), at least by 10 allowances
+                quota = np.maximum(10.0, 8.0 * moved)
                 explain_k = (lambda i, e=explain, m=moved: e(i) + f", measured summation sensitivity {m[i]:.3g} allowances")
-        assert_grad_close(k, g, o_grads[k], rtol=grad_rtol, explain=explain_k, ill=ill_k, ill_quota=10.0 if per_gaussian else None)
+        assert_grad_close(k, g, o_grads[k], rtol=grad_rtol, explain=explain_k, ill=ill_k, ill_quota=quota if per_gaussian else None)
     return h_out, h_grads, o_out, st
 
 

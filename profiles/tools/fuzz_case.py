@@ -1,3 +1,6 @@
+"""One seed of tests/test_gpu_fuzz.py with diagnostics: which gradient rows leave the per-row allowance in the atomic and in the
+deterministic backward (twice each), their conic conditioning, and the measured summation sensitivity of every tensor.
+    PYTHONPATH=.:tests python profiles/tools/fuzz_case.py <seed>"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')

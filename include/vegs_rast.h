@@ -111,7 +111,14 @@ typedef enum VrFlags {
      * heavy tiles' later rounds run at low parallelism: +0.04 ms on the headline view).  Default: chosen per call from
      * the number of list entries (rounds from 12 segments per tile on).  A needed-segment hint implies rounds. */
     VR_FLAG_ROUNDS_OFF = 1u << 10,
-    VR_FLAG_ROUNDS_ON = 1u << 11
+    VR_FLAG_ROUNDS_ON = 1u << 11,
+    /* opacities / scales / rotations are the model's RAW parameters (scene/gaussian_model.py:_opacity, _scaling,
+     * _rotation): the library applies the reference's activations itself -- sigmoid, exp, F.normalize (eps 1e-12),
+     * scene/gaussian_model.py:37-45, the arithmetic of vr_activations_forward -- inside the preprocess kernel, and
+     * dL_dopacities / dL_dscales / dL_drotations come back with respect to the RAW values.  Saves the two activation
+     * launches and their 64 bytes per Gaussian each way in a training iteration.  Needs scales and rotations (not
+     * cov3D_precomp). */
+    VR_FLAG_RAW_PARAMS = 1u << 12
 } VrFlags;
 
 /* The op's tensor arguments (reference gaussian_renderer/__init__.py:86-94). Exactly one of

@@ -564,6 +564,59 @@ def test_split_sh_storage_equals_concatenated(P, M, deg, dev):
     assert not dc.grad.cpu().numpy()[culled].any() and (M == 1 or not rest.grad.cpu().numpy()[culled].any())
 
 
+@pytest.mark.parametrize("P,split", [(20000, False), (3000, True), (65, False)])
+def test_raw_parameters_equal_activations_in_front_of_the_op(P, split, dev):
+    """VR_FLAG_RAW_PARAMS: the op given the model's raw _opacity / _scaling / _rotation == the model's activations
+    (vegs_amd.instances.activate, pinned by ref_activations.npz) in front of the op: images bit-identical, gradients of
+    the raw parameters equal (deterministic backward: the same per-Gaussian sums feed the same chain)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from vegs_amd import instances, rasterizer, scenes
+    sc, deg = scenes.scene_street(P=P, length=40.0, sh_degree=2, seed=P)
+    rng = np.random.default_rng(P)
+    raw = {"opacity": np.log(sc["opacities"] / (1 - sc["opacities"])).astype(np.float32),
+           "scaling": np.log(sc["scales"]).astype(np.float32),
+           "rotation": (sc["rotations"] * rng.uniform(0.3, 3.0, (P, 1))).astype(np.float32)}
+    raw["rotation"][0] = 0.0                                  # |q| below F.normalize's eps
+    cam = scenes.kitti_camera(2.0, 0.3, 344, 94)
+    st = _settings(cam, [0.1, 0.2, 0.3], deg, 1.0, dev)
+    gouts = [torch.tensor(rng.normal(size=s).astype(np.float32), device=dev) for s in [(3, 94, 344), (4, 94, 344), (3, 94, 344)]]
+
+    def run(raw_flag):
+        leaves = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in raw.items()}
+        xyz = torch.tensor(sc["means3D"], device=dev, requires_grad=True)
+        if split:
+            shs = (torch.tensor(sc["shs"][:, :1].copy(), device=dev, requires_grad=True),
+                   torch.tensor(sc["shs"][:, 1:].copy(), device=dev, requires_grad=True))
+        else:
+            shs = torch.tensor(sc["shs"], device=dev, requires_grad=True)
+        if raw_flag:
+            o, s_, r = leaves["opacity"], leaves["scaling"], leaves["rotation"]
+        else:
+            o, s_, r = instances.activate(leaves["opacity"], leaves["scaling"], leaves["rotation"])
+        m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
+        with rasterizer.flags(rasterizer.FLAG_DETERMINISTIC | (rasterizer.FLAG_RAW_PARAMS if raw_flag else 0)):
+            res = GaussianRasterizer(raster_settings=st)(means3D=xyz, means2D=m2d, shs=shs, opacities=o, scales=s_, rotations=r)
+            torch.autograd.backward([res[0], res[2], res[3]], gouts)
+        return res, leaves, xyz, m2d
+
+    ra, la, xa, ma = run(False)
+    rb, lb, xb, mb = run(True)
+    for a, b in zip(ra, rb):
+        assert torch.equal(a, b)
+    assert int((ra[5] > 0).sum()) > P // 4
+    assert torch.equal(xa.grad, xb.grad) and torch.equal(ma.grad, mb.grad)
+    for k in raw:
+        ga, gb = la[k].grad.cpu().numpy(), lb[k].grad.cpu().numpy()
+        assert np.isfinite(gb).all(), k
+        # same formulas in the same order; the compiler may contract differently inside the larger kernel
+        assert np.abs(ga - gb).max() <= 2e-6 * np.abs(ga).max(), (k, np.abs(ga - gb).max(), np.abs(ga).max())
+    # raw parameters with a precomputed covariance are refused
+    with rasterizer.flags(rasterizer.FLAG_RAW_PARAMS):
+        with pytest.raises(Exception, match="RAW_PARAMS"):
+            GaussianRasterizer(raster_settings=st)(means3D=xb.detach(), means2D=torch.zeros(P, 3, device=dev), shs=torch.tensor(sc["shs"], device=dev),
+                                                  opacities=lb["opacity"].detach(), cov3D_precomp=torch.zeros(P, 6, device=dev))
+
+
 def test_segment_rounds_never_change_results(dev):
     """VR_FLAG_ROUNDS_ON / _OFF and the default (chosen from the list density): the forward evaluates a tile's list
     segments all at once or in three rounds (6, then 24 ... 48 more for tiles with a live pixel left, then the rest).  A dense,

@@ -18,9 +18,10 @@ namespace vr {
 static_assert(FLAG_SCALE_MODIFIED == VR_FLAG_SCALE_MODIFIED && FLAG_DEPTH_NORMALIZED == VR_FLAG_DEPTH_NORMALIZED &&
               FLAG_EXTRA_NO_ALPHA_GRAD == VR_FLAG_EXTRA_NO_ALPHA_GRAD && FLAG_FILL_EMPTY == VR_FLAG_FILL_EMPTY &&
               FLAG_DETERMINISTIC == VR_FLAG_DETERMINISTIC && FLAG_SCAN_BINNING == VR_FLAG_SCAN_BINNING &&
-              FLAG_ROUNDS_OFF == VR_FLAG_ROUNDS_OFF && FLAG_ROUNDS_ON == VR_FLAG_ROUNDS_ON, "device-side flag constants must match include/vegs_rast.h");
+              FLAG_ROUNDS_OFF == VR_FLAG_ROUNDS_OFF && FLAG_ROUNDS_ON == VR_FLAG_ROUNDS_ON &&
+              FLAG_RAW_PARAMS == VR_FLAG_RAW_PARAMS, "device-side flag constants must match include/vegs_rast.h");
 constexpr uint32_t KNOWN_FLAGS = FLAG_SCALE_MODIFIED | FLAG_DEPTH_NORMALIZED | FLAG_EXTRA_NO_ALPHA_GRAD | FLAG_FILL_EMPTY |
-                                 FLAG_DETERMINISTIC | FLAG_SCAN_BINNING | FLAG_ROUNDS_OFF | FLAG_ROUNDS_ON;
+                                 FLAG_DETERMINISTIC | FLAG_SCAN_BINNING | FLAG_ROUNDS_OFF | FLAG_ROUNDS_ON | FLAG_RAW_PARAMS;
 
 static thread_local char g_err[512] = "";
 static thread_local VrCounters g_counters = {0, 0, 0, 0, 0};
@@ -228,6 +229,8 @@ static int check_inputs(const VrSettings* st, const VrInputs* in)
         if (sr == (in->cov3D_precomp != nullptr) || (sr && (!in->scales || !in->rotations)))
             return fail(VR_ERR_INVALID_ARGUMENT,
                         "exactly one of (scales, rotations) and cov3D_precomp must be given");
+        if ((st->flags & FLAG_RAW_PARAMS) && !sr)
+            return fail(VR_ERR_INVALID_ARGUMENT, "VR_FLAG_RAW_PARAMS needs scales and rotations (not cov3D_precomp)");
         if (in->shs) {
             int K = (st->sh_degree + 1) * (st->sh_degree + 1);
             if (in->M < K)
@@ -541,7 +544,7 @@ static int backward_second(const Camera& cam, const VrSettings* st, const VrInpu
     const int P = in->P;
     ProfScope ps2(VR_STAGE_PREPROCESS_BWD, s);
     return launch_preprocess_bwd(cam, P, in->means3D, in->shs, in->shs_rest, in->shs_tail ? (int)in->tail_start : P,
-                                 in->colors_precomp, in->scales, in->rotations, in->cov3D_precomp, radii,
+                                 in->colors_precomp, in->opacities, in->scales, in->rotations, in->cov3D_precomp, radii,
                                  (const uint8_t*)saved->geom + align_up((size_t)P * sizeof(Splat), 256),
                                  (const float*)((const char*)saved->geom + align_up((size_t)P * sizeof(Splat), 256) + align_up((size_t)P, 256)),
                                  gacc, gin->dL_dmeans2D, gin->dL_dmeans3D, gin->dL_dshs, gin->dL_dshs_rest,

@@ -254,7 +254,6 @@ __global__ void __launch_bounds__(64) k_inst_finish(InstFinArgs a, const double*
 // get_rotation = torch.nn.functional.normalize) for all Gaussians in ONE launch each way.  Through ATen this is
 // sigmoid + exp + (norm, clamp_min, expand, div) forward and twice that backward: ~15 launches streaming 2 M rows
 // each (0.25 ms of a 2.5 ms iteration).  One Gaussian per thread; 32 bytes in, 32 bytes out.
-constexpr float NORMALIZE_EPS = 1e-12f;   // F.normalize's default eps
 
 __global__ void __launch_bounds__(256)
 k_activate_fwd(const float* __restrict__ raw_opacity, const float* __restrict__ raw_scaling,
@@ -263,12 +262,14 @@ k_activate_fwd(const float* __restrict__ raw_opacity, const float* __restrict__ 
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    opacity[i] = 1.0f / (1.0f + expf(-raw_opacity[i]));
+    opacity[i] = act_sigmoid(raw_opacity[i]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) scales[3 * i + k] = expf(raw_scaling[3 * i + k]);
-    const float4 q = raw_rotation[i];
-    const float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), NORMALIZE_EPS);
-    rotations[i] = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
+    const float4 q4 = raw_rotation[i];
+    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+    float y[4];
+    act_normalize(q, y);
+    rotations[i] = make_float4(y[0], y[1], y[2], y[3]);
 }
 
 // y = sigmoid(x): dx = g y (1 - y);  y = exp(x): dx = g y;  y = x / n, n = max(|x|, eps): dx = (g - y <y, g>) / n
@@ -292,16 +293,11 @@ k_activate_bwd(const float* __restrict__ opacity, const float* __restrict__ scal
     if (d_rotation) {
         float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g_rotations) {
-            const float4 q = raw_rotation[i], g = g_rotations[i];
-            const float len = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-            if (len > NORMALIZE_EPS) {
-                const float inv = 1.0f / len;
-                const float yx = q.x * inv, yy = q.y * inv, yz = q.z * inv, yw = q.w * inv;
-                const float dot = yx * g.x + yy * g.y + yz * g.z + yw * g.w;
-                d = make_float4((g.x - yx * dot) * inv, (g.y - yy * dot) * inv, (g.z - yz * dot) * inv, (g.w - yw * dot) * inv);
-            } else {
-                d = make_float4(g.x / NORMALIZE_EPS, g.y / NORMALIZE_EPS, g.z / NORMALIZE_EPS, g.w / NORMALIZE_EPS);
-            }
+            const float4 q4 = raw_rotation[i], g4 = g_rotations[i];
+            const float q[4] = {q4.x, q4.y, q4.z, q4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w};
+            float dd[4];
+            act_normalize_bwd(q, g, dd);
+            d = make_float4(dd[0], dd[1], dd[2], dd[3]);
         }
         d_rotation[i] = d;
     }

@@ -77,6 +77,12 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
                 for (int k = 0; k < 3; ++k) sc[k] = scales[3 * (size_t)i + k];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) q[k] = rotations[4 * (size_t)i + k];
+                if (cam.flags & FLAG_RAW_PARAMS) {      // raw parameters: the model's activations, here
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) sc[k] = expf(sc[k]);
+                    const float qr[4] = {q[0], q[1], q[2], q[3]};
+                    act_normalize(qr, q);
+                }
                 cov3d_from_scale_rot(sc, cam.mod, q, c6);
             }
             Cov2D cv;
@@ -231,7 +237,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
 
     if (vis) {
         Splat s;
-        const float opac = opacities[i];
+        const float opac = (cam.flags & FLAG_RAW_PARAMS) ? act_sigmoid(opacities[i]) : opacities[i];
         s.x = px; s.y = py; s.conA = conA; s.conB = conB;
         s.conC = conC; s.opacity = opac; s.thr = splat_thr(opac); s.depth = t2;
         s.r = rgb[0]; s.g = rgb[1]; s.b = rgb[2]; s.qw = q[0];

@@ -73,7 +73,8 @@ __device__ __forceinline__ void sh_backward_factor(const Camera& cam, float px3,
 __global__ void __launch_bounds__(256)
 k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ means3D, const float* __restrict__ shs,
                  const float* __restrict__ shs_rest, float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dshs_tail,
-                 int tail_start, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
+                 int tail_start, const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+                 const float* __restrict__ scales,
                  const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
                  const int* __restrict__ radii, const uint8_t* __restrict__ clampb, const float* __restrict__ shd,
                  const float* __restrict__ gacc,
@@ -234,7 +235,7 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
         // ---- recompute the forward intermediates (identical expressions as preprocess)
         float t0, t1, t2;
         xform43(V, px3, py3, pz3, t0, t1, t2);
-        float c6[6], q[4] = {0.f, 0.f, 0.f, 0.f}, sc[3] = {0.f, 0.f, 0.f};
+        float c6[6], q[4] = {0.f, 0.f, 0.f, 0.f}, sc[3] = {0.f, 0.f, 0.f}, qraw[4] = {0.f, 0.f, 0.f, 0.f};
         if (cov3D_precomp) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * (size_t)i + k];
@@ -243,6 +244,13 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
             for (int k = 0; k < 3; ++k) sc[k] = scales[3 * (size_t)i + k];
 #pragma unroll
             for (int k = 0; k < 4; ++k) q[k] = rotations[4 * (size_t)i + k];
+            if (cam.flags & FLAG_RAW_PARAMS) {          // as in the forward; the raw quaternion is kept for the chain below
+#pragma unroll
+                for (int k = 0; k < 4; ++k) qraw[k] = q[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) sc[k] = expf(sc[k]);
+                act_normalize(qraw, q);
+            }
             cov3d_from_scale_rot(sc, cam.mod, q, c6);
         }
         Cov2D cv;
@@ -337,6 +345,16 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
             drot[1] = 2.f * (y * (D[1] + D[3]) + z * (D[2] + D[6]) + r * (D[7] - D[5])) - 4.f * x * (D[4] + D[8]) + ga[5];
             drot[2] = 2.f * (x * (D[1] + D[3]) + r * (D[2] - D[6]) + z * (D[5] + D[7])) - 4.f * y * (D[0] + D[8]) + ga[6];
             drot[3] = 2.f * (r * (D[3] - D[1]) + x * (D[2] + D[6]) + y * (D[5] + D[7])) - 4.f * z * (D[0] + D[4]) + ga[7];
+            if (cam.flags & FLAG_RAW_PARAMS) {          // chain through exp and F.normalize (vr_activations_backward's arithmetic)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dsc[k] = dsc[k] * sc[k];
+                const float g[4] = {drot[0], drot[1], drot[2], drot[3]};
+                act_normalize_bwd(qraw, g, drot);
+            }
+        }
+        if (cam.flags & FLAG_RAW_PARAMS) {              // ... and through the sigmoid
+            const float y = act_sigmoid(opacities[i]);
+            dop = dop * (1.0f - y) * y;
         }
     }
     if (!in_range) return;
@@ -370,7 +388,8 @@ bool preprocess_bwd_writes_all_sh(int M, const float* shs, const float* dL_dshs)
 }
 
 int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const float* shs, const float* shs_rest,
-                          int tail_start, const float* colors_precomp, const float* scales, const float* rotations,
+                          int tail_start, const float* colors_precomp, const float* opacities, const float* scales,
+                          const float* rotations,
                           const float* cov3D_precomp, const int* radii, const uint8_t* clampb, const float* shd, const float* gacc,
                           const float* gmean2D, float* dL_dmeans3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dshs_tail,
                           float* dL_dcolors,
@@ -380,7 +399,7 @@ int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const 
     if (P == 0) return 0;
     const int sh_staged = preprocess_bwd_writes_all_sh(cam.M, shs, dL_dshs) ? 1 : 0;
     hipLaunchKernelGGL(k_preprocess_bwd, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, sh_staged, means3D, shs, shs_rest,
-                       dL_dshs_rest, dL_dshs_tail, tail_start, colors_precomp, scales, rotations, cov3D_precomp, radii, clampb, shd, gacc, gmean2D, dL_dmeans3D,
+                       dL_dshs_rest, dL_dshs_tail, tail_start, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, clampb, shd, gacc, gmean2D, dL_dmeans3D,
                        dL_dshs, dL_dcolors,
                        dL_dopacities, dL_dscales, dL_drots, dL_dcov3D, dL_dcolors_sh, store_factor ? 1 : 0);
     VR_KERNEL_CHECK("preprocess_bwd", s, debug);

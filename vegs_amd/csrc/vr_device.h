@@ -39,6 +39,29 @@ constexpr uint32_t FLAG_DETERMINISTIC = 1u << 8;        // backward without atom
 constexpr uint32_t FLAG_SCAN_BINNING = 1u << 9;         // binning with the scan-based (multi-launch) radix passes
 constexpr uint32_t FLAG_ROUNDS_OFF = 1u << 10;          // forward: all list segments at once
 constexpr uint32_t FLAG_ROUNDS_ON = 1u << 11;           // forward: segment rounds whatever the list density
+constexpr uint32_t FLAG_RAW_PARAMS = 1u << 12;          // opacities / scales / rotations are raw parameters (activated here)
+
+// The model's activations (scene/gaussian_model.py:37-45), shared by vr_activations_* and the VR_FLAG_RAW_PARAMS path
+constexpr float NORMALIZE_EPS = 1e-12f;   // F.normalize's default eps
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ void act_normalize(const float q[4], float y[4])
+{
+    const float n = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), NORMALIZE_EPS);
+    y[0] = q[0] / n; y[1] = q[1] / n; y[2] = q[2] / n; y[3] = q[3] / n;
+}
+// y = x / n, n = max(|x|, eps): dx = (g - y <y, g>) / n where the norm is not clamped, g / eps where it is
+__device__ __forceinline__ void act_normalize_bwd(const float q[4], const float g[4], float d[4])
+{
+    const float len = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (len > NORMALIZE_EPS) {
+        const float inv = 1.0f / len;
+        const float y0 = q[0] * inv, y1 = q[1] * inv, y2 = q[2] * inv, y3 = q[3] * inv;
+        const float dot = y0 * g[0] + y1 * g[1] + y2 * g[2] + y3 * g[3];
+        d[0] = (g[0] - y0 * dot) * inv; d[1] = (g[1] - y1 * dot) * inv; d[2] = (g[2] - y2 * dot) * inv; d[3] = (g[3] - y3 * dot) * inv;
+    } else {
+        d[0] = g[0] / NORMALIZE_EPS; d[1] = g[1] / NORMALIZE_EPS; d[2] = g[2] / NORMALIZE_EPS; d[3] = g[3] / NORMALIZE_EPS;
+    }
+}
 
 struct Camera {
     int H, W, gx, gy;

@@ -138,7 +138,7 @@ int launch_count_blended(const Camera& cam, const int2* ranges, const uint32_t* 
 // ---- preprocess_bwd.hip
 bool preprocess_bwd_writes_all_sh(int M, const float* shs, const float* dL_dshs);
 int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const float* shs, const float* shs_rest,
-                          int tail_start, const float* colors_precomp, const float* scales, const float* rotations,
+                          int tail_start, const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
                           const float* cov3D_precomp, const int* radii, const uint8_t* clampb, const float* shd, const float* gacc,
                           const float* gmean2D, float* dL_dmeans3D, float* dL_dshs, float* dL_dshs_rest, float* dL_dshs_tail,
                           float* dL_dcolors,

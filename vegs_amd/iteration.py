@@ -65,6 +65,14 @@ def ssim_window(device):
 
 
 def render_model(p, boxes, cam, cam_t, deg, bg, fused, sh_sink=None):
+    if fused and not boxes:
+        # the op takes the RAW parameters and activates them in its preprocess kernel (VR_FLAG_RAW_PARAMS): no activation
+        # launches, gradients straight to _opacity / _scaling / _rotation
+        from . import rasterizer
+        t = {"means3D": p["xyz"], "opacities": p["opacity"], "scales": p["scaling"], "rotations": p["rotation"],
+             "shs": (p["f_dc"], p["f_rest"])}
+        with rasterizer.flags(rasterizer.get_flags() | rasterizer.FLAG_RAW_PARAMS):
+            return harness.render(cam, t, deg, bg, cam_t=cam_t, sh_color_grad=sh_sink)
     if fused:
         from . import instances
         opac, scal, rot = instances.activate(p["opacity"], p["scaling"], p["rotation"])

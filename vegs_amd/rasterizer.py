@@ -50,6 +50,7 @@ FLAG_DETERMINISTIC = _capi.FLAG_DETERMINISTIC              # backward without at
 FLAG_SCAN_BINNING = _capi.FLAG_SCAN_BINNING                # binning without inter-workgroup waits (multi-launch passes)
 FLAG_ROUNDS_OFF = _capi.FLAG_ROUNDS_OFF                    # forward: every list segment at once, whatever the list density
 FLAG_ROUNDS_ON = _capi.FLAG_ROUNDS_ON                      # forward: segment rounds, whatever the list density (default: by density)
+FLAG_RAW_PARAMS = _capi.FLAG_RAW_PARAMS                    # opacities / scales / rotations are the model's raw parameters: activated in the kernel
 _flags = int(os.environ.get("VEGS_RAST_FLAGS", "0"), 0)
 
 

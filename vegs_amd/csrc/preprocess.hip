@@ -37,6 +37,8 @@ __device__ __forceinline__ void sh_dot(const float* bas, int K, const float* sh,
     acc[0] = a0; acc[1] = a1; acc[2] = a2;
 }
 
+// RAW (VR_FLAG_RAW_PARAMS) is a compile-time switch: the default instantiation is the kernel as it was
+template <bool RAW>
 __global__ void __launch_bounds__(256)
 k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
              const float* __restrict__ shs_rest, const float* __restrict__ shs_tail, int tail_start,
@@ -77,11 +79,11 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
                 for (int k = 0; k < 3; ++k) sc[k] = scales[3 * (size_t)i + k];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) q[k] = rotations[4 * (size_t)i + k];
-                if (cam.flags & FLAG_RAW_PARAMS) {      // raw parameters: the model's activations, here
+                if (RAW && (cam.flags & FLAG_RAW_PARAMS)) {      // raw parameters: the model's activations, here (the run-time
+                                                                 // test keeps this instantiation at 160 VGPRs; without it: 170)
 #pragma unroll
                     for (int k = 0; k < 3; ++k) sc[k] = expf(sc[k]);
-                    const float qr[4] = {q[0], q[1], q[2], q[3]};
-                    act_normalize(qr, q);
+                    act_normalize(q, q);      // (in place: element-wise after the norm)
                 }
                 cov3d_from_scale_rot(sc, cam.mod, q, c6);
             }
@@ -237,7 +239,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
 
     if (vis) {
         Splat s;
-        const float opac = (cam.flags & FLAG_RAW_PARAMS) ? act_sigmoid(opacities[i]) : opacities[i];
+        const float opac = (RAW && (cam.flags & FLAG_RAW_PARAMS)) ? act_sigmoid(opacities[i]) : opacities[i];
         s.x = px; s.y = py; s.conA = conA; s.conB = conB;
         s.conC = conC; s.opacity = opac; s.thr = splat_thr(opac); s.depth = t2;
         s.r = rgb[0]; s.g = rgb[1]; s.b = rgb[2]; s.qw = q[0];
@@ -277,8 +279,12 @@ int launch_preprocess(const Camera& cam, int P, const float* means3D, const floa
                       uint32_t* depth_key, uint8_t* clampb, float* shd, hipStream_t s, bool debug)
 {
     if (P == 0) return 0;
-    hipLaunchKernelGGL(k_preprocess, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, means3D, shs, shs_rest, shs_tail,
-                       tail_start, colors_precomp, opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, clampb, shd);
+    if (cam.flags & FLAG_RAW_PARAMS)
+        hipLaunchKernelGGL(k_preprocess<true>, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, means3D, shs, shs_rest, shs_tail,
+                           tail_start, colors_precomp, opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, clampb, shd);
+    else
+        hipLaunchKernelGGL(k_preprocess<false>, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, means3D, shs, shs_rest, shs_tail,
+                           tail_start, colors_precomp, opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, clampb, shd);
     VR_KERNEL_CHECK("preprocess", s, debug);
     return 0;
 }

@@ -70,6 +70,7 @@ __device__ __forceinline__ void sh_backward_factor(const Camera& cam, float px3,
     for (int k = 0; k < 3; ++k) dmean[k] += (ddir[k] - dir[k] * dot) * il;
 }
 
+template <bool RAW>      // VR_FLAG_RAW_PARAMS, compile-time: the default instantiation is the kernel as it was
 __global__ void __launch_bounds__(256)
 k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ means3D, const float* __restrict__ shs,
                  const float* __restrict__ shs_rest, float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dshs_tail,
@@ -244,7 +245,7 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
             for (int k = 0; k < 3; ++k) sc[k] = scales[3 * (size_t)i + k];
 #pragma unroll
             for (int k = 0; k < 4; ++k) q[k] = rotations[4 * (size_t)i + k];
-            if (cam.flags & FLAG_RAW_PARAMS) {          // as in the forward; the raw quaternion is kept for the chain below
+            if (RAW) {          // as in the forward; the raw quaternion is kept for the chain below
 #pragma unroll
                 for (int k = 0; k < 4; ++k) qraw[k] = q[k];
 #pragma unroll
@@ -345,14 +346,14 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
             drot[1] = 2.f * (y * (D[1] + D[3]) + z * (D[2] + D[6]) + r * (D[7] - D[5])) - 4.f * x * (D[4] + D[8]) + ga[5];
             drot[2] = 2.f * (x * (D[1] + D[3]) + r * (D[2] - D[6]) + z * (D[5] + D[7])) - 4.f * y * (D[0] + D[8]) + ga[6];
             drot[3] = 2.f * (r * (D[3] - D[1]) + x * (D[2] + D[6]) + y * (D[5] + D[7])) - 4.f * z * (D[0] + D[4]) + ga[7];
-            if (cam.flags & FLAG_RAW_PARAMS) {          // chain through exp and F.normalize (vr_activations_backward's arithmetic)
+            if (RAW) {          // chain through exp and F.normalize (vr_activations_backward's arithmetic)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) dsc[k] = dsc[k] * sc[k];
                 const float g[4] = {drot[0], drot[1], drot[2], drot[3]};
                 act_normalize_bwd(qraw, g, drot);
             }
         }
-        if (cam.flags & FLAG_RAW_PARAMS) {              // ... and through the sigmoid
+        if (RAW) {              // ... and through the sigmoid
             const float y = act_sigmoid(opacities[i]);
             dop = dop * (1.0f - y) * y;
         }
@@ -398,7 +399,13 @@ int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const 
 {
     if (P == 0) return 0;
     const int sh_staged = preprocess_bwd_writes_all_sh(cam.M, shs, dL_dshs) ? 1 : 0;
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, sh_staged, means3D, shs, shs_rest,
+    if (cam.flags & FLAG_RAW_PARAMS)
+        hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, sh_staged, means3D, shs, shs_rest,
+                       dL_dshs_rest, dL_dshs_tail, tail_start, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, clampb, shd, gacc, gmean2D, dL_dmeans3D,
+                       dL_dshs, dL_dcolors,
+                       dL_dopacities, dL_dscales, dL_drots, dL_dcov3D, dL_dcolors_sh, store_factor ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, sh_staged, means3D, shs, shs_rest,
                        dL_dshs_rest, dL_dshs_tail, tail_start, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, clampb, shd, gacc, gmean2D, dL_dmeans3D,
                        dL_dshs, dL_dcolors,
                        dL_dopacities, dL_dscales, dL_drots, dL_dcov3D, dL_dcolors_sh, store_factor ? 1 : 0);

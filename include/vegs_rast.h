@@ -117,7 +117,8 @@ typedef enum VrFlags {
      * scene/gaussian_model.py:37-45, the arithmetic of vr_activations_forward -- inside the preprocess kernel, and
      * dL_dopacities / dL_dscales / dL_drotations come back with respect to the RAW values.  Saves the two activation
      * launches and their 64 bytes per Gaussian each way in a training iteration.  Needs scales and rotations (not
-     * cov3D_precomp). */
+     * cov3D_precomp).  With an SH tail (VrInputs.shs_tail) only the rows in front of tail_start are raw: the rows of the
+     * box instances behind the static model arrive activated and transformed (gaussian_renderer/__init__.py:121-186). */
     VR_FLAG_RAW_PARAMS = 1u << 12
 } VrFlags;
 

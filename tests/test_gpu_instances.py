@@ -181,3 +181,51 @@ def test_activation_argument_checks():
         activate(o.cpu(), s.cpu(), q.cpu())
     e = activate(o[:0], s[:0], q[:0])
     assert e[0].shape == (0, 1) and e[2].shape == (0, 4)
+
+
+def test_raw_static_model_with_instances_equals_activations_in_front():
+    """harness.render_all(static_raw=...): the static model's RAW _opacity / _scaling / _rotation in the concatenated
+    inputs, activated by the op for the rows in front of the instances (VR_FLAG_RAW_PARAMS + the SH tail's boundary) ==
+    vegs_amd.instances.activate in front of prepare_and_merge: images bit-identical, every gradient equal."""
+    import numpy as np
+    from vegs_amd import harness, instances, iteration, rasterizer, scenes
+    dev = torch.device("cuda", 0)
+    sc, deg = scenes.scene_street(P=30000, length=40.0, sh_degree=3, seed=12)
+    cam = scenes.kitti_camera(2.0, 0.3, 688, 188)
+    cam_t = harness.cam_tensors(cam, dev)
+    bg = torch.zeros(3, device=dev)
+    rng = np.random.default_rng(2)
+    gouts = [torch.tensor(rng.normal(size=s).astype(np.float32), device=dev) for s in [(3, 188, 688), (4, 188, 688), (3, 188, 688)]]
+
+    def run(raw):
+        p, _ = iteration.make_model(sc, dev)
+        with torch.no_grad():
+            p["rotation"].mul_(torch.tensor(rng2.uniform(0.5, 2.0, (p["rotation"].shape[0], 1)).astype(np.float32), device=dev))
+        boxes = iteration.make_boxes(3, dev, points=700)
+        t = {"means3D": p["xyz"], "shs": (p["f_dc"], p["f_rest"])}
+        rawd = {"opacities": p["opacity"], "scales": p["scaling"], "rotations": p["rotation"]}
+        with rasterizer.flags(rasterizer.FLAG_DETERMINISTIC):
+            if raw:
+                pkg = harness.render_all(cam, t, [b for b, _ in boxes], [w for _, w in boxes], deg, bg, cam_t=cam_t, fused=True,
+                                         static_raw=rawd)
+            else:
+                o, s_, r = instances.activate(rawd["opacities"], rawd["scales"], rawd["rotations"])
+                pkg = harness.render_all(cam, {**t, "opacities": o, "scales": s_, "rotations": r}, [b for b, _ in boxes],
+                                         [w for _, w in boxes], deg, bg, cam_t=cam_t, fused=True)
+            torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], gouts)
+        return pkg, p, boxes
+
+    rng2 = np.random.default_rng(5)
+    pa, ma, ba = run(False)
+    rng2 = np.random.default_rng(5)
+    pb, mb, bb = run(True)
+    for k in ("render", "render_depth", "render_cov_quat", "render_cov_scale", "alpha", "radii"):
+        assert torch.equal(pa[k], pb[k]), k
+    assert int((pb["radii"][30000:] > 0).sum()) > 200                      # the instances are in the frame
+    for k in ma:
+        ga, gb = ma[k].grad.cpu().numpy(), mb[k].grad.cpu().numpy()
+        assert np.abs(ga - gb).max() <= 2e-6 * np.abs(ga).max(), (k, np.abs(ga - gb).max(), np.abs(ga).max())
+    for (b1, w1), (b2, w2) in zip(ba, bb):
+        assert torch.equal(w1.grad, w2.grad)
+        for k in b1:
+            assert torch.equal(b1[k].grad, b2[k].grad), k

@@ -79,7 +79,8 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
                 for (int k = 0; k < 3; ++k) sc[k] = scales[3 * (size_t)i + k];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) q[k] = rotations[4 * (size_t)i + k];
-                if (RAW && (cam.flags & FLAG_RAW_PARAMS)) {      // raw parameters: the model's activations, here (the run-time
+                // (rows from tail_start on -- box instances behind the static model -- arrive activated and transformed)
+                if (RAW && (cam.flags & FLAG_RAW_PARAMS) && i < tail_start) {      // raw parameters: the model's activations, here (the run-time
                                                                  // test keeps this instantiation at 160 VGPRs; without it: 170)
 #pragma unroll
                     for (int k = 0; k < 3; ++k) sc[k] = expf(sc[k]);
@@ -239,7 +240,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
 
     if (vis) {
         Splat s;
-        const float opac = (RAW && (cam.flags & FLAG_RAW_PARAMS)) ? act_sigmoid(opacities[i]) : opacities[i];
+        const float opac = (RAW && (cam.flags & FLAG_RAW_PARAMS) && i < tail_start) ? act_sigmoid(opacities[i]) : opacities[i];
         s.x = px; s.y = py; s.conA = conA; s.conB = conB;
         s.conC = conC; s.opacity = opac; s.thr = splat_thr(opac); s.depth = t2;
         s.r = rgb[0]; s.g = rgb[1]; s.b = rgb[2]; s.qw = q[0];

@@ -245,7 +245,7 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
             for (int k = 0; k < 3; ++k) sc[k] = scales[3 * (size_t)i + k];
 #pragma unroll
             for (int k = 0; k < 4; ++k) q[k] = rotations[4 * (size_t)i + k];
-            if (RAW) {          // as in the forward; the raw quaternion is kept for the chain below
+            if (RAW && i < tail_start) {          // as in the forward; the raw quaternion is kept for the chain below
 #pragma unroll
                 for (int k = 0; k < 4; ++k) qraw[k] = q[k];
 #pragma unroll
@@ -346,14 +346,14 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
             drot[1] = 2.f * (y * (D[1] + D[3]) + z * (D[2] + D[6]) + r * (D[7] - D[5])) - 4.f * x * (D[4] + D[8]) + ga[5];
             drot[2] = 2.f * (x * (D[1] + D[3]) + r * (D[2] - D[6]) + z * (D[5] + D[7])) - 4.f * y * (D[0] + D[8]) + ga[6];
             drot[3] = 2.f * (r * (D[3] - D[1]) + x * (D[2] + D[6]) + y * (D[5] + D[7])) - 4.f * z * (D[0] + D[4]) + ga[7];
-            if (RAW) {          // chain through exp and F.normalize (vr_activations_backward's arithmetic)
+            if (RAW && i < tail_start) {          // chain through exp and F.normalize (vr_activations_backward's arithmetic)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) dsc[k] = dsc[k] * sc[k];
                 const float g[4] = {drot[0], drot[1], drot[2], drot[3]};
                 act_normalize_bwd(qraw, g, drot);
             }
         }
-        if (RAW) {              // ... and through the sigmoid
+        if (RAW && i < tail_start) {              // ... and through the sigmoid
             const float y = act_sigmoid(opacities[i]);
             dop = dop * (1.0f - y) * y;
         }

@@ -103,12 +103,25 @@ def merge_kwargs(a, b):
 
 
 def render_all(cam, static, boxes, box2worlds, sh_degree, bg_color, scaling_modifier=1.0, cam_t=None, fused=False,
-               sh_color_grad=None):
+               sh_color_grad=None, static_raw=None):
     """fused=False: the reference's op-by-op composition (device-agnostic; what the CPU checks run);
-    fused=True: vegs_amd.instances.prepare_and_merge (one HIP launch for all instances, GPU only)."""
+    fused=True: vegs_amd.instances.prepare_and_merge (one HIP launch for all instances, GPU only).
+    static_raw (fused only): {"opacities", "scales", "rotations"} = the static model's RAW parameters, used instead of
+    static's activated ones: the op activates the rows in front of the instances itself (VR_FLAG_RAW_PARAMS; the
+    instances' rows behind the SH tail's boundary arrive activated and transformed) -- no activation launches over
+    the static model.  Falls back to vegs_amd.instances.activate when the frame cannot use an SH tail."""
     if fused:
-        from .instances import prepare_and_merge
-        kw = prepare_and_merge(static, boxes, box2worlds)
+        from . import instances, rasterizer
+        if static_raw is not None and static is not None and boxes:
+            kw = instances.prepare_and_merge({**static, **static_raw}, boxes, box2worlds)
+            if isinstance(kw["shs"], (tuple, list)) and len(kw["shs"]) == 3:       # the tail marks where the raw rows end
+                with rasterizer.flags(rasterizer.get_flags() | rasterizer.FLAG_RAW_PARAMS):
+                    pkg = render(cam, kw, sh_degree, bg_color, scaling_modifier, cam_t=cam_t, sh_color_grad=sh_color_grad)
+                pkg["op_inputs"] = kw
+                return pkg
+            o, s_, r = instances.activate(static_raw["opacities"], static_raw["scales"], static_raw["rotations"])
+            static = {**static, "opacities": o, "scales": s_, "rotations": r}
+        kw = instances.prepare_and_merge(static, boxes, box2worlds)
     else:
         kw = prepare_rasterization(static)
         for t, b2w in zip(boxes, box2worlds):

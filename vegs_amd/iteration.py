@@ -74,19 +74,18 @@ def render_model(p, boxes, cam, cam_t, deg, bg, fused, sh_sink=None):
         with rasterizer.flags(rasterizer.get_flags() | rasterizer.FLAG_RAW_PARAMS):
             return harness.render(cam, t, deg, bg, cam_t=cam_t, sh_color_grad=sh_sink)
     if fused:
-        from . import instances
-        opac, scal, rot = instances.activate(p["opacity"], p["scaling"], p["rotation"])
-        t = {"means3D": p["xyz"], "opacities": opac, "scales": scal, "rotations": rot}
-    else:
-        t = {"means3D": p["xyz"], "opacities": torch.sigmoid(p["opacity"]), "scales": torch.exp(p["scaling"]),
-             "rotations": F.normalize(p["rotation"])}
+        # with instances in frame: the static model's raw parameters go into the concatenated inputs as they are and the op
+        # activates the rows in front of the instances (harness.render_all: static_raw)
+        t = {"means3D": p["xyz"], "shs": (p["f_dc"], p["f_rest"])}
+        raw = {"opacities": p["opacity"], "scales": p["scaling"], "rotations": p["rotation"]}
+        return harness.render_all(cam, t, [b for b, _ in boxes], [w for _, w in boxes], deg, bg, cam_t=cam_t, fused=True,
+                                  sh_color_grad=sh_sink, static_raw=raw)
+    # the reference's op-by-op composition (ATen activations, torch.cat of the SH tensors)
+    t = {"means3D": p["xyz"], "opacities": torch.sigmoid(p["opacity"]), "scales": torch.exp(p["scaling"]),
+         "rotations": F.normalize(p["rotation"]), "shs": torch.cat((p["f_dc"], p["f_rest"]), dim=1)}
     if not boxes:
-        # fused: the model's two SH tensors as they are (no torch.cat, no slicing copies in the backward)
-        t["shs"] = (p["f_dc"], p["f_rest"]) if fused else torch.cat((p["f_dc"], p["f_rest"]), dim=1)
         return harness.render(cam, t, deg, bg, cam_t=cam_t, sh_color_grad=sh_sink)
-    # fused: the model's two SH tensors as they are; prepare_and_merge hands the instances' rows over as an SH tail
-    t["shs"] = (p["f_dc"], p["f_rest"]) if fused else torch.cat((p["f_dc"], p["f_rest"]), dim=1)
-    return harness.render_all(cam, t, [b for b, _ in boxes], [w for _, w in boxes], deg, bg, cam_t=cam_t, fused=fused,
+    return harness.render_all(cam, t, [b for b, _ in boxes], [w for _, w in boxes], deg, bg, cam_t=cam_t, fused=False,
                               sh_color_grad=sh_sink)
 
 

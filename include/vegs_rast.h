@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VR_ABI_VERSION 6
+#define VR_ABI_VERSION 7
 
 typedef enum VrStatus {
     VR_OK = 0,

@@ -183,14 +183,17 @@ def test_activation_argument_checks():
     assert e[0].shape == (0, 1) and e[2].shape == (0, 4)
 
 
-def test_raw_static_model_with_instances_equals_activations_in_front():
+@pytest.mark.parametrize("sh_degree", [3, 2])
+def test_raw_static_model_with_instances_equals_activations_in_front(sh_degree):
     """harness.render_all(static_raw=...): the static model's RAW _opacity / _scaling / _rotation in the concatenated
     inputs, activated by the op for the rows in front of the instances (VR_FLAG_RAW_PARAMS + the SH tail's boundary) ==
     vegs_amd.instances.activate in front of prepare_and_merge: images bit-identical, every gradient equal."""
     import numpy as np
     from vegs_amd import harness, instances, iteration, rasterizer, scenes
     dev = torch.device("cuda", 0)
-    sc, deg = scenes.scene_street(P=30000, length=40.0, sh_degree=3, seed=12)
+    # (degree 2: M = 9, rows of 27 floats cannot form an SH tail -> the concatenated fallback, activations in front)
+    sc, deg = scenes.scene_street(P=30000, length=40.0, sh_degree=sh_degree, seed=12)
+    M = sc["shs"].shape[1]
     cam = scenes.kitti_camera(2.0, 0.3, 688, 188)
     cam_t = harness.cam_tensors(cam, dev)
     bg = torch.zeros(3, device=dev)
@@ -202,7 +205,9 @@ def test_raw_static_model_with_instances_equals_activations_in_front():
         with torch.no_grad():
             p["rotation"].mul_(torch.tensor(rng2.uniform(0.5, 2.0, (p["rotation"].shape[0], 1)).astype(np.float32), device=dev))
         boxes = iteration.make_boxes(3, dev, points=700)
-        t = {"means3D": p["xyz"], "shs": (p["f_dc"], p["f_rest"])}
+        for b, _ in boxes:
+            b["shs"] = b["shs"].detach()[:, :M].contiguous().requires_grad_(True)
+        t = {"means3D": p["xyz"], "shs": (p["f_dc"], p["f_rest"]) if M == 16 else torch.cat((p["f_dc"], p["f_rest"]), 1)}
         rawd = {"opacities": p["opacity"], "scales": p["scaling"], "rotations": p["rotation"]}
         with rasterizer.flags(rasterizer.FLAG_DETERMINISTIC):
             if raw:

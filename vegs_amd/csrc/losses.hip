@@ -18,8 +18,15 @@
 
 namespace vr {
 
-constexpr int SSIM_R = 5, SSIM_W = 11, PT = 16, PIN = PT + 2 * SSIM_R;   // 16x16 output tile, 26x26 input tile
+// Tile: TW x TH = 16 x 54 output pixels per 256-thread workgroup, input tile 26 x 64 (halo 5).  Both separable passes are
+// REGISTER-BLOCKED: a thread produces four adjacent outputs from 14 consecutive inputs it reads once (the 16 x 16 tile
+// with one output per thread read 11 inputs per output and was bound by LDS bandwidth: 95 LDS reads per pixel, now 27).
+// The horizontal pass has exactly 64 rows x 4 quarters = 256 work items; the vertical one 16 columns x 14 row groups.
+// Per output the taps are accumulated in the same order as before (k = 0 .. 10), so the maps are bit-identical.
+constexpr int SSIM_R = 5, SSIM_W = 11, TW = 16, TH = 54, TIN_W = TW + 2 * SSIM_R, TIN_H = TH + 2 * SSIM_R;   // 26 x 64
+constexpr int TX_STRIDE = TIN_W + 1, HZ_STRIDE = 20, BLK = 4, RUN = BLK + SSIM_W - 1;                        // 14 inputs per run
 constexpr float SSIM_C1 = 0.01f * 0.01f, SSIM_C2 = 0.03f * 0.03f;
+static_assert(TIN_H * (TW / BLK) == 256, "one horizontal work item per thread");
 
 struct SsimWin { float g[SSIM_W]; };
 
@@ -38,61 +45,77 @@ __global__ void __launch_bounds__(256)
 k_photo_fwd(const float* __restrict__ x, const float* __restrict__ y, int H, int W, SsimWin win,
             float* __restrict__ dmaps, size_t plane_all, double* __restrict__ partial)
 {
-    __shared__ float tx[PIN][PIN + 1], ty[PIN][PIN + 1];
-    __shared__ float hz[5][PIN][PT + 1];
+    __shared__ float tx[TIN_H][TX_STRIDE], ty[TIN_H][TX_STRIDE];
+    __shared__ float hz[5][TIN_H][HZ_STRIDE];
     __shared__ double red[4];
-    const int c = blockIdx.z, bx = blockIdx.x * PT, by = blockIdx.y * PT;
+    const int c = blockIdx.z, bx = blockIdx.x * TW, by = blockIdx.y * TH;
     const size_t cbase = (size_t)c * H * W;
-    for (int i = threadIdx.x; i < PIN * PIN; i += 256) {
-        const int r = i / PIN, q = i - r * PIN;
+    for (int i = threadIdx.x; i < TIN_H * TIN_W; i += 256) {
+        const int r = i / TIN_W, q = i - r * TIN_W;
         const int gy = by + r - SSIM_R, gx = bx + q - SSIM_R;
         const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
         tx[r][q] = in ? x[cbase + (size_t)gy * W + gx] : 0.0f;
         ty[r][q] = in ? y[cbase + (size_t)gy * W + gx] : 0.0f;
     }
     __syncthreads();
-    // horizontal pass on the five moments x, y, x^2, y^2, xy
-    for (int i = threadIdx.x; i < PIN * PT; i += 256) {
-        const int r = i / PT, q = i - r * PT;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    {   // horizontal pass on the five moments x, y, x^2, y^2, xy: row r, outputs 4 qt .. 4 qt + 3
+        const int r = threadIdx.x >> 2, q0 = (threadIdx.x & 3) * BLK;
+        float a[RUN], b[RUN];
 #pragma unroll
-        for (int k = 0; k < SSIM_W; ++k) {
-            const float a = tx[r][q + k], b = ty[r][q + k], g = win.g[k];
-            const float ga = g * a, gb = g * b;
-            s0 += ga; s1 += gb;
-            s2 = fmaf(ga, a, s2); s3 = fmaf(gb, b, s3); s4 = fmaf(ga, b, s4);
+        for (int j = 0; j < RUN; ++j) { a[j] = tx[r][q0 + j]; b[j] = ty[r][q0 + j]; }
+#pragma unroll
+        for (int o = 0; o < BLK; ++o) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+#pragma unroll
+            for (int k = 0; k < SSIM_W; ++k) {
+                const float g = win.g[k];
+                const float ga = g * a[o + k], gb = g * b[o + k];
+                s0 += ga; s1 += gb;
+                s2 = fmaf(ga, a[o + k], s2); s3 = fmaf(gb, b[o + k], s3); s4 = fmaf(ga, b[o + k], s4);
+            }
+            hz[0][r][q0 + o] = s0; hz[1][r][q0 + o] = s1; hz[2][r][q0 + o] = s2; hz[3][r][q0 + o] = s3; hz[4][r][q0 + o] = s4;
         }
-        hz[0][r][q] = s0; hz[1][r][q] = s1; hz[2][r][q] = s2; hz[3][r][q] = s3; hz[4][r][q] = s4;
     }
     __syncthreads();
-    const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
-    const int gy = by + ly, gx = bx + lx;
+    // vertical pass: column lx, output rows 4 grp .. 4 grp + 3
+    const int lx = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int gx = bx + lx;
     double l1 = 0.0, ss = 0.0;
-    if (gy < H && gx < W) {
-        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    if (grp * BLK < TH && gx < W) {
+        float col[5][RUN];
 #pragma unroll
-        for (int k = 0; k < SSIM_W; ++k) {
-            const float g = win.g[k];
-            mu1 = fmaf(g, hz[0][ly + k][lx], mu1);
-            mu2 = fmaf(g, hz[1][ly + k][lx], mu2);
-            e11 = fmaf(g, hz[2][ly + k][lx], e11);
-            e22 = fmaf(g, hz[3][ly + k][lx], e22);
-            e12 = fmaf(g, hz[4][ly + k][lx], e12);
-        }
-        const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
-        const float s1 = e11 - mu1s, s2 = e22 - mu2s, s12 = e12 - mu12;
-        const float A1 = 2.0f * mu12 + SSIM_C1, A2 = 2.0f * s12 + SSIM_C2;
-        const float B1 = mu1s + mu2s + SSIM_C1, B2 = s1 + s2 + SSIM_C2;
-        const float iB1 = 1.0f / B1, iB2 = 1.0f / B2;
-        const float S = A1 * A2 * iB1 * iB2;
-        ss = (double)S;
-        l1 = (double)fabsf(tx[ly + SSIM_R][lx + SSIM_R] - ty[ly + SSIM_R][lx + SSIM_R]);
-        if (dmaps) {
-            const size_t o = cbase + (size_t)gy * W + gx;
-            // dS/dmu1 (total: also through sigma1^2 = E11 - mu1^2 and sigma12 = E12 - mu1 mu2), dS/dE11, dS/dE12
-            dmaps[o] = 2.0f * mu2 * (A2 - A1) * iB1 * iB2 - 2.0f * mu1 * S * (iB1 - iB2);
-            dmaps[plane_all + o] = -S * iB2;
-            dmaps[2 * plane_all + o] = 2.0f * A1 * iB1 * iB2;
+        for (int m = 0; m < 5; ++m)
+#pragma unroll
+            for (int j = 0; j < RUN; ++j) col[m][j] = hz[m][min(grp * BLK + j, TIN_H - 1)][lx];   // (the last group's spare rows)
+#pragma unroll
+        for (int o = 0; o < BLK; ++o) {
+            const int ly = grp * BLK + o, gy = by + ly;
+            if (ly >= TH || gy >= H) continue;
+            float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+            for (int k = 0; k < SSIM_W; ++k) {
+                const float g = win.g[k];
+                mu1 = fmaf(g, col[0][o + k], mu1);
+                mu2 = fmaf(g, col[1][o + k], mu2);
+                e11 = fmaf(g, col[2][o + k], e11);
+                e22 = fmaf(g, col[3][o + k], e22);
+                e12 = fmaf(g, col[4][o + k], e12);
+            }
+            const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+            const float s1 = e11 - mu1s, s2 = e22 - mu2s, s12 = e12 - mu12;
+            const float A1 = 2.0f * mu12 + SSIM_C1, A2 = 2.0f * s12 + SSIM_C2;
+            const float B1 = mu1s + mu2s + SSIM_C1, B2 = s1 + s2 + SSIM_C2;
+            const float iB1 = 1.0f / B1, iB2 = 1.0f / B2;
+            const float S = A1 * A2 * iB1 * iB2;
+            ss += (double)S;
+            l1 += (double)fabsf(tx[ly + SSIM_R][lx + SSIM_R] - ty[ly + SSIM_R][lx + SSIM_R]);
+            if (dmaps) {
+                const size_t oo = cbase + (size_t)gy * W + gx;
+                // dS/dmu1 (total: also through sigma1^2 = E11 - mu1^2 and sigma12 = E12 - mu1 mu2), dS/dE11, dS/dE12
+                dmaps[oo] = 2.0f * mu2 * (A2 - A1) * iB1 * iB2 - 2.0f * mu1 * S * (iB1 - iB2);
+                dmaps[plane_all + oo] = -S * iB2;
+                dmaps[2 * plane_all + oo] = 2.0f * A1 * iB1 * iB2;
+            }
         }
     }
     const double bl1 = block_sum_double(l1, red);
@@ -122,14 +145,14 @@ k_photo_bwd(const float* __restrict__ x, const float* __restrict__ y, int H, int
             const float* __restrict__ dmaps, size_t plane_all, const float* __restrict__ g_l1,
             const float* __restrict__ g_ssim, float w_l1, float w_ssim, float inv_n, float* __restrict__ dx)
 {
-    __shared__ float t[3][PIN][PIN + 1];
-    __shared__ float hz[3][PIN][PT + 1];
-    const int c = blockIdx.z, bx = blockIdx.x * PT, by = blockIdx.y * PT;
+    __shared__ float t[3][TIN_H][TX_STRIDE];
+    __shared__ float hz[3][TIN_H][HZ_STRIDE];
+    const int c = blockIdx.z, bx = blockIdx.x * TW, by = blockIdx.y * TH;
     const size_t cbase = (size_t)c * H * W;
     // (upstream scalars from device memory, times the host-side weights of the combined training loss)
     const float wl1 = ((g_l1 ? *g_l1 : 0.0f) * w_l1) * inv_n, wss = ((g_ssim ? *g_ssim : 0.0f) * w_ssim) * inv_n;
-    for (int i = threadIdx.x; i < PIN * PIN; i += 256) {
-        const int r = i / PIN, q = i - r * PIN;
+    for (int i = threadIdx.x; i < TIN_H * TIN_W; i += 256) {
+        const int r = i / TIN_W, q = i - r * TIN_W;
         const int gy = by + r - SSIM_R, gx = bx + q - SSIM_R;
         const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
         const size_t o = cbase + (size_t)gy * W + gx;
@@ -137,31 +160,49 @@ k_photo_bwd(const float* __restrict__ x, const float* __restrict__ y, int H, int
         for (int m = 0; m < 3; ++m) t[m][r][q] = in ? dmaps[m * plane_all + o] : 0.0f;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < PIN * PT; i += 256) {
-        const int r = i / PT, q = i - r * PT;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    {
+        const int r = threadIdx.x >> 2, q0 = (threadIdx.x & 3) * BLK;
+        float v[3][RUN];
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int j = 0; j < RUN; ++j) v[m][j] = t[m][r][q0 + j];
+#pragma unroll
+        for (int o = 0; o < BLK; ++o) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < SSIM_W; ++k) {
+                const float g = win.g[k];
+                s0 = fmaf(g, v[0][o + k], s0); s1 = fmaf(g, v[1][o + k], s1); s2 = fmaf(g, v[2][o + k], s2);
+            }
+            hz[0][r][q0 + o] = s0; hz[1][r][q0 + o] = s1; hz[2][r][q0 + o] = s2;
+        }
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int gx = bx + lx;
+    if (grp * BLK >= TH || gx >= W) return;
+    float col[3][RUN];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int j = 0; j < RUN; ++j) col[m][j] = hz[m][min(grp * BLK + j, TIN_H - 1)][lx];
+#pragma unroll
+    for (int o = 0; o < BLK; ++o) {
+        const int ly = grp * BLK + o, gy = by + ly;
+        if (ly >= TH || gy >= H) continue;
+        float cmu = 0.f, c11 = 0.f, c12 = 0.f;
 #pragma unroll
         for (int k = 0; k < SSIM_W; ++k) {
             const float g = win.g[k];
-            s0 = fmaf(g, t[0][r][q + k], s0); s1 = fmaf(g, t[1][r][q + k], s1); s2 = fmaf(g, t[2][r][q + k], s2);
+            cmu = fmaf(g, col[0][o + k], cmu); c11 = fmaf(g, col[1][o + k], c11); c12 = fmaf(g, col[2][o + k], c12);
         }
-        hz[0][r][q] = s0; hz[1][r][q] = s1; hz[2][r][q] = s2;
+        const size_t oo = cbase + (size_t)gy * W + gx;
+        const float xv = x[oo], yv = y[oo];
+        const float d = xv - yv;
+        const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+        dx[oo] = fmaf(wss, cmu + 2.0f * xv * c11 + yv * c12, wl1 * sgn);
     }
-    __syncthreads();
-    const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
-    const int gy = by + ly, gx = bx + lx;
-    if (gy >= H || gx >= W) return;
-    float cmu = 0.f, c11 = 0.f, c12 = 0.f;
-#pragma unroll
-    for (int k = 0; k < SSIM_W; ++k) {
-        const float g = win.g[k];
-        cmu = fmaf(g, hz[0][ly + k][lx], cmu); c11 = fmaf(g, hz[1][ly + k][lx], c11); c12 = fmaf(g, hz[2][ly + k][lx], c12);
-    }
-    const size_t o = cbase + (size_t)gy * W + gx;
-    const float xv = x[o], yv = y[o];
-    const float d = xv - yv;
-    const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-    dx[o] = fmaf(wss, cmu + 2.0f * xv * c11 + yv * c12, wl1 * sgn);
 }
 
 // ---------------------------------------------------------------- normal guidance
@@ -292,7 +333,7 @@ static SsimWin make_window()
     return w;
 }
 
-static dim3 photo_grid(int C, int H, int W) { return dim3(cdiv(W, PT), cdiv(H, PT), C); }
+static dim3 photo_grid(int C, int H, int W) { return dim3(cdiv(W, TW), cdiv(H, TH), C); }
 
 size_t photometric_scratch_bytes(int C, int H, int W)
 {

@@ -65,6 +65,39 @@ int vr_activations_backward(const float* opacity, const float* scales, const flo
                             const float* g_opacity, const float* g_scales, const float* g_rotations,
                             float* dL_draw_opacity, float* dL_draw_scaling, float* dL_draw_rotation, void* stream);
 
+
+/* ---- BoxModel (model/boxmodel.py:6-49): per-instance learnable pose correction, optimised at train.py:270-274.
+ *     D        = [[diag(delta_s) @ quaternion_to_matrix(delta_r), delta_t], [0 0 0 1]]        d_box2world, :30-38
+ *     adjusted = box2world @ D                                                                  adjustbox2world, :40-42
+ * All instances of a frame in ONE launch each way (one thread per instance; the reference: ~15 ATen launches per instance
+ * forward, ~30 backward).  `boxes` / `grads` are HOST arrays of device pointers. */
+typedef struct VrBoxModel {
+    const float* box2world; /* [16] the annotated pose (obj_box2world, model/boxmodel.py:16-21); unused by the regularizer */
+    const float* delta_r;   /* [4] (w,x,y,z), NOT normalised (quaternion_to_matrix divides by |q|^2) */
+    const float* delta_s;   /* [3] */
+    const float* delta_t;   /* [3] */
+} VrBoxModel;
+
+typedef struct VrBoxModelGrads {
+    float* d_delta_r; /* [4] */
+    float* d_delta_s; /* [3] */
+    float* d_delta_t; /* [3] */
+} VrBoxModelGrads;
+
+/* adjusted [count,16] (row-major 4x4 each) */
+int vr_boxmodel_forward(const VrBoxModel* boxes, int32_t count, float* adjusted, void* stream);
+
+/* g_adjusted [count,16] = dL/d(adjusted); the three gradients of every instance are OVERWRITTEN.  nan_guard != 0 applies
+ * train.py:199-205: if dL/d(delta_r) or dL/d(delta_s) holds a NaN, all three gradients of that instance become zeros. */
+int vr_boxmodel_backward(const VrBoxModel* boxes, const VrBoxModelGrads* grads, int32_t count, const float* g_adjusted,
+                         int32_t nan_guard, void* stream);
+
+/* Gradient of BoxModel.regularize's loss (model/boxmodel.py:44-46)
+ *     lambda_reg * (|delta_r - (1,0,0,0)| + |delta_s - 1| + |delta_t|)
+ * as autograd returns it (x * lambda / |x|; zeros where the norm is 0), written over the three gradients. */
+int vr_boxmodel_regularizer_grad(const VrBoxModel* boxes, const VrBoxModelGrads* grads, int32_t count, float lambda_reg,
+                                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,12 +26,16 @@ typedef struct VrAdamTensor {
     int64_t n;
     double lr;      /* the group's learning rate at this step */
     int64_t step;   /* this tensor's step count AFTER the increment (>= 1) */
+    double eps;     /* this tensor's eps; negative = the call's `eps` (lets optimizers with different eps -- the models'
+                       1e-15, scene/gaussian_model.py:168, and the BoxModels' default 1e-8, model/boxmodel.py:13 -- share a launch) */
 } VrAdamTensor;
 
 /* Adam (no weight decay, no amsgrad), the arithmetic of torch.optim.Adam's default path:
  *   m += (g - m) * (1 - beta1);  v = v * beta2 + (1 - beta2) * g * g;
  *   p -= (lr / (1 - beta1^step)) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
- * `tensors` is a HOST array; all tensors are updated by one kernel launch per 8 tensors. */
+ * `tensors` is a HOST array; all tensors are updated by one kernel launch per 64 tensors (the static model's six, every
+ * in-frame instance model's six and every BoxModel's three of a frame with dynamic objects: train.py:254-275 as ONE
+ * launch up to 64 tensors). */
 int vr_adam_step(const VrAdamTensor* tensors, int32_t count, double beta1, double beta2, double eps, void* stream);
 
 /* For every Gaussian with radii > 0:  xyz_gradient_accum += ||means2D_grad[:2]||;  denom += 1;
@@ -54,7 +58,8 @@ typedef struct VrDensifySettings {
     double min_opacity;    /* 0.005 at train.py:312 */
     double extent;         /* scene.cameras_extent */
     double percent_dense;  /* training_args.percent_dense (scene/gaussian_model.py:155) */
-    int32_t prune_big;
+    int32_t prune_big;     /* 0: prune by opacity only; 1: also by world size; 2: the reference's prune=False (:394,:397) --
+                              clone and split only, no Gaussian is pruned (the split originals are still replaced) */
 } VrDensifySettings;
 
 /* int32 words of the `plan` buffer for P Gaussians */
@@ -90,10 +95,13 @@ int vr_reset_opacity(float* opacity, float* exp_avg, float* exp_avg_sq, int64_t 
  * Dense gradient from the factors of n_views views (what a view-sharded job all-gathers: 3 floats per Gaussian and
  * view instead of all-reducing 48):
  *   dL_dshs[i][k][c] = scale * sum_v basis_k(normalize(means3D[i] - campos[v])) * factors[v][i][c]   k < (deg+1)^2,
- * zeros for the inactive coefficients.  campos [n_views,3], factors [n_views,P,3], all on the device.  Output either
+ * zeros for the inactive coefficients.  campos [n_views,3], factors [n_views,P,3], all on the device;
+ * factor_view_stride = floats between the blocks of consecutive views (0 = packed, 3 P; larger when the P rows are the
+ * head of longer per-view blocks, e.g. the static model's rows of an all-gathered [n_views, P + instance rows, 3]).  Output either
  * whole (dL_dshs [P,M,3], dL_dshs_rest NULL) or split as the model stores it (dL_dshs [P,1,3] + dL_dshs_rest [P,M-1,3]). */
 int vr_sh_grad_from_factors(const float* means3D, int32_t P, const float* campos, const float* factors, int32_t n_views,
-                            int32_t sh_degree, int32_t M, float scale, float* dL_dshs, float* dL_dshs_rest, void* stream);
+                            int64_t factor_view_stride, int32_t sh_degree, int32_t M, float scale, float* dL_dshs,
+                            float* dL_dshs_rest, void* stream);
 
 /* One SH tensor of the optimizer (same meaning as VrAdamTensor, the gradient being implicit). */
 typedef struct VrShAdamTensor {
@@ -109,8 +117,8 @@ typedef struct VrShAdamTensor {
  * `dc` = f_dc [P,1,3] and `rest` = f_rest [P,M-1,3] (scene/gaussian_model.py:159-166), or dc = the whole [P,M,3] tensor
  * and rest = NULL.  Arithmetic = vr_adam_step's. */
 int vr_sh_adam_step(const float* means3D, int32_t P, const float* campos, const float* factors, int32_t n_views,
-                    int32_t sh_degree, int32_t M, float scale, const VrShAdamTensor* dc, const VrShAdamTensor* rest,
-                    double beta1, double beta2, double eps, void* stream);
+                    int64_t factor_view_stride, int32_t sh_degree, int32_t M, float scale, const VrShAdamTensor* dc,
+                    const VrShAdamTensor* rest, double beta1, double beta2, double eps, void* stream);
 
 #ifdef __cplusplus
 }

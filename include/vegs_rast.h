@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VR_ABI_VERSION 7
+#define VR_ABI_VERSION 8
 
 typedef enum VrStatus {
     VR_OK = 0,

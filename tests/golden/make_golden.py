@@ -420,12 +420,86 @@ def part_d():
     np.savez_compressed(os.path.join(HERE, "ref_densify.npz"), **blob)
 
 
+def part_e():
+    """ref_boxmodel.npz: the reference's OWN BoxModel class (model/boxmodel.py:4-57) on the CPU -- adjustbox2world() and its
+    autograd gradients w.r.t. delta_r / delta_s / delta_t for random upstream gradients, then three rounds of what
+    train.py:270-274 does with it (optimizer.step(); zero_grad(); regularize(iteration)) from given gradients, the deltas
+    recorded after every round.  Arranged for the CPU (none of it arithmetic): the file is loaded on its own (the `model`
+    package's __init__ pulls in the StyleGAN decoder), torch.tensor / torch.eye ignore device='cuda' and Tensor.cuda()
+    returns the tensor."""
+    import types
+    sys.path.insert(0, REF)
+    import utils.graphics_utils  # noqa: F401  (quaternion_to_matrix: the reference's own)
+    spec = importlib.util.spec_from_file_location("ref_boxmodel", os.path.join(REF, "model", "boxmodel.py"))
+    bm_mod = importlib.util.module_from_spec(spec)
+    real_tensor, real_cuda = torch.tensor, torch.Tensor.cuda
+
+    def tensor_cpu(*a, **k):
+        k.pop("device", None)
+        return real_tensor(*a, **k)
+    torch.tensor = tensor_cpu
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        spec.loader.exec_module(bm_mod)
+        rng = np.random.default_rng(41)
+        args = types.SimpleNamespace(boxmodel_lr=0.005, boxmodel_lambda_reg=0.001)
+        n = 6
+        blob = {"lr": np.float64(args.boxmodel_lr), "lambda_reg": np.float64(args.boxmodel_lambda_reg)}
+        base, d_r, d_s, d_t, adj, G, g_r, g_s, g_t = ([] for _ in range(9))
+        rounds = {k: [] for k in ("step_g_r", "step_g_s", "step_g_t", "after_r", "after_s", "after_t")}
+        for i in range(n):
+            ang = rng.uniform(0, 6.28)
+            Rm = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+            obj = types.SimpleNamespace(R=Rm * rng.uniform(0.8, 2.0), T=rng.normal(0, 10, 3))
+            bm = bm_mod.BoxModel(obj, args)
+            if i > 0:                                   # instance 0 stays at the identity: the norms' 0/0 case
+                with torch.no_grad():
+                    bm.delta_r += torch.tensor(rng.normal(0, 0.2, 4).astype(np.float32))
+                    bm.delta_s += torch.tensor(rng.normal(0, 0.1, 3).astype(np.float32))
+                    bm.delta_t += torch.tensor(rng.normal(0, 0.3, 3).astype(np.float32))
+            base.append(bm.box2world.numpy().copy())
+            d_r.append(bm.delta_r.detach().numpy().copy()); d_s.append(bm.delta_s.detach().numpy().copy())
+            d_t.append(bm.delta_t.detach().numpy().copy())
+            a = bm.adjustbox2world()
+            g = torch.tensor(rng.normal(size=(4, 4)).astype(np.float32))
+            a.backward(g)
+            adj.append(a.detach().numpy().copy()); G.append(g.numpy().copy())
+            g_r.append(bm.delta_r.grad.numpy().copy()); g_s.append(bm.delta_s.grad.numpy().copy())
+            g_t.append(bm.delta_t.grad.numpy().copy())
+            bm.optimizer.zero_grad()
+            per = {k: [] for k in rounds}
+            for it in range(3):                         # train.py:270-274
+                gr, gs, gt = (rng.normal(0, 1e-2, k).astype(np.float32) for k in (4, 3, 3))
+                bm.delta_r.grad, bm.delta_s.grad, bm.delta_t.grad = torch.tensor(gr), torch.tensor(gs), torch.tensor(gt)
+                bm.optimizer.step()
+                bm.optimizer.zero_grad()
+                bm.regularize(it + 1)
+                per["step_g_r"].append(gr); per["step_g_s"].append(gs); per["step_g_t"].append(gt)
+                per["after_r"].append(bm.delta_r.detach().numpy().copy())
+                per["after_s"].append(bm.delta_s.detach().numpy().copy())
+                per["after_t"].append(bm.delta_t.detach().numpy().copy())
+            for k in rounds:
+                rounds[k].append(np.stack(per[k]))
+        for name, v in (("box2world", base), ("delta_r", d_r), ("delta_s", d_s), ("delta_t", d_t), ("adjusted", adj),
+                        ("g_adjusted", G), ("grad_delta_r", g_r), ("grad_delta_s", g_s), ("grad_delta_t", g_t)):
+            blob[name] = np.stack(v).astype(np.float32)
+        for k, v in rounds.items():
+            blob[k] = np.stack(v).astype(np.float32)            # [instance, round, k]
+        np.savez_compressed(os.path.join(HERE, "ref_boxmodel.npz"), **blob)
+        print("ref_boxmodel.npz:", n, "instances")
+    finally:
+        torch.tensor, torch.Tensor.cuda = real_tensor, real_cuda
+
+
 if __name__ == "__main__":
     if "--densify" in sys.argv:
         part_d()
         sys.exit(0)
     if "--activations" in sys.argv:
         part_c()
+        sys.exit(0)
+    if "--boxmodel" in sys.argv:
+        part_e()
         sys.exit(0)
     # --new: keep the committed fixtures (their random draws are part of the pins) and only add missing ones
     new = "--new" in sys.argv
@@ -436,3 +510,5 @@ if __name__ == "__main__":
         part_c()
     if not new or not os.path.exists(os.path.join(HERE, "ref_densify.npz")):
         part_d()
+    if not new or not os.path.exists(os.path.join(HERE, "ref_boxmodel.npz")):
+        part_e()

@@ -1,0 +1,144 @@
+"""GPU (-m gpu): the WHOLE training iteration of a view-sharded job (BASELINE C4 / C5 as specified: N ranks, one view
+each, replicated models) -- render_all-shaped forward, loss block, split backward with the overlapped factor exchange,
+all-reduced densification statistics, Adam over the static model + every instance model + every BoxModel in one
+launch, BoxModel.regularize, and on schedule densify_and_prune / reset_opacity with an identically seeded draw.
+
+  * N ranks x 1 view  ==  1 process averaging the N views (parameters, Adam moments, step counters, statistics, row
+    order), through iterations that densify and reset -- bit for bit in the deterministic backward mode;
+  * every rank holds identical state after every iteration.
+
+RCCL refuses several ranks on one device, so the ranks of these tests talk over gloo (VEGS_DIST_BACKEND=gloo) while each
+renders on the one GPU of the box: rasterizer, exchange arithmetic and view assignment are the production code, only
+the transport differs (reference loop: train.py:143-168,196,254-320; model/boxmodel.py:6-49)."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORKER = r"""
+import hashlib, os, sys, numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from vegs_amd import dist as vdist
+import dist_train_case as case
+rank, world, local = vdist.init_from_env()
+assert world == %(world)d and torch.distributed.get_backend() == "gloo"
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+tr, deg, cams, gts, normals = case.make(world, rank, %(exchange)r, dev, n_boxes=%(boxes)d)
+digests = []
+def on_step(it, tr):
+    h = hashlib.sha256()
+    for k, v in sorted(case.state_numpy(tr).items()):
+        h.update(k.encode()); h.update(np.ascontiguousarray(v).tobytes())
+    digests.append(h.hexdigest())
+losses = case.run(tr, deg, cams, gts, normals, %(steps)d, world, world, rank, on_step)
+np.savez(os.path.join(%(out)r, "rank%%d.npz" %% rank), digests=np.array(digests), losses=np.array(losses),
+         **case.state_numpy(tr))
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+print("RANK_OK", rank)
+"""
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(tmp_path, world, exchange, steps, boxes):
+    script = WORKER % dict(root=ROOT, world=world, exchange=exchange, steps=steps, boxes=boxes, out=str(tmp_path))
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), VEGS_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs) and all("RANK_OK" in o for o in outs), "\n".join(o[-3000:] for o in outs)
+    return [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+
+
+@pytest.mark.parametrize("exchange", ["factored", "dense"])
+def test_two_ranks_equal_one_process_averaging_two_views(tmp_path, exchange):
+    """4 iterations: #2 and #4 densify the static model and both instance models (clone + split with the seeded draw +
+    prune), #3 resets the opacities and steps the new models."""
+    import dist_train_case as case
+    from vegs_amd import rasterizer
+    steps = 4
+    R = _run_ranks(tmp_path, 2, exchange, steps, boxes=2)
+    # every rank identical after EVERY iteration
+    assert list(R[0]["digests"]) == list(R[1]["digests"]) and len(R[0]["digests"]) == steps
+    # one process, both views per iteration, mean of the losses
+    old = rasterizer.get_flags()
+    try:
+        tr, deg, cams, gts, normals = case.make(1, 0, exchange, torch.device("cuda:0"), n_boxes=2)
+        sizes = []
+        losses = case.run(tr, deg, cams, gts, normals, steps, 2, 1, 0, on_step=lambda it, t: sizes.append(t.p["xyz"].shape[0]))
+        want = case.state_numpy(tr)
+    finally:
+        rasterizer.set_flags(old)
+    assert sizes[1] != sizes[0] and sizes[2] == sizes[1]                     # iteration 2 densified
+    assert np.allclose(np.array(losses), np.stack([R[0]["losses"][:, 0], R[1]["losses"][:, 0]], 1), rtol=0, atol=0)
+    keys = sorted(want)
+    assert keys == sorted(k for k in R[0].files if k not in ("digests", "losses"))
+    bad = [k for k in keys if not np.array_equal(R[0][k], want[k])]
+    assert not bad, [(k, float(np.abs(R[0][k] - want[k]).max()) if R[0][k].shape == want[k].shape else "shape") for k in bad][:8]
+    assert want["box0.delta_t"].shape == (3,) and np.abs(want["box0.delta_t"]).max() > 0        # the poses were optimised
+    assert float(want["inst0.xyz.step"]) == 2 and float(want["static.xyz.step"]) == 2   # (a densifying iteration skips Adam: new tensors without gradients, as in the reference)
+    assert float(want["box0.delta_r.step"]) == 2 * steps                     # the poses: optimizer.step + regularize, every iteration
+
+
+def test_fused_box_step_equals_the_reference_composition():
+    """The C5-shaped step with OPTIMISED instances on one GPU: fused (instances.activate, boxmodel.adjust_all, batched
+    pose gradient, one Adam launch over 6 + 6 n + 3 n tensors, regularize_all) against the reference's composition
+    (ATen activations, BoxModel op by op, one torch.optim.Adam per model, regularize() through autograd)."""
+    from vegs_amd import harness, iteration, scenes
+    dev = torch.device("cuda:0")
+    sc, deg = scenes.scene_street(P=40000, length=60.0, sh_degree=3, seed=31)
+    cams = [scenes.kitti_camera(2.0 * i, 0.3, 688, 188) for i in range(3)]
+    rng = np.random.default_rng(0)
+    gt = torch.tensor(rng.uniform(0, 1, (3, 188, 688)).astype(np.float32), device=dev)
+    normal = torch.tensor(rng.normal(size=(3, 188, 688)).astype(np.float32), device=dev)
+    bg = torch.zeros(3, device=dev)
+    out = []
+    for fused in (False, True):
+        tr = iteration.Trainer(sc, dev, n_boxes=3, fused=fused, box_points=1500, optimise_boxes=True)
+        first = None
+        for it in range(3):
+            cam = cams[it % 3]
+            loss, pkg, grads = tr.step(cam, harness.cam_tensors(cam, dev), deg, bg, gt, normal, keep_grads=(it == 0))
+            if it == 0:
+                first = (float(loss), {k: v.cpu().numpy() for k, v in grads.items()})
+        out.append((first, {k: v.detach().cpu().numpy() for k, v in tr.state_tensors().items()}))
+    (fa, sa), (fb, sb) = out
+    assert abs(fa[0] - fb[0]) <= 2e-5 * abs(fa[0])
+    from helpers import assert_grad_close
+    for k in fa[1]:
+        assert_grad_close("first-iteration " + k, fb[1][k], fa[1][k], rtol=2e-3, floor=2e-6)
+    assert sorted(sa) == sorted(sb)
+    for k in sa:
+        a, b = sa[k], sb[k]
+        assert a.shape == b.shape, k
+        if k.endswith(".step"):
+            assert float(a) == float(b) == 3.0 * (2 if k.startswith("box") else 1), (k, a, b)   # BoxModels step twice per iteration
+            continue
+        if ".exp_avg" in k or k in ("accum", "denom", "max_radii"):
+            continue
+        # Adam's first steps move by ~lr * sign(g): differences come from noise-level gradients changing sign
+        tol = 1e-4 * max(np.abs(a).max(), 1e-3)
+        assert float((np.abs(a - b) > tol).mean()) < 5e-3, (k, float(np.abs(a - b).max()))
+    for i in range(3):
+        assert np.abs(sb[f"box{i}.delta_t"]).max() > 0 and np.abs(sb[f"box{i}.delta_r"] - [1, 0, 0, 0]).max() > 0

@@ -1,0 +1,89 @@
+"""GPU (-m gpu): the direct peer-to-peer exchange (include/vegs_xgmi.h, vegs_amd/csrc/xgmi.hip, vegs_amd/xgmi.py) with
+N = 2 / 4 / 8 processes sharing the ONE GPU of this box: every process maps the other processes' windows with hipIpc,
+exactly as N GPUs of a node would, and pushes its shards into them.  The all-reduce must equal the FIXED-order sum
+((g0 + g1) + g2) + ... scaled by 1/N bit for bit (it is reduced in rank order by construction), the all-gather must
+deliver every rank's block unchanged; buffers are reused over iterations (epochs, the gather's two parities) and the
+window is re-created when the model grows.  The handles travel over gloo; the data never does."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+from vegs_amd import dist as vdist, xgmi
+rank, world, local = vdist.init_from_env()
+assert world == %(world)d and torch.distributed.get_backend() == "gloo"
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+ex = xgmi.DirectExchange(rank, world, dev)
+
+def data(it, r, P):
+    rng = np.random.default_rng(1000 * it + r)
+    g = [rng.normal(size=s).astype(np.float32) for s in ((P, 3), (P, 1), (P, 3), (P, 4))]
+    f = rng.normal(size=(1, P + 17, 3)).astype(np.float32)
+    c = rng.normal(size=(1, 3)).astype(np.float32)
+    return g, f, c
+
+sizes = [50001, 50001, 50001, 3, 120000, 120000]          # the window grows at iteration 4 (re-created collectively)
+for it, P in enumerate(sizes):
+    g, f, c = data(it, rank, P)
+    ps = [torch.nn.Parameter(torch.zeros(x.shape, device=dev)) for x in g]
+    for p, x in zip(ps, g):
+        p.grad = torch.tensor(x, device=dev)
+    F, C = ex.exchange(ps, torch.tensor(f, device=dev), torch.tensor(c, device=dev), 1)
+    ex.check()
+    allr = [data(it, r, P) for r in range(world)]
+    for k, p in enumerate(ps):
+        want = allr[0][0][k].copy()
+        for r in range(1, world):
+            want = want + allr[r][0][k]                      # float32, rank order
+        want = want * np.float32(1.0 / world)
+        got = p.grad.cpu().numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), (it, k, float(np.abs(got - want).max()))
+    assert F.shape == (world, P + 17, 3) and C.shape == (world, 3)
+    for r in range(world):
+        assert np.array_equal(F[r].cpu().numpy(), allr[r][1][0]) and np.array_equal(C[r].cpu().numpy(), allr[r][2][0]), (it, r)
+    # the gradients ARE the window (no un-bucketing copy): same storage as the window tensor
+    assert p.grad.untyped_storage().data_ptr() == ex.win.untyped_storage().data_ptr()
+torch.cuda.synchronize()
+torch.distributed.barrier()
+ex.close()
+torch.distributed.destroy_process_group()
+print("RANK_OK", rank)
+"""
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_direct_exchange_equals_fixed_order_sum(world):
+    script = WORKER % dict(root=ROOT, world=world)
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), VEGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs) and all("RANK_OK" in o for o in outs), "\n".join(o[-2500:] for o in outs)

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libvegsrast.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # VrSettings.flags (include/vegs_rast.h, VrFlags)
 FLAG_SCALE_MODIFIED, FLAG_DEPTH_NORMALIZED, FLAG_EXTRA_NO_ALPHA_GRAD, FLAG_FILL_EMPTY, FLAG_DETERMINISTIC = 1, 2, 4, 8, 256
@@ -28,7 +28,10 @@ EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_b
            "vr_normal_guidance_forward", "vr_normal_guidance_backward", "vr_training_loss_forward", "vr_training_loss_backward", "vr_adam_step", "vr_densify_stats",
            "vr_densify_plan_words", "vr_densify_plan", "vr_densify_apply", "vr_reset_opacity",
            "vr_sh_grad_from_factors", "vr_sh_adam_step",
-           "vr_instances_forward", "vr_instances_backward", "vr_activations_forward", "vr_activations_backward"]
+           "vr_instances_forward", "vr_instances_backward", "vr_activations_forward", "vr_activations_backward",
+           "vr_boxmodel_forward", "vr_boxmodel_backward", "vr_boxmodel_regularizer_grad",
+           "vr_xgmi_create", "vr_xgmi_detach", "vr_xgmi_destroy", "vr_xgmi_layout", "vr_xgmi_window", "vr_xgmi_handle", "vr_xgmi_attach",
+           "vr_xgmi_allreduce", "vr_xgmi_allgather_begin", "vr_xgmi_allgather_wait", "vr_xgmi_check"]
 STAGES = ["preprocess", "compact", "depth_sort", "emit", "tile_sort", "ranges", "render_fwd", "bwd_zero",
           "render_bwd", "preprocess_bwd", "k_seg_bwd"]
 
@@ -72,7 +75,7 @@ class VrInGrads(C.Structure):
 
 class VrAdamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
-                ("n", C.c_int64), ("lr", C.c_double), ("step", C.c_int64)]
+                ("n", C.c_int64), ("lr", C.c_double), ("step", C.c_int64), ("eps", C.c_double)]
 
 
 class VrDensifySettings(C.Structure):
@@ -98,6 +101,23 @@ class VrInstance(C.Structure):
 class VrInstanceGrads(C.Structure):
     _fields_ = [("dL_dmeans", C.c_void_p), ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p),
                 ("dL_dbox2world", C.c_void_p)]
+
+
+class VrBoxModel(C.Structure):
+    _fields_ = [("box2world", C.c_void_p), ("delta_r", C.c_void_p), ("delta_s", C.c_void_p), ("delta_t", C.c_void_p)]
+
+
+class VrBoxModelGrads(C.Structure):
+    _fields_ = [("d_delta_r", C.c_void_p), ("d_delta_s", C.c_void_p), ("d_delta_t", C.c_void_p)]
+
+
+class VrXgmiLayout(C.Structure):
+    _fields_ = [("recv_offset", C.c_int64), ("result_offset", C.c_int64), ("gather_offset", C.c_int64 * 2),
+                ("gather_slot", C.c_int64), ("total_floats", C.c_int64)]
+
+
+class VrXgmiSegment(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("n", C.c_int64)]
 
 
 class VrCounters(C.Structure):
@@ -184,9 +204,9 @@ def load():
     lib.vr_reset_opacity.restype = C.c_int
     lib.vr_reset_opacity.argtypes = [vp, vp, vp, C.c_int64, C.c_float, vp]
     lib.vr_sh_grad_from_factors.restype = C.c_int
-    lib.vr_sh_grad_from_factors.argtypes = [vp, i32, vp, vp, i32, i32, i32, C.c_float, vp, vp, vp]
+    lib.vr_sh_grad_from_factors.argtypes = [vp, i32, vp, vp, i32, C.c_int64, i32, i32, C.c_float, vp, vp, vp]
     lib.vr_sh_adam_step.restype = C.c_int
-    lib.vr_sh_adam_step.argtypes = [vp, i32, vp, vp, i32, i32, i32, C.c_float, C.POINTER(VrShAdamTensor),
+    lib.vr_sh_adam_step.argtypes = [vp, i32, vp, vp, i32, C.c_int64, i32, i32, C.c_float, C.POINTER(VrShAdamTensor),
                                     C.POINTER(VrShAdamTensor), C.c_double, C.c_double, C.c_double, vp]
     lib.vr_instances_forward.restype = C.c_int
     lib.vr_instances_forward.argtypes = [C.POINTER(VrInstance), i32, vp, vp, vp, vp]
@@ -196,6 +216,34 @@ def load():
     lib.vr_activations_forward.argtypes = [vp, vp, vp, C.c_int64, vp, vp, vp, vp]
     lib.vr_activations_backward.restype = C.c_int
     lib.vr_activations_backward.argtypes = [vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
+    lib.vr_boxmodel_forward.restype = C.c_int
+    lib.vr_boxmodel_forward.argtypes = [C.POINTER(VrBoxModel), i32, vp, vp]
+    lib.vr_boxmodel_backward.restype = C.c_int
+    lib.vr_boxmodel_backward.argtypes = [C.POINTER(VrBoxModel), C.POINTER(VrBoxModelGrads), i32, vp, i32, vp]
+    lib.vr_boxmodel_regularizer_grad.restype = C.c_int
+    lib.vr_boxmodel_regularizer_grad.argtypes = [C.POINTER(VrBoxModel), C.POINTER(VrBoxModelGrads), i32, C.c_float, vp]
+    lib.vr_xgmi_create.restype = C.c_int
+    lib.vr_xgmi_create.argtypes = [i32, i32, C.c_int64, C.c_int64, C.POINTER(vp)]
+    lib.vr_xgmi_destroy.restype = C.c_int
+    lib.vr_xgmi_destroy.argtypes = [vp]
+    lib.vr_xgmi_detach.restype = C.c_int
+    lib.vr_xgmi_detach.argtypes = [vp]
+    lib.vr_xgmi_layout.restype = C.c_int
+    lib.vr_xgmi_layout.argtypes = [vp, C.POINTER(VrXgmiLayout)]
+    lib.vr_xgmi_window.restype = vp
+    lib.vr_xgmi_window.argtypes = [vp]
+    lib.vr_xgmi_handle.restype = C.c_int
+    lib.vr_xgmi_handle.argtypes = [vp, vp]
+    lib.vr_xgmi_attach.restype = C.c_int
+    lib.vr_xgmi_attach.argtypes = [vp, vp]
+    lib.vr_xgmi_allreduce.restype = C.c_int
+    lib.vr_xgmi_allreduce.argtypes = [vp, C.POINTER(VrXgmiSegment), i32, C.c_float, C.POINTER(C.c_int64), vp]
+    lib.vr_xgmi_allgather_begin.restype = C.c_int
+    lib.vr_xgmi_allgather_begin.argtypes = [vp, C.POINTER(VrXgmiSegment), i32, i32, C.POINTER(C.c_int64), vp]
+    lib.vr_xgmi_allgather_wait.restype = C.c_int
+    lib.vr_xgmi_allgather_wait.argtypes = [vp, i32, vp]
+    lib.vr_xgmi_check.restype = C.c_int
+    lib.vr_xgmi_check.argtypes = [vp, vp]
     lib.vr_profile_level.restype = C.c_int
     lib.vr_profile_level.argtypes = [C.c_int]
     lib.vr_profile_collect.restype = C.c_int

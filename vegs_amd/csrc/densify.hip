@@ -44,7 +44,8 @@ __device__ __forceinline__ uint32_t classify(const DensifyRule& r, int i, const 
     const bool split = g >= r.max_grad && big;                              // :356-362
     const float op = 1.0f / (1.0f + expf(-opacity[i]));
     bool prune_old = op < r.min_opacity, prune_new = prune_old;             // :396-402 (the screen-size test cannot fire:
-    if (r.prune_big) {                                                      //  max_radii2D was reset by :349-351)
+    if (r.prune_big == 2) prune_old = prune_new = false;                    //  max_radii2D was reset by :349-351); prune=False (:394, :397)
+    if (r.prune_big == 1) {
         prune_old = prune_old || smax > r.world_thr;
         const float n0 = expf(logf(s0 / 1.6f)), n1 = expf(logf(s1 / 1.6f)), n2 = expf(logf(s2 / 1.6f));
         prune_new = prune_new || fmaxf(n0, fmaxf(n1, n2)) > r.world_thr;
@@ -256,7 +257,7 @@ static bool make_rule(const VrDensifySettings* s, DensifyRule& r)
     r.min_opacity = (float)s->min_opacity;
     r.dense_thr = (float)(s->percent_dense * s->extent);     // Python-float products, compared in float32
     r.world_thr = (float)(0.1 * s->extent);
-    r.prune_big = s->prune_big != 0;
+    r.prune_big = s->prune_big == 2 ? 2 : (s->prune_big != 0);
     return true;
 }
 

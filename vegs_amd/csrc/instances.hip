@@ -303,6 +303,149 @@ k_activate_bwd(const float* __restrict__ opacity, const float* __restrict__ scal
     }
 }
 
+
+// ---- BoxModel (model/boxmodel.py:6-49): the learnable correction of an instance's annotated pose.
+//   D = [[diag(delta_s) R(delta_r), delta_t], [0 0 0 1]],   adjusted = box2world @ D       (:30-42)
+// with R = quaternion_to_matrix (utils/graphics_utils.py:204-248: normalises by |q|^2).  The reference evaluates this per
+// instance with ~15 ATen launches forward and ~30 backward; ten numbers per instance -- one THREAD per instance here, all
+// instances of a frame in one launch each way.  The backward also applies the "do not update nan gradients" rule of
+// train.py:199-205, and vr_boxmodel_regularizer_grad is the gradient of BoxModel.regularize's loss (:44-49).
+constexpr int BOX_MAX = 64;
+struct BoxSeg { const float* B; const float* dr; const float* ds; const float* dt; float* g_r; float* g_s; float* g_t; };
+struct BoxArgs { BoxSeg seg[BOX_MAX]; int count; };
+
+__global__ void __launch_bounds__(64) k_box_fwd(BoxArgs a, float* __restrict__ out)
+{
+    const int b = threadIdx.x;
+    if (b >= a.count) return;
+    const BoxSeg s = a.seg[b];
+    const float q[4] = {s.dr[0], s.dr[1], s.dr[2], s.dr[3]};
+    float R[3][3], two_s;
+    quat_to_mat(q, R, two_s);
+    float D[4][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float sc = s.ds[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) D[i][j] = sc * R[i][j];
+        D[i][3] = s.dt[i];
+    }
+    D[3][0] = D[3][1] = D[3][2] = 0.0f; D[3][3] = 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float acc = s.B[4 * i] * D[0][j];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) acc = fmaf(s.B[4 * i + k], D[k][j], acc);
+            out[16 * b + 4 * i + j] = acc;
+        }
+}
+
+__global__ void __launch_bounds__(64) k_box_bwd(BoxArgs a, const float* __restrict__ g_out, int nan_guard)
+{
+    const int b = threadIdx.x;
+    if (b >= a.count) return;
+    const BoxSeg s = a.seg[b];
+    const float* G = g_out + 16 * b;
+    // dD = B^T G (rows 0..2 of D are the only ones that depend on the deltas)
+    float dD[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float acc = s.B[i] * G[j];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) acc = fmaf(s.B[4 * k + i], G[4 * k + j], acc);
+            dD[i][j] = acc;
+        }
+    const float q[4] = {s.dr[0], s.dr[1], s.dr[2], s.dr[3]};
+    float R[3][3], t;
+    quat_to_mat(q, R, t);
+    float gs[3], gt[3], dR[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        gt[i] = dD[i][3];
+        gs[i] = fmaf(dD[i][2], R[i][2], fmaf(dD[i][1], R[i][1], dD[i][0] * R[i][0]));
+        const float sc = s.ds[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dR[i][j] = sc * dD[i][j];
+    }
+    // R = I + t A(q), t = 2 / |q|^2:  dL/dq = t dA/dq : dR  +  (A : dR) dt/dq,  dt/dq = -t^2 q
+    const float r = q[0], i_ = q[1], j_ = q[2], k_ = q[3];
+    const float A00 = -(j_ * j_ + k_ * k_), A01 = i_ * j_ - k_ * r, A02 = i_ * k_ + j_ * r;
+    const float A10 = i_ * j_ + k_ * r, A11 = -(i_ * i_ + k_ * k_), A12 = j_ * k_ - i_ * r;
+    const float A20 = i_ * k_ - j_ * r, A21 = j_ * k_ + i_ * r, A22 = -(i_ * i_ + j_ * j_);
+    const float AdR = A00 * dR[0][0] + A01 * dR[0][1] + A02 * dR[0][2] + A10 * dR[1][0] + A11 * dR[1][1] + A12 * dR[1][2]
+                    + A20 * dR[2][0] + A21 * dR[2][1] + A22 * dR[2][2];
+    float gq[4];
+    gq[0] = t * (-k_ * dR[0][1] + j_ * dR[0][2] + k_ * dR[1][0] - i_ * dR[1][2] - j_ * dR[2][0] + i_ * dR[2][1]);
+    gq[1] = t * (j_ * dR[0][1] + k_ * dR[0][2] + j_ * dR[1][0] - 2.0f * i_ * dR[1][1] - r * dR[1][2] + k_ * dR[2][0] + r * dR[2][1]
+                 - 2.0f * i_ * dR[2][2]);
+    gq[2] = t * (-2.0f * j_ * dR[0][0] + i_ * dR[0][1] + r * dR[0][2] + i_ * dR[1][0] + k_ * dR[1][2] - r * dR[2][0] + k_ * dR[2][1]
+                 - 2.0f * j_ * dR[2][2]);
+    gq[3] = t * (-2.0f * k_ * dR[0][0] - r * dR[0][1] + i_ * dR[0][2] + r * dR[1][0] - 2.0f * k_ * dR[1][1] + j_ * dR[1][2]
+                 + i_ * dR[2][0] + j_ * dR[2][1]);
+    const float dt_scale = -(t * t) * AdR;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) gq[c] = fmaf(dt_scale, q[c], gq[c]);
+    if (nan_guard) {      // train.py:199-205: a NaN in delta_r.grad or delta_s.grad zeroes all three gradients
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bad |= (gq[c] != gq[c]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bad |= (gs[c] != gs[c]);
+        if (bad) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gq[c] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { gs[c] = 0.0f; gt[c] = 0.0f; }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s.g_r[c] = gq[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { s.g_s[c] = gs[c]; s.g_t[c] = gt[c]; }
+}
+
+// gradient of  lambda (|delta_r - (1,0,0,0)| + |delta_s - 1| + |delta_t|)  as autograd computes it: x (lambda / |x|), and 0
+// where the norm is 0 (torch's norm backward masks that case)
+__global__ void __launch_bounds__(64) k_box_reg(BoxArgs a, float lambda)
+{
+    const int b = threadIdx.x;
+    if (b >= a.count) return;
+    const BoxSeg s = a.seg[b];
+    const float xr[4] = {s.dr[0] - 1.0f, s.dr[1], s.dr[2], s.dr[3]};
+    const float xs[3] = {s.ds[0] - 1.0f, s.ds[1] - 1.0f, s.ds[2] - 1.0f};
+    const float xt[3] = {s.dt[0], s.dt[1], s.dt[2]};
+    const float nr = sqrtf(xr[0] * xr[0] + xr[1] * xr[1] + xr[2] * xr[2] + xr[3] * xr[3]);
+    const float ns = sqrtf(xs[0] * xs[0] + xs[1] * xs[1] + xs[2] * xs[2]);
+    const float nt = sqrtf(xt[0] * xt[0] + xt[1] * xt[1] + xt[2] * xt[2]);
+    const float fr = nr > 0.0f ? lambda / nr : 0.0f, fs = ns > 0.0f ? lambda / ns : 0.0f, ft = nt > 0.0f ? lambda / nt : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s.g_r[c] = xr[c] * fr;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { s.g_s[c] = xs[c] * fs; s.g_t[c] = xt[c] * ft; }
+}
+
+static int fill_box_args(const VrBoxModel* boxes, const VrBoxModelGrads* grads, int first, int n, bool need_base, BoxArgs& a)
+{
+    a.count = n;
+    for (int i = 0; i < n; ++i) {
+        const VrBoxModel& b = boxes[first + i];
+        if ((need_base && !b.box2world) || !b.delta_r || !b.delta_s || !b.delta_t)
+            { set_error("boxmodel: instance %d has a NULL array", first + i); return VR_ERR_INVALID_ARGUMENT; }
+        a.seg[i] = BoxSeg{b.box2world, b.delta_r, b.delta_s, b.delta_t, nullptr, nullptr, nullptr};
+        if (grads) {
+            const VrBoxModelGrads& g = grads[first + i];
+            if (!g.d_delta_r || !g.d_delta_s || !g.d_delta_t)
+                { set_error("boxmodel: instance %d has a NULL gradient array", first + i); return VR_ERR_INVALID_ARGUMENT; }
+            a.seg[i].g_r = g.d_delta_r; a.seg[i].g_s = g.d_delta_s; a.seg[i].g_t = g.d_delta_t;
+        }
+    }
+    return VR_OK;
+}
+
 }  // namespace vr
 
 using namespace vr;
@@ -447,5 +590,47 @@ extern "C" int vr_activations_backward(const float* opacity, const float* scales
                        (const float4*)raw_rotation, (long)P, g_opacity, g_scales, (const float4*)g_rotations, dL_draw_opacity,
                        dL_draw_scaling, (float4*)dL_draw_rotation);
     if (hipGetLastError() != hipSuccess) { set_error("activations: backward launch failed"); return VR_ERR_HIP; }
+    return VR_OK;
+}
+
+
+extern "C" int vr_boxmodel_forward(const VrBoxModel* boxes, int32_t count, float* adjusted, void* stream)
+{
+    if (count < 0 || (count > 0 && (!boxes || !adjusted))) { set_error("boxmodel: bad arguments"); return VR_ERR_INVALID_ARGUMENT; }
+    for (int first = 0; first < count; first += BOX_MAX) {
+        BoxArgs a;
+        const int n = count - first < BOX_MAX ? count - first : BOX_MAX;
+        if (int rc = fill_box_args(boxes, nullptr, first, n, true, a)) return rc;
+        hipLaunchKernelGGL(k_box_fwd, dim3(1), dim3(64), 0, (hipStream_t)stream, a, adjusted + 16 * (size_t)first);
+        if (hipGetLastError() != hipSuccess) { set_error("boxmodel: forward launch failed"); return VR_ERR_HIP; }
+    }
+    return VR_OK;
+}
+
+extern "C" int vr_boxmodel_backward(const VrBoxModel* boxes, const VrBoxModelGrads* grads, int32_t count,
+                                    const float* g_adjusted, int32_t nan_guard, void* stream)
+{
+    if (count < 0 || (count > 0 && (!boxes || !grads || !g_adjusted))) { set_error("boxmodel: bad arguments"); return VR_ERR_INVALID_ARGUMENT; }
+    for (int first = 0; first < count; first += BOX_MAX) {
+        BoxArgs a;
+        const int n = count - first < BOX_MAX ? count - first : BOX_MAX;
+        if (int rc = fill_box_args(boxes, grads, first, n, true, a)) return rc;
+        hipLaunchKernelGGL(k_box_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, a, g_adjusted + 16 * (size_t)first, (int)nan_guard);
+        if (hipGetLastError() != hipSuccess) { set_error("boxmodel: backward launch failed"); return VR_ERR_HIP; }
+    }
+    return VR_OK;
+}
+
+extern "C" int vr_boxmodel_regularizer_grad(const VrBoxModel* boxes, const VrBoxModelGrads* grads, int32_t count,
+                                            float lambda_reg, void* stream)
+{
+    if (count < 0 || (count > 0 && (!boxes || !grads))) { set_error("boxmodel: bad arguments"); return VR_ERR_INVALID_ARGUMENT; }
+    for (int first = 0; first < count; first += BOX_MAX) {
+        BoxArgs a;
+        const int n = count - first < BOX_MAX ? count - first : BOX_MAX;
+        if (int rc = fill_box_args(boxes, grads, first, n, false, a)) return rc;
+        hipLaunchKernelGGL(k_box_reg, dim3(1), dim3(64), 0, (hipStream_t)stream, a, lambda_reg);
+        if (hipGetLastError() != hipSuccess) { set_error("boxmodel: regularizer launch failed"); return VR_ERR_HIP; }
+    }
     return VR_OK;
 }

@@ -14,7 +14,7 @@
 
 namespace vr {
 
-constexpr int ADAM_MAX_T = 8;            // tensors per launch
+constexpr int ADAM_MAX_T = 64;           // tensors per launch (the table is a kernel argument: 64 x 56 B < the 4 KB limit)
 constexpr int ADAM_EPB = 256 * 4 * 4;    // elements per block: 256 threads x float4 x 4
 
 struct AdamSeg {
@@ -26,27 +26,29 @@ struct AdamSeg {
     float step_size;       // lr / (1 - beta1^step)
     float inv_bc2_sqrt;    // 1 / sqrt(1 - beta2^step)
     int block0;            // first block of this tensor
+    float eps;             // per tensor: the model's groups use 1e-15, the BoxModels' optimizers torch's default 1e-8
 };
 struct AdamArgs {
     AdamSeg seg[ADAM_MAX_T];
     int count;
-    float one_minus_b1, b2, one_minus_b2, eps;
+    float one_minus_b1, b2, one_minus_b2;
 };
 
 __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamSeg& s, const AdamArgs& a)
 {
     m = m + (g - m) * a.one_minus_b1;                      // exp_avg.lerp_(grad, 1 - beta1)
     v = v * a.b2 + (a.one_minus_b2 * g) * g;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
-    const float denom = sqrtf(v) * s.inv_bc2_sqrt + a.eps; // (sqrt(v) / bias_correction2_sqrt).add_(eps)
+    const float denom = sqrtf(v) * s.inv_bc2_sqrt + s.eps; // (sqrt(v) / bias_correction2_sqrt).add_(eps)
     p = p - s.step_size * (m / denom);                     // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
 __global__ void __launch_bounds__(256) k_adam(AdamArgs a)
 {
-    int t = 0;
-#pragma unroll
-    for (int i = 1; i < ADAM_MAX_T; ++i)
-        if (i < a.count && (int)blockIdx.x >= a.seg[i].block0) t = i;
+    int t = 0, hi = a.count - 1;          // the last tensor whose first block is <= blockIdx.x (scalar binary search)
+    while (t < hi) {
+        const int mid = (t + hi + 1) >> 1;
+        if ((int)blockIdx.x >= a.seg[mid].block0) t = mid; else hi = mid - 1;
+    }
     const AdamSeg s = a.seg[t];
     const long base = (long)(blockIdx.x - s.block0) * ADAM_EPB;
     const bool vec = ((((uintptr_t)s.p | (uintptr_t)s.g | (uintptr_t)s.m | (uintptr_t)s.v) & 15) == 0);
@@ -109,6 +111,7 @@ struct ShAdamSeg {
 };
 struct ShFactorArgs {
     const float* means3D; const float* campos; const float* factors;
+    long view_stride;                      // floats between the factor blocks of consecutive views (3 P when packed)
     int P, n_views, deg, M;
     float scale;
     ShAdamSeg dc, rest;                    // rest.p / rest.out == nullptr: `dc` is the whole [P,M,3] tensor
@@ -194,7 +197,7 @@ __global__ void __launch_bounds__(256) k_sh_factors(ShFactorArgs a)
     if (i < a.P) {
         const float px = a.means3D[3 * (size_t)i], py = a.means3D[3 * (size_t)i + 1], pz = a.means3D[3 * (size_t)i + 2];
         for (int v = 0; v < a.n_views; ++v) {
-            const float* f = a.factors + ((size_t)v * a.P + i) * 3;
+            const float* f = a.factors + (size_t)v * a.view_stride + (size_t)i * 3;
             const float f0 = f[0], f1 = f[1], f2v = f[2];
             if (f0 == 0.0f && f1 == 0.0f && f2v == 0.0f) continue;      // not visible in this view (or fully clamped)
             const float d0 = px - a.campos[3 * v], d1 = py - a.campos[3 * v + 1], d2 = pz - a.campos[3 * v + 2];
@@ -236,13 +239,16 @@ __global__ void __launch_bounds__(256) k_sh_factors(ShFactorArgs a)
 }
 
 static int sh_factor_args(ShFactorArgs& a, const float* means3D, int32_t P, const float* campos, const float* factors,
-                          int32_t n_views, int32_t sh_degree, int32_t M, float scale)
+                          int32_t n_views, int64_t view_stride, int32_t sh_degree, int32_t M, float scale)
 {
+    if (view_stride != 0 && view_stride < 3 * (int64_t)P)
+        { set_error("sh factors: factor_view_stride must be 0 (packed) or >= 3 P"); return VR_ERR_INVALID_ARGUMENT; }
     if (P < 0 || n_views < 1 || sh_degree < 0 || sh_degree > 3 || M < (sh_degree + 1) * (sh_degree + 1) || M > 16)
         { set_error("sh factors: need P >= 0, n_views >= 1, sh_degree 0..3 and (sh_degree+1)^2 <= M <= 16"); return VR_ERR_INVALID_ARGUMENT; }
     if (P > 0 && (!means3D || !campos || !factors)) { set_error("sh factors: means3D, campos and factors are required"); return VR_ERR_INVALID_ARGUMENT; }
     a.means3D = means3D; a.campos = campos; a.factors = factors;
     a.P = P; a.n_views = n_views; a.deg = sh_degree; a.M = M; a.scale = scale;
+    a.view_stride = view_stride ? (long)view_stride : 3L * P;
     a.dc = ShAdamSeg{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f};
     a.rest = a.dc;
     a.one_minus_b1 = a.b2 = a.one_minus_b2 = a.eps = 0.f;
@@ -254,11 +260,11 @@ static int sh_factor_args(ShFactorArgs& a, const float* means3D, int32_t P, cons
 using namespace vr;
 
 extern "C" int vr_sh_grad_from_factors(const float* means3D, int32_t P, const float* campos, const float* factors,
-                                       int32_t n_views, int32_t sh_degree, int32_t M, float scale, float* dL_dshs,
-                                       float* dL_dshs_rest, void* stream)
+                                       int32_t n_views, int64_t factor_view_stride, int32_t sh_degree, int32_t M, float scale,
+                                       float* dL_dshs, float* dL_dshs_rest, void* stream)
 {
     ShFactorArgs a;
-    int rc = sh_factor_args(a, means3D, P, campos, factors, n_views, sh_degree, M, scale);
+    int rc = sh_factor_args(a, means3D, P, campos, factors, n_views, factor_view_stride, sh_degree, M, scale);
     if (rc) return rc;
     if (P == 0) return VR_OK;
     if (!dL_dshs || (dL_dshs_rest && M < 2)) { set_error("sh factors: dL_dshs is required (and M >= 2 for split storage)"); return VR_ERR_INVALID_ARGUMENT; }
@@ -270,11 +276,11 @@ extern "C" int vr_sh_grad_from_factors(const float* means3D, int32_t P, const fl
 }
 
 extern "C" int vr_sh_adam_step(const float* means3D, int32_t P, const float* campos, const float* factors, int32_t n_views,
-                               int32_t sh_degree, int32_t M, float scale, const VrShAdamTensor* dc, const VrShAdamTensor* rest,
-                               double beta1, double beta2, double eps, void* stream)
+                               int64_t factor_view_stride, int32_t sh_degree, int32_t M, float scale, const VrShAdamTensor* dc,
+                               const VrShAdamTensor* rest, double beta1, double beta2, double eps, void* stream)
 {
     ShFactorArgs a;
-    int rc = sh_factor_args(a, means3D, P, campos, factors, n_views, sh_degree, M, scale);
+    int rc = sh_factor_args(a, means3D, P, campos, factors, n_views, factor_view_stride, sh_degree, M, scale);
     if (rc) return rc;
     if (P == 0) return VR_OK;
     if (!dc || !dc->param || !dc->exp_avg || !dc->exp_avg_sq || dc->step < 1 ||
@@ -305,6 +311,7 @@ extern "C" int vr_adam_step(const VrAdamTensor* tensors, int32_t count, double b
         const VrAdamTensor& t = tensors[i];
         if (t.n < 0 || t.step < 1 || (t.n > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq)))
             { set_error("adam: tensor with NULL array, negative size or step < 1"); return VR_ERR_INVALID_ARGUMENT; }
+        if (t.eps < 0.0 && !(eps >= 0.0)) { set_error("adam: tensor %d has no eps of its own and the call gives none", i); return VR_ERR_INVALID_ARGUMENT; }
     }
     // `first` advances by the entries CONSUMED (empty tensors are skipped without taking a slot), not by
     // ADAM_MAX_T: otherwise a batch that skipped an empty tensor would be followed by one that repeats its tail
@@ -314,7 +321,6 @@ extern "C" int vr_adam_step(const VrAdamTensor* tensors, int32_t count, double b
         a.one_minus_b1 = (float)(1.0 - beta1);
         a.b2 = (float)beta2;
         a.one_minus_b2 = (float)(1.0 - beta2);
-        a.eps = (float)eps;
         int blocks = 0;
         for (next = first; next < count && a.count < ADAM_MAX_T; ++next) {
             const VrAdamTensor& t = tensors[next];
@@ -326,9 +332,10 @@ extern "C" int vr_adam_step(const VrAdamTensor* tensors, int32_t count, double b
             s.step_size = (float)(t.lr / bc1);
             s.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
             s.block0 = blocks;
+            s.eps = (float)(t.eps >= 0.0 ? t.eps : eps);
             blocks += cdiv((long)t.n, ADAM_EPB);
         }
-        for (int i = a.count; i < ADAM_MAX_T; ++i) a.seg[i] = AdamSeg{nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0x7fffffff};
+        for (int i = a.count; i < ADAM_MAX_T; ++i) a.seg[i] = AdamSeg{nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0x7fffffff, 0.f};
         if (blocks == 0) continue;
         hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
         if (hipGetLastError() != hipSuccess) { set_error("adam: kernel launch failed"); return VR_ERR_HIP; }

@@ -107,11 +107,37 @@ def allreduce_grads(tensors, world=None, group=None, flat_bucket_bytes=1 << 20):
     if flat is not None:
         if not avg:
             flat.mul_(inv)
-        off = 0
+        off, parts = 0, []
         for g in small:
             n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
+            parts.append(flat[off:off + n].view_as(g))
             off += n
+        torch._foreach_copy_(small, parts)          # one multi-tensor launch instead of one copy per gradient
+
+
+def all_gather_views(factors, campos, world=None, group=None):
+    """All-gather of the ranks' SH factors [n_local, rows, 3] and camera centres [n_local, 3] -> ([world * n_local, rows,
+    3], [world * n_local, 3]), rank-major (rank r's views at r * n_local ...).  RCCL: one collective each; gloo (tests,
+    several ranks on one GPU): staged through the host."""
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    f = factors.detach().contiguous()
+    c = campos.detach().to(f.device, torch.float32).contiguous()
+    if world <= 1:
+        return f, c
+    if dist.get_backend(group) == "nccl":
+        out_f = torch.empty((world * f.shape[0],) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device)
+        out_c = torch.empty((world * c.shape[0], 3), dtype=c.dtype, device=c.device)
+        dist.all_gather_into_tensor(out_f, f, group=group)
+        dist.all_gather_into_tensor(out_c, c, group=group)
+        return out_f, out_c
+    staged = f.is_cuda
+    src_f, src_c = (f.cpu(), c.cpu()) if staged else (f, c)
+    fs = [torch.empty_like(src_f) for _ in range(world)]
+    cs = [torch.empty_like(src_c) for _ in range(world)]
+    dist.all_gather(fs, src_f, group=group)
+    dist.all_gather(cs, src_c, group=group)
+    return torch.cat(fs).to(f.device), torch.cat(cs).to(f.device)
 
 
 def allreduce_densification_stats(viewspace_grad, visibility, radii, group=None):
@@ -182,6 +208,9 @@ def allreduce_rows(tensors, radii, world=None, group=None, threshold=0.7):
     if world <= 1 or not grads:
         return 0
     P = grads[0].shape[0]
+    if radii.numel() != P:
+        raise ValueError(f"allreduce_rows: radii has {radii.numel()} rows, the gradients {P} (op-level radii that include "
+                         "instance rows must be sliced to the model's rows first)")
     vis = (radii > 0).to(torch.uint8)
     _all_reduce(vis, dist.ReduceOp.MAX, group)
     idx = torch.nonzero(vis).reshape(-1)
@@ -218,13 +247,39 @@ class FactorExchange:
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.group, self.sparse_rows = group, sparse_rows
         self._work, self._out_f, self._out_c, self._campos, self._f = [], None, None, None, None
+        self._armed, self._old_hook = False, None
         self.rows_exchanged = None
 
     def begin(self, campos):
         from . import rasterizer
+        if self._armed:
+            raise RuntimeError("FactorExchange.begin(): already armed (finish() or abort() the previous iteration first)")
         self._campos = campos
         self._work, self._out_f, self._out_c, self._f = [], None, None, None
         self._old_hook = rasterizer.set_backward_split_hook(self._on_factors)
+        self._armed = True
+
+    def abort(self):
+        """Take the hook out again without exchanging anything (the backward raised): later, unrelated backward passes
+        must not start stale collectives."""
+        from . import rasterizer
+        if self._armed:
+            rasterizer.set_backward_split_hook(self._old_hook)
+            self._armed = False
+
+    def armed(self, campos):
+        """`with ex.armed(campos): loss.backward()` -- begin(), and abort() if the backward raises."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            self.begin(campos)
+            try:
+                yield self
+            except BaseException:
+                self.abort()
+                raise
+        return scope()
 
     def _on_factors(self, factor):
         """Called by the op's backward between its two halves: `factor` [P,3] is complete in stream order."""
@@ -242,8 +297,7 @@ class FactorExchange:
             self._c = c
 
     def finish(self, tensors, radii=None):
-        from . import rasterizer
-        rasterizer.set_backward_split_hook(self._old_hook)
+        self.abort()                             # (the hook is needed during the backward only)
         if self._f is None:
             raise RuntimeError("FactorExchange.finish(): the backward did not deliver a factor "
                                "(was the op called with sh_color_grad?)")

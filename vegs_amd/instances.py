@@ -21,16 +21,26 @@ def _check(name, t, cols, device):
 
 
 class _TransformConcat(torch.autograd.Function):
-    """inputs: (means_0, scales_0, rot_0, box2world_0 | None, means_1, ...) -> (means, scales, rotations)"""
+    """inputs: (box2world_all | None, means_0, scales_0, rot_0, box2world_0 | row index | None, means_1, ...)
+    -> (means, scales, rotations).  With `box2world_all` [n,4,4] (what vegs_amd.boxmodel.adjust_all returns) an instance
+    names its pose by ROW INDEX: one gradient tensor for all poses instead of a select/accumulate chain per instance."""
 
     @staticmethod
-    def forward(ctx, *flat):
+    def forward(ctx, b_all, *flat):
         lib = _capi.load()
         n_inst = len(flat) // 4
         device = flat[0].device
+        if b_all is not None:
+            if not b_all.is_cuda or b_all.dtype != torch.float32 or b_all.dim() != 3 or tuple(b_all.shape[1:]) != (4, 4):
+                raise ValueError("batched box2world must be a float32 GPU tensor [n,4,4]")
+            b_all = b_all.contiguous()
         items, offset, keep = [], 0, []
         for i in range(n_inst):
             m, s, r, b = flat[4 * i:4 * i + 4]
+            if isinstance(b, int):
+                if b_all is None or not 0 <= b < b_all.shape[0]:
+                    raise ValueError("box2world row index without (or outside) the batched box2world tensor")
+                b = b_all[b]
             _check("means3D", m, 3, device); _check("scales", s, 3, device); _check("rotations", r, 4, device)
             if s.shape[0] != m.shape[0] or r.shape[0] != m.shape[0]:
                 raise ValueError("means3D, scales and rotations of an instance must have the same number of rows")
@@ -53,6 +63,8 @@ class _TransformConcat(torch.autograd.Function):
         _capi.check(rc)
         ctx.keep = keep
         ctx.device = device
+        ctx.b_all = b_all
+        ctx.b_rows = [b if isinstance(b, int) else None for b in flat[3::4]]
         return out_m, out_s, out_r
 
     @staticmethod
@@ -61,15 +73,21 @@ class _TransformConcat(torch.autograd.Function):
         device = ctx.device
         g_m, g_s, g_r = g_m.contiguous(), g_s.contiguous(), g_r.contiguous()
         items, gitems, grads, offset = [], [], [], 0
-        for (m, s, r, b) in ctx.keep:
+        # (rows of the batched pose tensor that no instance uses get a zero gradient)
+        db_all = None if ctx.b_all is None else torch.zeros_like(ctx.b_all)
+        for (m, s, r, b), row in zip(ctx.keep, ctx.b_rows):
             n = m.shape[0]
             if b is None:                       # static model: its gradients ARE rows of the concatenated gradients
                 grads += [g_m[offset:offset + n], g_s[offset:offset + n], g_r[offset:offset + n], None]
                 gi = _capi.VrInstanceGrads(None, None, None, None)
             else:
                 dm, ds, dr = torch.empty_like(m), torch.empty_like(s), torch.empty_like(r)
-                db = torch.empty((4, 4), dtype=torch.float32, device=device)
-                grads += [dm, ds, dr, db]
+                if row is None:
+                    db = torch.empty((4, 4), dtype=torch.float32, device=device)
+                    grads += [dm, ds, dr, db]
+                else:
+                    db = db_all[row]
+                    grads += [dm, ds, dr, None]
                 gi = _capi.VrInstanceGrads(_capi.ptr(dm), _capi.ptr(ds), _capi.ptr(dr), db.data_ptr())
             items.append(_capi.VrInstance(_capi.ptr(m), _capi.ptr(s), _capi.ptr(r), None if b is None else b.data_ptr(),
                                           n, offset))
@@ -87,23 +105,26 @@ class _TransformConcat(torch.autograd.Function):
         if arena.error is not None:
             raise arena.error
         _capi.check(rc)
-        return tuple(grads)
+        return (db_all,) + tuple(grads)
 
 
 def prepare_and_merge(static, boxes, box2worlds):
     """Op inputs for a frame with dynamic instances: the result of
         kw = prepare_rasterization(static); for each box: kw = merge_kwargs(kw, prepare_rasterization(box, box2world))
     (gaussian_renderer/__init__.py:274-303).  `static` / `boxes[i]`: dicts with means3D, shs, opacities, scales,
-    rotations; `box2worlds[i]`: differentiable 4x4 tensors.  `static` may be None (render_dyn)."""
+    rotations; `box2worlds[i]`: differentiable 4x4 tensors -- or ONE tensor [n,4,4] for all instances (what
+    vegs_amd.boxmodel.adjust_all returns: a single gradient tensor for all poses).  `static` may be None (render_dyn)."""
     if len(boxes) != len(box2worlds):
         raise ValueError("one box2world per box instance")
-    models = ([] if static is None else [(static, None)]) + list(zip(boxes, box2worlds))
+    b_all = box2worlds if isinstance(box2worlds, torch.Tensor) else None
+    poses = list(range(len(boxes))) if b_all is not None else list(box2worlds)
+    models = ([] if static is None else [(static, None)]) + list(zip(boxes, poses))
     if not models:
         raise ValueError("nothing to render")
     flat = []
     for t, b in models:
         flat += [t["means3D"], t["scales"], t["rotations"], b]
-    means, scales, rotations = _TransformConcat.apply(*flat)
+    means, scales, rotations = _TransformConcat.apply(b_all, *flat)
     cat = (lambda k: models[0][0][k]) if len(models) == 1 else (lambda k: torch.cat([t[k] for t, _ in models], 0))
     # SH: the instances' rows go behind the static model's as an SH TAIL (the rasterizer reads the static model's tensor(s)
     # where they are: whole [P0,M,3] or the pair (features_dc, features_rest)); merge_kwargs' torch.cat would copy the whole

@@ -64,7 +64,16 @@ def ssim_window(device):
     return (g1[:, None] @ g1[None, :]).expand(3, 1, 11, 11).contiguous().to(device)
 
 
+def _boxes_and_poses(boxes):
+    """boxes: [(tensors, box2world), ...] or (list of tensors, ONE pose tensor [n,4,4])."""
+    if isinstance(boxes, tuple) and len(boxes) == 2 and isinstance(boxes[1], torch.Tensor):
+        return boxes
+    return [b for b, _ in boxes], [w for _, w in boxes]
+
+
 def render_model(p, boxes, cam, cam_t, deg, bg, fused, sh_sink=None):
+    b_in, poses = _boxes_and_poses(boxes) if boxes else ([], [])
+    boxes = b_in
     if fused and not boxes:
         # the op takes the RAW parameters and activates them in its preprocess kernel (VR_FLAG_RAW_PARAMS): no activation
         # launches, gradients straight to _opacity / _scaling / _rotation
@@ -78,15 +87,13 @@ def render_model(p, boxes, cam, cam_t, deg, bg, fused, sh_sink=None):
         # activates the rows in front of the instances (harness.render_all: static_raw)
         t = {"means3D": p["xyz"], "shs": (p["f_dc"], p["f_rest"])}
         raw = {"opacities": p["opacity"], "scales": p["scaling"], "rotations": p["rotation"]}
-        return harness.render_all(cam, t, [b for b, _ in boxes], [w for _, w in boxes], deg, bg, cam_t=cam_t, fused=True,
-                                  sh_color_grad=sh_sink, static_raw=raw)
+        return harness.render_all(cam, t, b_in, poses, deg, bg, cam_t=cam_t, fused=True, sh_color_grad=sh_sink, static_raw=raw)
     # the reference's op-by-op composition (ATen activations, torch.cat of the SH tensors)
     t = {"means3D": p["xyz"], "opacities": torch.sigmoid(p["opacity"]), "scales": torch.exp(p["scaling"]),
          "rotations": F.normalize(p["rotation"]), "shs": torch.cat((p["f_dc"], p["f_rest"]), dim=1)}
     if not boxes:
         return harness.render(cam, t, deg, bg, cam_t=cam_t, sh_color_grad=sh_sink)
-    return harness.render_all(cam, t, [b for b, _ in boxes], [w for _, w in boxes], deg, bg, cam_t=cam_t, fused=False,
-                              sh_color_grad=sh_sink)
+    return harness.render_all(cam, t, b_in, poses, deg, bg, cam_t=cam_t, fused=False, sh_color_grad=sh_sink)
 
 
 def aten_loss(pkg, gt, normal, win, R_c2w):
@@ -122,25 +129,147 @@ def op_inputs(p):
                 "rotations": F.normalize(p["rotation"]).detach()}
 
 
-class Trainer:
-    """State of one variant: parameters, optimizer, densification statistics."""
+class Schedule:
+    """The densification / reset schedule of densification_and_optimization (train.py:283-320) with the reference's
+    defaults (arguments/__init__.py:89-97); `extent` = scene.cameras_extent."""
 
-    def __init__(self, sc, device, n_boxes=0, fused=True, box_points=8196, factored_sh=False, lrs=None):
+    def __init__(self, extent, densify_from_iter=500, densify_until_iter=15_000, densify_until_iter_box=50_000,
+                 densification_interval=100, opacity_reset_interval=3000, densify_grad_threshold=0.0002, percent_dense=0.01,
+                 min_opacity=0.005, white_background=False):
+        self.extent = extent
+        self.densify_from_iter, self.densify_until_iter = densify_from_iter, densify_until_iter
+        self.densify_until_iter_box, self.densification_interval = densify_until_iter_box, densification_interval
+        self.opacity_reset_interval, self.densify_grad_threshold = opacity_reset_interval, densify_grad_threshold
+        self.percent_dense, self.min_opacity, self.white_background = percent_dense, min_opacity, white_background
+
+    def actions(self, iteration, box):
+        """(collect statistics?, densify: (grad threshold, size threshold) | None, reset opacity?) at `iteration`."""
+        if not iteration < (self.densify_until_iter_box if box else self.densify_until_iter):
+            return False, None, False
+        densify = None
+        if iteration > self.densify_from_iter and iteration % self.densification_interval == 0:
+            size = 20 if iteration > self.opacity_reset_interval else None
+            thr = self.densify_grad_threshold
+            if box:
+                thr *= 0.5
+                size = size * 0.5 if size is not None else None
+            densify = (thr, size)
+        reset = iteration % self.opacity_reset_interval == 0 or (self.white_background and iteration == self.densify_from_iter)
+        return True, densify, reset
+
+
+class InstanceModel:
+    """One dynamic object's Gaussian model as the training loop holds it (scene.gaussian_box_models[instanceId]: a
+    GaussianModel with its own optimizer, scene/gaussian_model.py:154-168): raw parameters + the six named groups."""
+
+    def __init__(self, sc, device, fused, lrs=None):
+        from . import optim
+        self.p, groups = make_model(sc, device, lrs)
+        self.opt = (optim.Adam if fused else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
+
+    @property
+    def rows(self):
+        return self.p["xyz"].shape[0]
+
+
+def make_instance_models(n, device, fused, points=8196, seed=5, spacing=12.0, lrs=None, box_lr=0.005, lambda_reg=0.001):
+    """n dynamic objects: (InstanceModel, BoxModel) pairs -- the Gaussians of make_boxes as raw parameters with optimizers,
+    the pose as the reference's BoxModel (annotated box2world + the learnable deltas)."""
+    from . import boxmodel
+    models, boxes = [], []
+    brng = np.random.default_rng(seed)
+    for i in range(n):
+        b, _ = scenes.scene_random(P=points, sh_degree=3, seed=100 + i, extent=1.0, scale=0.05)
+        B = np.eye(4, dtype=np.float32)
+        ang = brng.uniform(0, 6.28)
+        B[:3, :3] = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32) * 1.5
+        B[:3, 3] = [10.0 + spacing * i, brng.uniform(-3, 3), -0.8]
+        models.append(InstanceModel(b, device, fused, lrs))
+        boxes.append(boxmodel.BoxModel(torch.tensor(B), lr=box_lr, lambda_reg=lambda_reg, device=device, fused=fused))
+    return models, boxes
+
+
+class Trainer:
+    """State of one variant: parameters, optimizer(s), densification statistics -- on one GPU, or replicated on the
+    `world` ranks of a view-sharded job (one process per GPU, SURVEY 8e / BASELINE C4, C5).
+
+    step_views(views, ...) is ONE iteration over a batch of views with  loss = mean over the views of the per-view loss
+    (one view per iteration reproduces the reference's loop exactly):
+      * single process: `views` is the whole batch;
+      * distributed (world > 1): `views` is THIS rank's share (normally one view: vegs_amd.dist.view_for_rank); the
+        gradients are exchanged (vegs_amd.dist: factored + overlapped, or dense) so that every rank ends the iteration with
+        the same parameters, optimizer state, statistics and -- every `schedule.densification_interval` iterations -- the
+        same densified model (same statistics -> same plan; same generator seed -> same split draw,
+        scene/gaussian_model.py:365-367).
+    N ranks x 1 view == 1 process x N views: tests/test_gpu_dist_train.py."""
+
+    def __init__(self, sc, device, n_boxes=0, fused=True, box_points=8196, factored_sh=False, lrs=None,
+                 optimise_boxes=False, world=1, rank=0, group=None, exchange="factored", schedule=None, seed=0):
         """factored_sh (fused variant): the op returns the 3-float factor of the SH gradient and Adam consumes it directly
         (optim.adam_step_sh_factored) -- the static model's dense [P,16,3] gradient is never written.  With box instances
         in frame the factor covers the concatenated op inputs: the static model's rows feed Adam, the instances' few
-        thousand rows are rebuilt densely (optim.sh_grad_from_factors on their world-space means)."""
+        thousand rows are rebuilt densely (optim.sh_grad_from_factors on their world-space means).
+        optimise_boxes: the instances are InstanceModels with their own optimizers and BoxModels with learnable pose
+        corrections, all stepped every iteration (train.py:254-275); False keeps them as plain leaf tensors (gradients only).
+        world / rank / group: the view-sharded job; exchange: "factored" (default: forces factored_sh), "dense", or
+        "direct" (vegs_amd.xgmi: hand-written peer-to-peer exchange)."""
         from . import optim
         self.device, self.fused = device, fused
+        self.world, self.rank, self.group, self.exchange = int(world), int(rank), group, exchange
+        if self.world > 1 and exchange in ("factored", "direct"):
+            factored_sh = True
         self.factored_sh = bool(factored_sh and fused)
         self.p, groups = make_model(sc, device, lrs)
-        self.boxes = make_boxes(n_boxes, device, box_points) if n_boxes else []
+        self.optimise_boxes = bool(optimise_boxes and n_boxes)
+        self.instances, self.box_models, self.boxes = [], [], []
+        if self.optimise_boxes:
+            self.instances, self.box_models = make_instance_models(n_boxes, device, fused, box_points, lrs=lrs)
+        elif n_boxes:
+            self.boxes = make_boxes(n_boxes, device, box_points)
         self.opt = (optim.Adam if fused else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
-        P = self.p["xyz"].shape[0] + sum(b["means3D"].shape[0] for b, _ in self.boxes)   # statistics over the op inputs
+        P = self._rows()                                        # statistics over the op inputs
         self.accum = torch.zeros(P, 1, device=device)
         self.denom = torch.zeros(P, 1, device=device)
         self.max_radii = torch.zeros(P, device=device)
         self.win = ssim_window(device)
+        self.schedule, self.iteration = schedule, 0
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(int(seed))
+        self.xch = None
+        if self.world > 1 and self.factored_sh and exchange == "factored":
+            from . import dist as vdist
+            self.xch = vdist.FactorExchange(self.world, group)
+        self.direct = None
+        if self.world > 1 and exchange == "direct":
+            from . import xgmi
+            self.direct = xgmi.DirectExchange(self.rank, self.world, device, group)
+        self.last = {}
+
+    # ---- layout of the op inputs: static rows, then the instances' in order
+    def _instance_rows(self):
+        if self.optimise_boxes:
+            return [m.rows for m in self.instances]
+        return [b["means3D"].shape[0] for b, _ in self.boxes]
+
+    def _rows(self):
+        return self.p["xyz"].shape[0] + sum(self._instance_rows())
+
+    def _box_inputs(self):
+        """(boxes, box2worlds) for render_model: activated instance tensors + poses."""
+        if not self.optimise_boxes:
+            return [b for b, _ in self.boxes], [w for _, w in self.boxes]
+        from . import boxmodel, instances
+        poses = boxmodel.adjust_all(self.box_models)                  # [n,4,4]: one launch (fused) / op by op
+        out = []
+        for m in self.instances:
+            p = m.p
+            if self.fused:
+                o, s_, r = instances.activate(p["opacity"], p["scaling"], p["rotation"])
+            else:
+                o, s_, r = torch.sigmoid(p["opacity"]), torch.exp(p["scaling"]), F.normalize(p["rotation"])
+            out.append({"means3D": p["xyz"], "shs": torch.cat((p["f_dc"], p["f_rest"]), dim=1), "opacities": o, "scales": s_,
+                        "rotations": r})
+        return out, poses
 
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, percent_dense=0.01, noise=None):
         """train.py:303-312 for the static model (fused variant): optim.densify_and_prune on the optimizer's tensors, the
@@ -152,22 +281,63 @@ class Trainer:
         rows_boxes = self.accum.shape[0] - P0
         new, (accum, denom, max_radii) = optim.densify_and_prune(
             self.opt, self.accum[:P0].contiguous(), self.denom[:P0].contiguous(), max_grad, min_opacity, extent,
-            max_screen_size, percent_dense, noise=noise)
+            max_screen_size, percent_dense, noise=noise, generator=self.gen)
         self.p = new
-        if rows_boxes:                        # the instances' rows of the statistics follow the static model's
-            pad = torch.zeros(rows_boxes, 1, device=self.device)
-            accum, denom = torch.cat((accum, pad)), torch.cat((denom, pad))
-            max_radii = torch.cat((max_radii, pad[:, 0]))
+        if rows_boxes:                        # the instances' rows of the statistics are kept behind the static model's
+            accum, denom = torch.cat((accum, self.accum[P0:])), torch.cat((denom, self.denom[P0:]))
+            max_radii = torch.cat((max_radii, self.max_radii[P0:]))
         self.accum, self.denom, self.max_radii = accum, denom, max_radii
         return new["xyz"].shape[0]
+
+    def _scheduled(self):
+        """densification_and_optimization's schedule part (train.py:283-316) for the static model and, with box=True
+        thresholds, for every instance model (:254-268).  Returns the set of models whose parameters were replaced (the
+        reference's optimizer.step() then finds no gradients on them: new nn.Parameter objects)."""
+        from . import optim
+        replaced = set()
+        sch = self.schedule
+        if sch is None or not self.fused:
+            return replaced
+        it = self.iteration
+        P0 = self.p["xyz"].shape[0]
+        _, dens, reset = sch.actions(it, box=False)
+        if dens is not None:
+            self.densify_and_prune(dens[0], sch.min_opacity, sch.extent, dens[1], sch.percent_dense)
+            replaced.add("static")
+        if reset:
+            self.p["opacity"] = optim.reset_opacity(self.opt)
+            replaced.add("static-opacity")
+        if self.optimise_boxes:
+            _, dens, reset = sch.actions(it, box=True)
+            if dens is not None or reset:
+                P0 = self.p["xyz"].shape[0]
+                acc, den, mr, row = [self.accum[:P0]], [self.denom[:P0]], [self.max_radii[:P0]], P0
+                for i, m in enumerate(self.instances):
+                    n = m.rows
+                    a, d, r = self.accum[row:row + n], self.denom[row:row + n], self.max_radii[row:row + n]
+                    row += n
+                    if dens is not None:
+                        new, (a, d, r) = optim.densify_and_prune(m.opt, a.contiguous(), d.contiguous(), dens[0], sch.min_opacity,
+                                                                  sch.extent, dens[1], sch.percent_dense, generator=self.gen)
+                        m.p = new
+                        replaced.add(("instance", i))
+                    if reset:
+                        m.p["opacity"] = optim.reset_opacity(m.opt)
+                    acc.append(a); den.append(d); mr.append(r)
+                self.accum, self.denom, self.max_radii = torch.cat(acc), torch.cat(den), torch.cat(mr)
+        return replaced
 
     def forward_loss(self, cam, cam_t, deg, bg, gt, normal):
         sink = None
         if self.factored_sh and torch.is_grad_enabled():
-            rows = self.p["xyz"].shape[0] + sum(b["means3D"].shape[0] for b, _ in self.boxes)
             # (only its .grad is used: no fill)
-            sink = torch.empty((rows, 3), dtype=torch.float32, device=self.device, requires_grad=True)
-        pkg = render_model(self.p, self.boxes, cam, cam_t, deg, bg, self.fused, sh_sink=sink)
+            sink = torch.empty((self._rows(), 3), dtype=torch.float32, device=self.device, requires_grad=True)
+        if self.optimise_boxes:
+            b_in, poses = self._box_inputs()
+            boxes = list(zip(b_in, poses)) if not isinstance(poses, torch.Tensor) else (b_in, poses)
+        else:
+            boxes = self.boxes
+        pkg = render_model(self.p, boxes, cam, cam_t, deg, bg, self.fused, sh_sink=sink)
         pkg["sh_sink"] = sink
         # NaN guard for pixels no Gaussian covers (A-5: exact zeros; the reference's 2/|q|^2 is NaN there) -- same in
         # both variants
@@ -181,38 +351,156 @@ class Trainer:
         return loss, pkg
 
     def step(self, cam, cam_t, deg, bg, gt, normal, keep_grads=False):
-        from . import optim
-        loss, pkg = self.forward_loss(cam, cam_t, deg, bg, gt, normal)
-        loss.backward()
-        with torch.no_grad():
-            vis, radii, vsp = pkg["visibility_filter"], pkg["radii"], pkg["viewspace_points"]
-            if self.fused:
-                optim.add_densification_stats(vsp.grad, radii, self.accum, self.denom, self.max_radii)
+        """One iteration on one view (the reference's loop; in a distributed job: this rank's view)."""
+        losses, pkgs, grads = self.step_views([dict(cam=cam, cam_t=cam_t, gt=gt, normal=normal)], deg, bg, keep_grads)
+        return losses[0], pkgs[0], grads
+
+    # ---- the per-view statistics (scene/gaussian_model.py:411-413, train.py:299), into `dst` = (accum, denom, max_radii)
+    def _view_stats(self, pkg, dst):
+        vis, radii, vsp = pkg["visibility_filter"], pkg["radii"], pkg["viewspace_points"]
+        accum, denom, max_radii = dst
+        if self.fused:
+            from . import optim
+            optim.add_densification_stats(vsp.grad, radii, accum, denom, max_radii)
+        else:
+            max_radii[vis] = torch.max(max_radii[vis], radii[vis].float())
+            accum[vis] += torch.norm(vsp.grad[vis, :2], dim=-1, keepdim=True)
+            denom[vis] += 1
+
+    def _small_params(self, with_sh):
+        """Everything optimised besides the static model: instance parameters (+ box tensors / pose corrections)."""
+        out = []
+        for m in self.instances:
+            out += [m.p[k] for k in ("xyz", "opacity", "scaling", "rotation")] + ([m.p["f_dc"], m.p["f_rest"]] if with_sh else [])
+        for bm in self.box_models:
+            out += [bm.delta_r, bm.delta_s, bm.delta_t]
+        for b, w in self.boxes:
+            out += [t for k, t in b.items() if with_sh or k != "shs"] + [w]
+        return out
+
+    def step_views(self, views, deg, bg, keep_grads=False):
+        """One iteration over `views` (dicts cam, cam_t, gt, normal): this process's share of the iteration's view batch."""
+        from . import boxmodel, optim
+        from . import dist as vdist
+        self.iteration += 1
+        world, n_local = self.world, len(views)
+        n_total = n_local * world
+        rows, P0 = self._rows(), self.p["xyz"].shape[0]
+        collect = True if self.schedule is None else self.schedule.actions(self.iteration, box=False)[0] or \
+            (self.optimise_boxes and self.schedule.actions(self.iteration, box=True)[0])
+        single = n_total == 1
+        # statistics of THIS iteration's view batch: summed over the views first (and over the ranks), then added -- so that
+        # N ranks x 1 view and 1 process x N views add the same numbers in the same order
+        tmp = None if single else torch.zeros(3, rows, device=self.device)
+        overlap = self.xch is not None and n_local == 1
+        factors, campos, losses, pkgs = [], [], [], []
+        for v in views:
+            ct = v.get("cam_t") or harness.cam_tensors(v["cam"], self.device)
+            loss, pkg = self.forward_loss(v["cam"], ct, deg, bg, v["gt"], v["normal"])
+            if overlap:          # the factors start travelling between the backward's two halves
+                with self.xch.armed(ct["campos"]):
+                    loss.backward()
             else:
-                self.max_radii[vis] = torch.max(self.max_radii[vis], radii[vis].float())             # train.py:299
-                self.accum[vis] += torch.norm(vsp.grad[vis, :2], dim=-1, keepdim=True)                # gaussian_model.py:411-413
-                self.denom[vis] += 1
-        grads = {k: v.grad.detach().clone() for k, v in self.p.items() if v.grad is not None} if keep_grads else None
-        if pkg.get("sh_sink") is not None:
-            ct = cam_t if cam_t is not None else harness.cam_tensors(cam, self.device)
-            campos = ct["campos"].reshape(1, 3)
-            factors = pkg["sh_sink"].grad
-            P0 = self.p["xyz"].shape[0]
-            optim.adam_step_sh_factored(self.opt, self.p["f_dc"], self.p["f_rest"], self.p["xyz"].detach(), campos,
-                                        factors[:P0][None], deg, 1.0)
-            if self.boxes:      # the instances' SH gradients, densely, from their rows of the factor and their WORLD-space means
-                means = pkg["op_inputs"]["means3D"].detach()
-                g_all = optim.sh_grad_from_factors(means[P0:], campos, factors[P0:][None], deg, self.boxes[0][0]["shs"].shape[1])
-                row = 0
-                for b, _ in self.boxes:       # (one launch for all instances; the gradients are row slices of its result)
-                    n = b["means3D"].shape[0]
-                    b["shs"].grad = g_all[row:row + n]
+                loss.backward()
+            with torch.no_grad():
+                if collect:
+                    self._view_stats(pkg, (self.accum, self.denom, self.max_radii) if single else
+                                     (tmp[0].unsqueeze(1), tmp[1].unsqueeze(1), tmp[2]))
+            if pkg.get("sh_sink") is not None:
+                factors.append(pkg["sh_sink"].grad)
+                campos.append(ct["campos"].reshape(3))
+            losses.append(loss.detach())
+            pkgs.append(pkg)
+
+        # ---- the exchange: mean over ALL views of the iteration
+        static_sh = [] if self.factored_sh else [self.p["f_dc"], self.p["f_rest"]]
+        static_others = [self.p[k] for k in ("xyz", "opacity", "scaling", "rotation")]
+        small = self._small_params(with_sh=not self.factored_sh)
+        Fv = Cv = None
+        with torch.no_grad():
+            if self.factored_sh:
+                Fv = factors[0][None] if n_local == 1 else torch.stack(factors)          # [n_local, rows, 3]
+                Cv = torch.stack(campos).to(self.device, torch.float32)
+            if world > 1:
+                if self.direct is not None:
+                    Fv, Cv = self.direct.exchange(static_others, Fv, Cv, n_local)
+                elif overlap:
+                    Fv, Cv = self.xch.finish(static_others)
+                elif self.factored_sh:
+                    vdist.allreduce_grads(static_others, world, self.group)
+                    Fv, Cv = vdist.all_gather_views(Fv, Cv, world, self.group)
+                else:
+                    vdist.allreduce_grads(static_others + static_sh, world, self.group)
+                vdist.allreduce_grads(small, world, self.group, flat_bucket_bytes=1 << 40)
+                if collect:
+                    vdist._all_reduce(tmp[:2], torch.distributed.ReduceOp.SUM, self.group)
+                    vdist._all_reduce(tmp[2], torch.distributed.ReduceOp.MAX, self.group)
+            if n_local > 1:          # (the ranks' mean rides in the collective; the local views' is taken here)
+                gs = [t.grad for t in static_others + static_sh + small if t.grad is not None]
+                if gs:
+                    torch._foreach_mul_(gs, 1.0 / n_local)
+            if tmp is not None and collect:
+                self.accum += tmp[0].unsqueeze(1)
+                self.denom += tmp[1].unsqueeze(1)
+                self.max_radii = torch.maximum(self.max_radii, tmp[2])
+            grads = {k: v.grad.detach().clone() for k, v in self.p.items() if v.grad is not None} if keep_grads else None
+
+            # the instances' SH gradients, densely, from their rows of the factors and their WORLD-space means (identical
+            # for every view: the poses are replicated) -- already the mean over all views
+            if self.factored_sh and rows > P0:
+                means = pkgs[0]["op_inputs"]["means3D"].detach()
+                M = (self.instances[0].p["f_dc"].shape[1] + self.instances[0].p["f_rest"].shape[1]) if self.optimise_boxes \
+                    else self.boxes[0][0]["shs"].shape[1]
+                g_all = optim.sh_grad_from_factors(means[P0:], Cv, Fv[:, P0:], deg, M, 1.0 / n_total, split=self.optimise_boxes)
+                row = 0                   # (one launch for all instances; the gradients are row slices of its result)
+                for i, n in enumerate(self._instance_rows()):
+                    if self.optimise_boxes:
+                        self.instances[i].p["f_dc"].grad = g_all[0][row:row + n]
+                        self.instances[i].p["f_rest"].grad = g_all[1][row:row + n]
+                    else:
+                        self.boxes[i][0]["shs"].grad = g_all[row:row + n]
                     row += n
-        self.opt.step()
-        self.opt.zero_grad(set_to_none=True)
+
+            # ---- densification / opacity reset on schedule, then the optimizers (train.py:283-320, :254-275)
+            replaced = self._scheduled()
+            if self.factored_sh and "static" not in replaced:
+                optim.adam_step_sh_factored(self.opt, self.p["f_dc"], self.p["f_rest"], self.p["xyz"].detach(), Cv,
+                                            Fv[:, :P0], deg, 1.0 / n_total)
+            opts = [self.opt] + [m.opt for m in self.instances] + [bm.optimizer for bm in self.box_models]
+            if self.fused:
+                optim.step_many(opts)               # ONE multi-tensor launch: static model, instance models, pose corrections
+            else:
+                for o in opts:
+                    o.step()
+            for o in opts:
+                o.zero_grad(set_to_none=True)
+            if self.box_models:
+                boxmodel.regularize_all(self.box_models)                    # train.py:274
         if not keep_grads:
-            for b, w in self.boxes:                  # box tensors are not optimizer parameters here
+            for b, w in self.boxes:                  # plain box tensors are not optimizer parameters
                 w.grad = None
                 for t in b.values():
                     t.grad = None
-        return loss.detach(), pkg, grads
+        self.last = {"factors": Fv, "campos": Cv, "replaced": replaced}
+        return losses, pkgs, grads
+
+    # ---- what must be identical on every rank after an iteration
+    def state_tensors(self):
+        out = {"static." + k: v for k, v in self.p.items()}
+        for name, opt, p in [("static", self.opt, self.p)] + [(f"inst{i}", m.opt, m.p) for i, m in enumerate(self.instances)]:
+            for k, v in p.items():
+                out[f"{name}.{k}"] = v
+                st = opt.state.get(v, {})
+                for sk in ("exp_avg", "exp_avg_sq", "step"):
+                    if sk in st:
+                        out[f"{name}.{k}.{sk}"] = st[sk]
+        for i, bm in enumerate(self.box_models):
+            for k in ("delta_r", "delta_s", "delta_t"):
+                t = getattr(bm, k)
+                out[f"box{i}.{k}"] = t
+                st = bm.optimizer.state.get(t, {})
+                for sk in ("exp_avg", "exp_avg_sq", "step"):
+                    if sk in st:
+                        out[f"box{i}.{k}.{sk}"] = st[sk]
+        out["accum"], out["denom"], out["max_radii"] = self.accum, self.denom, self.max_radii
+        return out

@@ -36,40 +36,58 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        lib = _capi.load()
-        by_cfg = {}
-        keep = []                                            # keeps contiguous gradient copies alive until launch
-        for group in self.param_groups:
-            b1, b2 = group["betas"]
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                if not p.is_cuda:
-                    raise ValueError("fused Adam expects GPU parameters (there is no CPU path)")
-                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse:
-                    raise ValueError("fused Adam expects dense float32 parameters and gradients")
-                if not p.is_contiguous():
-                    raise ValueError("fused Adam expects contiguous parameters")
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                m, v = st["exp_avg"], st["exp_avg_sq"]
-                if m.shape != p.shape or v.shape != p.shape or not m.is_contiguous() or not v.is_contiguous():
-                    raise ValueError("optimizer state does not match its parameter")
-                keep.append(g)
-                by_cfg.setdefault((p.device, float(b1), float(b2), float(group["eps"])), []).append(
-                    _capi.VrAdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
-                                       float(group["lr"]), int(st["step"].item())))
-        for (device, b1, b2, eps), items in by_cfg.items():
-            arr = (_capi.VrAdamTensor * len(items))(*items)
-            with torch.cuda.device(device):
-                rc = lib.vr_adam_step(arr, len(items), b1, b2, eps, torch.cuda.current_stream(device).cuda_stream)
-            _capi.check(rc)
+        step_many([self])
         return loss
+
+
+def _collect(optimizer, by_cfg, keep):
+    """The VrAdamTensor entries of one optimizer (vegs_amd.optim.Adam or torch.optim.Adam: same state layout), its step
+    counters advanced as torch.optim.Adam.step does; parameters without a gradient are skipped."""
+    for group in optimizer.param_groups:
+        b1, b2 = group["betas"]
+        if group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or group.get("maximize", False):
+            raise NotImplementedError("the fused Adam covers the reference's configuration: no weight decay, no amsgrad")
+        for p in group["params"]:
+            if p.grad is None:
+                continue
+            if not p.is_cuda:
+                raise ValueError("fused Adam expects GPU parameters (there is no CPU path)")
+            if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse:
+                raise ValueError("fused Adam expects dense float32 parameters and gradients")
+            if not p.is_contiguous():
+                raise ValueError("fused Adam expects contiguous parameters")
+            st = optimizer.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            m, v = st["exp_avg"], st["exp_avg_sq"]
+            if m.shape != p.shape or v.shape != p.shape or not m.is_contiguous() or not v.is_contiguous():
+                raise ValueError("optimizer state does not match its parameter")
+            st["step"] += 1
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            keep.append(g)
+            by_cfg.setdefault((p.device, float(b1), float(b2)), []).append(
+                _capi.VrAdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                                   float(group["lr"]), int(st["step"].item()), float(group["eps"])))
+
+
+@torch.no_grad()
+def step_many(optimizers):
+    """optimizer.step() of SEVERAL Adam optimizers as one launch (per 64 tensors): what train.py:254-275 does one optimizer
+    after the other when dynamic objects are in frame -- the static model's six groups, six more per instance model
+    (densification_and_optimization(..., box=True)) and the three pose corrections of every BoxModel
+    (box_model.optimizer.step(), model/boxmodel.py:13) -- with every tensor's own learning rate, step count and eps in
+    the kernel's block->tensor table.  Optimizers may be vegs_amd.optim.Adam or torch.optim.Adam (same state layout)."""
+    lib = _capi.load()
+    by_cfg, keep = {}, []
+    for opt in optimizers:
+        _collect(opt, by_cfg, keep)
+    for (device, b1, b2), items in by_cfg.items():
+        arr = (_capi.VrAdamTensor * len(items))(*items)
+        with torch.cuda.device(device):
+            rc = lib.vr_adam_step(arr, len(items), b1, b2, -1.0, torch.cuda.current_stream(device).cuda_stream)
+        _capi.check(rc)
 
 
 def add_densification_stats(viewspace_point_grad, radii, xyz_gradient_accum, denom, max_radii2D):
@@ -122,7 +140,7 @@ def _model_tensor(name, p, P, width=None):
 
 
 def densify_and_prune(optimizer, xyz_gradient_accum, denom, max_grad, min_opacity, extent, max_screen_size,
-                      percent_dense, noise=None, generator=None, empty_cache=True):
+                      percent_dense, noise=None, generator=None, empty_cache=True, prune=True):
     """GaussianModel.densify_and_prune (scene/gaussian_model.py:384-403) on the tensors of `optimizer`'s six named groups:
     clone the small Gaussians whose mean screen-space gradient `xyz_gradient_accum / denom` reaches `max_grad`, replace
     the large ones by two samples, prune by opacity (and, if `max_screen_size` is truthy, by world size -- the
@@ -134,7 +152,8 @@ def densify_and_prune(optimizer, xyz_gradient_accum, denom, max_grad, min_opacit
     One planned gather instead of the reference's two concatenations and two mask passes per tensor: the result has
     the same rows in the same order.  `noise` [2 S, 3] is the unit-normal draw behind torch.normal (:367), S = number
     of split Gaussians; drawn here with `generator` when not given -- pass it to make the step reproducible.
-    `empty_cache`: finish with torch.cuda.empty_cache() as the reference does (:403)."""
+    `empty_cache`: finish with torch.cuda.empty_cache() as the reference does (:403).  `prune=False` is the reference's
+    argument of that name (:384, :397): clone and split only, nothing is pruned by opacity or size."""
     groups = _named_groups(optimizer)
     par = {n: groups[n]["params"][0] for n in DENSIFY_NAMES}
     P = par["xyz"].shape[0]
@@ -146,7 +165,7 @@ def densify_and_prune(optimizer, xyz_gradient_accum, denom, max_grad, min_opacit
             raise ValueError(f"{n} must be a contiguous float32 GPU tensor with one value per Gaussian")
     lib = _capi.load()
     settings = _capi.VrDensifySettings(float(max_grad), float(min_opacity), float(extent), float(percent_dense),
-                                       1 if max_screen_size else 0)
+                                       2 if not prune else (1 if max_screen_size else 0))
     stream = torch.cuda.current_stream(dev).cuda_stream
     with torch.cuda.device(dev), torch.no_grad():
         plan = torch.empty(max(int(lib.vr_densify_plan_words(P)), 1), dtype=torch.int32, device=dev)
@@ -251,13 +270,18 @@ def _check_factor_inputs(means3D, campos, factors):
     n = campos.shape[0]
     if factors.dtype != torch.float32 or tuple(factors.shape) != (n, P, 3):
         raise ValueError(f"factors must be float32 [{n},{P},3] (got {tuple(factors.shape)})")
-    return P, n, means3D.contiguous(), campos.contiguous(), factors.contiguous()
+    # the P rows may be the HEAD of longer per-view blocks (the static model's rows of an all-gathered
+    # [n_views, P + instance rows, 3]): passed with its view stride instead of a copy
+    if not (factors.stride(2) == 1 and factors.stride(1) == 3 and (n == 1 or factors.stride(0) >= 3 * P)):
+        factors = factors.contiguous()
+    stride = factors.stride(0) if n > 1 else 0
+    return P, n, means3D.contiguous(), campos.contiguous(), factors, stride
 
 
 def sh_grad_from_factors(means3D, campos, factors, sh_degree, M, scale=1.0, split=False):
     """Dense dL/dshs from the factors of `n_views` views: scale * sum_v basis(dir(means3D, campos[v])) x factors[v].
     Returns [P,M,3], or (dc [P,1,3], rest [P,M-1,3]) with split=True (the model's own storage)."""
-    P, n, means3D, campos, factors = _check_factor_inputs(means3D, campos, factors)
+    P, n, means3D, campos, factors, fstride = _check_factor_inputs(means3D, campos, factors)
     dev = means3D.device
     if split:
         out = torch.empty((P, 1, 3), dtype=torch.float32, device=dev)
@@ -265,7 +289,7 @@ def sh_grad_from_factors(means3D, campos, factors, sh_degree, M, scale=1.0, spli
     else:
         out, rest = torch.empty((P, M, 3), dtype=torch.float32, device=dev), None
     with torch.cuda.device(dev):
-        rc = _capi.load().vr_sh_grad_from_factors(_capi.ptr(means3D), P, _capi.ptr(campos), _capi.ptr(factors), n,
+        rc = _capi.load().vr_sh_grad_from_factors(_capi.ptr(means3D), P, _capi.ptr(campos), _capi.ptr(factors), n, fstride,
                                                   int(sh_degree), int(M), float(scale), _capi.ptr(out), _capi.ptr(rest),
                                                   torch.cuda.current_stream(dev).cuda_stream)
     _capi.check(rc)
@@ -299,7 +323,7 @@ def adam_step_sh_factored(opt, features_dc, features_rest, means3D, campos, fact
     features_rest=None) of optimizer `opt` (vegs_amd.optim.Adam or torch.optim.Adam: same state layout) straight from
     the factors -- the dense gradient is built per Gaussian in registers and never written.  Equivalent to setting
     .grad = sh_grad_from_factors(...) on the two parameters and stepping only them."""
-    P, n, means3D, campos, factors = _check_factor_inputs(means3D, campos, factors)
+    P, n, means3D, campos, factors, fstride = _check_factor_inputs(means3D, campos, factors)
     M = features_dc.shape[1] + (features_rest.shape[1] if features_rest is not None else 0)
     items, states, betas, eps = [], [], None, None
     for p in (features_dc, features_rest):
@@ -321,7 +345,7 @@ def adam_step_sh_factored(opt, features_dc, features_rest, means3D, campos, fact
         raise ValueError(f"sh_degree {sh_degree} needs {K} coefficients, the parameters hold {M}")
     dev = means3D.device
     with torch.cuda.device(dev):
-        rc = _capi.load().vr_sh_adam_step(_capi.ptr(means3D), P, _capi.ptr(campos), _capi.ptr(factors), n, int(sh_degree),
+        rc = _capi.load().vr_sh_adam_step(_capi.ptr(means3D), P, _capi.ptr(campos), _capi.ptr(factors), n, fstride, int(sh_degree),
                                           int(M), float(scale), C.byref(items[0]),
                                           C.byref(items[1]) if items[1] is not None else None, betas[0], betas[1], eps,
                                           torch.cuda.current_stream(dev).cuda_stream)

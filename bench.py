@@ -30,6 +30,31 @@ sys.path.insert(0, ROOT)
 from vegs_amd import _capi, dist as vdist, harness, scenes  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guide: MI355X_MICROARCH.md chip table)
+VALU_PEAK_GINST = 1228.8   # wave64 VALU instructions per ns: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles (same guide)
+
+
+def profile_figures(kern, sources):
+    """(HBM traffic bytes per launch, VALU wave-instructions per launch, provenance) of `kern` from the committed PMC
+    profile (profiles/pmc_traffic.json) -- or (None, None, reason) when a source file of that kernel has changed since
+    the counters were collected: a stale figure must not ride along silently."""
+    import hashlib
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(tpath))
+    except Exception as e:
+        return None, None, f"unavailable ({e.__class__.__name__})"
+    rec = d.get("_sources") or {}
+    for f in sources:
+        try:
+            h = hashlib.sha256(open(os.path.join(ROOT, "vegs_amd", "csrc", f), "rb").read()).hexdigest()[:16]
+        except OSError:
+            h = None
+        if rec.get(f) != h:
+            print(f"warning: profiles/pmc_traffic.json was collected on another version of {f}; roofline.traffic and "
+                  "roofline.secondary.valu are reported as null until the counters are re-collected "
+                  "(profiles/tools/collect_round.sh)", file=sys.stderr)
+            return None, None, f"stale: {f} changed since {d.get('_collected')}"
+    return d.get(kern), (d.get("_valu_insts") or {}).get(kern), d.get("_collected")
 
 
 def build_workload(args):
@@ -104,6 +129,7 @@ def prepare(sc, deg, cams, device, rng, count=True, cam_ts=None):
         if count:
             c["F"] = _capi.count_fragments(pkg["render"].grad_fn, H, W, device)
             c["B"] = _capi.count_blended(pkg["render"].grad_fn, H, W, device)
+            c["A"] = _capi.count_flushes(pkg["render"].grad_fn, H, W, device)
             rs = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, bg, 1.0, cam_ts[v]["viewmatrix"],
                                                cam_ts[v]["projmatrix"], deg, cam_ts[v]["campos"], False, False)
             c["Pz"] = int(GaussianRasterizer(rs).markVisible(T["means3D"]).sum().item())
@@ -126,12 +152,20 @@ def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="trai
     torch.no_grad(), as the reference's evaluation and video paths call it (train.py:338-508, render_video.py:162,202)."""
     T, cams, cam_ts, gouts, params, deg, bg = (wl[k] for k in ("T", "cams", "cam_ts", "gouts", "params", "deg", "bg"))
     n_views = len(cams)
-    fact_x = world > 1 and exchange == "factored" and vps == 1
+    fact_x = world > 1 and exchange in ("factored", "direct") and vps == 1
     factored = factored or fact_x
     others = [T[k] for k in ("means3D", "opacities", "scales", "rotations")]
     from vegs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     m2d = torch.zeros_like(T["means3D"], requires_grad=True) if mode == "noglue" else None
-    xch = vdist.FactorExchange(world) if fact_x and exchange_on else None
+    xch = None
+    if fact_x and exchange_on:
+        if exchange == "direct":           # hand-written peer-to-peer exchange over hipIpc mappings (vegs_amd/xgmi.py)
+            from vegs_amd import xgmi
+            xch = xgmi.DirectExchange(rank, world, T["means3D"].device)
+            P_ = T["means3D"].shape[0]
+            xch.reserve(11 * P_ + 64, 3 * P_ + 64)        # (collective allocation: outside the timed region)
+        else:
+            xch = vdist.FactorExchange(world)
     if fact_x and not exchange_on:
         fact_x = False             # (measurement aid: the same step without any collective)
 
@@ -162,8 +196,10 @@ def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="trai
         sink = torch.zeros_like(T["means3D"], requires_grad=True) if factored else None
         pkg = harness.render(cams[v], T, deg, bg, cam_t=cam_ts[v], sh_color_grad=sink)
         if fact_x:          # overlapped exchange: the factors start travelling between the backward's two halves
-            xch.begin(cam_ts[v]["campos"])
-        torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], [gc, gq, gs])
+            with xch.armed(cam_ts[v]["campos"]):
+                torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], [gc, gq, gs])
+        else:
+            torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], [gc, gq, gs])
 
     def step(i):
         done = []
@@ -360,25 +396,86 @@ def cpu_plan(cores):
     return out
 
 
+def bench_c5(args, rank, world, device):
+    """BASELINE config C5: 5 M static Gaussians + 8 dynamic box instances x 8,196 Gaussians, the FULL training step --
+    render_all-shaped forward (instance transform + concatenation), L1 + SSIM + normal guidance as one node, backward,
+    gradient exchange (N > 1), densification statistics, Adam over the static model, every instance model and every
+    BoxModel, BoxModel.regularize (reference train.py:143-168,196,254-320) -- one view per rank per iteration
+    (vegs_amd.iteration.Trainer).  Prints the bench line of that workload."""
+    from vegs_amd import iteration
+    P = args.gaussians or 5_000_000
+    sc, deg = scenes.scene_street(P=P, length=250.0, sh_degree=3, seed=2)
+    cams = [scenes.kitti_camera(10.0 * s_, y, args.width, args.height) for s_ in range(8) for y in (0.3, -0.3)]
+    cam_ts = [harness.cam_tensors(c, device) for c in cams]
+    rng = np.random.default_rng(99)
+    H, W = args.height, args.width
+    gts = [torch.tensor(rng.uniform(0, 1, (3, H, W)).astype(np.float32), device=device) for _ in range(4)]
+    normals = [torch.tensor(rng.normal(size=(3, H, W)).astype(np.float32), device=device) for _ in range(4)]
+    bg = torch.zeros(3, device=device)
+    tr = iteration.Trainer(sc, device, n_boxes=args.boxes, fused=True, factored_sh=True, lrs=iteration.REFERENCE_LRS,
+                           optimise_boxes=True, world=world, rank=rank, exchange=args.exchange)
+
+    def step(i):
+        v = vdist.view_for_rank(i, rank, world, len(cams))
+        tr.step(cams[v], cam_ts[v], deg, bg, gts[i % 4], normals[i % 4])
+        return [v]
+    for i in range(args.warmup):
+        step(i)
+    tr.sh_adam_events = []
+    elapsed, views_done, region_s = timed_median(step, args.steps, world, args.repeats, first=args.warmup)
+    events, tr.sh_adam_events = tr.sh_adam_events, None
+    torch.cuda.synchronize()
+    if rank != 0:
+        return
+    ms_k = float(np.median([a.elapsed_time(b) for a, b in events])) if events else 0.0
+    rows = tr._rows()
+    # dominant kernel: the SH Adam straight from the factors (k_sh_factors<true>): reads and writes param / exp_avg /
+    # exp_avg_sq of the 48 SH floats per Gaussian (24 B per float) + the factors of the N views and the means
+    bytes_k = 24.0 * 48 * P + 12.0 * P * (world + 1)
+    achieved = bytes_k / (ms_k * 1e-3) / 1e9 if ms_k > 0 else 0.0
+    res = {"metric": "rasterizer fwd+bwd views/sec + Mfragments/sec, 2M Gaussians @1376x376",
+           "value": round(args.steps * world / elapsed, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "repeats": len(region_s),
+           "ms_per_step_regions": [round(r / args.steps * 1e3, 4) for r in region_s],
+           "config": {"workload": f"c5 (NOT the headline workload): {P} street Gaussians + {args.boxes} box instances x 8196 Gaussians "
+                                  f"with learnable BoxModel poses, SH deg {deg}, {W}x{H}; one view per GPU per iteration; FULL training "
+                                  "step: render_all-shaped forward, L1+SSIM + normal guidance, backward, exchange, densification "
+                                  "statistics, Adam over static + instance models + BoxModels (one launch), BoxModel.regularize",
+                      "gaussians": P, "rows_rendered": rows, "boxes": args.boxes, "width": W, "height": H,
+                      "parallelism": f"view-sharded x{world}" + ("" if world == 1 else f" + {args.exchange} exchange")},
+           "roofline": {"bound": "hbm", "kernel": "k_sh_factors<true> (Adam of the 48 SH floats per Gaussian straight from the "
+                                                  "views' 3-float factors)", "achieved": round(achieved, 2),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "alg_bytes_per_launch": round(bytes_k), "avg_launch_ms": round(ms_k, 4), "launches_timed": len(events)},
+           "cpu_baseline": None}
+    print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--workload", choices=["c3", "c2"], default="c3")
+    ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3",
+                    help="c3 = the headline (BASELINE.json); c2 = 500 k Gaussians; c5 = 5 M + box instances, the FULL training step")
+    ap.add_argument("--boxes", type=int, default=8, help="c5: dynamic box instances in frame")
     ap.add_argument("--gaussians", type=int, default=0)
     ap.add_argument("--width", type=int, default=1376)
     ap.add_argument("--height", type=int, default=376)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra 1408x376 / dense-scene measurements")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage time breakdown to stderr")
-    ap.add_argument("--exchange", choices=["factored", "dense"], default="factored",
-                    help="N > 1: gradient exchange scheme (factored = all-gather of the rank-1 SH factors + all-reduce of "
-                         "the other 11 floats; dense = all-reduce of all 59 floats per Gaussian)")
+    ap.add_argument("--exchange", choices=["factored", "dense", "direct"], default="factored",
+                    help="N > 1: gradient exchange scheme (factored = RCCL all-gather of the rank-1 SH factors + all-reduce of "
+                         "the other 11 floats; dense = RCCL all-reduce of all 59 floats per Gaussian; direct = the factored "
+                         "scheme over hand-written peer-to-peer kernels: every rank pushes 1/N shards into all peers' hipIpc "
+                         "windows at once, vegs_amd/csrc/xgmi.hip)")
     ap.add_argument("--hints", choices=["off", "warm"], default="off",
                     help="per-camera needed-segment hints in the HEADLINE: off (default: every view costs what a camera's "
                          "first visit costs -- a number any training loop meets) or warm (zero model drift: the best case)")
-    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported "
+                    "(the driver fixes --steps 20 = 26 ms per region: five regions make the median robust)")
     ap.add_argument("--disc-scale", type=float, default=1.0,
                     help="multiply every Gaussian's scales (3.0 = the 'dense' variant's scene); a profiling aid, changes the workload")
     ap.add_argument("--streams", type=int, default=1,
@@ -395,6 +492,8 @@ def main():
     device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     _capi.load()
+    if args.workload == "c5":
+        return bench_c5(args, rank, world, device)
 
     sc, deg, cams, P = build_workload(args)
     H, W = args.height, args.width
@@ -438,13 +537,14 @@ def main():
     if world > 1:
         # what the exchange costs: the same K steps once more WITHOUT any collective (every rank; outside the headline's
         # timed regions).  exposed = ms per step with - without: the part of the exchange that compute does not hide.
-        step0 = make_step(wl, rank, world, vps, factored=(args.exchange == "factored" and vps == 1), exchange=args.exchange,
-                          exchange_on=False)
+        fact = args.exchange in ("factored", "direct") and vps == 1
+        step0 = make_step(wl, rank, world, vps, factored=fact, exchange=args.exchange, exchange_on=False)
         dt0, _, _ = timed_median(step0, args.steps, world, 1, first=args.warmup)
-        scheme = "factored" if args.exchange == "factored" and vps == 1 else "dense"
+        scheme = args.exchange if fact else "dense"
         exchange = {"scheme": scheme + (" (all-gather of the SH factors started between the backward's two halves, "
-                                        "all-reduce of the other 11 floats after it; one wait)" if scheme == "factored" else ""),
-                    "exchange_bytes_per_rank": vdist.exchange_bytes_per_rank(P, world, scheme),
+                                        "all-reduce of the other 11 floats after it; one wait)" if fact else "")
+                              + (" -- peer-to-peer over hipIpc windows, no RCCL" if scheme == "direct" else ""),
+                    "exchange_bytes_per_rank": vdist.exchange_bytes_per_rank(P, world, "factored" if fact else "dense"),
                     "ms_per_step_without_exchange": round(dt0 / args.steps * 1e3, 4),
                     "exchange_exposed_ms": round((elapsed - dt0) / args.steps * 1e3, 4)}
     if rank != 0:
@@ -462,13 +562,21 @@ def main():
     ms_k = stage[kern][0] / max(stage[kern][1], 1)
     bytes_k = 72 * mean["R"] + 56 * N + 68 * mean["V"]
     achieved = bytes_k / (ms_k * 1e-3) / 1e9 if ms_k > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(kern)
-        except Exception:
-            traffic = None
+    traffic, valu_insts, traffic_from = profile_figures(kern, ("render_bwd.hip", "vr_segment.h"))
+    # secondary ceilings (reported, not graded): VALU issue -- wave-level VALU instructions of the kernel (SQ
+    # counters of the committed profile) against 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction -- and the L2
+    # atomics of the backward: 17 fp32 atomics per (list entry, 8x8 region) flush, counted on the device per view
+    flushes = float(np.mean([counters[v]["A"] for v in views_done])) if "A" in counters[views_done[0]] else None
+    secondary = {"valu": None if not valu_insts or ms_k <= 0 else {
+                     "kernel": kern, "wave_instructions_per_launch": valu_insts,
+                     "achieved_ginst_per_s": round(valu_insts / (ms_k * 1e-3) / 1e9, 1), "peak_ginst_per_s": VALU_PEAK_GINST,
+                     "frac": round(valu_insts / (ms_k * 1e-3) / 1e9 / VALU_PEAK_GINST, 4),
+                     "note": "issue slots only: packed fp32 and transcendental instructions take more than one"},
+                 "l2_atomics": None if flushes is None else {
+                     "kernel": kern, "flushes_per_view": round(flushes), "atomics_per_view": round(17 * flushes),
+                     "achieved_gatomics_per_s": round(17 * flushes / (ms_k * 1e-3) / 1e9, 2) if ms_k > 0 else None,
+                     "peak": None, "note": "fp32 global atomics (hardware, -munsafe-fp-atomics), 17 per (entry, region) flush; "
+                                           "no published L2 atomic peak for gfx950"}}
     res = {
         "metric": "rasterizer fwd+bwd views/sec + Mfragments/sec, 2M Gaussians @1376x376",
         "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -490,12 +598,15 @@ def main():
                    "hints": args.hints,
                    "gaussians": P, "width": W, "height": H, "views_per_step_per_gpu": vps,
                    "parallelism": f"view-sharded x{world}" + ("" if world == 1 else
+                                                              " + direct hipIpc all-gather of SH factors (3 f32) + reduce-scatter/all-gather (11 f32) per Gaussian"
+                                                              if args.exchange == "direct" and vps == 1 else
                                                               " + RCCL all-gather of SH factors (3 f32) + all-reduce (11 f32) per Gaussian"
                                                               if args.exchange == "factored" and vps == 1 else
                                                               " + RCCL grad all-reduce (59 f32/Gaussian)"),
                    "mean_counters": {k: round(v, 1) for k, v in mean.items()}},
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "traffic_collected": traffic_from, "secondary": secondary,
                      "alg_bytes_per_launch": round(bytes_k), "avg_launch_ms": round(ms_k, 4),
                      "launches_timed": int(stage[kern][1]),
                      "stage_ms": stage_ms,

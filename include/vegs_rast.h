@@ -276,6 +276,12 @@ int vr_count_fragments(const VrSaved* saved, int32_t image_height, int32_t image
 int vr_count_blended(const VrSaved* saved, int32_t image_height, int32_t image_width, void* stream,
                      int64_t* blended);
 
+/* Flushes of the render backward for the forward whose state is `saved`: (list entry, 8x8 region) pairs of the NEEDED
+ * segments whose relevance bit is set.  The backward issues 17 global fp32 atomics per flush (mean2D 2, conic 3, opacity 1,
+ * colour 3, depth 1, quaternion 4, scale 3): atomics per view = 17 x this -- the L2-atomic figure benchmarks report next
+ * to the HBM roofline; blocks the host. */
+int vr_count_flushes(const VrSaved* saved, int32_t image_height, int32_t image_width, void* stream, int64_t* flushes);
+
 /* Copies the per-tile number of needed list segments of the forward whose state is `saved` into `out`
  * (device, uint32 [tiles], tiles = ceil(W/16) * ceil(H/16)); asynchronous on `stream`.  Feed it back as
  * VrSaved.needed_hint of the next forward of the same camera. */

@@ -22,7 +22,8 @@ def make(world, rank, exchange, device, n_boxes=2, P=40000, seed=31, determinist
     if deterministic:
         rasterizer.set_flags(rasterizer.get_flags() | rasterizer.FLAG_DETERMINISTIC)
     tr = iteration.Trainer(sc, device, n_boxes=n_boxes, fused=True, box_points=1500, factored_sh=(exchange != "dense"),
-                           lrs=iteration.REFERENCE_LRS, optimise_boxes=True, world=world, rank=rank, exchange=exchange,
+                           lrs=iteration.REFERENCE_LRS, optimise_boxes=True, world=world, rank=rank,
+                           exchange=exchange if world > 1 or exchange == "dense" else "factored",
                            schedule=sch, seed=5)
     return tr, deg, cams, gts, normals
 

@@ -224,11 +224,17 @@ def test_bench_line_contract_single_gpu():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["unit"] == "views/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
-    assert d["config"]["hints"] == "off" and d["repeats"] == 3 and len(d["ms_per_step_regions"]) == 3
+    assert d["config"]["hints"] == "off" and d["repeats"] == 5 and len(d["ms_per_step_regions"]) == 5
     assert min(d["ms_per_step_regions"]) <= d["ms_per_step"] <= max(d["ms_per_step_regions"])
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0 < rf["frac"] < 1 and "traffic" in rf
+    # provenance of the counter figures, and the secondary ceilings (VALU issue, L2 atomics of the backward)
+    assert "traffic_collected" in rf and (rf["traffic"] is None) == (isinstance(rf["traffic_collected"], str))
+    sec = rf["secondary"]
+    assert sec["l2_atomics"]["atomics_per_view"] == 17 * sec["l2_atomics"]["flushes_per_view"] > 0
+    if rf["traffic"] is not None:
+        assert 0 < sec["valu"]["frac"] < 1 and sec["valu"]["peak_ginst_per_s"] == 1228.8
     assert set(("preprocess", "render_fwd", "render_bwd", "preprocess_bwd", "k_seg_bwd")) <= set(rf["stage_ms"])
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == "views/s"

@@ -71,7 +71,7 @@ def _run_ranks(tmp_path, world, exchange, steps, boxes):
     return [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
 
 
-@pytest.mark.parametrize("exchange", ["factored", "dense"])
+@pytest.mark.parametrize("exchange", ["factored", "dense", "direct"])
 def test_two_ranks_equal_one_process_averaging_two_views(tmp_path, exchange):
     """4 iterations: #2 and #4 densify the static model and both instance models (clone + split with the seeded draw +
     prune), #3 resets the opacities and steps the new models."""

@@ -23,7 +23,7 @@ VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH, VR_BUF_BACKWARD = 0, 
 
 # every symbol include/vegs_rast.h declares
 EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_backward_render", "vr_backward_preprocess", "vr_mark_visible", "vr_get_counters",
-           "vr_count_fragments", "vr_count_blended", "vr_export_needed", "vr_debug_export_binning", "vr_debug_set_guard", "vr_debug_raise_guard", "vr_profile_level", "vr_profile_collect",
+           "vr_count_fragments", "vr_count_blended", "vr_count_flushes", "vr_export_needed", "vr_debug_export_binning", "vr_debug_set_guard", "vr_debug_raise_guard", "vr_profile_level", "vr_profile_collect",
            "vr_knn3_mean_dist2", "vr_photometric_forward", "vr_photometric_backward",
            "vr_normal_guidance_forward", "vr_normal_guidance_backward", "vr_training_loss_forward", "vr_training_loss_backward", "vr_adam_step", "vr_densify_stats",
            "vr_densify_plan_words", "vr_densify_plan", "vr_densify_apply", "vr_reset_opacity",
@@ -165,6 +165,8 @@ def load():
     lib.vr_count_fragments.argtypes = [C.POINTER(VrSaved), C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]
     lib.vr_count_blended.restype = C.c_int
     lib.vr_count_blended.argtypes = [C.POINTER(VrSaved), C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]
+    lib.vr_count_flushes.restype = C.c_int
+    lib.vr_count_flushes.argtypes = [C.POINTER(VrSaved), C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]
     lib.vr_export_needed.restype = C.c_int
     lib.vr_export_needed.argtypes = [C.POINTER(VrSaved), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.vr_debug_export_binning.restype = C.c_int
@@ -339,6 +341,15 @@ def count_blended(grad_fn, H, W, device):
     out = C.c_int64(0)
     with torch.cuda.device(device):
         check(load().vr_count_blended(C.byref(saved), H, W, torch.cuda.current_stream(device).cuda_stream, C.byref(out)))
+    return out.value
+
+
+def count_flushes(grad_fn, H, W, device):
+    """(list entry, region) flushes of the render backward behind `grad_fn`: x 17 = its global fp32 atomics."""
+    saved = saved_of(grad_fn)
+    out = C.c_int64(0)
+    with torch.cuda.device(device):
+        check(load().vr_count_flushes(C.byref(saved), H, W, torch.cuda.current_stream(device).cuda_stream, C.byref(out)))
     return out.value
 
 

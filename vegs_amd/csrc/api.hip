@@ -764,6 +764,34 @@ int vr_count_blended(const VrSaved* saved, int32_t H, int32_t W, void* stream, i
     return VR_OK;
 }
 
+int vr_count_flushes(const VrSaved* saved, int32_t H, int32_t W, void* stream, int64_t* flushes)
+{
+    g_err[0] = 0;
+    if (!saved || !saved->image || !saved->binning || !flushes || H <= 0 || W <= 0)
+        return fail(VR_ERR_INVALID_ARGUMENT, "count_flushes: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (int rt = check_ticket(saved->ticket, s)) return rt;
+    Camera cam = {};
+    cam.H = H; cam.W = W;
+    cam.gx = (W + TILE - 1) / TILE;
+    cam.gy = (H + TILE - 1) / TILE;
+    const size_t N = (size_t)H * W, T = (size_t)cam.gx * cam.gy;
+    const ImageLayout IL = image_layout(N);
+    const size_t cap = saved->binning_capacity > 0 ? (size_t)saved->binning_capacity : (size_t)saved->num_rendered;
+    const BinLayout BL = bin_layout(T, cap);
+    unsigned long long* ctr = (unsigned long long*)((char*)saved->image + IL.counters) + 1;
+    *flushes = 0;
+    if (saved->num_rendered == 0) return VR_OK;
+    int rc = launch_count_flushes(cam, (long)cap, (const uint32_t*)((const char*)saved->binning + BL.seg_off),
+                                  (const unsigned long long*)((const char*)saved->binning + BL.segmask), ctr, s);
+    if (rc) return rc;
+    unsigned long long host = 0;
+    VR_HIP(hipMemcpyAsync(&host, ctr, sizeof host, hipMemcpyDeviceToHost, s));
+    VR_HIP(hipStreamSynchronize(s));
+    *flushes = (int64_t)host;
+    return VR_OK;
+}
+
 int vr_export_needed(const VrSaved* saved, int32_t H, int32_t W, uint32_t* out, void* stream)
 {
     g_err[0] = 0;

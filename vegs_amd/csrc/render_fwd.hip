@@ -668,6 +668,38 @@ int launch_count_blended(const Camera& cam, const int2* ranges, const uint32_t* 
     return 0;
 }
 
+// (entry, region) pairs of the NEEDED segments whose relevance bit is set: each is one flush of k_seg_bwd = 17 global
+// fp32 atomics (the L2-atomic figure of SURVEY 8d)
+__global__ void __launch_bounds__(256)
+k_count_flushes(const uint32_t* __restrict__ seg_off, int ntiles, uint32_t nseg, const unsigned long long* __restrict__ segmask,
+                unsigned long long* __restrict__ out)
+{
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long cnt = 0;
+    if (b < nseg) {
+        const int4 si = reinterpret_cast<const int4*>(seg_off + seg_tile_offset(ntiles))[b];
+        if (si.x >= 0 && ((uint32_t)si.w >> 30) != 0u)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cnt += (unsigned long long)__popcll(segmask[(size_t)b * 16 + k]);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(out, cnt);
+}
+
+int launch_count_flushes(const Camera& cam, long R, const uint32_t* seg_off, const unsigned long long* segmask,
+                         unsigned long long* out_dev, hipStream_t s)
+{
+    VR_HIP(hipMemsetAsync(out_dev, 0, sizeof(unsigned long long), s));
+    const int ntiles = cam.gx * cam.gy;
+    const size_t nseg = seg_capacity(R, ntiles);
+    if (ntiles > 0 && nseg > 0) {
+        hipLaunchKernelGGL(k_count_flushes, dim3(cdiv((long)nseg, 256)), dim3(256), 0, s, seg_off, ntiles, (uint32_t)nseg, segmask, out_dev);
+        VR_KERNEL_CHECK("count_flushes", s, false);
+    }
+    return 0;
+}
+
 size_t render_fwd_scratch_bytes(long R, int ntiles)
 {
     const size_t nseg = seg_capacity(R, ntiles);

@@ -134,6 +134,8 @@ size_t render_bwd_det_bytes(long R, int P);
 // B = blended (pixel, splat) pairs of a finished forward (one thread per pixel walks its list; bookkeeping only)
 int launch_count_blended(const Camera& cam, const int2* ranges, const uint32_t* point_list, const Splat* rec,
                          const uint32_t* n_contrib, unsigned long long* out_dev, hipStream_t s);
+int launch_count_flushes(const Camera& cam, long R, const uint32_t* seg_off, const unsigned long long* segmask,
+                         unsigned long long* out_dev, hipStream_t s);
 
 // ---- preprocess_bwd.hip
 bool preprocess_bwd_writes_all_sh(int M, const float* shs, const float* dL_dshs);

@@ -244,6 +244,7 @@ class Trainer:
             from . import xgmi
             self.direct = xgmi.DirectExchange(self.rank, self.world, device, group)
         self.last = {}
+        self.sh_adam_events = None
 
     # ---- layout of the op inputs: static rows, then the instances' in order
     def _instance_rows(self):
@@ -392,13 +393,15 @@ class Trainer:
         # statistics of THIS iteration's view batch: summed over the views first (and over the ranks), then added -- so that
         # N ranks x 1 view and 1 process x N views add the same numbers in the same order
         tmp = None if single else torch.zeros(3, rows, device=self.device)
-        overlap = self.xch is not None and n_local == 1
+        overlap = (self.xch is not None or self.direct is not None) and n_local == 1
+        if self.direct is not None:      # (collective; a no-op while the model fits the window)
+            self.direct.reserve(11 * P0 + 64, 3 * rows * n_local + 3 * n_local + 64)
         factors, campos, losses, pkgs = [], [], [], []
         for v in views:
             ct = v.get("cam_t") or harness.cam_tensors(v["cam"], self.device)
             loss, pkg = self.forward_loss(v["cam"], ct, deg, bg, v["gt"], v["normal"])
             if overlap:          # the factors start travelling between the backward's two halves
-                with self.xch.armed(ct["campos"]):
+                with (self.xch if self.xch is not None else self.direct).armed(ct["campos"]):
                     loss.backward()
             else:
                 loss.backward()
@@ -423,7 +426,7 @@ class Trainer:
                 Cv = torch.stack(campos).to(self.device, torch.float32)
             if world > 1:
                 if self.direct is not None:
-                    Fv, Cv = self.direct.exchange(static_others, Fv, Cv, n_local)
+                    Fv, Cv = self.direct.finish(static_others) if overlap else self.direct.exchange(static_others, Fv, Cv, n_local)
                 elif overlap:
                     Fv, Cv = self.xch.finish(static_others)
                 elif self.factored_sh:
@@ -464,8 +467,14 @@ class Trainer:
             # ---- densification / opacity reset on schedule, then the optimizers (train.py:283-320, :254-275)
             replaced = self._scheduled()
             if self.factored_sh and "static" not in replaced:
+                ev = self.sh_adam_events          # (benchmarks: a HIP event pair around the SH Adam launch, when armed)
+                if ev is not None:
+                    ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+                    ev[-1][0].record()
                 optim.adam_step_sh_factored(self.opt, self.p["f_dc"], self.p["f_rest"], self.p["xyz"].detach(), Cv,
                                             Fv[:, :P0], deg, 1.0 / n_total)
+                if ev is not None:
+                    ev[-1][1].record()
             opts = [self.opt] + [m.opt for m in self.instances] + [bm.optimizer for bm in self.box_models]
             if self.fused:
                 optim.step_many(opts)               # ONE multi-tensor launch: static model, instance models, pose corrections

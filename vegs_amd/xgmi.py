@@ -36,6 +36,7 @@ class DirectExchange:
         self.win = None
         self.parity = 0
         self._pending = None
+        self._side = None
 
     # ---- window management (collective: every rank must make the same calls with the same sizes)
     def _ensure(self, reduce_floats, gather_floats):
@@ -179,6 +180,45 @@ class DirectExchange:
     def check(self):
         with torch.cuda.device(self.device):
             _capi.check(_capi.load().vr_xgmi_check(self.ctx, torch.cuda.current_stream(self.device).cuda_stream))
+
+    # ---- overlapped use, like vegs_amd.dist.FactorExchange: the factors start travelling between the backward's halves
+    def armed(self, campos):
+        """`with ex.armed(campos): loss.backward()` -- the op's backward hands its SH factor [rows,3] to begin_gather on a
+        SIDE stream as soon as the render backward has produced it, so the pushes to the peers run under
+        k_preprocess_bwd.  Size the window first (reserve()): nothing may be re-allocated while a gather is in flight."""
+        import contextlib
+        from . import rasterizer
+
+        @contextlib.contextmanager
+        def scope():
+            if self._side is None:
+                self._side = torch.cuda.Stream(self.device)
+            c = campos.detach().to(self.device, torch.float32).reshape(1, 3).contiguous()
+
+            def on_factors(factor):
+                cur = torch.cuda.current_stream(self.device)
+                self._side.wait_stream(cur)
+                f = factor.detach()
+                f.record_stream(self._side)
+                self.begin_gather([f[None], c], stream=self._side)
+            old = rasterizer.set_backward_split_hook(on_factors)
+            try:
+                yield self
+            finally:
+                rasterizer.set_backward_split_hook(old)
+        return scope()
+
+    def finish(self, tensors, n_local=1):
+        """After the armed backward: all-reduce (mean) of the tensors' gradients -- left as views of the window -- and the
+        gathered (F [world, rows, 3], C [world, 3])."""
+        if self._pending is None:
+            raise RuntimeError("DirectExchange.finish(): the backward did not deliver a factor (was the op called with sh_color_grad?)")
+        grads = [t for t in tensors if t.grad is not None]
+        out = self.allreduce_mean([t.grad for t in grads], 1.0 / self.world)
+        for t, g in zip(grads, out):
+            t.grad = g
+        F, Cc = self.finish_gather()
+        return F.reshape((self.world * n_local,) + tuple(F.shape[2:])), Cc.reshape(self.world * n_local, 3)
 
     # ---- the trainer's exchange (vegs_amd.iteration.Trainer, exchange="direct")
     def exchange(self, tensors, Fv, Cv, n_local):

@@ -207,6 +207,27 @@ def test_bench_two_ranks_gloo_transport(tmp_path):
     assert ex["ms_per_step_without_exchange"] > 0 and "exchange_exposed_ms" in ex
 
 
+@pytest.mark.parametrize("exchange", ["factored", "direct"])
+def test_bench_eight_ranks_full_size_dry_run(exchange):
+    """BASELINE C4 at FULL size -- 2 M Gaussians, 8 views per iteration, one per rank -- as the driver launches it
+    (torch.distributed.run, bench.py --gpus 8), with the eight ranks sharing the one GPU of this box (8 x ~2.2 GB): the
+    production view assignment, split backward, overlapped exchange and local SH rebuild at the headline size.  Transport:
+    gloo staged through the host ("factored": what stands in for RCCL here, which refuses several ranks per device) and
+    the direct hipIpc exchange (the ranks map each other's windows exactly as eight GPUs would).  What a single-GPU box
+    cannot show is RCCL itself at N = 8 and the xGMI links."""
+    import json
+    env = dict(os.environ, VEGS_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2",
+           "--warmup", "1", "--repeats", "1", "--no-cpu-baseline", "--no-variants", "--exchange", exchange]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 8 and res["config"]["gaussians"] == 2_000_000 and res["value"] > 0
+    assert res["exchange"]["scheme"].startswith(exchange) and res["exchange"]["exchange_bytes_per_rank"] == 7 * 12 * 2_000_000 + int(14 / 8 * 44 * 2_000_000)
+    assert res["mfragments_per_s"] > 0 and res["roofline"]["launches_timed"] > 0
+
+
 def test_bench_line_contract_single_gpu():
     """bench.py's one JSON line carries everything the driver and the judge read (N = 1, small workload)."""
     import json

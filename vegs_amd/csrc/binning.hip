@@ -526,6 +526,10 @@ constexpr long ONESWEEP_MAX_N = (long)FAN * FAN * FAN * RADIX_BLOCK;   // 16.7 M
 // alternative to a bound would be a hung queue.
 constexpr int SPIN_CHECK = 256;
 constexpr unsigned long long SPIN_TICKS = 200000000ull;   // 2 s at 100 MHz
+// ... AND the waiter must itself have polled for about as long: the wall clock also runs while the whole process is
+// switched out (several processes time-slicing one GPU), when its predecessors cannot post either.  A poll is a round of
+// dependent device-scope loads (1 ... 2.5 us): 2^20 of them are 1 ... 2.5 s of the waiter's own execution.
+constexpr int SPIN_MIN_POLLS = 1 << 20;
 struct SpinClock {
     unsigned long long t0 = 0;
     // true once the wait has lasted longer than SPIN_TICKS (call once per poll)
@@ -534,7 +538,7 @@ struct SpinClock {
         if ((polls & (SPIN_CHECK - 1)) != SPIN_CHECK - 1) return false;
         const unsigned long long now = __builtin_amdgcn_s_memrealtime();
         if (t0 == 0) { t0 = now | 1ull; return false; }
-        return now - t0 > SPIN_TICKS;
+        return now - t0 > SPIN_TICKS && polls >= SPIN_MIN_POLLS;
     }
 };
 
@@ -1118,6 +1122,9 @@ k_tile_ranges(const uint32_t* __restrict__ tkeys, long R, int2* __restrict__ ran
         __hip_atomic_store(&post[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (j >= R) return;
+    // A timed-out wait left the lists of THIS view invalid (keys may be stale memory): leave every tile empty -- the ranges
+    // were cleared by the compaction -- so that nothing downstream indexes with them; the view is reported through the ring.
+    if (err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     uint32_t k = tkeys[j];
     if (j == 0) ranges[k].x = 0;
     else {

@@ -333,7 +333,9 @@ extern "C" int vr_xgmi_attach(VrXgmi* x, const void* handles)
 static int xg_grid(long floats)
 {
     const long g = (floats + XG_CHUNK - 1) / XG_CHUNK;
-    return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));      // link-bound kernels: a modest grid leaves the CUs to compute kernels
+    return (int)(g < 1 ? 1 : (g > 128 ? 128 : g));      // link-bound kernels: a modest grid leaves the CUs to compute kernels
+                                                        // (and, with N processes on ONE GPU, room for every process's pushes
+                                                        // beside the others' spinning reduce workgroups: 8 x 128 x 256 threads)
 }
 
 extern "C" int vr_xgmi_allreduce(VrXgmi* x, const VrXgmiSegment* segs, int32_t count, float scale,

@@ -33,7 +33,23 @@ def init_from_env(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        _shared_device_precautions(world)
     return rank, world, local
+
+
+def _shared_device_precautions(world):
+    """Several ranks on ONE GPU (the single-GPU test configuration; production is one process per GPU): the single-launch
+    radix passes of the binning make a workgroup wait for lower-indexed workgroups of the same launch, which is safe as
+    long as that launch's workgroups are dispatched in order onto free CUs -- not when eight processes' launches
+    oversubscribe the chip and wait on each other's CU slots (observed: 8 ranks x 2 M Gaussians on one MI355X: waits
+    timing out, views failed).  Those ranks take the multi-launch passes without inter-workgroup waits instead
+    (VR_FLAG_SCAN_BINNING: same lists, bit for bit)."""
+    if not torch.cuda.is_available():
+        return
+    per_node = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if per_node > torch.cuda.device_count():
+        from . import rasterizer
+        rasterizer.set_flags(rasterizer.get_flags() | rasterizer.FLAG_SCAN_BINNING)
 
 
 def view_for_rank(step, rank, world, n_views):

@@ -272,41 +272,6 @@ def stage_profile(step, steps):
     return {k: round(v[0] / max(v[1], 1), 4) for k, v in st.items() if v[1] > 0}
 
 
-def drift_by_training(sc, deg, cams, cam_ts, gouts, device, iters, seed=9):
-    """What lies between two visits of a camera in the reference's loop (train.py:126-128 pops cameras without
-    replacement: one visit per epoch): `iters` iterations of the counterpart of train.py:143-168,196,292-320 -- render,
-    L1+SSIM + normal guidance against fixed random targets, backward, densification statistics, fused Adam at the
-    REFERENCE's learning rates -- followed by one prune (opacity < 0.005, scene/gaussian_model.py:397-407) and one clone
-    of the Gaussians with the largest accumulated screen-space gradient (top 1 %, :365-395).  Runs with the hint cache
-    suspended (the cache keeps what the cameras' LAST visit before this epoch recorded).  Returns the new scene dict."""
-    from vegs_amd import iteration, rasterizer
-    rng = np.random.default_rng(seed)
-    tr = iteration.Trainer(sc, device, fused=True, lrs=iteration.REFERENCE_LRS)
-    bg = torch.zeros(3, device=device)
-    H, W = cams[0].image_height, cams[0].image_width
-    gts = [torch.tensor(rng.uniform(0, 1, (3, H, W)).astype(np.float32), device=device) for _ in range(4)]
-    normals = [torch.tensor(rng.normal(size=(3, H, W)).astype(np.float32), device=device) for _ in range(4)]
-    was = rasterizer._use_hints
-    rasterizer._use_hints = False          # suspended, NOT cleared
-    try:
-        for it in range(iters):
-            v = int(rng.integers(len(cams)))
-            tr.step(cams[v], cam_ts[v], deg, bg, gts[it % 4], normals[it % 4])
-    finally:
-        rasterizer._use_hints = was
-    T = iteration.op_inputs(tr.p)
-    grad = (tr.accum / tr.denom.clamp(min=1)).reshape(-1)
-    keep = T["opacities"].reshape(-1) >= 0.005
-    thr = torch.quantile(grad[torch.randperm(grad.numel(), device=device)[:1_000_000]], 0.99)
-    clone = keep & (grad >= thr)
-    idx = torch.cat((torch.nonzero(keep).reshape(-1), torch.nonzero(clone).reshape(-1)))
-    out = {k: v[idx].contiguous().cpu().numpy() for k, v in T.items()}
-    info = {"iterations": iters, "pruned": int((~keep).sum()), "cloned": int(clone.sum()), "gaussians_after": int(idx.numel())}
-    del tr
-    torch.cuda.empty_cache()
-    return out, info
-
-
 def warm_hints(step, n_views):
     """Two passes over every camera: a key's hint array exists from its second sighting on (vegs_amd/rasterizer.py)."""
     for i in range(2 * n_views):
@@ -314,49 +279,26 @@ def warm_hints(step, n_views):
 
 
 def variant(name, sc, deg, cams, device, steps, warmup, factored=False, hints="off", mode="train", repeats=3, vps=1,
-            streams=1):
+            streams=1, flags=0):
     """A few steps of another scene / camera / operator configuration, reported next to the headline (N = 1 only).
-    hints: "off" = per-camera needed-segment hints disabled, as in the headline; "warm" = every camera was rendered
-    before with the SAME model (the best case: zero drift); "epoch" = the hints are one epoch old: recorded, then the
-    model went through drift_by_training (300 iterations at the reference's learning rates + one prune/clone), then the
-    timed first visits.  mode: see make_step."""
+    hints: "off" = per-camera needed-segment hints disabled, as in the headline; "warm" (forward-only modes: the cache
+    serves forwards under no_grad only, vegs_amd/rasterizer.py) = every camera was rendered before with the SAME model --
+    evaluation of fixed cameras.  mode: see make_step."""
     from vegs_amd import rasterizer
     old = rasterizer.needed_hints(hints != "off")
+    old_flags = rasterizer.set_flags(rasterizer.get_flags() | flags)
     extra = {}
     try:
         wl = prepare(sc, deg, cams, device, np.random.default_rng(77))
         step = make_step(wl, 0, 1, vps, factored, mode=mode, streams=streams)
         if hints == "warm":
             warm_hints(step, len(cams))
-        elif hints == "epoch":
-            warm_hints(step, len(cams))                      # hints of the model as it is now
-            sc2, info = drift_by_training(sc, deg, cams, wl["cam_ts"], wl["gouts"], device, 300)
-            extra["drift"] = info
-            cam_ts = wl["cam_ts"]
-            del wl, step
-            torch.cuda.empty_cache()
-            was = rasterizer._use_hints
-            rasterizer._use_hints = False                    # counters of the drifted model without touching the hints
-            wl = prepare(sc2, deg, cams, device, np.random.default_rng(77), cam_ts=cam_ts)
-            rasterizer._use_hints = was
-            step = make_step(wl, 0, 1, 1, factored, mode=mode)
-            rasterizer._use_hints = False                    # allocator / caches warm for the new model size, hints untouched
-            for i in range(4):
-                step(i)
-            rasterizer._use_hints = was
-            warmup, repeats = 0, 1                           # the timed steps ARE the first visits after the epoch
-            steps = min(steps, len(cams))
         for i in range(warmup):
             step(i)
         dt, done, runs = timed_median(step, steps, 1, repeats)
-        if hints == "epoch":               # the same drifted model without hints: what the stale hints are measured against
-            was = rasterizer._use_hints
-            rasterizer._use_hints = False
-            dt_off, _, _ = timed_median(step, steps, 1, 3)
-            rasterizer._use_hints = was
-            extra["same_model_hints_off_ms_per_view"] = round(dt_off / steps * 1e3, 4)
     finally:
         rasterizer.needed_hints(old)
+        rasterizer.set_flags(old_flags)
     cn = wl["counters"]
     mean = {k: float(np.mean([cn[v][k] for v in done])) for k in ("V", "R", "F", "B")}
     nv = len(done)                      # steps x views per step
@@ -471,9 +413,6 @@ def main():
                          "the other 11 floats; dense = RCCL all-reduce of all 59 floats per Gaussian; direct = the factored "
                          "scheme over hand-written peer-to-peer kernels: every rank pushes 1/N shards into all peers' hipIpc "
                          "windows at once, vegs_amd/csrc/xgmi.hip)")
-    ap.add_argument("--hints", choices=["off", "warm"], default="off",
-                    help="per-camera needed-segment hints in the HEADLINE: off (default: every view costs what a camera's "
-                         "first visit costs -- a number any training loop meets) or warm (zero model drift: the best case)")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported "
                     "(the driver fixes --steps 20 = 26 ms per region: five regions make the median robust)")
     ap.add_argument("--disc-scale", type=float, default=1.0,
@@ -501,14 +440,12 @@ def main():
     K = (deg + 1) ** 2
     n_views = len(cams)
     from vegs_amd import rasterizer
-    rasterizer.needed_hints(args.hints == "warm")
+    rasterizer.needed_hints(False)
     wl = prepare(sc, deg, cams, device, np.random.default_rng(1234))
     counters, gouts = wl["counters"], wl["gouts"]
     vps = max(1, args.views_per_step)
     step = make_step(wl, rank, world, vps, exchange=args.exchange, streams=args.streams)
 
-    if args.hints == "warm":
-        warm_hints(step, n_views)
     for i in range(args.warmup):
         step(i)
     _capi.profile_level(1)          # level 1: HIP events around the roofline kernel only (one launch in four), inside the timed region
@@ -592,10 +529,8 @@ def main():
         "config": {"workload": f"{args.workload}: {P} street Gaussians (VEGS disc init), SH deg {deg}, {W}x{H} "
                                f"KITTI-360 intrinsics, {n_views} views cycled, 12 output channels + colour/quat/scale grads; "
                                + (f"EVERY DISC x{args.disc_scale} (--disc-scale: not the headline workload); " if args.disc_scale != 1.0 else "")
-                               + ("per-camera needed-segment hints OFF: every view is rendered as a camera's first visit"
-                                  if args.hints == "off" else
-                                  "per-camera needed-segment hints WARM with zero model drift (best case; see variants)"),
-                   "hints": args.hints,
+                               + "every view is rendered as a camera's first visit (no per-camera state carried between views)",
+                   "hints": "off",
                    "gaussians": P, "width": W, "height": H, "views_per_step_per_gpu": vps,
                    "parallelism": f"view-sharded x{world}" + ("" if world == 1 else
                                                               " + direct hipIpc all-gather of SH factors (3 f32) + reduce-scatter/all-gather (11 f32) per Gaussian"
@@ -632,11 +567,10 @@ def main():
                     cams[:8], device, 8, 2),
             variant("headline scene, SH gradient returned as its 3-float factor (sh_color_grad) instead of [P,16,3]", sc,
                     deg, cams[:8], device, 16, 4, factored=True),
-            variant("headline scene, needed-segment hints WARM, zero model drift (every camera rendered twice before with "
-                    "the same model): the best case of the hint cache", sc, deg, cams, device, 16, 4, hints="warm"),
-            variant("headline scene, hints ONE EPOCH OLD: recorded, then 300 training iterations at the reference's "
-                    "learning rates + one prune/clone (train.py:126-128,292-320), then the timed first visits", sc, deg,
-                    cams, device, 16, 0, hints="epoch"),
+            variant("headline scene, FORWARD ONLY under no_grad with per-camera needed-segment hints WARM (the same fixed "
+                    "cameras of a static model rendered again: the one place the hint cache is offered -- in training it lost "
+                    "1.5 % once the hints were an epoch old, BENCH_r03, and a differentiated forward no longer gets one)", sc,
+                    deg, cams, device, 16, 4, hints="warm", mode="forward"),
             variant("headline scene, op called without the reference's render() glue (one persistent means2D leaf instead "
                     "of zeros_like + 0 / retain_grad per view): the difference to the headline is ATen glue", sc, deg, cams,
                     device, 16, 4, mode="noglue"),
@@ -648,9 +582,12 @@ def main():
                     "autograd: + a dense accumulate per view)", sc, deg, cams, device, 4, 1, vps=8),
             variant("headline scene, a batch of 8 views per iteration, TWO VIEWS IN FLIGHT on two HIP streams", sc, deg,
                     cams, device, 4, 1, vps=8, streams=2),
+            variant("headline scene with VR_FLAG_FAST_EXP: the compositing's 2^x by v_exp_f32 in forward AND backward (lists "
+                    "bit-exact, images within 1e-5 of the bit-exact mode but for threshold fragments; NOT the headline mode)",
+                    sc, deg, cams, device, 16, 4, flags=rasterizer.FLAG_FAST_EXP),
         ]
-        res["aten_glue_ms_per_view"] = round(res["ms_per_step"] / vps - res["variants"][5]["ms_per_view"], 4) \
-            if args.hints == "off" else None
+        noglue = [v for v in res["variants"] if "without the reference's render() glue" in v["workload"]][0]
+        res["aten_glue_ms_per_view"] = round(res["ms_per_step"] / vps - noglue["ms_per_view"], 4)
     if world == 1 and not args.no_cpu_baseline:
         cpu_views = [0, 2, 4, 6, 8, 10, 12, 14]           # ~1.6 s each on the box's host cores: 10 ... 15 s of CPU work
         dt, frags, cores = cpu_baseline(sc, deg, cams, gouts, cpu_views)

@@ -119,7 +119,14 @@ typedef enum VrFlags {
      * launches and their 64 bytes per Gaussian each way in a training iteration.  Needs scales and rotations (not
      * cov3D_precomp).  With an SH tail (VrInputs.shs_tail) only the rows in front of tail_start are raw: the rows of the
      * box instances behind the static model arrive activated and transformed (gaussian_renderer/__init__.py:121-186). */
-    VR_FLAG_RAW_PARAMS = 1u << 12
+    VR_FLAG_RAW_PARAMS = 1u << 12,
+    /* ABI v8.  The Gaussian's 2^x in the compositing kernels by the hardware's transcendental instruction (v_exp_f32,
+     * ~1 ulp) instead of the bit-exact polynomial the CPU checker restates -- in the forward AND in the backward of the
+     * view (the same instruction both ways: they agree on which fragments reach alpha >= 1/255).  Tile lists, radii and
+     * ranges are unaffected (bit-exact); images move by ~1e-6, except that a fragment whose alpha sits within an ulp of
+     * 1/255 (about one in 10^7) may be classified the other way, which moves its pixel by up to ~1/255 of a channel --
+     * as any two correct implementations of exp() differ.  The bit-exact mode stays the default and the test mode. */
+    VR_FLAG_FAST_EXP = 1u << 13
 } VrFlags;
 
 /* The op's tensor arguments (reference gaussian_renderer/__init__.py:86-94). Exactly one of

@@ -5,18 +5,19 @@ import os
 
 def test_needed_hint_cache_is_opt_in(monkeypatch):
     """The per-camera needed-segment hints pay only while the model stands still between two visits of a camera; a
-    training loop revisits a camera once per epoch, where they cost time: off unless asked for."""
+    training loop revisits a camera once per epoch, where they cost time: off unless asked for,
+    and then for forwards that will not be differentiated (evaluation) only."""
     from vegs_amd import rasterizer
     monkeypatch.delenv("VEGS_RAST_HINTS", raising=False)
     r = importlib.reload(rasterizer)
     assert r._use_hints is False
     monkeypatch.setenv("VEGS_RAST_HINTS", "1")
     r = importlib.reload(rasterizer)
-    assert r._use_hints is True
+    assert r._use_hints == "eval"            # forwards under no_grad only: a training forward never gets a hint
     monkeypatch.setenv("VEGS_RAST_HINTS", "0")
     r = importlib.reload(rasterizer)
     assert r._use_hints is False
-    assert r.needed_hints(True) is False and r.needed_hints(False) is True
+    assert r.needed_hints(True) is False and r.needed_hints("always") == "eval" and r.needed_hints(False) == "always"
 
 
 def test_flag_constants_match_the_header():

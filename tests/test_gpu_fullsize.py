@@ -243,7 +243,7 @@ def _oracle_parity(name, sc_inputs, deg, cam, dev, hip_runs=1):
     gouts = [rng.normal(size=s).astype(np.float32) * 1e-3 if m else None
              for s, m in zip([(3, H, W), (1, H, W), (4, H, W), (3, H, W), (1, H, W)], (1, 0, 1, 1, 0))]
     settings = _settings(cam, [0, 0, 0], deg, 1.0, dev)        # ONE set of camera tensors: the hint key
-    old = rasterizer.needed_hints(True)
+    old = rasterizer.needed_hints("always")
     try:
         rasterizer._NEEDED.clear()
         for run in range(hip_runs):

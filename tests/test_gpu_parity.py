@@ -70,6 +70,9 @@ def _run_hip(settings, inputs, dev, gouts=None, flags=0):
     return out, grads, res
 
 
+FAST_EXP = 8192        # VR_FLAG_FAST_EXP (include/vegs_rast.h)
+
+
 def _export_binning(res, H, W, dev):
     """(point_list, ranges) of the forward that produced `res`, through vr_debug_export_binning."""
     from vegs_amd import _capi
@@ -104,9 +107,22 @@ def _check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=0, grad_rtol=GRAD
     assert res[0].grad_fn.num_rendered == st["R"]
     assert np.array_equal(rg, st["ranges"])
     assert np.array_equal(pl, st["point_list"])
-    # forward images: same fp32 operation order -> bit exact
-    for n in OUT_NAMES:
-        assert np.array_equal(h_out[n], o_out[n]), (n, np.abs(h_out[n] - o_out[n]).max())
+    if hip_flags & FAST_EXP:
+        # VR_FLAG_FAST_EXP: indices (above) stay bit-exact; the images follow v_exp_f32 instead of the checker's polynomial:
+        # <= 1e-5 abs (north star: 1e-4), except where a fragment's alpha sits within an ulp of 1/255 and is classified
+        # the other way -- its pixel moves by at most alpha * |attribute| ~ 1/255 of a channel.  Few, and bounded.
+        flipped = 0
+        for n in OUT_NAMES:
+            d = np.abs(h_out[n] - o_out[n])
+            scale = max(1.0, float(np.abs(o_out[n]).max()))
+            off = d > 1e-5 * scale
+            flipped = max(flipped, int(off.any(axis=0).sum()))
+            assert float(d.max()) <= 1.01 / 255.0 * scale, (n, float(d.max()))
+        assert flipped <= max(2, int(2e-5 * H * W)), flipped
+    else:
+        # forward images: same fp32 operation order -> bit exact
+        for n in OUT_NAMES:
+            assert np.array_equal(h_out[n], o_out[n]), (n, np.abs(h_out[n] - o_out[n]).max())
     o_grads = orc.backward(oc, st, *gouts)
     # geometry gradients of edge-on discs (conic conditioning > 20x the median) amplify the rounding of the sums they start
     # from; such rows are printed with their conditioning and held to 10 allowances (helpers.assert_grad_close)
@@ -236,6 +252,28 @@ def test_deterministic_backward_is_bit_reproducible(dev):
     for k in ("means3D", "shs", "opacities", "scales", "rotations", "means2D"):
         assert_grad_close("det " + k, runs[0][k], og[k], rtol=2e-4, floor=2e-7, outliers=1e-4, explain=explain, ill=ill)
         assert_grad_close("atomic vs det " + k, atomic[k], runs[0][k], rtol=1e-3, floor=1e-6, explain=explain, ill=ill)
+
+
+@pytest.mark.parametrize("det", [0, 256])
+def test_fast_exp_mode_against_the_oracle(det, dev):
+    """VR_FLAG_FAST_EXP: v_exp_f32 in k_seg_alpha, k_seg_blend AND k_seg_bwd.  Radii, lists and ranges bit-exact; images
+    within 1e-5 of the bit-exact checker (but for threshold fragments, bounded); gradients per row as in the default mode
+    -- forward and backward use the same instruction, so they agree on which fragments contributed (a mixed pair did
+    not: DESIGN section 4) --, with the atomic and with the deterministic backward; the latter bit-reproducible."""
+    from vegs_amd import scenes
+    sc, deg = scenes.scene_street(P=40000, length=60.0, sh_degree=3, seed=11)
+    cam = scenes.kitti_camera(0.0, 0.3, 688, 188)
+    inputs = dict(means3D=sc["means3D"], shs=sc["shs"], colors_precomp=None, opacities=sc["opacities"], scales=sc["scales"],
+                  rotations=sc["rotations"], cov3D_precomp=None)
+    h_out, h_grads, _, _ = _check_against_oracle(inputs, cam, [0.1, 0.2, 0.3], deg, 1.0, dev, seed=3, hip_flags=FAST_EXP | det)
+    if det:
+        again, g2, _, _ = _check_against_oracle(inputs, cam, [0.1, 0.2, 0.3], deg, 1.0, dev, seed=3, hip_flags=FAST_EXP | det)
+        for k in h_grads:
+            if h_grads[k] is not None:
+                assert np.array_equal(h_grads[k], g2[k]), k
+    # and it IS a different function: some image value differs from the bit-exact mode in the last bits
+    exact, _, _ = _run_hip(_settings(cam, [0.1, 0.2, 0.3], deg, 1.0, dev), inputs, dev)
+    assert any(not np.array_equal(exact[n], h_out[n]) for n in OUT_NAMES)
 
 
 def test_c1_random_10k(dev):
@@ -823,7 +861,7 @@ def test_needed_hint_never_changes_results(dev):
                             sc["rotations"], None)
         return o
 
-    old = rasterizer.needed_hints(True)
+    old = rasterizer.needed_hints("always")
     try:
         rasterizer._NEEDED.clear()
         a, fa, ga = run(1.0)                       # (1) first sighting of the camera: no hint, nothing allocated for it

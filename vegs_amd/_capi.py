@@ -18,6 +18,7 @@ FLAG_SCALE_MODIFIED, FLAG_DEPTH_NORMALIZED, FLAG_EXTRA_NO_ALPHA_GRAD, FLAG_FILL_
 FLAG_SCAN_BINNING = 512
 FLAG_ROUNDS_OFF, FLAG_ROUNDS_ON = 1024, 2048
 FLAG_RAW_PARAMS = 4096
+FLAG_FAST_EXP = 8192
 
 VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH, VR_BUF_BACKWARD = 0, 1, 2, 3, 4
 

@@ -21,7 +21,7 @@ static_assert(FLAG_SCALE_MODIFIED == VR_FLAG_SCALE_MODIFIED && FLAG_DEPTH_NORMAL
               FLAG_ROUNDS_OFF == VR_FLAG_ROUNDS_OFF && FLAG_ROUNDS_ON == VR_FLAG_ROUNDS_ON &&
               FLAG_RAW_PARAMS == VR_FLAG_RAW_PARAMS, "device-side flag constants must match include/vegs_rast.h");
 constexpr uint32_t KNOWN_FLAGS = FLAG_SCALE_MODIFIED | FLAG_DEPTH_NORMALIZED | FLAG_EXTRA_NO_ALPHA_GRAD | FLAG_FILL_EMPTY |
-                                 FLAG_DETERMINISTIC | FLAG_SCAN_BINNING | FLAG_ROUNDS_OFF | FLAG_ROUNDS_ON | FLAG_RAW_PARAMS;
+                                 FLAG_DETERMINISTIC | FLAG_SCAN_BINNING | FLAG_ROUNDS_OFF | FLAG_ROUNDS_ON | FLAG_RAW_PARAMS | FLAG_FAST_EXP;
 
 static thread_local char g_err[512] = "";
 static thread_local VrCounters g_counters = {0, 0, 0, 0, 0};
@@ -33,7 +33,10 @@ constexpr int MAX_DEVICES = 64;
 // it stands after all of that view's waiting passes (k_tile_ranges).  vr_backward / the export calls find the slot
 // through VrSaved.ticket = (mailbox id + 1) << 32 | seq -- PyTorch runs the op's backward on its autograd thread, so
 // the mailboxes are also registered process-wide.
-constexpr int RING_AT = 64, RING_SLOTS = 64, MAIL_BYTES = (RING_AT + 2 * RING_SLOTS) * 4;
+// RING_SLOTS bounds the forwards that may lie between a forward and ITS backward on one thread and device (each holds its
+// saved buffers -- GBs at the headline size -- so 1024 outstanding forwards is beyond any batch; 8 KB of pinned memory).
+// Beyond that the slot has been reused: check_ticket then says so instead of guessing.
+constexpr int RING_AT = 64, RING_SLOTS = 1024, MAIL_BYTES = (RING_AT + 2 * RING_SLOTS) * 4;
 struct Mailbox { uint32_t* pinned; uint32_t* pinned_dev; uint32_t seq; uint32_t* guard; uint32_t id; };
 static thread_local Mailbox g_mail[MAX_DEVICES] = {};
 struct MailRef { uint32_t* pinned; uint32_t* guard; int dev; };
@@ -91,7 +94,12 @@ static int check_ticket(uint64_t ticket, hipStream_t s)
     for (unsigned spins = 1;; ++spins) {
         const uint32_t got = __atomic_load_n(&slot[0], __ATOMIC_ACQUIRE);
         if (got == seq) break;
-        if ((int32_t)(got - seq) > 0 || synced) return VR_OK;   // reused by a later forward / never posted (failed forward)
+        if (synced) return VR_OK;                                // never posted (a forward that failed before its binning)
+        if ((int32_t)(got - seq) > 0) {                          // reused: more than RING_SLOTS forwards since this one
+            set_error("more than %d forwards lie between this call and the forward it belongs to: the record of that "
+                      "forward's binning guard is gone (run the backward closer to its forward)", RING_SLOTS);
+            return VR_ERR_INVALID_ARGUMENT;
+        }
         __builtin_ia32_pause();
         if ((spins & 4095u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
             VR_HIP(hipStreamSynchronize(s));   // the forward ran on this stream (same-stream contract of the op)

@@ -194,7 +194,7 @@ k_seg_suffix(int ntiles, uint32_t cap, const uint32_t* __restrict__ seg_off, con
 // 1.05 strips on average, so combining the strips in LDS before the global flush bought almost nothing.
 // NO_EXTRA / DET are compile-time (VR_FLAG_EXTRA_NO_ALPHA_GRAD, VR_FLAG_DETERMINISTIC): the common instantiation carries
 // neither their branches nor their registers (round 2 added them as run-time tests: 360 -> 373 us).
-template <bool NO_EXTRA, bool DET>
+template <bool NO_EXTRA, bool DET, bool FAST>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off, uint32_t cap,
           const uint32_t* __restrict__ seg_needed, const uint32_t* __restrict__ point_list,
@@ -338,7 +338,10 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                 // arithmetic; +14 us per view over two v_exp_f32 -- and so did the two cheaper-looking alternatives (a band
                 // test around the threshold with the exact function inline or out of line in the rare branch).
                 f2 G;
-                {
+                if (FAST) {      // VR_FLAG_FAST_EXP: the instruction the forward of this view used
+                    G.x = __builtin_amdgcn_exp2f(power.x);
+                    G.y = __builtin_amdgcn_exp2f(power.y);
+                } else {
                     const f2 n = {rintf(power.x), rintf(power.y)};
                     const f2 f = power - n;
                     f2 p = f2_splat(EXP2_C5);
@@ -519,16 +522,18 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
     hipLaunchKernelGGL(k_seg_suffix, dim3(2 * ntiles), dim3(256), 0, s, ntiles, (uint32_t)nseg, seg_off, seg_needed, Ubuf);
     VR_KERNEL_CHECK("seg_suffix", s, debug);
     prof_begin(VR_STAGE_K_SEG_BWD, s);
-#define VR_BWD(NOX, DETM)                                                                                              \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_bwd<NOX, DETM>), dim3(nseg * 4), dim3(64), 0, s, cam, ranges, seg_off,    \
+#define VR_BWD2(NOX, DETM, FST)                                                                                        \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_bwd<NOX, DETM, FST>), dim3(nseg * 4), dim3(64), 0, s, cam, ranges, seg_off, \
                        (uint32_t)nseg, seg_needed, point_list, rec, Tbuf, (const float*)Ubuf, final_T, n_contrib, dL_dcolor, dL_ddepth, \
                        dL_dquat, dL_dscale, dL_dalpha, gacc, gmean2D, segmask, dsum, gpart)
+#define VR_BWD(NOX, DETM) do { if (cam.flags & FLAG_FAST_EXP) VR_BWD2(NOX, DETM, true); else VR_BWD2(NOX, DETM, false); } while (0)
     {
         const bool nox = (cam.flags & FLAG_EXTRA_NO_ALPHA_GRAD) != 0u;
         if (gpart) { if (nox) VR_BWD(true, true); else VR_BWD(false, true); }
         else { if (nox) VR_BWD(true, false); else VR_BWD(false, false); }
     }
 #undef VR_BWD
+#undef VR_BWD2
     prof_end(VR_STAGE_K_SEG_BWD, s);
     VR_KERNEL_CHECK("seg_bwd", s, debug);
     if (gpart) {

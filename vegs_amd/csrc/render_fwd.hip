@@ -27,6 +27,7 @@
 
 namespace vr {
 
+constexpr int NPART = 13;      // planes of `part` per segment: 11 channel sums, the local product, the last contributor
 __device__ __forceinline__ uint32_t hinted_limit(uint32_t h) { return h + 2u + (h >> 3); }
 constexpr uint32_t AUTO_FIRST = 6u;    // segments of every tile computed in round 0 of a forward with automatic rounds
 // ... and at least this many more in round 1.  Swept 12 ... 48 at 13 and at 24 list segments per tile: the sparser scene wants
@@ -64,6 +65,7 @@ k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict_
             // is still alive behind them (k_seg_scan) -- most tiles never need more
             a = hint ? min(n, hinted_limit(min(hint[t], 0x3FFFFFFFu))) : min(n, auto_first);
             limit[t] = a;
+            a -= a > 0u ? 1u : 0u;      // the tile's FIRST segment is not on the list: k_seg_first takes it (below)
         }
         uint32_t incl = n, incl_a = a;      // two scans: all segments (global ids), round-0 segments (list positions)
 #pragma unroll
@@ -113,7 +115,7 @@ k_seg_tiles(int ntiles, const int2* __restrict__ ranges, uint32_t* __restrict__ 
     // flag 3 = behind the round-0 prefix of its tile: not in the round-0 list, k_seg_scan decides (and rewrites the flag)
     const bool up_front = (uint32_t)sl < limit[lo];
     seg_info[b] = make_int4(lo, first, min(SEG, r.y - first), sl | (up_front ? 0 : (int)(3u << 30)));
-    if (up_front) seg_off[seg_list_offset(ntiles, cap, 0) + seg_off[seg_actoff_offset(ntiles, cap) + lo] + sl] = b;
+    if (up_front && sl > 0) seg_off[seg_list_offset(ntiles, cap, 0) + seg_off[seg_actoff_offset(ntiles, cap) + lo] + sl - 1] = b;
 }
 
 // ---- NEEDED-SEGMENT HINT.  Half of the segments lie behind the point where every pixel of their tile has stopped
@@ -131,6 +133,7 @@ k_seg_tiles(int ntiles, const int2* __restrict__ ranges, uint32_t* __restrict__ 
 
 // Product of (1 - alpha) over one segment for the calling thread's pixel; also builds the segment's strip-relevance
 // masks and stores them.  Called by all 256 threads of a workgroup (contains block barriers).
+template <bool FAST>
 __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t* __restrict__ point_list,
                                                 const Splat* __restrict__ rec, float4 (*lds)[SEG],
                                                 unsigned long long* masks, unsigned long long* __restrict__ segmask)
@@ -163,7 +166,7 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
         const float power = splat_power2(a.x, a.y, a.z, a.w, b.x, pxf, pyf, dx, dy);
         const bool pre = !(power > 0.0f) && power >= b.z;
         if (__ballot(pre) == 0ull) return;  // cannot reach 1/255 anywhere in this strip
-        const float alpha = fminf(ALPHA_MAX, b.y * vr_exp2_unclamped(power));
+        const float alpha = fminf(ALPHA_MAX, b.y * exp2_sel<FAST>(power));
         const bool valid = pre && !(alpha < ALPHA_MIN);
         p = valid ? p * (1.0f - alpha) : p;
     };
@@ -194,6 +197,122 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
     return p;
 }
 
+// ---- A + C for a tile's FIRST segment in one pass.  Its boundary transmittance is 1 by definition, so nothing has to
+// wait for the chain: the workgroup builds the relevance masks and the local product like k_seg_alpha AND blends like
+// k_seg_blend (same expressions, same order: `part`, last contributor and the stop test are bit for bit what the two
+// kernels produced) -- alpha is evaluated once instead of twice for what are the most expensive segments of a view (every
+// pixel alive), their records are gathered once, and k_seg_blend's list loses a fifth of its entries.  For a pixel whose
+// stop test fires inside the segment the stored product is the one that fired it (< 1e-4: k_seg_scan takes the same
+// decision as with the product over the whole segment, fp32 products by factors <= 1 being monotone).
+// The first `ntiles` workgroups of k_seg_alpha<0>'s launch run this (one launch: the heavy first-segment workgroups start
+// first and the plain ones fill in behind them; as a launch of its own the 2064 workgroups -- a single resident set --
+// took 56 us, most of it waiting for the longest of them).
+template <bool FAST>
+__device__ __forceinline__ void seg_first_body(const Camera& cam, const int tile, const int2* __restrict__ ranges,
+                                               const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ point_list,
+                                               const Splat* __restrict__ rec, float* __restrict__ Pbuf,
+                                               unsigned long long* __restrict__ segmask, float* __restrict__ part,
+                                               float4 (*lds)[SEG], unsigned long long* masks)
+{
+    const uint32_t seg0 = seg_off[tile];
+    if (seg_off[tile + 1] == seg0) return;                     // empty tile
+    SegCtx c;
+    if (!seg_setup_at(cam, ranges, seg_off, seg0, threadIdx.x >> 6, c)) return;
+    {
+        const bool have = (int)threadIdx.x < c.count;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+        if (have) {
+            const float4* src = reinterpret_cast<const float4*>(rec + point_list[c.first + threadIdx.x]);
+            q0 = src[0];
+            q1 = src[1];
+            float4 s0 = q0, s1 = q1;       // x y kA kB | kC opacity thr2 depth (splat_k2: log2 units)
+            splat_k2(q0.z, q0.w, q1.x, q1.z, s0.z, s0.w, s1.x, s1.z);
+            lds[0][threadIdx.x] = s0;
+            lds[1][threadIdx.x] = s1;
+            lds[2][threadIdx.x] = src[2];  // r g b qw
+            lds[3][threadIdx.x] = src[3];  // qx qy qz s0
+            lds[4][threadIdx.x] = src[4];  // s1 s2 (clamp bits, pad)
+        }
+        seg_build_masks(c, have, q0, q1, masks);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) segmask[(size_t)c.seg * 16 + threadIdx.x] = masks[threadIdx.x];
+    const int w = threadIdx.x >> 6;
+    const float pyf = (float)c.py;
+    constexpr float GATED = 1e30f;            // (k_seg_blend: a finished pixel is moved out of reach)
+    constexpr float Tb = 1.0f;
+    float gx = c.inside ? (float)c.px : GATED;
+    float p = 1.0f, pstop = 1.0f;
+    f2 Cp[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) Cp[k] = f2_splat(0.0f);
+    float Cd = 0.0f;
+    int lastk = -1;
+    auto blend_one = [&](const int i, const float4 a, const float4 b) {
+        float dx, dy;
+        const float power = splat_power2(a.x, a.y, a.z, a.w, b.x, gx, pyf, dx, dy);
+        const bool pre = !(power > 0.0f) && power >= b.z;
+        if (__builtin_amdgcn_ballot_w64(pre) == 0ull) return;
+        const float alpha = fminf(ALPHA_MAX, b.y * exp2_sel<FAST>(power));
+        const bool valid = pre && !(alpha < ALPHA_MIN);
+        const float pn = p * (1.0f - alpha);
+        const bool stop = valid && (Tb * pn < T_EPS);
+        const bool apply = valid && !stop;
+        gx = stop ? GATED : gx;
+        pstop = stop ? pn : pstop;
+        if (__builtin_amdgcn_ballot_w64(apply) == 0ull) return;
+        const float wgt = apply ? alpha * (Tb * p) : 0.0f;
+        const float4 cc = lds[2][i];
+        const float4 d = lds[3][i];
+        const float2 e2 = *reinterpret_cast<const float2*>(&lds[4][i]);
+        const f2 w2 = f2_splat(wgt);
+        Cp[0] = f2_fma((f2){cc.x, cc.y}, w2, Cp[0]);
+        Cp[1] = f2_fma((f2){cc.z, cc.w}, w2, Cp[1]);
+        Cp[2] = f2_fma((f2){d.x, d.y}, w2, Cp[2]);
+        Cp[3] = f2_fma((f2){d.z, d.w}, w2, Cp[3]);
+        Cp[4] = f2_fma((f2){e2.x, e2.y}, w2, Cp[4]);
+        Cd = fmaf(b.w, wgt, Cd);
+        p = apply ? pn : p;
+        lastk = apply ? i : lastk;
+    };
+    for (int part_i = 0; part_i < 4; ++part_i) {
+        unsigned long long m = uniform64(masks[w * 4 + part_i]);
+        while (m) {
+            constexpr int NB = 4;
+            int kk[NB];
+            float4 av[NB], bv[NB];
+            int nb = 0;
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                if (m) {
+                    kk[t] = part_i * 64 + __builtin_ctzll(m);
+                    m &= m - 1;
+                    nb = t + 1;
+                } else {
+                    kk[t] = kk[0];
+                }
+                av[t] = lds[0][kk[t]];
+                bv[t] = lds[1][kk[t]];
+            }
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+                if (t < nb) blend_one(kk[t], av[t], bv[t]);
+        }
+        if (__builtin_amdgcn_ballot_w64(gx != GATED) == 0ull) break;     // every pixel of the strip is finished
+    }
+    const bool stopped = c.inside && gx == GATED;
+    Pbuf[(size_t)c.seg * SEG + threadIdx.x] = stopped ? pstop : p;
+    if (c.inside) {
+        float* dst = part + (size_t)c.seg * (NPART * SEG) + threadIdx.x;
+        const float Cs[NCH] = {Cp[0].x, Cp[0].y, Cp[1].x, Cd, Cp[1].y, Cp[2].x, Cp[2].y, Cp[3].x, Cp[3].y, Cp[4].x, Cp[4].y};
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) dst[k * SEG] = Cs[k];
+        dst[11 * SEG] = p;
+        const uint32_t last = lastk >= 0 ? (uint32_t)(lastk + 1) : 0u;       // (sl = 0: tile-relative index + 1)
+        dst[12 * SEG] = __uint_as_float(last | (stopped ? 0x80000000u : 0u));
+    }
+}
+
 // Window of a short tile's list that catch-up round ROUND (1, 2) of a hinted forward covers, given where the previous
 // round stopped (`lo`, from seg_needed) and the tile's segment count: round 1 looks half as far again (+ 8 segments) --
 // after an epoch of training the heavy tiles' counts have moved by up to +-50 % (profiles/tools/epoch_drift.py: 55 short
@@ -207,23 +326,27 @@ __device__ __forceinline__ uint32_t catchup_end(int round, uint32_t lo, uint32_t
 // ---- A: per (tile, segment, pixel) product of (1 - alpha).  ROUND 0 = the segments inside the hinted prefix of their
 // tile (all of them without a hint); ROUND 1, 2 = the catch-up rounds for the short tiles of a hinted forward (see
 // k_seg_scan): the segments still flagged 3 that fall into the round's window.
-template <int ROUND>
+template <int ROUND, bool FAST>
 __global__ void __launch_bounds__(256)
 k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off, uint32_t cap,
             const uint32_t* __restrict__ point_list, const Splat* __restrict__ rec, float* __restrict__ Pbuf,
-            unsigned long long* __restrict__ segmask)
+            unsigned long long* __restrict__ segmask, float* __restrict__ part)
 {
-    __shared__ float4 lds[2][SEG];
+    __shared__ float4 lds[ROUND == 0 ? 5 : 2][SEG];
     __shared__ unsigned long long masks[16];
     // the round's work list: round 0 one workgroup per entry (the grid is sized for it: AUTO_FIRST segments per tile
     // without a hint); the catch-up rounds a fixed grid striding over a list whose length only the device knows
     const int ntiles = cam.gx * cam.gy;
+    if (ROUND == 0 && (int)blockIdx.x < ntiles) {      // the tiles' FIRST segments: alpha and blend in one pass
+        seg_first_body<FAST>(cam, (int)blockIdx.x, ranges, seg_off, point_list, rec, Pbuf, segmask, part, lds, masks);
+        return;
+    }
     const uint32_t count = seg_off[seg_counts_offset(ntiles, cap) + ROUND];
     const uint32_t* const list = seg_off + seg_list_offset(ntiles, cap, ROUND);
-    for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+    for (uint32_t item = blockIdx.x - (ROUND == 0 ? (uint32_t)ntiles : 0u); item < count; item += gridDim.x) {
         SegCtx c;
         if (seg_setup_at(cam, ranges, seg_off, list[item], threadIdx.x >> 6, c)) {
-            const float p = seg_alpha_body(c, point_list, rec, lds, masks, segmask);
+            const float p = seg_alpha_body<FAST>(c, point_list, rec, lds, masks, segmask);
             Pbuf[(size_t)c.seg * SEG + threadIdx.x] = p;
         }
         if (ROUND == 0) break;       // (grid >= count in round 0)
@@ -356,9 +479,9 @@ k_seg_merge(int ntiles, uint32_t* __restrict__ seg_off, uint32_t cap)
 }
 
 // ---- C: blend one segment from its boundary transmittance into segment-local sums.
-// part[seg][k][pix], k = 0..10 channel sums, 11 = local product p, 12 = local last-contributor | done<<31
-constexpr int NPART = 13;
+// part[seg][k][pix], k = 0..10 channel sums, 11 = local product p, 12 = local last-contributor | done<<31 (NPART, above)
 
+template <bool FAST>
 __global__ void __launch_bounds__(64)
 k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off, uint32_t cap,
             const uint32_t* __restrict__ seg_needed, const uint32_t* __restrict__ point_list,
@@ -377,6 +500,7 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     const int ntiles = cam.gx * cam.gy;
     if ((blockIdx.x >> 2) >= seg_off[seg_counts_offset(ntiles, cap) + SEG_LIST_NEEDED]) return;    // beyond the needed list
     if (!seg_setup_at(cam, ranges, seg_off, seg_off[seg_list_offset(ntiles, cap, SEG_LIST_NEEDED) + (blockIdx.x >> 2)], w, c)) return;
+    if (c.sl == 0) return;                // a tile's first segment was blended by k_seg_first
     const int lane = threadIdx.x;
     const int pixslot = w * 64 + lane;
     // one batch of independent loads right after the segment descriptor (boundary transmittance, relevance masks,
@@ -442,7 +566,7 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
             const float power = splat_power2(a.x, a.y, a.z, a.w, b.x, gx, pyf, dx, dy);
             const bool pre = !(power > 0.0f) && power >= b.z;
             if (__builtin_amdgcn_ballot_w64(pre) == 0ull) return;
-            const float alpha = fminf(ALPHA_MAX, b.y * vr_exp2_unclamped(power));
+            const float alpha = fminf(ALPHA_MAX, b.y * exp2_sel<FAST>(power));
             const bool valid = pre && !(alpha < ALPHA_MIN);
             const float pn = p * (1.0f - alpha);
             const bool stop = valid && (Tb * pn < T_EPS);
@@ -647,7 +771,7 @@ k_count_blended(Camera cam, const int2* __restrict__ ranges, const uint32_t* __r
             splat_k2(a.z, a.w, b.x, b.z, kA, kB, kC, thr2);
             const float power = splat_power2(a.x, a.y, kA, kB, kC, pxf, pyf, dx, dy);
             if (power > 0.0f) continue;
-            const float alpha = fminf(ALPHA_MAX, b.y * vr_exp2(power));
+            const float alpha = fminf(ALPHA_MAX, b.y * ((cam.flags & FLAG_FAST_EXP) ? __builtin_amdgcn_exp2f(power) : vr_exp2(power)));
             if (!(alpha < ALPHA_MIN)) ++cnt;
         }
     }
@@ -737,23 +861,32 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     const size_t bound0 = (size_t)AUTO_FIRST * ntiles;      // round 0 of the automatic rounds: at most AUTO_FIRST segments per tile
     const unsigned grid0 = (unsigned)(!auto_rounds || nseg < bound0 ? nseg : bound0);
     const unsigned gridc = (unsigned)(nseg < 4096 ? nseg : 4096);
+    const bool fast = (cam.flags & FLAG_FAST_EXP) != 0u;
+#define VR_ALPHA(RD, FST, GRID)                                                                                           \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_alpha<RD, FST>), dim3(GRID), dim3(256), 0, s, cam, ranges,                   \
+                       (const uint32_t*)seg_off, (uint32_t)nseg, point_list, rec, Pbuf, segmask, part)
 #define VR_ROUND(RD, GRID)                                                                                                \
-    if (R > 0) hipLaunchKernelGGL(k_seg_alpha<RD>, dim3(GRID), dim3(256), 0, s, cam, ranges, (const uint32_t*)seg_off,     \
-                                  (uint32_t)nseg, point_list, rec, Pbuf, segmask);                                        \
+    if (R > 0) { if (fast) VR_ALPHA(RD, true, GRID); else VR_ALPHA(RD, false, GRID); }                                    \
     if (R > 0 || RD == 0) hipLaunchKernelGGL(k_seg_scan<RD>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (uint32_t)nseg, second, \
                                              (const float*)Pbuf, Tbuf, seg_needed, needed_hint)
-    VR_ROUND(0, grid0);
+    VR_ROUND(0, grid0 + (unsigned)ntiles);        // (+ the tiles' first segments: the launch's first `ntiles` workgroups)
     if (rounds) {
         VR_ROUND(1, gridc);
         VR_ROUND(2, gridc);
     }
 #undef VR_ROUND
+#undef VR_ALPHA
     VR_KERNEL_CHECK("seg_alpha / seg_scan rounds", s, debug);
     hipLaunchKernelGGL(k_seg_merge, dim3(cdiv((long)nseg, 256), SEG_QUEUES), dim3(256), 0, s, ntiles, seg_off, (uint32_t)nseg);
     if (R > 0) {
-        hipLaunchKernelGGL(k_seg_blend, dim3((unsigned)nseg * 4), dim3(64), 0, s, cam, ranges, (const uint32_t*)seg_off,
-                           (uint32_t)nseg, (const uint32_t*)seg_needed, point_list, rec, (const float*)Tbuf, part,
-                           (const unsigned long long*)segmask);
+        if (fast)
+            hipLaunchKernelGGL(k_seg_blend<true>, dim3((unsigned)nseg * 4), dim3(64), 0, s, cam, ranges, (const uint32_t*)seg_off,
+                               (uint32_t)nseg, (const uint32_t*)seg_needed, point_list, rec, (const float*)Tbuf, part,
+                               (const unsigned long long*)segmask);
+        else
+            hipLaunchKernelGGL(k_seg_blend<false>, dim3((unsigned)nseg * 4), dim3(64), 0, s, cam, ranges, (const uint32_t*)seg_off,
+                               (uint32_t)nseg, (const uint32_t*)seg_needed, point_list, rec, (const float*)Tbuf, part,
+                               (const unsigned long long*)segmask);
         VR_KERNEL_CHECK("seg_blend", s, debug);
     }
     hipLaunchKernelGGL(k_seg_combine, dim3(2 * ntiles, 3), dim3(256), 0, s, cam, (uint32_t)nseg, (const uint32_t*)seg_off,

@@ -40,6 +40,7 @@ constexpr uint32_t FLAG_SCAN_BINNING = 1u << 9;         // binning with the scan
 constexpr uint32_t FLAG_ROUNDS_OFF = 1u << 10;          // forward: all list segments at once
 constexpr uint32_t FLAG_ROUNDS_ON = 1u << 11;           // forward: segment rounds whatever the list density
 constexpr uint32_t FLAG_RAW_PARAMS = 1u << 12;          // opacities / scales / rotations are raw parameters (activated here)
+constexpr uint32_t FLAG_FAST_EXP = 1u << 13;            // the compositing's 2^x by the hardware's v_exp_f32 (forward AND backward)
 
 // The model's activations (scene/gaussian_model.py:37-45), shared by vr_activations_* and the VR_FLAG_RAW_PARAMS path
 constexpr float NORMALIZE_EPS = 1e-12f;   // F.normalize's default eps
@@ -110,6 +111,11 @@ __device__ __forceinline__ float vr_exp2_unclamped(float x)
     return ldexpf(p, (int)n);
 }
 __device__ __forceinline__ float vr_exp2(float x) { return x < -126.0f ? 0.0f : vr_exp2_unclamped(x); }
+// The compositing kernels' 2^x: the bit-exact polynomial above (FAST = false: what the CPU checker restates), or ONE
+// transcendental instruction (VR_FLAG_FAST_EXP: v_exp_f32, ~1 ulp, flushes below 2^-126 -- never used there).  The same
+// choice in k_seg_alpha, k_seg_blend and k_seg_bwd of a view: forward and backward then agree on every fragment's alpha.
+template <bool FAST>
+__device__ __forceinline__ float exp2_sel(float x) { return FAST ? __builtin_amdgcn_exp2f(x) : vr_exp2_unclamped(x); }
 
 // ---- wave-cooperative linear copies between a contiguous global block and LDS (n floats, one wave).  16-byte
 // vector path when the global address is aligned (all of a lane's loads in flight before the first store), plus a

@@ -112,7 +112,9 @@ def render_all(cam, static, boxes, box2worlds, sh_degree, bg_color, scaling_modi
     the static model.  Falls back to vegs_amd.instances.activate when the frame cannot use an SH tail."""
     if fused:
         from . import instances, rasterizer
-        if static_raw is not None and static is not None and boxes:
+        # (RAW only when the static model HAS rows: with an empty head the op would take every row -- the instances',
+        # which arrive activated -- for raw parameters and activate them a second time)
+        if static_raw is not None and static is not None and boxes and static["means3D"].shape[0] > 0:
             kw = instances.prepare_and_merge({**static, **static_raw}, boxes, box2worlds)
             if isinstance(kw["shs"], (tuple, list)) and len(kw["shs"]) == 3:       # the tail marks where the raw rows end
                 with rasterizer.flags(rasterizer.get_flags() | rasterizer.FLAG_RAW_PARAMS):

@@ -51,6 +51,7 @@ FLAG_SCAN_BINNING = _capi.FLAG_SCAN_BINNING                # binning without int
 FLAG_ROUNDS_OFF = _capi.FLAG_ROUNDS_OFF                    # forward: every list segment at once, whatever the list density
 FLAG_ROUNDS_ON = _capi.FLAG_ROUNDS_ON                      # forward: segment rounds, whatever the list density (default: by density)
 FLAG_RAW_PARAMS = _capi.FLAG_RAW_PARAMS                    # opacities / scales / rotations are the model's raw parameters: activated in the kernel
+FLAG_FAST_EXP = _capi.FLAG_FAST_EXP                        # 2^x by v_exp_f32 in the compositing kernels, forward and backward (images ~1e-6 off the bit-exact mode)
 _flags = int(os.environ.get("VEGS_RAST_FLAGS", "0"), 0)
 
 
@@ -129,19 +130,30 @@ _LAST_R = {}
 # is never trusted -- a wrong one (a reused address, a scene that changed) only costs time, the kernels redo what it
 # missed -- so no invalidation is needed.  A key's hint array is created on its SECOND sighting (value None until then):
 # a camera has to come back before anything is spent on it.
-# OFF by default: a hint pays only while the model stands still between two visits of a camera (repeated rendering of
-# fixed views: -3 %); in training a camera comes back once per epoch, and hints one epoch old cost 4 % (DESIGN.md section
-# 12).  VEGS_RAST_HINTS=1 (or needed_hints(True)) turns the cache on.
+# An EVALUATION-ONLY feature, OFF by default: a hint pays only while the model stands still between two visits of a
+# camera (re-rendering fixed views of a trained model under torch.no_grad(): -3 % of the forward); in training a camera
+# comes back once per epoch, and hints one epoch old COST 1.5 ... 4 % (BENCH_r03) -- so a forward
+# that will be differentiated never gets one: needed_hints(True) / VEGS_RAST_HINTS=1 turn the cache on for forwards under
+# no_grad only.  ("always" -- tests: the hinted kernels' catch-up rounds under a backward -- lifts that restriction.)
 _NEEDED = {}
 _NEEDED_MAX = 4096
-_use_hints = os.environ.get("VEGS_RAST_HINTS", "0") not in ("0", "")
+
+
+def _hint_mode(v):
+    if v in (False, None, 0, "0", "", "off"):
+        return False
+    return "always" if v == "always" else "eval"
+
+
+_use_hints = _hint_mode(os.environ.get("VEGS_RAST_HINTS", "0"))
 
 
 def needed_hints(enabled):
-    """Enable / disable the per-camera needed-segment hints; returns the previous setting."""
+    """Per-camera needed-segment hints for forwards under no_grad (True), for every forward ("always": tests), or off
+    (False, the default); returns the previous setting."""
     global _use_hints
-    old, _use_hints = _use_hints, bool(enabled)
-    if not enabled:
+    old, _use_hints = _use_hints, _hint_mode(enabled)
+    if not _use_hints:
         _NEEDED.clear()
     return old
 
@@ -228,7 +240,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             saved.binning_capacity = int(hint * 1.125) + 65536 if hint > 0 else 0
             stream = torch.cuda.current_stream(device).cuda_stream
             need_key, need_t = None, None
-            if _use_hints and P > 0 and isinstance(rs.viewmatrix, torch.Tensor) and isinstance(rs.projmatrix, torch.Tensor):
+            hinted = _use_hints == "always" or (_use_hints and not any(ctx.needs_input_grad))
+            if hinted and P > 0 and isinstance(rs.viewmatrix, torch.Tensor) and isinstance(rs.projmatrix, torch.Tensor):
                 need_key = (device.index, H, W, rs.viewmatrix.data_ptr(), rs.projmatrix.data_ptr())
                 if need_key not in _NEEDED:
                     # FIRST sighting: only remember the key.  Cameras that are rendered once and thrown away (the

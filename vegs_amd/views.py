@@ -112,4 +112,9 @@ def view_batch(views, fwd_bwd_fn, device, streams=2):
     vs = ViewStreams(device, streams)
     outs = [vs.run(fwd_bwd_fn, v)[0] for v in views]
     vs.join()
+    if vs.side:      # results were allocated on the side streams: the caller's stream uses them from here on
+        main = torch.cuda.current_stream(vs.device)
+        for t in _tensors_of(outs):
+            if t.is_cuda:
+                t.record_stream(main)
     return outs

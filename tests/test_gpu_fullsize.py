@@ -5,6 +5,8 @@ index-exact against it.  C3 (2M Gaussians, the headline config) is checked throu
 properties: run-to-run determinism of the forward, structure and sortedness of the tile lists,
 exact background linearity, linearity of the backward in the upstream gradients.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -230,6 +232,14 @@ def test_c3_backward_is_linear_in_upstream_gradients(c3, dev):
 #     median); all other rows -- > 99.5 % -- pass at 2e-4, and at most 0.01 % of all rows are off by more than 3x.
 
 
+# A row outside rtol 2e-4 must lie within EXPLAIN_FACTOR x what the summation-rounding model moves the checker's own result
+# by (round 3: 8; round 4: the deterministic mode adds each Gaussian's slots in double and divides IEEE-exactly, so what is
+# left to explain is the per-fragment fp32 arithmetic and the <= 64-pixel sums inside a slot); rows whose measured movement
+# exceeds EXEMPT_FROM_CAP allowances are exempt from the 3x cap (not from the explanation).
+EXPLAIN_FACTOR = float(os.environ.get("VEGS_EXPLAIN_FACTOR", "3.0"))
+EXEMPT_FROM_CAP = float(os.environ.get("VEGS_EXEMPT_FROM_CAP", "1.0"))
+
+
 def _oracle_parity(name, sc_inputs, deg, cam, dev, hip_runs=1):
     """sc_inputs: op kwargs (numpy).  Renders `hip_runs` times through the operator (same camera tensors: with the hint
     cache on, the third run uses a warm needed-segment hint), checks every run bit-exact against the oracle's forward and
@@ -267,7 +277,7 @@ def _oracle_parity(name, sc_inputs, deg, cam, dev, hip_runs=1):
     moved = summation_sensitivity(oc, st, og, names=names)
     for k in names:
         plain = k in ("means2D", "opacities", "shs")
-        ill = moved[k] > 0.25
+        ill = moved[k] > EXEMPT_FROM_CAP
         assert ill.mean() < 5e-2, (name, k, "fraction of rows the oracle itself cannot resolve to a quarter allowance", float(ill.mean()))
         bad = assert_grad_close(f"{name} det {k}", h_grads[k], og[k], rtol=2e-4, floor=2e-7, outliers=1e-5 if plain else 1e-4,
                                 near=1e-5 if plain else 1e-3, cap=3.0, explain=explain, ill=ill)
@@ -275,7 +285,11 @@ def _oracle_parity(name, sc_inputs, deg, cam, dev, hip_runs=1):
         # own result by (plus the allowance) -- the model takes the largest of three 1-sigma draws, the actual rounding
         # may sit at 3 sigma
         _, ratio = grad_mismatch(h_grads[k], og[k], 2e-4, 2e-7)
-        unexplained = bad[ratio[bad] > 1.0 + 8.0 * moved[k][bad]]
+        unexplained = bad[ratio[bad] > 1.0 + EXPLAIN_FACTOR * moved[k][bad]]
+        # how many rows needed an explanation at all, and the largest multiple of its measured movement any of them used
+        used = float(((ratio[bad] - 1.0) / np.maximum(moved[k][bad], 1e-9)).max()) if len(bad) else 0.0
+        print(f"[{name}] {k}: {len(bad)} of {len(ratio)} rows outside rtol 2e-4 needed an explanation "
+              f"(largest: {used:.2f} x its measured summation sensitivity; allowed {EXPLAIN_FACTOR})")
         assert len(unexplained) == 0, (name, k, "rows outside 2e-4 beyond what fp32 summation explains",
                                        [(int(i), float(ratio[i]), float(moved[k][i])) for i in unexplained[:8]])
     return st

@@ -194,6 +194,11 @@ k_seg_suffix(int ntiles, uint32_t cap, const uint32_t* __restrict__ seg_off, con
 // 1.05 strips on average, so combining the strips in LDS before the global flush bought almost nothing.
 // NO_EXTRA / DET are compile-time (VR_FLAG_EXTRA_NO_ALPHA_GRAD, VR_FLAG_DETERMINISTIC): the common instantiation carries
 // neither their branches nor their registers (round 2 added them as run-time tests: 360 -> 373 us).
+// 1 / x: v_rcp_f32 (1 ulp) in the production instantiations, the correctly rounded division in the deterministic one (the
+// mode the full-size tests compare with the checker: its reciprocals are then the checker's)
+template <bool EXACT>
+__device__ __forceinline__ float bwd_rcp(float x) { return EXACT ? 1.0f / x : __builtin_amdgcn_rcpf(x); }
+
 template <bool NO_EXTRA, bool DET, bool FAST>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off, uint32_t cap,
@@ -366,7 +371,7 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                 const f2 om = f2_splat(1.0f) - a_eff;
                 float pa = om.x, pb = om.y;
                 wave_prefix_mul_x2(pa, pb);                               // prod over entries >= mine
-                const f2 Tl = Tc * (f2){__builtin_amdgcn_rcpf(pa), __builtin_amdgcn_rcpf(pb)};   // T in front of my splat
+                const f2 Tl = Tc * (f2){bwd_rcp<DET>(pa), bwd_rcp<DET>(pb)};   // T in front of my splat
                 const f2 wgt = a_eff * Tl;
                 // <attr, g> in two independent chains (a dependent v_pk_fma_f32 costs an extra wait state)
                 f2 u0 = f2_splat(at[0]) * g[0], u1 = f2_splat(at[1]) * g[1];
@@ -401,7 +406,7 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                     // instead of 20) and the signs applied once per entry at the flush.  (The conic cannot be pulled out of
                     // the mean2D sums as well: A sum(a dx) + B sum(a dy) cancels AFTER the sums were rounded, and for edge-on
                     // discs that lost two digits -- the C-harness test caught rows off by 2 %.)
-                    const f2 inv_om = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                    const f2 inv_om = {bwd_rcp<DET>(om.x), bwd_rcp<DET>(om.y)};
                     // (finite also for a lane that does not contribute: its alpha is 0, so 1 - alpha = 1, and the prefix
                     // product of at most 64 factors >= 0.01 it divides by cannot reach zero before Tc itself has)
                     const f2 dLda = f2_fma(Tl, u, -(behind + bgterm) * inv_om);
@@ -471,20 +476,23 @@ k_det_reduce(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ val
     if (i >= R) return;
     const uint32_t gid = keys[i];
     if (i > 0 && keys[i - 1] == gid) return;          // not the first list entry of its Gaussian
-    float acc[NACC];
+    // DOUBLE accumulators (round 4): a test mode, its speed is irrelevant -- what the comparison with the checker's double
+    // sums should see is the kernels' per-fragment arithmetic, not the rounding of a second fp32 summation over a
+    // Gaussian's (up to tens of thousands of) list entries
+    double acc[NACC];
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
     for (long t = i; t < R && keys[t] == gid; ++t) {
         const float* src = gpart + (size_t)vals[t] * 4 * NACC;
         for (int q = 0; q < 4 * NACC; q += NACC) {
 #pragma unroll
-            for (int k = 0; k < NACC; ++k) acc[k] += src[q + k];
+            for (int k = 0; k < NACC; ++k) acc[k] += (double)src[q + k];
         }
     }
 #pragma unroll
-    for (int k = 0; k < 15; ++k) gacc[(size_t)gid * 16 + k] = acc[k];
-    gmean2D[(size_t)gid * 3 + 0] = acc[15];
-    gmean2D[(size_t)gid * 3 + 1] = acc[16];
+    for (int k = 0; k < 15; ++k) gacc[(size_t)gid * 16 + k] = (float)acc[k];
+    gmean2D[(size_t)gid * 3 + 0] = (float)acc[15];
+    gmean2D[(size_t)gid * 3 + 1] = (float)acc[16];
 }
 
 size_t render_bwd_det_bytes(long R, int P)

@@ -22,6 +22,8 @@
 // fixes (oracle: or_render_fwd), so the images stay bit-identical to the sequential oracle.
 // One 256-thread workgroup = one 16x16 tile = 4 wave64, lane = pixel (one 8x8 region = "strip" per wave); splat
 // records are gathered with dwordx4 loads into LDS and read back as wave-uniform broadcasts.
+#include <stdlib.h>
+
 #include "vr_host.h"
 #include "vr_segment.h"
 
@@ -45,7 +47,7 @@ constexpr uint32_t AUTO_DENSITY = 12u; // ... which are used from this many list
 constexpr int SEGOFF_THREADS = 1024;
 __global__ void __launch_bounds__(SEGOFF_THREADS)
 k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict__ seg_off,
-              const uint32_t* __restrict__ hint, uint32_t* __restrict__ limit, uint32_t cap, uint32_t auto_first)
+              const uint32_t* __restrict__ hint, uint32_t* __restrict__ limit, uint32_t cap, uint32_t auto_first, int first_fused)
 {
     constexpr int NW = SEGOFF_THREADS / 64;
     __shared__ uint32_t wsum[NW], wsum_a[NW];
@@ -65,7 +67,7 @@ k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict_
             // is still alive behind them (k_seg_scan) -- most tiles never need more
             a = hint ? min(n, hinted_limit(min(hint[t], 0x3FFFFFFFu))) : min(n, auto_first);
             limit[t] = a;
-            a -= a > 0u ? 1u : 0u;      // the tile's FIRST segment is not on the list: k_seg_first takes it (below)
+            if (first_fused) a -= a > 0u ? 1u : 0u;      // the tile's FIRST segment is not on the list: k_seg_first takes it (below)
         }
         uint32_t incl = n, incl_a = a;      // two scans: all segments (global ids), round-0 segments (list positions)
 #pragma unroll
@@ -98,7 +100,7 @@ k_seg_offsets(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict_
 // segment table entries (vr_segment.h): one thread per segment of the launch grid
 __global__ void __launch_bounds__(256)
 k_seg_tiles(int ntiles, const int2* __restrict__ ranges, uint32_t* __restrict__ seg_off,
-            const uint32_t* __restrict__ limit, uint32_t cap)
+            const uint32_t* __restrict__ limit, uint32_t cap, int first_fused)
 {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= cap) return;
@@ -115,7 +117,7 @@ k_seg_tiles(int ntiles, const int2* __restrict__ ranges, uint32_t* __restrict__ 
     // flag 3 = behind the round-0 prefix of its tile: not in the round-0 list, k_seg_scan decides (and rewrites the flag)
     const bool up_front = (uint32_t)sl < limit[lo];
     seg_info[b] = make_int4(lo, first, min(SEG, r.y - first), sl | (up_front ? 0 : (int)(3u << 30)));
-    if (up_front && sl > 0) seg_off[seg_list_offset(ntiles, cap, 0) + seg_off[seg_actoff_offset(ntiles, cap) + lo] + sl - 1] = b;
+    if (up_front && sl >= first_fused) seg_off[seg_list_offset(ntiles, cap, 0) + seg_off[seg_actoff_offset(ntiles, cap) + lo] + sl - first_fused] = b;
 }
 
 // ---- NEEDED-SEGMENT HINT.  Half of the segments lie behind the point where every pixel of their tile has stopped
@@ -212,7 +214,7 @@ __device__ __forceinline__ void seg_first_body(const Camera& cam, const int tile
                                                const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ point_list,
                                                const Splat* __restrict__ rec, float* __restrict__ Pbuf,
                                                unsigned long long* __restrict__ segmask, float* __restrict__ part,
-                                               float4 (*lds)[SEG], unsigned long long* masks)
+                                               float4 (*lds)[SEG], float2* lds_s, unsigned long long* masks)
 {
     const uint32_t seg0 = seg_off[tile];
     if (seg_off[tile + 1] == seg0) return;                     // empty tile
@@ -231,7 +233,8 @@ __device__ __forceinline__ void seg_first_body(const Camera& cam, const int tile
             lds[1][threadIdx.x] = s1;
             lds[2][threadIdx.x] = src[2];  // r g b qw
             lds[3][threadIdx.x] = src[3];  // qx qy qz s0
-            lds[4][threadIdx.x] = src[4];  // s1 s2 (clamp bits, pad)
+            const float4 q4 = src[4];      // s1 s2 (clamp bits, pad)
+            lds_s[threadIdx.x] = make_float2(q4.x, q4.y);
         }
         seg_build_masks(c, have, q0, q1, masks);
     }
@@ -264,7 +267,7 @@ __device__ __forceinline__ void seg_first_body(const Camera& cam, const int tile
         const float wgt = apply ? alpha * (Tb * p) : 0.0f;
         const float4 cc = lds[2][i];
         const float4 d = lds[3][i];
-        const float2 e2 = *reinterpret_cast<const float2*>(&lds[4][i]);
+        const float2 e2 = lds_s[i];
         const f2 w2 = f2_splat(wgt);
         Cp[0] = f2_fma((f2){cc.x, cc.y}, w2, Cp[0]);
         Cp[1] = f2_fma((f2){cc.z, cc.w}, w2, Cp[1]);
@@ -330,20 +333,22 @@ template <int ROUND, bool FAST>
 __global__ void __launch_bounds__(256)
 k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off, uint32_t cap,
             const uint32_t* __restrict__ point_list, const Splat* __restrict__ rec, float* __restrict__ Pbuf,
-            unsigned long long* __restrict__ segmask, float* __restrict__ part)
+            unsigned long long* __restrict__ segmask, float* __restrict__ part, int first_fused)
 {
-    __shared__ float4 lds[ROUND == 0 ? 5 : 2][SEG];
+    // (18.5 KB in round 0: eight workgroups per CU, as with the 8 KB of the plain path alone)
+    __shared__ float4 lds[ROUND == 0 ? 4 : 2][SEG];
+    __shared__ float2 lds_s[ROUND == 0 ? SEG : 1];
     __shared__ unsigned long long masks[16];
     // the round's work list: round 0 one workgroup per entry (the grid is sized for it: AUTO_FIRST segments per tile
     // without a hint); the catch-up rounds a fixed grid striding over a list whose length only the device knows
     const int ntiles = cam.gx * cam.gy;
-    if (ROUND == 0 && (int)blockIdx.x < ntiles) {      // the tiles' FIRST segments: alpha and blend in one pass
-        seg_first_body<FAST>(cam, (int)blockIdx.x, ranges, seg_off, point_list, rec, Pbuf, segmask, part, lds, masks);
+    if (ROUND == 0 && first_fused && (int)blockIdx.x < ntiles) {      // the tiles' FIRST segments: alpha and blend in one pass
+        seg_first_body<FAST>(cam, (int)blockIdx.x, ranges, seg_off, point_list, rec, Pbuf, segmask, part, lds, lds_s, masks);
         return;
     }
     const uint32_t count = seg_off[seg_counts_offset(ntiles, cap) + ROUND];
     const uint32_t* const list = seg_off + seg_list_offset(ntiles, cap, ROUND);
-    for (uint32_t item = blockIdx.x - (ROUND == 0 ? (uint32_t)ntiles : 0u); item < count; item += gridDim.x) {
+    for (uint32_t item = blockIdx.x - (ROUND == 0 && first_fused ? (uint32_t)ntiles : 0u); item < count; item += gridDim.x) {
         SegCtx c;
         if (seg_setup_at(cam, ranges, seg_off, list[item], threadIdx.x >> 6, c)) {
             const float p = seg_alpha_body<FAST>(c, point_list, rec, lds, masks, segmask);
@@ -486,7 +491,7 @@ __global__ void __launch_bounds__(64)
 k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off, uint32_t cap,
             const uint32_t* __restrict__ seg_needed, const uint32_t* __restrict__ point_list,
             const Splat* __restrict__ rec, const float* __restrict__ Tbuf, float* __restrict__ part,
-            const unsigned long long* __restrict__ segmask)
+            const unsigned long long* __restrict__ segmask, int first_fused)
 {
     // ONE WAVE (8x8 region = "strip") PER WORKGROUP, like k_seg_bwd: the four strips of a segment see very different numbers
     // of relevant entries and live pixels; as independent 64-thread workgroups they are scheduled and retire
@@ -500,7 +505,7 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     const int ntiles = cam.gx * cam.gy;
     if ((blockIdx.x >> 2) >= seg_off[seg_counts_offset(ntiles, cap) + SEG_LIST_NEEDED]) return;    // beyond the needed list
     if (!seg_setup_at(cam, ranges, seg_off, seg_off[seg_list_offset(ntiles, cap, SEG_LIST_NEEDED) + (blockIdx.x >> 2)], w, c)) return;
-    if (c.sl == 0) return;                // a tile's first segment was blended by k_seg_first
+    if (c.sl == 0 && first_fused) return;                // a tile's first segment was blended by k_seg_first
     const int lane = threadIdx.x;
     const int pixslot = w * 64 + lane;
     // one batch of independent loads right after the segment descriptor (boundary transmittance, relevance masks,
@@ -840,6 +845,7 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     if (ntiles == 0) return 0;
     const size_t nseg = seg_capacity(R, ntiles);
     float* Pbuf = (float*)scratch;
+    constexpr int first_fused = 1;     // (0 = the round-3 structure: every first segment through k_seg_alpha and k_seg_blend; A/B on one box: same time)
     // Rounds without a hint ("auto"): worth it on dense lists only.  On the headline view (7 segments per tile on
     // average) the heavy tiles' catch-up rounds run at low parallelism behind everybody else's round 0 and cost 40 us more
     // than the 22 % fewer segments save; with discs three times larger (25 per tile, 70 % of them never needed) the forward
@@ -849,9 +855,9 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     const bool rounds = needed_hint || auto_rounds;
     const uint32_t second = (size_t)R / SEG >= (size_t)AUTO_SECOND_SPLIT * ntiles ? AUTO_SECOND_DENSE : AUTO_SECOND_SPARSE;
     hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(SEGOFF_THREADS), 0, s, ranges, ntiles, seg_off,
-                       (const uint32_t*)needed_hint, seg_needed, (uint32_t)nseg, auto_rounds ? AUTO_FIRST : 0x3FFFFFFFu);
+                       (const uint32_t*)needed_hint, seg_needed, (uint32_t)nseg, auto_rounds ? AUTO_FIRST : 0x3FFFFFFFu, first_fused);
     hipLaunchKernelGGL(k_seg_tiles, dim3(cdiv((long)nseg, 256)), dim3(256), 0, s, ntiles, ranges, seg_off,
-                       (const uint32_t*)seg_needed, (uint32_t)nseg);
+                       (const uint32_t*)seg_needed, (uint32_t)nseg, first_fused);
     VR_KERNEL_CHECK("seg_offsets", s, debug);
     // Three rounds over work lists (vr_segment.h).  Round 0: the first AUTO_FIRST segments of every tile (with a hint:
     // the hinted prefix -- its length is only known on the device, so the grid covers every slot); k_seg_scan walks them
@@ -864,12 +870,12 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     const bool fast = (cam.flags & FLAG_FAST_EXP) != 0u;
 #define VR_ALPHA(RD, FST, GRID)                                                                                           \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_alpha<RD, FST>), dim3(GRID), dim3(256), 0, s, cam, ranges,                   \
-                       (const uint32_t*)seg_off, (uint32_t)nseg, point_list, rec, Pbuf, segmask, part)
+                       (const uint32_t*)seg_off, (uint32_t)nseg, point_list, rec, Pbuf, segmask, part, first_fused)
 #define VR_ROUND(RD, GRID)                                                                                                \
     if (R > 0) { if (fast) VR_ALPHA(RD, true, GRID); else VR_ALPHA(RD, false, GRID); }                                    \
     if (R > 0 || RD == 0) hipLaunchKernelGGL(k_seg_scan<RD>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (uint32_t)nseg, second, \
                                              (const float*)Pbuf, Tbuf, seg_needed, needed_hint)
-    VR_ROUND(0, grid0 + (unsigned)ntiles);        // (+ the tiles' first segments: the launch's first `ntiles` workgroups)
+    VR_ROUND(0, grid0 + (first_fused ? (unsigned)ntiles : 0u));        // (+ the tiles' first segments: the launch's first `ntiles` workgroups)
     if (rounds) {
         VR_ROUND(1, gridc);
         VR_ROUND(2, gridc);
@@ -882,11 +888,11 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
         if (fast)
             hipLaunchKernelGGL(k_seg_blend<true>, dim3((unsigned)nseg * 4), dim3(64), 0, s, cam, ranges, (const uint32_t*)seg_off,
                                (uint32_t)nseg, (const uint32_t*)seg_needed, point_list, rec, (const float*)Tbuf, part,
-                               (const unsigned long long*)segmask);
+                               (const unsigned long long*)segmask, first_fused);
         else
             hipLaunchKernelGGL(k_seg_blend<false>, dim3((unsigned)nseg * 4), dim3(64), 0, s, cam, ranges, (const uint32_t*)seg_off,
                                (uint32_t)nseg, (const uint32_t*)seg_needed, point_list, rec, (const float*)Tbuf, part,
-                               (const unsigned long long*)segmask);
+                               (const unsigned long long*)segmask, first_fused);
         VR_KERNEL_CHECK("seg_blend", s, debug);
     }
     hipLaunchKernelGGL(k_seg_combine, dim3(2 * ntiles, 3), dim3(256), 0, s, cam, (uint32_t)nseg, (const uint32_t*)seg_off,

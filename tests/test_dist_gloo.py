@@ -139,3 +139,54 @@ def test_overlapped_factor_exchange_with_sparse_rows_gloo(tmp_path, world):
         for q in range(world):
             assert torch.equal(R[r]["F"][q], R[q]["factor"]) and torch.equal(R[r]["C"][q], R[q]["campos"])
         assert R[r]["bytes"] == int((world - 1) * 12 * 4000 + 2.0 * (world - 1) / world * 44 * union)
+
+
+def _worker_views(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from vegs_amd import dist as vdist
+    vdist.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(7 + rank)
+    # two local views per rank: [n_local, rows, 3] factors and [n_local, 3] camera centres, gathered rank-major
+    f, c = torch.randn(2, 301, 3, generator=g), torch.randn(2, 3, generator=g)
+    F, Cc = vdist.all_gather_views(f, c, world)
+    # everything small in ONE flat bucket (instance models + BoxModel deltas of the trainer), copied back by one foreach
+    ps = [torch.zeros(s, requires_grad=True) for s in [(40, 3), (40, 1, 3), (4,), (3,), (3,), (0, 3), (17, 4)]]
+    local = [torch.randn(p.shape, generator=g) for p in ps]
+    for p, l in zip(ps, local):
+        p.grad = l.clone()
+    ps[5].grad = None                                   # a parameter without a gradient is skipped (same on every rank)
+    vdist.allreduce_grads(ps, world, flat_bucket_bytes=1 << 40)
+    # the overlapped exchange's hook is taken out again when the backward raises
+    from vegs_amd import rasterizer
+    ex = vdist.FactorExchange(world)
+    try:
+        with ex.armed(torch.zeros(3)):
+            assert rasterizer._split_hook is not None
+            with pytest.raises(RuntimeError):
+                ex.begin(torch.zeros(3))                # nested begin refused
+            raise KeyError("backward failed")
+    except KeyError:
+        pass
+    assert rasterizer._split_hook is None and not ex._armed
+    torch.save(dict(f=f, c=c, F=F, C=Cc, grads=[p.grad for p in ps], local=local), os.path.join(outdir, f"v{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_views_and_flat_bucket_gloo(tmp_path):
+    """The pieces the multi-rank trainer adds to the exchange (vegs_amd/iteration.py: Trainer.step_views): rank-major
+    all-gather of several local views, one flat bucket for many small gradients, the hook hygiene of FactorExchange."""
+    world = 2
+    mp.spawn(_worker_views, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    R = [torch.load(tmp_path / f"v{r}.pt") for r in range(world)]
+    for r in range(world):
+        assert R[r]["F"].shape == (4, 301, 3) and R[r]["C"].shape == (4, 3)
+        for q in range(world):
+            assert torch.equal(R[r]["F"][2 * q:2 * q + 2], R[q]["f"]) and torch.equal(R[r]["C"][2 * q:2 * q + 2], R[q]["c"])
+    for k in range(7):
+        if k == 5:
+            assert R[0]["grads"][k] is None
+            continue
+        want = (R[0]["local"][k] + R[1]["local"][k]) * 0.5
+        assert torch.equal(R[0]["grads"][k], R[1]["grads"][k]) and torch.allclose(R[0]["grads"][k], want, rtol=0, atol=1e-7)

@@ -825,6 +825,38 @@ def test_non_finite_inputs_do_not_crash_or_poison_the_frame(dev):
             assert torch.isfinite(pkg["render"]).all(), (key, val)
 
 
+def test_needed_hints_are_offered_to_no_grad_forwards_only(dev):
+    """needed_hints(True): the per-camera cache serves forwards that will not be differentiated (evaluation of fixed
+    cameras); a training forward never gets a hint -- hints one epoch old cost time."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from vegs_amd import rasterizer, scenes
+    sc, deg = scenes.scene_street(P=30000, length=40.0, sh_degree=1, seed=3)
+    cam = scenes.kitti_camera(0.0, 0.0, 344, 94)
+    rs = GaussianRasterizationSettings(94, 344, cam.tanfovx, cam.tanfovy, torch.zeros(3, device=dev), 1.0,
+                                       torch.tensor(cam.world_view_transform, device=dev),
+                                       torch.tensor(cam.full_proj_transform, device=dev), deg,
+                                       torch.tensor(cam.camera_center, device=dev), False, False)
+    T = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in sc.items()}
+
+    def fwd():
+        m2d = torch.zeros(30000, 3, device=dev, requires_grad=True)
+        return GaussianRasterizer(rs)(means3D=T["means3D"], means2D=m2d, opacities=T["opacities"], shs=T["shs"],
+                                      scales=T["scales"], rotations=T["rotations"])
+    old = rasterizer.needed_hints(True)
+    try:
+        rasterizer._NEEDED.clear()
+        train = [fwd()[0] for _ in range(3)]
+        assert len(rasterizer._NEEDED) == 0                       # differentiated forwards: no cache entry, no hint
+        with torch.no_grad():
+            evals = [fwd()[0] for _ in range(3)]
+        hints = list(rasterizer._NEEDED.values())
+        assert len(hints) == 1 and hints[0] is not None and int(hints[0].max()) < 0x3FFFFFFF   # third run: a recorded hint
+        for img in train[1:] + evals:
+            assert torch.equal(img, train[0])
+    finally:
+        rasterizer.needed_hints(old)
+
+
 def test_needed_hint_never_changes_results(dev):
     """VrSaved.needed_hint (per-camera cache in vegs_amd.rasterizer): the forward skips the list segments behind the
     hinted prefix of every tile and recomputes on the spot where the hint was too small.  Same camera tensors rendered

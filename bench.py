@@ -140,7 +140,8 @@ def prepare(sc, deg, cams, device, rng, count=True, cam_ts=None):
                 cam_ts=cam_ts, gouts=gouts, counters=counters, deg=deg)
 
 
-def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="train", exchange_on=True, streams=1):
+def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="train", exchange_on=True, streams=1,
+              direct=None):
     """One step = `vps` views forward + backward on this rank, then (N > 1) the gradient exchange.
     exchange "dense": all-reduce of the 59-float/Gaussian gradients.  "factored": the op returns the 3-float factor of
     the SH gradient, the ranks all-gather the factors (12 B) and all-reduce the other 11 floats (44 B), and every rank
@@ -161,9 +162,11 @@ def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="trai
     if fact_x and exchange_on:
         if exchange == "direct":           # hand-written peer-to-peer exchange over hipIpc mappings (vegs_amd/xgmi.py)
             from vegs_amd import xgmi
-            xch = xgmi.DirectExchange(rank, world, T["means3D"].device)
-            P_ = T["means3D"].shape[0]
-            xch.reserve(11 * P_ + 64, 3 * P_ + 64)        # (collective allocation: outside the timed region)
+            xch = direct
+            if xch is None:
+                xch = xgmi.DirectExchange(rank, world, T["means3D"].device)
+                P_ = T["means3D"].shape[0]
+                xch.reserve(11 * P_ + 64, 3 * P_ + 64)    # (collective allocation: outside the timed region)
         else:
             xch = vdist.FactorExchange(world)
     if fact_x and not exchange_on:
@@ -240,6 +243,50 @@ def timed(step, warmup, steps, world, first=None):
         torch.distributed.barrier()
     torch.cuda.synchronize()
     return time.perf_counter() - t0, views_done
+
+
+def _max_over_ranks(x, world):
+    if world <= 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=torch.device("cuda") if torch.distributed.get_backend() == "nccl" else "cpu")
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(t[0])
+
+
+def choose_exchange(wl, rank, world, vps, P, device):
+    """--exchange auto (N > 1, the default): a few untimed-for-the-record steps with the RCCL exchange (factored, overlapped)
+    and with the direct peer-to-peer exchange -- if its windows can be set up on this node and a small exchange verifies on
+    every rank (vegs_amd.xgmi.DirectExchange.try_setup: all-or-nothing across the ranks) -- and the FASTER one runs the
+    timed regions; the decision is the same on every rank (max over ranks of each timing).  Returns (scheme, direct
+    exchange object or None, record for the bench line)."""
+    from vegs_amd import xgmi
+    rec = {}
+    step_r = make_step(wl, rank, world, vps, exchange="factored")
+    dt_r, _ = timed(step_r, 3, 6, world)
+    rec["factored_ms_per_step"] = round(_max_over_ranks(dt_r, world) / 6 * 1e3, 4)
+    del step_r
+    xd = xgmi.DirectExchange(rank, world, device)
+    ok = vps == 1 and xd.try_setup(11 * P + 64, 3 * P + 64)
+    rec["direct_available"] = bool(ok)
+    if not ok:
+        return "factored", None, rec
+    try:
+        step_d = make_step(wl, rank, world, vps, exchange="direct", direct=xd)
+        dt_d, _ = timed(step_d, 3, 6, world)
+        xd.check()
+        good = True
+    except Exception as e:            # (a peer that did not arrive within the wait bound, an IPC error ...)
+        good, dt_d = False, float("inf")
+        rec["direct_error"] = f"{e.__class__.__name__}: {e}"[:200]
+    good = xd._agree(good)
+    if not good:
+        xd._drop()
+        return "factored", None, rec
+    rec["direct_ms_per_step"] = round(_max_over_ranks(dt_d, world) / 6 * 1e3, 4)
+    if rec["direct_ms_per_step"] < rec["factored_ms_per_step"]:
+        return "direct", xd, rec
+    xd.close()
+    return "factored", None, rec
 
 
 def timed_median(step, steps, world, repeats, first=0):
@@ -355,7 +402,8 @@ def bench_c5(args, rank, world, device):
     normals = [torch.tensor(rng.normal(size=(3, H, W)).astype(np.float32), device=device) for _ in range(4)]
     bg = torch.zeros(3, device=device)
     tr = iteration.Trainer(sc, device, n_boxes=args.boxes, fused=True, factored_sh=True, lrs=iteration.REFERENCE_LRS,
-                           optimise_boxes=True, world=world, rank=rank, exchange=args.exchange)
+                           optimise_boxes=True, world=world, rank=rank,
+                           exchange="factored" if args.exchange == "auto" else args.exchange)
 
     def step(i):
         v = vdist.view_for_rank(i, rank, world, len(cams))
@@ -385,7 +433,7 @@ def bench_c5(args, rank, world, device):
                                   "step: render_all-shaped forward, L1+SSIM + normal guidance, backward, exchange, densification "
                                   "statistics, Adam over static + instance models + BoxModels (one launch), BoxModel.regularize",
                       "gaussians": P, "rows_rendered": rows, "boxes": args.boxes, "width": W, "height": H,
-                      "parallelism": f"view-sharded x{world}" + ("" if world == 1 else f" + {args.exchange} exchange")},
+                      "parallelism": f"view-sharded x{world}" + ("" if world == 1 else f" + {tr.exchange} exchange")},
            "roofline": {"bound": "hbm", "kernel": "k_sh_factors<true> (Adam of the 48 SH floats per Gaussian straight from the "
                                                   "views' 3-float factors)", "achieved": round(achieved, 2),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
@@ -408,8 +456,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra 1408x376 / dense-scene measurements")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage time breakdown to stderr")
-    ap.add_argument("--exchange", choices=["factored", "dense", "direct"], default="factored",
-                    help="N > 1: gradient exchange scheme (factored = RCCL all-gather of the rank-1 SH factors + all-reduce of "
+    ap.add_argument("--exchange", choices=["auto", "factored", "dense", "direct"], default="auto",
+                    help="N > 1: gradient exchange scheme (auto = time a few steps of `factored` and -- where its windows can "
+                         "be set up and verified -- of `direct`, run the faster; factored = RCCL all-gather of the rank-1 SH factors + all-reduce of "
                          "the other 11 floats; dense = RCCL all-reduce of all 59 floats per Gaussian; direct = the factored "
                          "scheme over hand-written peer-to-peer kernels: every rank pushes 1/N shards into all peers' hipIpc "
                          "windows at once, vegs_amd/csrc/xgmi.hip)")
@@ -444,7 +493,13 @@ def main():
     wl = prepare(sc, deg, cams, device, np.random.default_rng(1234))
     counters, gouts = wl["counters"], wl["gouts"]
     vps = max(1, args.views_per_step)
-    step = make_step(wl, rank, world, vps, exchange=args.exchange, streams=args.streams)
+    auto_rec, direct_x = None, None
+    if args.exchange == "auto":
+        if world > 1:
+            args.exchange, direct_x, auto_rec = choose_exchange(wl, rank, world, vps, P, device)
+        else:
+            args.exchange = "factored"
+    step = make_step(wl, rank, world, vps, exchange=args.exchange, streams=args.streams, direct=direct_x)
 
     for i in range(args.warmup):
         step(i)
@@ -475,13 +530,14 @@ def main():
         # what the exchange costs: the same K steps once more WITHOUT any collective (every rank; outside the headline's
         # timed regions).  exposed = ms per step with - without: the part of the exchange that compute does not hide.
         fact = args.exchange in ("factored", "direct") and vps == 1
-        step0 = make_step(wl, rank, world, vps, factored=fact, exchange=args.exchange, exchange_on=False)
+        step0 = make_step(wl, rank, world, vps, factored=fact, exchange=args.exchange, exchange_on=False, direct=direct_x)
         dt0, _, _ = timed_median(step0, args.steps, world, 1, first=args.warmup)
         scheme = args.exchange if fact else "dense"
         exchange = {"scheme": scheme + (" (all-gather of the SH factors started between the backward's two halves, "
                                         "all-reduce of the other 11 floats after it; one wait)" if fact else "")
                               + (" -- peer-to-peer over hipIpc windows, no RCCL" if scheme == "direct" else ""),
                     "exchange_bytes_per_rank": vdist.exchange_bytes_per_rank(P, world, "factored" if fact else "dense"),
+                    "auto": auto_rec,
                     "ms_per_step_without_exchange": round(dt0 / args.steps * 1e3, 4),
                     "exchange_exposed_ms": round((elapsed - dt0) / args.steps * 1e3, 4)}
     if rank != 0:

@@ -195,7 +195,7 @@ def test_bench_two_ranks_gloo_transport(tmp_path):
     env = dict(os.environ, VEGS_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--gaussians", "200000", "--no-cpu-baseline"]
+           "--warmup", "1", "--gaussians", "200000", "--no-cpu-baseline", "--exchange", "factored"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -226,6 +226,23 @@ def test_bench_eight_ranks_full_size_dry_run(exchange):
     assert res["n_gpus"] == 8 and res["config"]["gaussians"] == 2_000_000 and res["value"] > 0
     assert res["exchange"]["scheme"].startswith(exchange) and res["exchange"]["exchange_bytes_per_rank"] == 7 * 12 * 2_000_000 + int(14 / 8 * 44 * 2_000_000)
     assert res["mfragments_per_s"] > 0 and res["roofline"]["launches_timed"] > 0
+
+
+def test_bench_exchange_auto_picks_and_reports(tmp_path):
+    """bench.py --gpus 2 with the DEFAULT exchange (auto): both schemes are tried in warm-up -- the direct one after its
+    all-or-nothing set-up and verification -- and the line says which one ran the timed regions and what each took."""
+    import json
+    env = dict(os.environ, VEGS_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--repeats", "1", "--gaussians", "200000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    auto = res["exchange"]["auto"]
+    assert auto["direct_available"] is True and auto["factored_ms_per_step"] > 0 and auto["direct_ms_per_step"] > 0
+    faster = "direct" if auto["direct_ms_per_step"] < auto["factored_ms_per_step"] else "factored"
+    assert res["exchange"]["scheme"].startswith(faster)
 
 
 def test_bench_line_contract_single_gpu():

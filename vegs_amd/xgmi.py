@@ -39,7 +39,7 @@ class DirectExchange:
         self._side = None
 
     # ---- window management (collective: every rank must make the same calls with the same sizes)
-    def _ensure(self, reduce_floats, gather_floats):
+    def _ensure(self, reduce_floats, gather_floats, agree=False):
         """Collective (re)allocation when a capacity is exceeded.  Views handed out earlier (gradients, gathered blocks)
         die with the old window: callers hold them for one iteration only.  The NEW window is created and mapped by
         everybody while the old one still exists (two live allocations cannot be mistaken for each other by the IPC
@@ -61,9 +61,20 @@ class DirectExchange:
         HB = 72
         ctx = C.c_void_p()
         with torch.cuda.device(self.device):
-            _capi.check(lib.vr_xgmi_create(self.rank, self.world, self.reduce_cap, self.gather_cap, C.byref(ctx)))
             handle = (C.c_ubyte * HB)()
-            _capi.check(lib.vr_xgmi_handle(ctx, handle))
+            try:
+                _capi.check(lib.vr_xgmi_create(self.rank, self.world, self.reduce_cap, self.gather_cap, C.byref(ctx)))
+                _capi.check(lib.vr_xgmi_handle(ctx, handle))
+                made = True
+            except Exception:
+                if not agree:
+                    raise
+                made = False
+            if agree and not self._agree(made):       # (try_setup: nobody goes on to the handle exchange alone)
+                if made:
+                    lib.vr_xgmi_destroy(ctx)
+                self.reduce_cap = self.gather_cap = 0
+                return
             if multi:
                 mine = torch.tensor(list(handle), dtype=torch.uint8)
                 if dist.get_backend(self.group) == "nccl":
@@ -75,7 +86,18 @@ class DirectExchange:
                     dist.all_gather(parts, mine, group=self.group)
                     allh = torch.stack(parts)
                 buf = (C.c_ubyte * (HB * self.world))(*allh.reshape(-1).tolist())
-                _capi.check(lib.vr_xgmi_attach(ctx, buf))
+                try:
+                    _capi.check(lib.vr_xgmi_attach(ctx, buf))
+                    mapped = True
+                except Exception:
+                    if not agree:
+                        raise
+                    mapped = False
+                if agree and not self._agree(mapped):
+                    torch.cuda.synchronize(self.device)
+                    lib.vr_xgmi_destroy(ctx)
+                    self.reduce_cap = self.gather_cap = 0
+                    return
                 dist.barrier(group=self.group)          # nobody pushes before everybody has mapped everybody
         self.win = None
         if old is not None:
@@ -90,6 +112,62 @@ class DirectExchange:
         self.win = torch.as_tensor(_Window(lib.vr_xgmi_window(ctx), lay.total_floats), device=self.device)
         self.parity = 0
         self._pending = None
+
+    def _agree(self, ok):
+        """True iff `ok` on EVERY rank (one tiny collective: ranks must take the same branch after a step that may fail
+        locally -- a rank that went on alone would wait for the others forever)."""
+        if self.world <= 1 or not dist.is_initialized():
+            return bool(ok)
+        dev = self.device if dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
+
+    def try_setup(self, reduce_floats, gather_floats, verify=True):
+        """Collective, failure-tolerant set-up for callers that have a fall-back (bench.py --exchange auto): allocates and
+        maps the windows and -- `verify` -- runs one small exchange whose result every rank checks against what it must be.
+        Returns True on every rank or False on every rank (after tearing down whatever was built); never raises for
+        device / IPC errors."""
+        try:
+            self._ensure(int(reduce_floats), int(gather_floats), agree=True)
+            ok = self.ctx is not None
+        except Exception:
+            ok = False
+        if not self._agree(ok):
+            self._drop()
+            return False
+        if not verify:
+            return True
+        try:
+            n = 4099
+            g = torch.full((n,), float(self.rank + 1), device=self.device)
+            f = torch.full((1, 33, 3), float(self.rank + 1), device=self.device)
+            c = torch.full((1, 3), float(10 * self.rank), device=self.device)
+            self.begin_gather([f, c])
+            (r,) = self.allreduce_mean([g], 1.0)
+            F, Cc = self.finish_gather()
+            self.check()
+            want = float(self.world * (self.world + 1) // 2)
+            ok = bool((r == want).all()) and all(bool((F[j] == float(j + 1)).all()) and bool((Cc[j] == float(10 * j)).all())
+                                                  for j in range(self.world))
+        except Exception:
+            ok = False
+        if not self._agree(ok):
+            self._drop()
+            return False
+        return True
+
+    def _drop(self):
+        """Tear down without collectives (the peers are doing the same, or never got this far)."""
+        try:
+            if self.ctx is not None:
+                torch.cuda.synchronize(self.device)
+                self.win = None
+                _capi.load().vr_xgmi_destroy(self.ctx)
+        except Exception:
+            pass
+        self.ctx, self.win, self._pending = None, None, None
+        self.reduce_cap = self.gather_cap = 0
 
     def close(self):
         if self.ctx is not None:

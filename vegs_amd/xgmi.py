@@ -71,7 +71,7 @@ class DirectExchange:
                     raise
                 made = False
             if agree and not self._agree(made):       # (try_setup: nobody goes on to the handle exchange alone)
-                if made:
+                if ctx.value:
                     lib.vr_xgmi_destroy(ctx)
                 self.reduce_cap = self.gather_cap = 0
                 return

@@ -240,7 +240,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             saved.binning_capacity = int(hint * 1.125) + 65536 if hint > 0 else 0
             stream = torch.cuda.current_stream(device).cuda_stream
             need_key, need_t = None, None
-            hinted = _use_hints == "always" or (_use_hints and not any(ctx.needs_input_grad))
+            # (ctx.needs_input_grad says which inputs require grad, also under no_grad: the caller's grad mode decides)
+            hinted = _use_hints == "always" or (_use_hints and not (_will_differentiate and any(ctx.needs_input_grad)))
             if hinted and P > 0 and isinstance(rs.viewmatrix, torch.Tensor) and isinstance(rs.projmatrix, torch.Tensor):
                 need_key = (device.index, H, W, rs.viewmatrix.data_ptr(), rs.projmatrix.data_ptr())
                 if need_key not in _NEEDED:
@@ -357,8 +358,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         return d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, d_sh_rest, d_sink, d_sh_tail
 
 
+_will_differentiate = True      # grad mode of the CALLER of the op (inside Function.forward it is always off)
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings, sh_rest=None, sh_color_grad=None, sh_tail=None):
+    global _will_differentiate
+    _will_differentiate = torch.is_grad_enabled()
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings, sh_rest, sh_color_grad, sh_tail)
 

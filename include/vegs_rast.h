@@ -126,7 +126,13 @@ typedef enum VrFlags {
      * ranges are unaffected (bit-exact); images move by ~1e-6, except that a fragment whose alpha sits within an ulp of
      * 1/255 (about one in 10^7) may be classified the other way, which moves its pixel by up to ~1/255 of a channel --
      * as any two correct implementations of exp() differ.  The bit-exact mode stays the default and the test mode. */
-    VR_FLAG_FAST_EXP = 1u << 13
+    VR_FLAG_FAST_EXP = 1u << 13,
+    /* ABI v8.  The host waits for the forward's binning guard word before it queues the render stage and, if a bounded
+     * look-back wait of the single-launch radix passes gave up, bins the view once more with the wait-free passes of
+     * VR_FLAG_SCAN_BINNING (same lists): the view is rendered correctly instead of being failed at its backward.  Costs
+     * the forward its run-ahead over the binning (about one launch latency of GPU idle per view); the default leaves a
+     * tripped view empty and reports it (vr_backward: VR_ERR_HIP). */
+    VR_FLAG_VERIFY_BINNING = 1u << 14
 } VrFlags;
 
 /* The op's tensor arguments (reference gaussian_renderer/__init__.py:86-94). Exactly one of
@@ -330,6 +336,8 @@ int vr_debug_export_binning(const VrSaved* saved, int32_t image_height, int32_t 
  * a timed-out wait would. */
 int vr_debug_set_guard(uint32_t value, void* stream);
 int vr_debug_raise_guard(int on);
+/* views of the calling thread that VR_FLAG_VERIFY_BINNING binned a second time (tests) */
+int vr_debug_rebinned(void);
 
 #ifdef __cplusplus
 }

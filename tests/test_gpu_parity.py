@@ -451,6 +451,33 @@ def test_binning_guard_raised_by_a_view_fails_that_views_backward(dev):
     assert torch.equal(tg["opacities"].grad, ta["opacities"].grad) or torch.allclose(tg["opacities"].grad, ta["opacities"].grad, rtol=1e-4, atol=1e-7)
 
 
+def test_verify_binning_flag_rebins_a_tripped_view(dev):
+    """VR_FLAG_VERIFY_BINNING: the forward waits for its binning's guard word and bins a tripped view once more with the
+    wait-free passes -- the view renders correctly (bit-exact vs the untripped run) and its backward succeeds, where the
+    default leaves it empty and fails its backward."""
+    from vegs_amd import _capi, harness, rasterizer, scenes
+    sc, deg = scenes.scene_street(P=30000, length=40.0, sh_degree=1, seed=9)
+    cam = scenes.kitti_camera(0.0, 0.0, 344, 94)
+    bg = torch.zeros(3, device=dev)
+
+    def run(trip, flags):
+        T = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in sc.items()}
+        with rasterizer.flags(flags):
+            if trip:
+                _capi.check(_capi.load().vr_debug_raise_guard(1))
+            pkg = harness.render(cam, T, deg, bg)
+            pkg["render"].sum().backward()
+        torch.cuda.synchronize()
+        return pkg["render"].detach().clone(), T["means3D"].grad.clone()
+    img0, g0 = run(False, rasterizer.FLAG_DETERMINISTIC)
+    before = _capi.load().vr_debug_rebinned()
+    img1, g1 = run(True, rasterizer.FLAG_DETERMINISTIC | rasterizer.FLAG_VERIFY_BINNING)
+    assert _capi.load().vr_debug_rebinned() == before + 1                  # the tripped view went through the second binning
+    assert torch.equal(img0, img1) and torch.equal(g0, g1)
+    img2, g2 = run(False, rasterizer.FLAG_DETERMINISTIC | rasterizer.FLAG_VERIFY_BINNING)
+    assert _capi.load().vr_debug_rebinned() == before + 1 and torch.equal(img0, img2) and torch.equal(g0, g2)
+
+
 def test_binning_guard_of_a_forward_only_view_is_reported_by_the_next_forward(dev):
     """A view rendered under no_grad never gets a backward: its raised guard is reported by the next forward of the
     thread (which fails and clears the word), as before."""

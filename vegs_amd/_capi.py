@@ -19,12 +19,13 @@ FLAG_SCAN_BINNING = 512
 FLAG_ROUNDS_OFF, FLAG_ROUNDS_ON = 1024, 2048
 FLAG_RAW_PARAMS = 4096
 FLAG_FAST_EXP = 8192
+FLAG_VERIFY_BINNING = 16384
 
 VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH, VR_BUF_BACKWARD = 0, 1, 2, 3, 4
 
 # every symbol include/vegs_rast.h declares
 EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_backward_render", "vr_backward_preprocess", "vr_mark_visible", "vr_get_counters",
-           "vr_count_fragments", "vr_count_blended", "vr_count_flushes", "vr_export_needed", "vr_debug_export_binning", "vr_debug_set_guard", "vr_debug_raise_guard", "vr_profile_level", "vr_profile_collect",
+           "vr_count_fragments", "vr_count_blended", "vr_count_flushes", "vr_export_needed", "vr_debug_export_binning", "vr_debug_set_guard", "vr_debug_raise_guard", "vr_debug_rebinned", "vr_profile_level", "vr_profile_collect",
            "vr_knn3_mean_dist2", "vr_photometric_forward", "vr_photometric_backward",
            "vr_normal_guidance_forward", "vr_normal_guidance_backward", "vr_training_loss_forward", "vr_training_loss_backward", "vr_adam_step", "vr_densify_stats",
            "vr_densify_plan_words", "vr_densify_plan", "vr_densify_apply", "vr_reset_opacity",
@@ -177,6 +178,8 @@ def load():
     lib.vr_debug_set_guard.argtypes = [C.c_uint32, C.c_void_p]
     lib.vr_debug_raise_guard.restype = C.c_int
     lib.vr_debug_raise_guard.argtypes = [C.c_int]
+    lib.vr_debug_rebinned.restype = C.c_int
+    lib.vr_debug_rebinned.argtypes = []
     lib.vr_knn3_mean_dist2.restype = C.c_int
     lib.vr_knn3_mean_dist2.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, VrAllocFn, C.c_void_p, C.c_void_p]
     vp, i32 = C.c_void_p, C.c_int32

@@ -21,7 +21,7 @@ static_assert(FLAG_SCALE_MODIFIED == VR_FLAG_SCALE_MODIFIED && FLAG_DEPTH_NORMAL
               FLAG_ROUNDS_OFF == VR_FLAG_ROUNDS_OFF && FLAG_ROUNDS_ON == VR_FLAG_ROUNDS_ON &&
               FLAG_RAW_PARAMS == VR_FLAG_RAW_PARAMS, "device-side flag constants must match include/vegs_rast.h");
 constexpr uint32_t KNOWN_FLAGS = FLAG_SCALE_MODIFIED | FLAG_DEPTH_NORMALIZED | FLAG_EXTRA_NO_ALPHA_GRAD | FLAG_FILL_EMPTY |
-                                 FLAG_DETERMINISTIC | FLAG_SCAN_BINNING | FLAG_ROUNDS_OFF | FLAG_ROUNDS_ON | FLAG_RAW_PARAMS | FLAG_FAST_EXP;
+                                 FLAG_DETERMINISTIC | FLAG_SCAN_BINNING | FLAG_ROUNDS_OFF | FLAG_ROUNDS_ON | FLAG_RAW_PARAMS | FLAG_FAST_EXP | FLAG_VERIFY_BINNING;
 
 static thread_local char g_err[512] = "";
 static thread_local VrCounters g_counters = {0, 0, 0, 0, 0};
@@ -43,6 +43,7 @@ struct MailRef { uint32_t* pinned; uint32_t* guard; int dev; };
 static std::mutex g_mail_mu;
 static std::vector<MailRef> g_mail_reg;
 static thread_local bool g_raise_guard = false;   // test hook: vr_debug_raise_guard
+static thread_local int g_rebinned = 0;           // views re-binned under VR_FLAG_VERIFY_BINNING (vr_debug_rebinned)
 
 // the calling thread's mailbox for the current device, created on first use
 static int get_mailbox(int dev_id, hipStream_t s, Mailbox** out);
@@ -427,6 +428,34 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
                         ranges, ranges_zeroed, status_zeroed, mail.guard,
                         mail.pinned_dev + RING_AT + 2 * (mail.seq % RING_SLOTS), mail.seq, raise, s, debug);
     if (rc) return rc;
+    if ((st->flags & FLAG_VERIFY_BINNING) && lists && !(cam.flags & FLAG_SCAN_BINNING)) {
+        // VR_FLAG_VERIFY_BINNING: the host waits for this view's guard word (posted by the last binning kernel) BEFORE it
+        // queues the render stage; a view whose look-back wait gave up is binned once more with the wait-free multi-launch
+        // passes -- same lists bit for bit -- instead of being failed at its backward.  Costs the forward its run-ahead
+        // over the binning (a launch-latency bubble per view): opt-in.
+        uint32_t* slot = g_pinned + RING_AT + 2 * (mail.seq % RING_SLOTS);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 1; __atomic_load_n(&slot[0], __ATOMIC_ACQUIRE) != mail.seq; ++spins) {
+            __builtin_ia32_pause();
+            if ((spins & 4095u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+                VR_HIP(hipStreamSynchronize(s));
+                break;
+            }
+        }
+        if (__atomic_load_n(&slot[1], __ATOMIC_RELAXED) != 0u) {
+            // the slot is posted a second time by the re-run's last kernel: until then it reads "not posted yet"
+            __atomic_store_n(&slot[1], 0u, __ATOMIC_RELAXED);
+            __atomic_store_n(&slot[0], 0u, __ATOMIC_RELEASE);
+            VR_HIP(hipMemsetAsync(mail.guard, 0, 4, s));
+            Camera again = cam;
+            again.flags |= FLAG_SCAN_BINNING;
+            rc = launch_binning(again, P, (int)V, (long)R, key_min, key_bits, vis_key, vis_id, rect, scan_scr, scr2, point_list,
+                                ranges, false, false, mail.guard, mail.pinned_dev + RING_AT + 2 * (mail.seq % RING_SLOTS),
+                                mail.seq, false, s, debug);
+            if (rc) return rc;
+            ++g_rebinned;
+        }
+    }
     prof_begin(VR_STAGE_RENDER_FWD, s);
     rc = launch_render_fwd(cam, (long)R, ranges, point_list, rec, (uint32_t*)((char*)binning + BL.seg_off),
                            (uint32_t*)((char*)binning + BL.seg_needed), (float*)((char*)binning + BL.tbuf),
@@ -832,6 +861,8 @@ int vr_debug_raise_guard(int on)
     g_raise_guard = on != 0;
     return VR_OK;
 }
+
+int vr_debug_rebinned(void) { return g_rebinned; }
 
 int vr_debug_export_binning(const VrSaved* saved, int32_t H, int32_t W, uint32_t* point_list, int32_t* ranges,
                             void* stream)

@@ -126,10 +126,20 @@ def prepare(sc, deg, cams, device, rng, count=True, cam_ts=None):
         pkg = harness.render(cam, T, deg, bg, cam_t=cam_ts[v])
         gouts.append(upstream_grads(pkg, cam, rng, device))
         c = _capi.counters()
+        c["R_lists"], c["V_lists"] = c["R"], c["V"]      # entries of the build's own (tight) tile lists; Gaussians that have any
         if count:
-            c["F"] = _capi.count_fragments(pkg["render"].grad_fn, H, W, device)
+            c["F_lists"] = _capi.count_fragments(pkg["render"].grad_fn, H, W, device)
             c["B"] = _capi.count_blended(pkg["render"].grad_fn, H, W, device)
             c["A"] = _capi.count_flushes(pkg["render"].grad_fn, H, W, device)
+            # R and F as BASELINE.md / SURVEY 8(d) define them: on the REFERENCE's tile rectangles (every tile of the
+            # rectangle an entry, every entry a pixel walks a fragment) -- one more, untimed render with
+            # VR_FLAG_FULL_TILE_LISTS; the build's default lists leave out the pairs that cannot reach any pixel
+            from vegs_amd import rasterizer as _r
+            with _r.flags(_r.get_flags() | _r.FLAG_FULL_TILE_LISTS):
+                ref = harness.render(cam, T, deg, bg, cam_t=cam_ts[v])
+                c["R"], c["V"] = _capi.counters()["R"], _capi.counters()["V"]
+                c["F"] = _capi.count_fragments(ref["render"].grad_fn, H, W, device)
+            del ref
             rs = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, bg, 1.0, cam_ts[v]["viewmatrix"],
                                                cam_ts[v]["projmatrix"], deg, cam_ts[v]["campos"], False, False)
             c["Pz"] = int(GaussianRasterizer(rs).markVisible(T["means3D"]).sum().item())
@@ -347,11 +357,12 @@ def variant(name, sc, deg, cams, device, steps, warmup, factored=False, hints="o
         rasterizer.needed_hints(old)
         rasterizer.set_flags(old_flags)
     cn = wl["counters"]
-    mean = {k: float(np.mean([cn[v][k] for v in done])) for k in ("V", "R", "F", "B")}
+    mean = {k: float(np.mean([cn[v][k] for v in done])) for k in ("V", "R", "R_lists", "F", "F_lists", "B")}
     nv = len(done)                      # steps x views per step
     res = {"workload": name, "views_per_s": round(nv / dt, 2), "ms_per_view": round(dt / nv * 1e3, 4),
            "ms_per_view_runs": [round(r / nv * 1e3, 4) for r in runs],
            "mfragments_per_s": round(sum(cn[v]["F"] for v in done) / dt / 1e6, 1),
+           "mfragments_per_s_own_lists": round(sum(cn[v]["F_lists"] for v in done) / dt / 1e6, 1),
            "blended_mfragments_per_s": round(sum(cn[v]["B"] for v in done) / dt / 1e6, 1),
            "mean_counters": {k: round(v, 1) for k, v in mean.items()}}
     res.update(extra)
@@ -437,7 +448,9 @@ def bench_c5(args, rank, world, device):
            "roofline": {"bound": "hbm", "kernel": "k_sh_factors<true> (Adam of the 48 SH floats per Gaussian straight from the "
                                                   "views' 3-float factors)", "achieved": round(achieved, 2),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                        "alg_bytes_per_launch": round(bytes_k), "avg_launch_ms": round(ms_k, 4), "launches_timed": len(events)},
+                        "alg_bytes_per_launch": round(bytes_k), "avg_launch_ms": round(ms_k, 4),
+                     "alg_bytes_note": "72 R + 56 N + 68 V with R on the reference's full tile rectangles (SURVEY 8d)",
+                     "frac_on_own_lists": round(bytes_k_own / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms_k > 0 else 0.0, "launches_timed": len(events)},
            "cpu_baseline": None}
     print(json.dumps(res))
 
@@ -515,15 +528,16 @@ def main():
     mallocs1 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
 
     frag_local = float(sum(counters[v]["F"] for v in views_done))
+    frag_own_local = float(sum(counters[v]["F_lists"] for v in views_done))
     blend_local = float(sum(counters[v]["B"] for v in views_done))
     if world > 1:
         # host tensors with gloo (the single-GPU test transport), device tensors with RCCL
         red_dev = device if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
-        t = torch.tensor([frag_local, blend_local], dtype=torch.float64, device=red_dev)
+        t = torch.tensor([frag_local, blend_local, frag_own_local], dtype=torch.float64, device=red_dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
-        frag_total, blend_total = float(t[0]), float(t[1])
+        frag_total, blend_total, frag_own_total = float(t[0]), float(t[1]), float(t[2])
     else:
-        frag_total, blend_total = frag_local, blend_local
+        frag_total, blend_total, frag_own_total = frag_local, blend_local, frag_own_local
 
     exchange = None
     if world > 1:
@@ -545,7 +559,7 @@ def main():
     stage_ms = stage_profile(step, 8) if world == 1 else {}
     views = args.steps * world * vps
     value = views / elapsed
-    mean = {k: float(np.mean([counters[v][k] for v in views_done])) for k in ("Pz", "V", "R", "F", "B")}
+    mean = {k: float(np.mean([counters[v][k] for v in views_done])) for k in ("Pz", "V", "R", "R_lists", "F", "F_lists", "B")}
     # algorithmic bytes per view, SURVEY.md section 8(d)
     b_alg = 32 * P + 28 * mean["Pz"] + (294 + 24 * K) * mean["V"] + 188 * mean["R"] + 112 * N + (56 + 12 * K) * P
     # dominant kernel: k_seg_bwd (gradients of one (tile, segment)), timed with HIP events recorded by the
@@ -553,9 +567,14 @@ def main():
     # whole render-backward step (72R + 56N + 68V), of which it is the only heavy kernel.
     kern = "k_seg_bwd"
     ms_k = stage[kern][0] / max(stage[kern][1], 1)
+    # R = list entries as SURVEY 8(d) counts them: one per tile of the REFERENCE's rectangles.  The build's own lists are a
+    # third shorter (tiles a splat cannot reach are not listed): `frac_on_own_lists` prices the kernel on those.
     bytes_k = 72 * mean["R"] + 56 * N + 68 * mean["V"]
+    bytes_k_own = 72 * mean["R_lists"] + 56 * N + 68 * mean["V"]
     achieved = bytes_k / (ms_k * 1e-3) / 1e9 if ms_k > 0 else 0.0
-    traffic, valu_insts, traffic_from = profile_figures(kern, ("render_bwd.hip", "vr_segment.h"))
+    # (the kernel's own sources AND everything upstream that shapes its work: lists, masks, records)
+    traffic, valu_insts, traffic_from = profile_figures(kern, ("render_bwd.hip", "vr_segment.h", "vr_device.h", "render_fwd.hip",
+                                                               "binning.hip", "preprocess.hip"))
     # secondary ceilings (reported, not graded): VALU issue -- wave-level VALU instructions of the kernel (SQ
     # counters of the committed profile) against 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction -- and the L2
     # atomics of the backward: 17 fp32 atomics per (list entry, 8x8 region) flush, counted on the device per view
@@ -579,11 +598,15 @@ def main():
         "repeats": len(region_s), "ms_per_step_regions": [round(r / args.steps * 1e3, 4) for r in region_s],
         # F = sum of n_contrib = list entries TRAVERSED by the forward blend loop (BASELINE.md's fragment definition);
         # B = (pixel, splat) pairs actually BLENDED (alpha >= 1/255 before the stop) -- an order of magnitude fewer
+        # ... on the REFERENCE's tile rectangles (BASELINE.md's definition of a fragment); `..._own_lists`: entries of the
+        # build's tighter lists actually walked (a third of the reference's pairs cannot reach any pixel and are not listed)
         "mfragments_per_s": round(frag_total / elapsed / 1e6, 2),
+        "mfragments_per_s_own_lists": round(frag_own_total / elapsed / 1e6, 2),
         "blended_mfragments_per_s": round(blend_total / elapsed / 1e6, 2),
         "exchange": exchange,
         "config": {"workload": f"{args.workload}: {P} street Gaussians (VEGS disc init), SH deg {deg}, {W}x{H} "
-                               f"KITTI-360 intrinsics, {n_views} views cycled, 12 output channels + colour/quat/scale grads; "
+                               f"KITTI-360 intrinsics, {n_views} views cycled, 12 output channels + colour/quat/scale grads; tile lists "
+                               f"without the (Gaussian, tile) pairs that cannot reach a pixel (R, F quoted on the reference's full rectangles); "
                                + (f"EVERY DISC x{args.disc_scale} (--disc-scale: not the headline workload); " if args.disc_scale != 1.0 else "")
                                + "every view is rendered as a camera's first visit (no per-camera state carried between views)",
                    "hints": "off",
@@ -599,6 +622,8 @@ def main():
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "traffic_collected": traffic_from, "secondary": secondary,
                      "alg_bytes_per_launch": round(bytes_k), "avg_launch_ms": round(ms_k, 4),
+                     "alg_bytes_note": "72 R + 56 N + 68 V with R on the reference's full tile rectangles (SURVEY 8d)",
+                     "frac_on_own_lists": round(bytes_k_own / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms_k > 0 else 0.0,
                      "launches_timed": int(stage[kern][1]),
                      "stage_ms": stage_ms,
                      "whole_view_alg_bytes": round(b_alg),
@@ -638,6 +663,9 @@ def main():
                     "autograd: + a dense accumulate per view)", sc, deg, cams, device, 4, 1, vps=8),
             variant("headline scene, a batch of 8 views per iteration, TWO VIEWS IN FLIGHT on two HIP streams", sc, deg,
                     cams, device, 4, 1, vps=8, streams=2),
+            variant("headline scene with VR_FLAG_FULL_TILE_LISTS: every tile of the reference's rectangles a list entry (the "
+                    "build's default leaves out the third of them whose tile the splat cannot reach: same images, radii and "
+                    "gradients) -- what the tight lists buy", sc, deg, cams, device, 16, 4, flags=rasterizer.FLAG_FULL_TILE_LISTS),
             variant("headline scene with VR_FLAG_FAST_EXP: the compositing's 2^x by v_exp_f32 in forward AND backward (lists "
                     "bit-exact, images within 1e-5 of the bit-exact mode but for threshold fragments; NOT the headline mode)",
                     sc, deg, cams, device, 16, 4, flags=rasterizer.FLAG_FAST_EXP),

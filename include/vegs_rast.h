@@ -132,7 +132,17 @@ typedef enum VrFlags {
      * VR_FLAG_SCAN_BINNING (same lists): the view is rendered correctly instead of being failed at its backward.  Costs
      * the forward its run-ahead over the binning (about one launch latency of GPU idle per view); the default leaves a
      * tripped view empty and reports it (vr_backward: VR_ERR_HIP). */
-    VR_FLAG_VERIFY_BINNING = 1u << 14
+    VR_FLAG_VERIFY_BINNING = 1u << 14,
+    /* ABI v8.  TILE LISTS.  The reference emits one list entry per tile of a Gaussian's rectangle, and the rectangle
+     * comes from the 3-sigma radius of the LARGER axis: on a street scene a third of those (Gaussian, tile) pairs cannot
+     * reach alpha >= 1/255 at any pixel centre of the tile -- for every pixel the blend rule skips them.  By default the
+     * library leaves such pairs out (rectangles of up to 64 tiles are tested tile by tile with a conservative
+     * ellipse-vs-rectangle test written in IEEE basic operations, which the CPU checker restates bit for bit): images,
+     * radii and gradients are what the full rectangles give -- bit-identical images -- while the lists the sorts and the
+     * compositing kernels work on are a third shorter.  num_rendered, n_contrib and vr_count_fragments then refer to the
+     * shorter lists.  This flag restores the reference's full rectangles (for comparisons with the fork's internal
+     * buffers, or with BASELINE.md's definition of a fragment). */
+    VR_FLAG_FULL_TILE_LISTS = 1u << 15
 } VrFlags;
 
 /* The op's tensor arguments (reference gaussian_renderer/__init__.py:86-94). Exactly one of
@@ -181,7 +191,7 @@ typedef struct VrSaved {
     void* binning;
     void* image;
     int64_t num_rendered;     /* R: tile-list entries */
-    int64_t num_visible;      /* V: Gaussians with radii > 0 */
+    int64_t num_visible;      /* V: Gaussians with at least one tile-list entry (= radii > 0 with VR_FLAG_FULL_TILE_LISTS) */
     int64_t binning_capacity; /* entries the binning buffer was laid out for (>= R) */
     uint32_t* needed_hint;    /* IN/OUT, optional (NULL = none): device array [tiles], tiles = ceil(W/16)*ceil(H/16) in
                                  row-major tile order, owned by the caller and kept PER CAMERA.  On entry: the number of

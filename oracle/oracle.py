@@ -108,17 +108,17 @@ def forward(cam, means3D, shs, colors_precomp, opacities, scales, rotations, cov
         depth=np.zeros(P, np.float32), xy=np.zeros((P, 2), np.float32), cov3D=np.zeros((P, 6), np.float32),
         conic_op=np.zeros((P, 4), np.float32), rgb=np.zeros((P, 3), np.float32),
         clamped=np.zeros((P, 3), np.uint8), radii=np.zeros(P, np.int32), rect=np.zeros((P, 4), np.int32),
-        tiles_touched=np.zeros(P, np.uint32),
+        tiles_touched=np.zeros(P, np.uint32), tile_mask=np.zeros(P, np.uint64),
     )
     L.or_preprocess(C.byref(cam), P, _p(means3D), _p(shs), _p(colors_precomp), _p(opacities), _p(scales),
                     _p(rotations), _p(cov3D_precomp), _p(st["depth"]), _p(st["xy"]), _p(st["cov3D"]),
                     _p(st["conic_op"]), _p(st["rgb"]), _p(st["clamped"]), _p(st["radii"]), _p(st["rect"]),
-                    _p(st["tiles_touched"]))
+                    _p(st["tiles_touched"]), _p(st["tile_mask"]))
     R = int(L.or_count_rendered(P, _p(st["tiles_touched"])))
     keys = np.zeros(max(R, 1), np.uint64)
     point_list = np.zeros(max(R, 1), np.uint32)
     ranges = np.zeros((gx * gy, 2), np.int32)
-    L.or_binning(C.byref(cam), P, _p(st["depth"]), _p(st["rect"]), _p(st["tiles_touched"]), C.c_long(R),
+    L.or_binning(C.byref(cam), P, _p(st["depth"]), _p(st["rect"]), _p(st["tiles_touched"]), _p(st["tile_mask"]), C.c_long(R),
                  _p(keys), _p(point_list), _p(ranges))
     out = dict(
         color=np.zeros((3, H, W), np.float32), depth=np.zeros((1, H, W), np.float32),

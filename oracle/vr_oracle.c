@@ -53,6 +53,7 @@ typedef struct {
 #define FLAG_DEPTH_NORMALIZED 2u    /* depth = sum(w z) / (1 - T_final), 0 where nothing contributes (A-1 variant) */
 #define FLAG_EXTRA_NO_ALPHA_GRAD 4u /* depth/quat/scale: gradients reach the attributes only, not alpha (A.5 variant) */
 #define FLAG_FILL_EMPTY 8u          /* cov_quat += T_final * (1,0,0,0)                              (A-5 variant) */
+#define FLAG_FULL_TILE_LISTS 32768u /* tile lists hold the full rectangles (VR_FLAG_FULL_TILE_LISTS); default: tight lists */
 
 /* ------------------------------------------------------------------ math */
 
@@ -220,17 +221,69 @@ static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ?
 
 /* ------------------------------------------------------------ preprocess */
 
+/* ---- TIGHT TILE LISTS (vegs_amd/csrc/vr_device.h: the same functions, operation for operation).  A (Gaussian, tile) pair
+ * whose footprint ellipse -- alpha >= 1/255 -- cannot reach any pixel centre of the tile is a no-op for every pixel (the
+ * per-pixel rule of or_render_fwd skips it), so it is left out of the tile list; images, radii and gradients are what the
+ * full rectangles give.  Rectangles of more than 64 tiles are emitted whole.  IEEE basic operations only. */
+#define TIGHT_MAX_TILES 64
+#define VR_LN2 0.693147180559945309f
+static float vr_ln_repro(float v)
+{
+    uint32_t b;
+    memcpy(&b, &v, 4);
+    int e = (int)(b >> 23) - 127;
+    uint32_t mb = (b & 0x007FFFFFu) | 0x3F800000u;
+    float m;
+    memcpy(&m, &mb, 4);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    const float s = (m - 1.0f) / (m + 1.0f);
+    const float s2 = s * s;
+    float p = fmaf(s2, 0.142857149f, 0.2f);
+    p = fmaf(s2, p, 0.333333343f);
+    p = fmaf(s2, p, 1.0f);
+    return fmaf((float)e, VR_LN2, (2.0f * s) * p);
+}
+typedef struct { int mode; float lim, inv_A, inv_C; } TileTest;
+static TileTest tile_test_setup(float A, float B, float C, float opacity)
+{
+    TileTest t;
+    const float k = 2.0f * (vr_ln_repro(255.0f * opacity) + 0.01f);
+    t.lim = k * 1.001f + 0.001f;
+    t.inv_A = 1.0f / A;
+    t.inv_C = 1.0f / C;
+    const float det = A * C - B * B;
+    t.mode = !(k > 0.0f) ? 0 : ((!(A > 0.0f) || !(C > 0.0f) || !(det > 0.0f)) ? 1 : 2);
+    return t;
+}
+static float tile_edge_min(float a, float inv_a, float b, float c, float fixed, float lo, float hi)
+{
+    const float t = fminf(hi, fmaxf(lo, -b * fixed * inv_a));
+    return fmaf(fmaf(a, t, 2.0f * b * fixed), t, c * fixed * fixed);
+}
+static int tile_reachable(const TileTest* t, float sx, float sy, float A, float B, float C, int tx, int ty)
+{
+    if (t->mode != 2) return t->mode == 1;
+    const float xl = (float)(tx * TILE) - sx, xh = xl + (float)(TILE - 1);
+    const float yl = (float)(ty * TILE) - sy, yh = yl + (float)(TILE - 1);
+    const int in = xl <= 0.0f && xh >= 0.0f && yl <= 0.0f && yh >= 0.0f;
+    float q = tile_edge_min(A, t->inv_A, B, C, yl, xl, xh);
+    q = fminf(q, tile_edge_min(A, t->inv_A, B, C, yh, xl, xh));
+    q = fminf(q, tile_edge_min(C, t->inv_C, B, A, xl, yl, yh));
+    q = fminf(q, tile_edge_min(C, t->inv_C, B, A, xh, yl, yh));
+    return in || q <= t->lim;
+}
+
 /* A.2. Per Gaussian outputs (dense [P]); radii==0 marks culled/invisible. rect = xmin,ymin,xmax,ymax */
 void or_preprocess(const OrCam* cam, int P, const float* means3D, const float* shs,
                    const float* colors_precomp, const float* opacities, const float* scales,
                    const float* rotations, const float* cov3D_precomp,
                    float* depth, float* xy, float* cov3D, float* conic_op, float* rgb,
-                   unsigned char* clamped, int* radii, int* rect, uint32_t* tiles_touched)
+                   unsigned char* clamped, int* radii, int* rect, uint32_t* tiles_touched, uint64_t* tile_mask)
 {
     int gx = (cam->W + TILE - 1) / TILE, gy = (cam->H + TILE - 1) / TILE;
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < P; ++i) {
-        radii[i] = 0; tiles_touched[i] = 0;
+        radii[i] = 0; tiles_touched[i] = 0; tile_mask[i] = 0;
         depth[i] = 0.f; xy[2 * i] = xy[2 * i + 1] = 0.f;
         for (int k = 0; k < 6; ++k) cov3D[6 * i + k] = 0.f;
         for (int k = 0; k < 4; ++k) { conic_op[4 * i + k] = 0.f; rect[4 * i + k] = 0; }
@@ -288,7 +341,23 @@ void or_preprocess(const OrCam* cam, int P, const float* means3D, const float* s
         conic_op[4 * i + 2] = cv.a * det_inv;
         conic_op[4 * i + 3] = opacities[i];
         rect[4 * i + 0] = x0; rect[4 * i + 1] = y0; rect[4 * i + 2] = x1; rect[4 * i + 3] = y1;
-        tiles_touched[i] = (uint32_t)((x1 - x0) * (y1 - y0));
+        {   /* tiles the Gaussian's list entries go to: the reachable ones of its rectangle (bit j = tile j, row-major) */
+            const int area = (x1 - x0) * (y1 - y0);
+            uint64_t mask = 0;
+            if (area > TIGHT_MAX_TILES || (cam->flags & FLAG_FULL_TILE_LISTS)) {
+                mask = area >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << area) - 1);
+                tiles_touched[i] = (uint32_t)area;
+            } else {
+                const float A = conic_op[4 * i + 0], B = conic_op[4 * i + 1], Cc = conic_op[4 * i + 2];
+                const TileTest tt = tile_test_setup(A, B, Cc, opacities[i]);
+                int j = 0, cnt = 0;
+                for (int y = y0; y < y1; ++y)
+                    for (int x = x0; x < x1; ++x, ++j)
+                        if (tile_reachable(&tt, px, py, A, B, Cc, x, y)) { mask |= (uint64_t)1 << j; ++cnt; }
+                tiles_touched[i] = (uint32_t)cnt;
+            }
+            tile_mask[i] = mask;
+        }
     }
 }
 
@@ -321,7 +390,8 @@ long or_count_rendered(int P, const uint32_t* tiles_touched)
 
 /* A.3: keys (tile<<32 | depth bits), sorted by (tile, depth, id); ranges[2*t] = start,end */
 void or_binning(const OrCam* cam, int P, const float* depth, const int* rect,
-                const uint32_t* tiles_touched, long R, uint64_t* keys, uint32_t* point_list, int* ranges)
+                const uint32_t* tiles_touched, const uint64_t* tile_mask, long R, uint64_t* keys, uint32_t* point_list,
+                int* ranges)
 {
     int gx = (cam->W + TILE - 1) / TILE, gy = (cam->H + TILE - 1) / TILE;
     KV* kv = (KV*)malloc(sizeof(KV) * (size_t)(R > 0 ? R : 1));
@@ -330,8 +400,11 @@ void or_binning(const OrCam* cam, int P, const float* depth, const int* rect,
         if (!tiles_touched[i]) continue;
         uint32_t dbits;
         memcpy(&dbits, depth + i, 4);
+        const int masked = (rect[4 * i + 2] - rect[4 * i + 0]) * (rect[4 * i + 3] - rect[4 * i + 1]) <= TIGHT_MAX_TILES;
+        int j = 0;
         for (int y = rect[4 * i + 1]; y < rect[4 * i + 3]; ++y)
-            for (int x = rect[4 * i + 0]; x < rect[4 * i + 2]; ++x) {
+            for (int x = rect[4 * i + 0]; x < rect[4 * i + 2]; ++x, ++j) {
+                if (masked && !((tile_mask[i] >> j) & 1)) continue;      /* (tight lists: this tile cannot be reached) */
                 kv[off].key = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
                 kv[off].id = (uint32_t)i;
                 ++off;

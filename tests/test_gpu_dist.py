@@ -270,7 +270,11 @@ def test_bench_line_contract_single_gpu():
     # provenance of the counter figures, and the secondary ceilings (VALU issue, L2 atomics of the backward)
     assert "traffic_collected" in rf and (rf["traffic"] is None) == (isinstance(rf["traffic_collected"], str))
     sec = rf["secondary"]
-    assert sec["l2_atomics"]["atomics_per_view"] == 17 * sec["l2_atomics"]["flushes_per_view"] > 0
+    assert abs(sec["l2_atomics"]["atomics_per_view"] - 17 * sec["l2_atomics"]["flushes_per_view"]) <= 17 and sec["l2_atomics"]["flushes_per_view"] > 0
+    # fragments and list entries are quoted on the REFERENCE's full tile rectangles (BASELINE.md's definition); the build's
+    # own, tighter lists are reported beside them
+    mc = d["config"]["mean_counters"]
+    assert mc["R_lists"] < mc["R"] and mc["F_lists"] < mc["F"] and d["mfragments_per_s_own_lists"] < d["mfragments_per_s"]
     if rf["traffic"] is not None:
         assert 0 < sec["valu"]["frac"] < 1 and sec["valu"]["peak_ginst_per_s"] == 1228.8
     assert set(("preprocess", "render_fwd", "render_bwd", "preprocess_bwd", "k_seg_bwd")) <= set(rf["stage_ms"])

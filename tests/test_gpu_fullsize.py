@@ -310,7 +310,7 @@ def test_c3_headline_views_match_oracle(c3, dev):
     sc, deg, cam, T = c3
     cams = _bench_cams()
     st = _oracle_parity("c3 cam5", _inputs(sc), deg, cams[5], dev, hip_runs=3)
-    assert st["R"] > 3_000_000
+    assert st["R"] > 2_500_000          # (tight tile lists: about 4.2 M pairs with the reference's full rectangles)
     _oracle_parity("c3 cam10", _inputs(sc), deg, cams[10], dev)
 
 

@@ -933,7 +933,7 @@ def test_needed_hint_never_changes_results(dev):
             assert np.array_equal(x, y)
         hint1 = rasterizer._NEEDED[key].clone()
         assert int(hint1.max()) >= 3               # the scene really has multi-segment tiles
-        assert fa.num_rendered // 256 > int(hint1.sum()) + 500   # ... and many of their segments are never needed
+        assert fa.num_rendered // 256 > int(hint1.sum()) + 200   # ... and many of their segments are never needed (fewer since the tile lists are tight)
         b, fb, gb = run(1.0)                       # (2) perfect hint
         c, fc, gc = run(0.05)                      # (3) hint far too small -> fallback
         hint3 = rasterizer._NEEDED[key].clone()

@@ -20,6 +20,7 @@ FLAG_ROUNDS_OFF, FLAG_ROUNDS_ON = 1024, 2048
 FLAG_RAW_PARAMS = 4096
 FLAG_FAST_EXP = 8192
 FLAG_VERIFY_BINNING = 16384
+FLAG_FULL_TILE_LISTS = 32768
 
 VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH, VR_BUF_BACKWARD = 0, 1, 2, 3, 4
 

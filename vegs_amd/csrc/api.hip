@@ -21,7 +21,7 @@ static_assert(FLAG_SCALE_MODIFIED == VR_FLAG_SCALE_MODIFIED && FLAG_DEPTH_NORMAL
               FLAG_ROUNDS_OFF == VR_FLAG_ROUNDS_OFF && FLAG_ROUNDS_ON == VR_FLAG_ROUNDS_ON &&
               FLAG_RAW_PARAMS == VR_FLAG_RAW_PARAMS, "device-side flag constants must match include/vegs_rast.h");
 constexpr uint32_t KNOWN_FLAGS = FLAG_SCALE_MODIFIED | FLAG_DEPTH_NORMALIZED | FLAG_EXTRA_NO_ALPHA_GRAD | FLAG_FILL_EMPTY |
-                                 FLAG_DETERMINISTIC | FLAG_SCAN_BINNING | FLAG_ROUNDS_OFF | FLAG_ROUNDS_ON | FLAG_RAW_PARAMS | FLAG_FAST_EXP | FLAG_VERIFY_BINNING;
+                                 FLAG_DETERMINISTIC | FLAG_SCAN_BINNING | FLAG_ROUNDS_OFF | FLAG_ROUNDS_ON | FLAG_RAW_PARAMS | FLAG_FAST_EXP | FLAG_VERIFY_BINNING | FLAG_FULL_TILE_LISTS;
 
 static thread_local char g_err[512] = "";
 static thread_local VrCounters g_counters = {0, 0, 0, 0, 0};
@@ -345,17 +345,17 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     // ---- transient, P-sized
     const size_t s1 = binning_stage1_scratch_bytes(P);
     const size_t arr = align_up(p1 * 4, 256);
-    void* scr = alloc(user, VR_BUF_SCRATCH, 5 * arr + s1 + 256);
+    void* scr = alloc(user, VR_BUF_SCRATCH, 7 * arr + s1 + 256);
     if (!geom || !image || !scr) return fail(VR_ERR_ALLOC, "allocator returned NULL");
     Splat* rec = (Splat*)geom;
     float* final_T = (float*)((char*)image + IL.final_T);
     uint32_t* n_contrib = (uint32_t*)((char*)image + IL.n_contrib);
-    uint2* rect = (uint2*)scr;                                   // 8 B per Gaussian
-    uint32_t* depth_key = (uint32_t*)((char*)scr + 2 * arr);
-    uint32_t* vis_key = (uint32_t*)((char*)scr + 3 * arr);
-    uint32_t* vis_id = (uint32_t*)((char*)scr + 4 * arr);
-    void* scan_scr = (char*)scr + 5 * arr;
-    uint32_t* totals_dev = (uint32_t*)((char*)scr + 5 * arr + s1);
+    uint4* rect = (uint4*)scr;                                   // 16 B per Gaussian: rectangle + tile mask
+    uint32_t* depth_key = (uint32_t*)((char*)scr + 4 * arr);
+    uint32_t* vis_key = (uint32_t*)((char*)scr + 5 * arr);
+    uint32_t* vis_id = (uint32_t*)((char*)scr + 6 * arr);
+    void* scan_scr = (char*)scr + 7 * arr;
+    uint32_t* totals_dev = (uint32_t*)((char*)scr + 7 * arr + s1);
     bool ranges_zeroed = false, status_zeroed = false;
 
     uint32_t V = 0, R = 0, key_min = 0;

@@ -75,10 +75,18 @@ constexpr int HIST_WORDS = 4 * 512;   // digit totals of one sort: passes << dig
 
 // ---------------------------------------------------------------- generic 3-kernel scan
 
-__device__ __forceinline__ uint32_t rect_area(uint2 r) { return (r.y & 0xFFFFu) * (r.y >> 16); }
+// tiles a Gaussian's list entries go to: the reachable tiles of its rectangle (vr_device.h: TIGHT TILE LISTS; mask bit j =
+// tile j of the rectangle, row-major), or the whole rectangle when it has more than 64 tiles
+__device__ __forceinline__ uint32_t rect_area(uint4 r)
+{
+    const uint32_t area = (r.y & 0xFFFFu) * (r.y >> 16);
+    return area > (uint32_t)TIGHT_MAX_TILES ? area : (uint32_t)(__popc(r.z) + __popc(r.w));
+}
+__device__ __forceinline__ unsigned long long rect_mask(uint4 r) { return ((unsigned long long)r.w << 32) | r.z; }
+__device__ __forceinline__ bool rect_masked(uint4 r) { return (r.y & 0xFFFFu) * (r.y >> 16) <= (uint32_t)TIGHT_MAX_TILES; }
 
 struct SrcFlagTiles {  // 1 for visible Gaussians; secondary value = tiles touched (summed only);
-    const uint2* rect;  // also the min / max depth key of the visible ones (range of the depth sort)
+    const uint4* rect;  // also the min / max depth key of the visible ones (range of the depth sort)
     const uint32_t* depth_key;
     static constexpr bool MINMAX = true;
     __device__ uint32_t operator()(long i) const { return rect_area(rect[i]) ? 1u : 0u; }
@@ -86,7 +94,7 @@ struct SrcFlagTiles {  // 1 for visible Gaussians; secondary value = tiles touch
     __device__ uint32_t key(long i) const { return depth_key[i]; }
 };
 struct SrcRectSorted {  // tiles touched, in depth-sorted order (rectangles already gathered: coalesced reads)
-    const uint2* rect_sorted;
+    const uint4* rect_sorted;
     static constexpr bool MINMAX = false;
     __device__ uint32_t operator()(long i) const { return rect_area(rect_sorted[i]); }
     __device__ uint32_t second(long) const { return 0; }
@@ -255,7 +263,7 @@ size_t binning_stage1_scratch_bytes(int P)
 
 // Two halves: the totals {V, R, min key, max key} reach the host (host_mail, see k_scan_totals) while the apply kernel
 // runs, so the round trip overlaps with that kernel instead of idling the GPU.
-int launch_compact_reduce(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,
+int launch_compact_reduce(int P, const uint4* rect, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,
                           const uint32_t* err_in, uint32_t* host_mail, uint32_t seq, hipStream_t s, bool debug)
 {
     int nb = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
@@ -337,8 +345,8 @@ template <int BITS, bool GATHER>
 __global__ void __launch_bounds__(256)
 k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, long n, uint32_t kmin, int shift,
-                const uint32_t* __restrict__ hist_scanned, int nblk, const uint2* __restrict__ rect,
-                uint2* __restrict__ rect_sorted)
+                const uint32_t* __restrict__ hist_scanned, int nblk, const uint4* __restrict__ rect,
+                uint4* __restrict__ rect_sorted)
 {
     constexpr int SIZE = 1 << BITS;
     __shared__ uint32_t cnt[4][SIZE];
@@ -432,7 +440,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
 }
 
 // One pass = histogram -> scan (reduce + apply) -> scatter.
-struct RadixGather { const uint2* rect; uint2* rect_sorted; };
+struct RadixGather { const uint4* rect; uint4* rect_sorted; };
 template <int BITS>
 static int radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, long n, uint32_t kmin,
                       int shift, uint32_t* hist, uint32_t* bsum, const RadixGather* gather, hipStream_t s, bool debug)
@@ -449,7 +457,7 @@ static int radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, 
                            n, kmin, shift, (const uint32_t*)hist, nblk, gather->rect, gather->rect_sorted);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_radix_scatter<BITS, false>), dim3(nblk), dim3(256), 0, s, kin, vin, kout, vout,
-                           n, kmin, shift, (const uint32_t*)hist, nblk, (const uint2*)nullptr, (uint2*)nullptr);
+                           n, kmin, shift, (const uint32_t*)hist, nblk, (const uint4*)nullptr, (uint4*)nullptr);
     VR_KERNEL_CHECK("radix_scatter", s, debug);
     return 0;
 }
@@ -870,7 +878,7 @@ static int onesweep_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
 // histogram of this block's depth keys -- the digit plan follows from the totals the previous kernel left in device
 // memory, the host learns them in parallel --, and the clearing of the tile ranges and of the view's status region.
 __global__ void __launch_bounds__(256)
-k_compact_apply(const uint2* __restrict__ rect, const uint32_t* __restrict__ depth_key, long n,
+k_compact_apply(const uint4* __restrict__ rect, const uint32_t* __restrict__ depth_key, long n,
                 const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ totals, int tile_bits,
                 uint32_t* __restrict__ vis_key, uint32_t* __restrict__ vis_id, uint32_t* __restrict__ partial,
                 uint32_t* __restrict__ zero_a, long zero_na, uint4* __restrict__ status, long status_bytes)
@@ -934,7 +942,7 @@ k_compact_apply(const uint2* __restrict__ rect, const uint32_t* __restrict__ dep
     for (int d = threadIdx.x; d < words; d += 256) partial[(size_t)blockIdx.x * words + d] = h[d];
 }
 
-int launch_compact_apply(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, const uint32_t* totals_dev,
+int launch_compact_apply(int P, const uint4* rect, const uint32_t* depth_key, void* scratch, const uint32_t* totals_dev,
                          int tile_bits, uint32_t* vis_key, uint32_t* vis_id, uint32_t* zero_a, long zero_na,
                          void* status, size_t status_bytes, hipStream_t s, bool debug)
 {
@@ -954,8 +962,8 @@ int launch_compact_apply(int P, const uint2* rect, const uint32_t* depth_key, vo
 // the block's LDS prefix), so long rectangles do not serialise a lane and writes are coalesced.
 // the only gather of the binning stage: rectangles of the depth-sorted Gaussians (8 B each)
 __global__ void __launch_bounds__(256)
-k_gather_rect(int V, const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ rect,
-              uint2* __restrict__ rect_sorted)
+k_gather_rect(int V, const uint32_t* __restrict__ sorted_id, const uint4* __restrict__ rect,
+              uint4* __restrict__ rect_sorted)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r < V) rect_sorted[r] = rect[sorted_id[r]];
@@ -966,43 +974,63 @@ k_gather_rect(int V, const uint32_t* __restrict__ sorted_id, const uint2* __rest
 // consecutive lanes own consecutive output ranges, so the stores stay nearly coalesced; a large
 // rectangle is written by its whole wave, 64 entries per step.
 constexpr int EMIT_SMALL = 8;
+
+// The (tile, id) pairs of one wave's 64 rectangles, `cnt` kept tiles each (rect_area) from output position `off` on.
+// Small ones (<= EMIT_SMALL kept tiles: the vast majority) are written by their own lane, a large one by the whole wave.
+// Within a rectangle the kept tiles go out in row-major order (the reference's emission order, minus the tiles the mask
+// drops).
+__device__ __forceinline__ void emit_rects(uint4 rc, uint32_t cnt, uint32_t off, uint32_t id, int gx, int lane,
+                                           uint32_t* __restrict__ tkeys, uint32_t* __restrict__ tvals)
+{
+    const int x0 = (int)(rc.x & 0xFFFFu), y0 = (int)(rc.x >> 16), w = max((int)(rc.y & 0xFFFFu), 1);
+    const uint32_t area = (rc.y & 0xFFFFu) * (rc.y >> 16);
+    const bool masked = area <= (uint32_t)TIGHT_MAX_TILES;
+    const unsigned long long mask = rect_mask(rc);
+    if (cnt > 0 && cnt <= (uint32_t)EMIT_SMALL) {
+        int rx = 0, ry = 0;
+        uint32_t k = 0;
+        for (uint32_t j = 0; k < cnt; ++j) {
+            if (!masked || ((mask >> j) & 1ull)) {
+                tkeys[off + k] = (uint32_t)((y0 + ry) * gx + x0 + rx);
+                tvals[off + k] = id;
+                ++k;
+            }
+            if (++rx == w) { rx = 0; ++ry; }
+        }
+    }
+    // large ones: one at a time, all 64 lanes of the wave
+    for (unsigned long long big = __ballot(cnt > (uint32_t)EMIT_SMALL); big; big &= big - 1) {
+        const int src = __builtin_ctzll(big);
+        const uint32_t b_off = (uint32_t)__shfl((int)off, src, 64), b_area = (uint32_t)__shfl((int)area, src, 64);
+        const uint32_t b_id = (uint32_t)__shfl((int)id, src, 64);
+        const int b_x0 = __shfl(x0, src, 64), b_y0 = __shfl(y0, src, 64), b_w = __shfl(w, src, 64);
+        const unsigned long long b_mask = ((unsigned long long)(uint32_t)__shfl((int)rc.w, src, 64) << 32) |
+                                          (uint32_t)__shfl((int)rc.z, src, 64);
+        const bool b_masked = b_area <= (uint32_t)TIGHT_MAX_TILES;
+        for (uint32_t k = lane; k < b_area; k += 64) {
+            if (b_masked && !((b_mask >> k) & 1ull)) continue;
+            const uint32_t pos = b_masked ? (uint32_t)__popcll(b_mask & ((1ull << k) - 1ull)) : k;
+            const int ry = (int)(k / (uint32_t)b_w), rx = (int)(k - (uint32_t)ry * (uint32_t)b_w);
+            tkeys[b_off + pos] = (uint32_t)((b_y0 + ry) * gx + b_x0 + rx);
+            tvals[b_off + pos] = b_id;
+        }
+    }
+}
 __global__ void __launch_bounds__(256)
 k_emit(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ offs,
-       const uint2* __restrict__ rect_sorted, uint32_t* __restrict__ tkeys, uint32_t* __restrict__ tvals)
+       const uint4* __restrict__ rect_sorted, uint32_t* __restrict__ tkeys, uint32_t* __restrict__ tvals)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t off = 0, cnt = 0, id = 0;
-    int x0 = 0, y0 = 0, w = 1;
+    uint4 rc = make_uint4(0u, 0u, 0u, 0u);
     if (r < V) {
-        const uint2 rc = rect_sorted[r];
+        rc = rect_sorted[r];
         off = offs[r];
         cnt = rect_area(rc);
         id = sorted_id[r];
-        x0 = (int)(rc.x & 0xFFFFu);
-        y0 = (int)(rc.x >> 16);
-        w = max((int)(rc.y & 0xFFFFu), 1);
     }
-    if (cnt <= EMIT_SMALL) {
-        int rx = 0, ry = 0;
-        for (uint32_t k = 0; k < cnt; ++k) {
-            tkeys[off + k] = (uint32_t)((y0 + ry) * gx + x0 + rx);
-            tvals[off + k] = id;
-            if (++rx == w) { rx = 0; ++ry; }
-        }
-    }
-    // large rectangles: one at a time, all 64 lanes of the wave
-    for (unsigned long long big = __ballot(cnt > EMIT_SMALL); big; big &= big - 1) {
-        const int src = __builtin_ctzll(big);
-        const uint32_t b_off = (uint32_t)__shfl((int)off, src, 64), b_cnt = (uint32_t)__shfl((int)cnt, src, 64);
-        const uint32_t b_id = (uint32_t)__shfl((int)id, src, 64);
-        const int b_x0 = __shfl(x0, src, 64), b_y0 = __shfl(y0, src, 64), b_w = __shfl(w, src, 64);
-        for (uint32_t k = lane; k < b_cnt; k += 64) {
-            const int ry = (int)(k / (uint32_t)b_w), rx = (int)(k - (uint32_t)ry * (uint32_t)b_w);
-            tkeys[b_off + k] = (uint32_t)((b_y0 + ry) * gx + b_x0 + rx);
-            tvals[b_off + k] = b_id;
-        }
-    }
+    emit_rects(rc, cnt, off, id, gx, lane, tkeys, tvals);
 }
 
 // The same emission with the offset scan folded in: a workgroup sums its 256 rectangle areas, posts the sum and adds
@@ -1043,7 +1071,7 @@ __device__ __forceinline__ unsigned long long sum_posted_wave(const unsigned lon
 }
 
 __global__ void __launch_bounds__(256)
-k_emit_scan(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ rect,
+k_emit_scan(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint4* __restrict__ rect,
             unsigned long long* __restrict__ status, uint32_t* __restrict__ err, uint32_t* __restrict__ tkeys,
             uint32_t* __restrict__ tvals)
 {
@@ -1052,16 +1080,13 @@ k_emit_scan(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint2* 
     const int r = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t cnt = 0, id = 0;
-    int x0 = 0, y0 = 0, w = 1;
+    uint4 rc = make_uint4(0u, 0u, 0u, 0u);
     if (r < V) {
-        // the packed rectangle is gathered by id HERE (1.65 M random 8-byte reads): this kernel is bound by the
-        // latency of its waits, not by bandwidth, and hides them; in the last depth-sort pass they cost 22 us
+        // the packed rectangle + tile mask is gathered by id HERE (1.65 M random 16-byte reads): this kernel is bound by
+        // the latency of its waits, not by bandwidth, and hides them; in the last depth-sort pass they cost 22 us
         id = sorted_id[r];
-        const uint2 rc = rect[id];
+        rc = rect[id];
         cnt = rect_area(rc);
-        x0 = (int)(rc.x & 0xFFFFu);
-        y0 = (int)(rc.x >> 16);
-        w = max((int)(rc.y & 0xFFFFu), 1);
     }
     uint32_t total;
     const uint32_t ex = block_excl_scan(cnt, total, lds4);
@@ -1086,26 +1111,7 @@ k_emit_scan(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint2* 
     }
     __syncthreads();
     const uint32_t off = (uint32_t)s_before + ex;
-    if (cnt <= EMIT_SMALL) {
-        int rx = 0, ry = 0;
-        for (uint32_t k = 0; k < cnt; ++k) {
-            const uint32_t t = (uint32_t)((y0 + ry) * gx + x0 + rx);
-            tkeys[off + k] = t;
-            tvals[off + k] = id;
-            if (++rx == w) { rx = 0; ++ry; }
-        }
-    }
-    for (unsigned long long big = __ballot(cnt > EMIT_SMALL); big; big &= big - 1) {
-        const int src = __builtin_ctzll(big);
-        const uint32_t b_off = (uint32_t)__shfl((int)off, src, 64), b_cnt = (uint32_t)__shfl((int)cnt, src, 64);
-        const uint32_t b_id = (uint32_t)__shfl((int)id, src, 64);
-        const int b_x0 = __shfl(x0, src, 64), b_y0 = __shfl(y0, src, 64), b_w = __shfl(w, src, 64);
-        for (uint32_t k = lane; k < b_cnt; k += 64) {
-            const int ry = (int)(k / (uint32_t)b_w), rx = (int)(k - (uint32_t)ry * (uint32_t)b_w);
-            tkeys[b_off + k] = (uint32_t)((b_y0 + ry) * gx + b_x0 + rx);
-            tvals[b_off + k] = b_id;
-        }
-    }
+    emit_rects(rc, cnt, off, id, gx, lane, tkeys, tvals);
 }
 
 // Also (thread 0 of the launch): the look-back guard word as it stands after ALL waiting passes of this view, posted
@@ -1161,7 +1167,7 @@ static Stage2Layout stage2_layout(int V, long R, int ntiles)
     L.tmp_key = take(v * 4);
     L.tmp_id = take(v * 4);
     L.offs = take(v * 4);
-    L.rect_sorted = take(v * 8);
+    L.rect_sorted = take(v * 16);
     L.tkeysA = take(r * 4);
     L.tkeysB = take(r * 4);
     L.tvalsB = take(r * 4);
@@ -1187,13 +1193,13 @@ int binning_tile_bits(int ntiles) { return tile_bits_of(ntiles); }
 // The 4-launch passes and the separate offset scan (inputs too long for 30-bit look-back counts; also the shape of
 // the generic launch_sort_pairs used by knn.hip and the deterministic backward).
 static int binning_multi_launch(const Camera& cam, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
-                                uint32_t* vis_id, const uint2* rect, char* base, const Stage2Layout& L,
+                                uint32_t* vis_id, const uint4* rect, char* base, const Stage2Layout& L,
                                 uint32_t* point_list, uint32_t** tile_keys, hipStream_t s, bool debug)
 {
     uint32_t* tmp_key = (uint32_t*)(base + L.tmp_key);
     uint32_t* tmp_id = (uint32_t*)(base + L.tmp_id);
     uint32_t* offs = (uint32_t*)(base + L.offs);
-    uint2* rect_sorted = (uint2*)(base + L.rect_sorted);
+    uint4* rect_sorted = (uint4*)(base + L.rect_sorted);
     uint32_t* tkeysA = (uint32_t*)(base + L.tkeysA);
     uint32_t* tkeysB = (uint32_t*)(base + L.tkeysB);
     uint32_t* tvalsB = (uint32_t*)(base + L.tvalsB);
@@ -1226,7 +1232,7 @@ static int binning_multi_launch(const Camera& cam, int V, long R, uint32_t key_m
     uint32_t* vb = (passes % 2 == 0) ? tvalsB : point_list;
     uint32_t *ka = tkeysA, *kb = tkeysB;
     hipLaunchKernelGGL(k_emit, dim3(cdiv(V, 256)), dim3(256), 0, s, V, cam.gx, (const uint32_t*)sorted_id,
-                       (const uint32_t*)offs, (const uint2*)rect_sorted, ka, va);
+                       (const uint32_t*)offs, (const uint4*)rect_sorted, ka, va);
     VR_KERNEL_CHECK("emit", s, debug);
     prof_end(VR_STAGE_EMIT, s);
     ProfScope ps(VR_STAGE_TILE_SORT, s);
@@ -1238,7 +1244,7 @@ static int binning_multi_launch(const Camera& cam, int V, long R, uint32_t key_m
 }
 
 int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
-                   uint32_t* vis_id, const uint2* rect, const void* stage1_scratch, void* scratch, uint32_t* point_list,
+                   uint32_t* vis_id, const uint4* rect, const void* stage1_scratch, void* scratch, uint32_t* point_list,
                    int2* ranges, bool ranges_zeroed, bool status_zeroed, uint32_t* err, uint32_t* guard_post,
                    uint32_t guard_seq, bool debug_raise_guard, hipStream_t s, bool debug)
 {

@@ -40,6 +40,7 @@ constexpr uint32_t FLAG_SCAN_BINNING = 1u << 9;         // binning with the scan
 constexpr uint32_t FLAG_ROUNDS_OFF = 1u << 10;          // forward: all list segments at once
 constexpr uint32_t FLAG_ROUNDS_ON = 1u << 11;           // forward: segment rounds whatever the list density
 constexpr uint32_t FLAG_RAW_PARAMS = 1u << 12;          // opacities / scales / rotations are raw parameters (activated here)
+constexpr uint32_t FLAG_FULL_TILE_LISTS = 1u << 15;     // tile lists hold the reference's full rectangles (no tile test)
 constexpr uint32_t FLAG_VERIFY_BINNING = 1u << 14;      // forward: wait for the binning's guard word; a tripped view is re-binned without waits
 constexpr uint32_t FLAG_FAST_EXP = 1u << 13;            // the compositing's 2^x by the hardware's v_exp_f32 (forward AND backward)
 
@@ -263,6 +264,68 @@ __device__ __forceinline__ uint32_t strips_relevant_exact(float sx, float sy, fl
         bits |= rect_relevant(A, inv_A, B, C, inv_C, lim, xl, xh, yl, yh) ? (1u << s) : 0u;
     }
     return bits;
+}
+
+// ---- TIGHT TILE LISTS (round 4).  The reference's tile rectangle comes from the 3-sigma radius of the LARGER axis: on a
+// street scene a third of the (Gaussian, tile) pairs it emits cannot reach alpha >= 1/255 at ANY pixel centre of the tile
+// (thin discs, faint splats; profiles/experiments/README.md).  Such a pair is a no-op for every pixel -- the per-pixel rule
+// skips it -- so leaving it out of the tile list changes no image, no radius and no gradient; it shortens the lists the
+// sorts, the compositing kernels and their per-segment buffers are sized by.  The preprocess kernel therefore tests every
+// tile of a rectangle of up to 64 tiles (the same conservative ellipse-vs-rectangle test as the strip masks, over the
+// tile's 16 x 16 pixel centres) and hands the binning a 64-bit tile mask with the rectangle.  The test is part of the
+// LIST DEFINITION -- the CPU checker builds the same lists -- so it is written with IEEE basic operations only (no rcp,
+// no hardware log): bit-identical on host and device.  VR_FLAG_FULL_TILE_LISTS restores the reference's full rectangles.
+constexpr int TIGHT_MAX_TILES = 64;
+constexpr float VR_LN2 = 0.693147180559945309f;
+// ln(v), v > 0: v = m 2^e with m in [sqrt(1/2), sqrt(2)), ln m = 2 atanh(s), s = (m - 1) / (m + 1), four odd terms
+// (|s| <= 0.172: truncation < 4e-8).  The caller adds 1 % slack; what matters is that host and device agree bit for bit.
+__host__ __device__ inline float vr_ln_repro(float v)
+{
+    uint32_t b;
+    __builtin_memcpy(&b, &v, 4);
+    int e = (int)(b >> 23) - 127;
+    uint32_t mb = (b & 0x007FFFFFu) | 0x3F800000u;
+    float m;
+    __builtin_memcpy(&m, &mb, 4);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    const float s = (m - 1.0f) / (m + 1.0f);
+    const float s2 = s * s;
+    float p = fmaf(s2, 0.142857149f, 0.2f);
+    p = fmaf(s2, p, 0.333333343f);
+    p = fmaf(s2, p, 1.0f);
+    return fmaf((float)e, VR_LN2, (2.0f * s) * p);
+}
+// Per-splat constants of the tile test.  mode: 0 = reaches no tile at all (opacity below 1/255), 1 = every tile counts (not
+// a proper ellipse in fp32: the per-pixel rule decides), 2 = test with lim / inv_A / inv_C.
+struct TileTest { int mode; float lim, inv_A, inv_C; };
+__host__ __device__ inline TileTest tile_test_setup(float A, float B, float C, float opacity)
+{
+    TileTest t;
+    const float k = 2.0f * (vr_ln_repro(255.0f * opacity) + 0.01f);     // = -2 (ln(1 / (255 opacity)) - 0.01)
+    t.lim = k * 1.001f + 0.001f;
+    t.inv_A = 1.0f / A;
+    t.inv_C = 1.0f / C;
+    const float det = A * C - B * B;
+    t.mode = !(k > 0.0f) ? 0 : ((!(A > 0.0f) || !(C > 0.0f) || !(det > 0.0f)) ? 1 : 2);
+    return t;
+}
+__host__ __device__ inline float tile_edge_min(float a, float inv_a, float b, float c, float fixed, float lo, float hi)
+{
+    const float t = fminf(hi, fmaxf(lo, -b * fixed * inv_a));
+    return fmaf(fmaf(a, t, 2.0f * b * fixed), t, c * fixed * fixed);
+}
+// can the splat reach alpha >= 1/255 at a pixel centre of tile (tx, ty)?  (conservative: true when in doubt)
+__host__ __device__ inline bool tile_reachable(const TileTest& t, float sx, float sy, float A, float B, float C, int tx, int ty)
+{
+    if (t.mode != 2) return t.mode == 1;
+    const float xl = (float)(tx * TILE) - sx, xh = xl + (float)(TILE - 1);
+    const float yl = (float)(ty * TILE) - sy, yh = yl + (float)(TILE - 1);
+    const bool in = xl <= 0.0f && xh >= 0.0f && yl <= 0.0f && yh >= 0.0f;
+    float q = tile_edge_min(A, t.inv_A, B, C, yl, xl, xh);
+    q = fminf(q, tile_edge_min(A, t.inv_A, B, C, yh, xl, xh));
+    q = fminf(q, tile_edge_min(C, t.inv_C, B, A, xl, yl, yh));
+    q = fminf(q, tile_edge_min(C, t.inv_C, B, A, xh, yl, yh));
+    return in || q <= t.lim;
 }
 
 // The Gaussian exponent at a pixel in units of log2 e:  power2 = log2(e) (-1/2 (A dx^2 + C dy^2) - B dx dy)

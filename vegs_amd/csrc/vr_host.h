@@ -46,7 +46,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 int launch_preprocess(const Camera& cam, int P, const float* means3D, const float* shs, const float* shs_rest,
                       const float* shs_tail, int tail_start, const float* colors_precomp,
                       const float* opacities, const float* scales, const float* rotations,
-                      const float* cov3D_precomp, Splat* rec, int* radii, uint2* rect,
+                      const float* cov3D_precomp, Splat* rec, int* radii, uint4* rect,
                       uint32_t* depth_key, uint8_t* clampb, float* shd, hipStream_t s, bool debug);
 int launch_mark_visible(const float* xyz, int P, const float* view, uint8_t* present, hipStream_t s);
 
@@ -55,12 +55,12 @@ int launch_mark_visible(const float* xyz, int P, const float* view, uint8_t* pre
 // depth key, [4] = *err_in (the look-back guard word, see launch_binning).
 size_t binning_stage1_scratch_bytes(int P);
 // host_mail: device address of the caller's pinned, coherent mailbox; receives the five words, then host_mail[8] = seq.
-int launch_compact_reduce(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,
+int launch_compact_reduce(int P, const uint4* rect, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,
                           const uint32_t* err_in, uint32_t* host_mail, uint32_t seq, hipStream_t s, bool debug);
 // Second half of the compaction.  Side duties: the partial digit histograms of the depth keys (into `scratch`, for
 // the depth sort), clearing zero_a (the tile ranges) and, when `status` = binning_stage2_status(stage-2 scratch) is
 // given, the posted-sum status region of this view (else launch_binning clears it with a fill).
-int launch_compact_apply(int P, const uint2* rect, const uint32_t* depth_key, void* scratch, const uint32_t* totals_dev,
+int launch_compact_apply(int P, const uint4* rect, const uint32_t* depth_key, void* scratch, const uint32_t* totals_dev,
                          int tile_bits, uint32_t* vis_key, uint32_t* vis_id, uint32_t* zero_a, long zero_na,
                          void* status, size_t status_bytes, hipStream_t s, bool debug);
 
@@ -75,7 +75,7 @@ int binning_tile_bits(int ntiles);
 // pinned {seq, guard} slot that the last binning kernel fills with this view's sequence number and the guard word as it
 // stands after all waiting passes (NULL = none).  debug_raise_guard: test hook, raises the word as a timed-out wait would.
 int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
-                   uint32_t* vis_id, const uint2* rect, const void* stage1_scratch, void* scratch, uint32_t* point_list,
+                   uint32_t* vis_id, const uint4* rect, const void* stage1_scratch, void* scratch, uint32_t* point_list,
                    int2* ranges, bool ranges_zeroed, bool status_zeroed, uint32_t* err, uint32_t* guard_post,
                    uint32_t guard_seq, bool debug_raise_guard, hipStream_t s, bool debug);
 

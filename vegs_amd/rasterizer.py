@@ -51,6 +51,7 @@ FLAG_SCAN_BINNING = _capi.FLAG_SCAN_BINNING                # binning without int
 FLAG_ROUNDS_OFF = _capi.FLAG_ROUNDS_OFF                    # forward: every list segment at once, whatever the list density
 FLAG_ROUNDS_ON = _capi.FLAG_ROUNDS_ON                      # forward: segment rounds, whatever the list density (default: by density)
 FLAG_RAW_PARAMS = _capi.FLAG_RAW_PARAMS                    # opacities / scales / rotations are the model's raw parameters: activated in the kernel
+FLAG_FULL_TILE_LISTS = _capi.FLAG_FULL_TILE_LISTS          # tile lists hold the reference's full rectangles (default: tiles a splat cannot reach are left out)
 FLAG_VERIFY_BINNING = _capi.FLAG_VERIFY_BINNING            # forward waits for the binning guard; a tripped view is re-binned without waits (opt-in)
 FLAG_FAST_EXP = _capi.FLAG_FAST_EXP                        # 2^x by v_exp_f32 in the compositing kernels, forward and backward (images ~1e-6 off the bit-exact mode)
 _flags = int(os.environ.get("VEGS_RAST_FLAGS", "0"), 0)

@@ -664,8 +664,8 @@ def main():
             variant("headline scene, a batch of 8 views per iteration, TWO VIEWS IN FLIGHT on two HIP streams", sc, deg,
                     cams, device, 4, 1, vps=8, streams=2),
             variant("headline scene with VR_FLAG_FULL_TILE_LISTS: every tile of the reference's rectangles a list entry (the "
-                    "build's default leaves out the third of them whose tile the splat cannot reach: same images, radii and "
-                    "gradients) -- what the tight lists buy", sc, deg, cams, device, 16, 4, flags=rasterizer.FLAG_FULL_TILE_LISTS),
+                    "build's default leaves out the third of them whose tile the splat cannot reach: same radii, images and "
+                    "gradients to rounding) -- what the tight lists buy", sc, deg, cams, device, 16, 4, flags=rasterizer.FLAG_FULL_TILE_LISTS),
             variant("headline scene with VR_FLAG_FAST_EXP: the compositing's 2^x by v_exp_f32 in forward AND backward (lists "
                     "bit-exact, images within 1e-5 of the bit-exact mode but for threshold fragments; NOT the headline mode)",
                     sc, deg, cams, device, 16, 4, flags=rasterizer.FLAG_FAST_EXP),

@@ -138,7 +138,8 @@ typedef enum VrFlags {
      * reach alpha >= 1/255 at any pixel centre of the tile -- for every pixel the blend rule skips them.  By default the
      * library leaves such pairs out (rectangles of up to 64 tiles are tested tile by tile with a conservative
      * ellipse-vs-rectangle test written in IEEE basic operations, which the CPU checker restates bit for bit): images,
-     * radii and gradients are what the full rectangles give -- bit-identical images -- while the lists the sorts and the
+     * radii and gradients are what the full rectangles give -- images to rounding (~5e-7: the sums are grouped by
+     * 256-entry list segments, which start at other entries), radii exactly -- while the lists the sorts and the
      * compositing kernels work on are a third shorter.  num_rendered, n_contrib and vr_count_fragments then refer to the
      * shorter lists.  This flag restores the reference's full rectangles (for comparisons with the fork's internal
      * buffers, or with BASELINE.md's definition of a fragment). */

@@ -64,9 +64,10 @@ def _p(a):
 
 
 def make_cam(H, W, tanfovx, tanfovy, bg, scale_modifier, viewmatrix, projmatrix, campos, sh_degree, M, flags=0):
-    """flags: VrFlags bits 0-3 of include/vegs_rast.h (the fork assumptions of SURVEY.md A.8 as switches)."""
+    """flags: VrFlags bits 0-3 of include/vegs_rast.h (the fork assumptions of SURVEY.md A.8 as switches) and bit 15
+    (VR_FLAG_FULL_TILE_LISTS: the reference's full tile rectangles instead of the tight lists)."""
     cam = OrCam()
-    cam.flags = int(flags) & 0xF
+    cam.flags = int(flags) & (0xF | 32768)
     cam.H, cam.W = int(H), int(W)
     cam.tanfovx, cam.tanfovy = float(tanfovx), float(tanfovy)
     cam.bg[:] = [float(x) for x in np.asarray(bg, dtype=np.float32).reshape(3)]

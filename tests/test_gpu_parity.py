@@ -278,6 +278,31 @@ def test_fast_exp_mode_against_the_oracle(det, dev):
     assert any(not np.array_equal(exact[n], h_out[n]) for n in OUT_NAMES)
 
 
+def test_tight_and_full_tile_lists(dev):
+    """Default = tight tile lists (pairs that cannot reach a pixel are not listed); VR_FLAG_FULL_TILE_LISTS = the reference's
+    full rectangles.  Both modes bit-exact against the checker in the same mode (lists, images); between the modes: radii
+    identical, every tile's tight list a sub-sequence of its full list, images and gradients equal to rounding."""
+    from vegs_amd import scenes
+    FULL = 32768
+    sc, deg = scenes.scene_street(P=40000, length=60.0, sh_degree=3, seed=11)
+    sc["scales"][:200] *= 8.0                                   # some rectangles beyond 64 tiles: emitted whole
+    cam = scenes.kitti_camera(0.0, 0.3, 688, 188)
+    inputs = dict(means3D=sc["means3D"], shs=sc["shs"], colors_precomp=None, opacities=sc["opacities"], scales=sc["scales"],
+                  rotations=sc["rotations"], cov3D_precomp=None)
+    t_out, t_grads, _, st_t = _check_against_oracle(inputs, cam, [0.1, 0.2, 0.3], deg, 1.0, dev, seed=3, hip_flags=256)
+    f_out, f_grads, _, st_f = _check_against_oracle(inputs, cam, [0.1, 0.2, 0.3], deg, 1.0, dev, seed=3, flags=FULL, hip_flags=256)
+    assert st_t["R"] < 0.85 * st_f["R"] and np.array_equal(t_out["radii"], f_out["radii"])
+    for t in range(st_f["ranges"].shape[0]):
+        full = st_f["point_list"][st_f["ranges"][t, 0]:st_f["ranges"][t, 1]]
+        tight = st_t["point_list"][st_t["ranges"][t, 0]:st_t["ranges"][t, 1]]
+        assert np.array_equal(full[np.isin(full, tight)], tight), t
+    for n in OUT_NAMES:
+        assert np.abs(t_out[n] - f_out[n]).max() <= 1e-6 * max(1.0, float(np.abs(f_out[n]).max())), n
+    for k in t_grads:
+        if t_grads[k] is not None:
+            assert_grad_close("tight vs full " + k, t_grads[k], f_grads[k], rtol=1e-4, floor=1e-7)
+
+
 def test_c1_random_10k(dev):
     """BASELINE config 1: 10k random Gaussians, 256x256, SH degree 0."""
     from vegs_amd import scenes

@@ -269,7 +269,8 @@ __device__ __forceinline__ uint32_t strips_relevant_exact(float sx, float sy, fl
 // ---- TIGHT TILE LISTS (round 4).  The reference's tile rectangle comes from the 3-sigma radius of the LARGER axis: on a
 // street scene a third of the (Gaussian, tile) pairs it emits cannot reach alpha >= 1/255 at ANY pixel centre of the tile
 // (thin discs, faint splats; profiles/experiments/README.md).  Such a pair is a no-op for every pixel -- the per-pixel rule
-// skips it -- so leaving it out of the tile list changes no image, no radius and no gradient; it shortens the lists the
+// skips it -- so leaving it out of the tile list changes no radius and images / gradients by rounding only (the sums are
+// grouped by 256-entry list segments, which start at other entries: ~5e-7); it shortens the lists the
 // sorts, the compositing kernels and their per-segment buffers are sized by.  The preprocess kernel therefore tests every
 // tile of a rectangle of up to 64 tiles (the same conservative ellipse-vs-rectangle test as the strip masks, over the
 // tile's 16 x 16 pixel centres) and hands the binning a 64-bit tile mask with the rectangle.  The test is part of the

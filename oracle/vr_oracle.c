@@ -265,12 +265,13 @@ static int tile_reachable(const TileTest* t, float sx, float sy, float A, float 
     if (t->mode != 2) return t->mode == 1;
     const float xl = (float)(tx * TILE) - sx, xh = xl + (float)(TILE - 1);
     const float yl = (float)(ty * TILE) - sy, yh = yl + (float)(TILE - 1);
-    const int in = xl <= 0.0f && xh >= 0.0f && yl <= 0.0f && yh >= 0.0f;
-    float q = tile_edge_min(A, t->inv_A, B, C, yl, xl, xh);
-    q = fminf(q, tile_edge_min(A, t->inv_A, B, C, yh, xl, xh));
-    q = fminf(q, tile_edge_min(C, t->inv_C, B, A, xl, yl, yh));
-    q = fminf(q, tile_edge_min(C, t->inv_C, B, A, xh, yl, yh));
-    return in || q <= t->lim;
+    const int in_x = xl <= 0.0f && xh >= 0.0f, in_y = yl <= 0.0f && yh >= 0.0f;
+    const float fy = yl > 0.0f ? yl : yh, fx = xl > 0.0f ? xl : xh;
+    /* minimum over the rectangle of pixel centres: on the boundary FACING the centre (two edges at most) */
+    const float qy = tile_edge_min(A, t->inv_A, B, C, fy, xl, xh);
+    const float qx = tile_edge_min(C, t->inv_C, B, A, fx, yl, yh);
+    const float q = in_y ? qx : (in_x ? qy : fminf(qx, qy));
+    return (in_x && in_y) || q <= t->lim;
 }
 
 /* A.2. Per Gaussian outputs (dense [P]); radii==0 marks culled/invisible. rect = xmin,ymin,xmax,ymax */

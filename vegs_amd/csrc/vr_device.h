@@ -316,17 +316,20 @@ __host__ __device__ inline float tile_edge_min(float a, float inv_a, float b, fl
     return fmaf(fmaf(a, t, 2.0f * b * fixed), t, c * fixed * fixed);
 }
 // can the splat reach alpha >= 1/255 at a pixel centre of tile (tx, ty)?  (conservative: true when in doubt)
+// Minimum of the convex quadratic over the tile's rectangle of pixel centres: 0 when the centre lies inside; otherwise on
+// the boundary FACING the centre -- the horizontal edge on the centre's side when it lies above / below, the vertical one
+// when it lies left / right, the smaller of the two when both (two edge minimisations, not four).
 __host__ __device__ inline bool tile_reachable(const TileTest& t, float sx, float sy, float A, float B, float C, int tx, int ty)
 {
     if (t.mode != 2) return t.mode == 1;
     const float xl = (float)(tx * TILE) - sx, xh = xl + (float)(TILE - 1);
     const float yl = (float)(ty * TILE) - sy, yh = yl + (float)(TILE - 1);
-    const bool in = xl <= 0.0f && xh >= 0.0f && yl <= 0.0f && yh >= 0.0f;
-    float q = tile_edge_min(A, t.inv_A, B, C, yl, xl, xh);
-    q = fminf(q, tile_edge_min(A, t.inv_A, B, C, yh, xl, xh));
-    q = fminf(q, tile_edge_min(C, t.inv_C, B, A, xl, yl, yh));
-    q = fminf(q, tile_edge_min(C, t.inv_C, B, A, xh, yl, yh));
-    return in || q <= t.lim;
+    const bool in_x = xl <= 0.0f && xh >= 0.0f, in_y = yl <= 0.0f && yh >= 0.0f;
+    const float fy = yl > 0.0f ? yl : yh, fx = xl > 0.0f ? xl : xh;
+    const float qy = tile_edge_min(A, t.inv_A, B, C, fy, xl, xh);       // along the facing horizontal edge
+    const float qx = tile_edge_min(C, t.inv_C, B, A, fx, yl, yh);       // along the facing vertical edge
+    const float q = in_y ? qx : (in_x ? qy : fminf(qx, qy));
+    return (in_x && in_y) || q <= t.lim;
 }
 
 // The Gaussian exponent at a pixel in units of log2 e:  power2 = log2(e) (-1/2 (A dx^2 + C dy^2) - B dx dy)

@@ -129,3 +129,86 @@ void quad_stats(int H, int W, const int* ranges, const uint32_t* point_list, con
     }
     for (int k = 0; k < 10; ++k) out[k] = o[k];
 }
+
+/* chunk statistics of k_seg_bwd's pixel loop (needed segments only).  The kernel compacts a region's relevant entries (any
+ * pixel of the region reaches alpha >= 1/255), cuts them into chunks of CH entries from the front (the last chunk is the
+ * partial one) and, per chunk, walks the region's pixels in groups: a group is skipped outright when none of its pixels has
+ * its last contributor behind the chunk's first entry ("cheap"), rejected after the exponent test when no entry of the
+ * chunk reaches any of its pixels ("reject"), accepted otherwise.  scheme 0: CH = 64, 32 groups of 2 pixels (lanes 2pp, 2pp+1);
+ * scheme 1: CH = 32, 16 groups of 4 pixels (pairs pp and pp + 16); scheme 2: CH = 32, 16 groups of 4 = pairs 2pp', 2pp'+1
+ * (a 4 x 1 run).  out[3*s + 0..2] = cheap, reject, accepted trips; out[9 + s] = chunks; out[12] = units */
+void chunk_stats(int H, int W, const int* ranges, const uint32_t* point_list, const float* xy, const float* conic_op,
+                 const uint32_t* n_contrib, double* out)
+{
+    int gx = (W + 15) / 16, gy = (H + 15) / 16;
+    double o[13] = {0};
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gx * gy; ++tile) {
+        int tx = tile % gx, ty = tile / gx;
+        int s = ranges[2 * tile], e = ranges[2 * tile + 1];
+        double lo[13] = {0};
+        int maxnc = 0;
+        for (int ly = 0; ly < 16; ++ly) for (int lx = 0; lx < 16; ++lx) {
+            int px = tx * 16 + lx, py = ty * 16 + ly;
+            if (px < W && py < H && (int)n_contrib[(size_t)py * W + px] > maxnc) maxnc = n_contrib[(size_t)py * W + px];
+        }
+        static __thread unsigned long long hit[256];   /* per relevant entry: which of the 64 pixels it contributes to (e < nc) */
+        static __thread int relj[256];
+        for (int sb = s; sb < e && sb - s < maxnc; sb += 256) {
+            int se = sb + 256 < e ? sb + 256 : e;
+            for (int reg = 0; reg < 4; ++reg) {
+                int nrel = 0, nc[64], wmax = 0;
+                for (int l = 0; l < 64; ++l) {
+                    int px = tx * 16 + (reg % 2) * 8 + (l % 8), py = ty * 16 + (reg / 2) * 8 + (l / 8);
+                    nc[l] = (px < W && py < H) ? (int)n_contrib[(size_t)py * W + px] : 0;
+                    if (nc[l] > wmax) wmax = nc[l];
+                }
+                for (int j = sb; j < se; ++j) {
+                    int id = point_list[j];
+                    unsigned long long h = 0; int any = 0;
+                    for (int l = 0; l < 64; ++l) {
+                        int px = tx * 16 + (reg % 2) * 8 + (l % 8), py = ty * 16 + (reg / 2) * 8 + (l / 8);
+                        if (px >= W || py >= H) continue;
+                        float dx = xy[2 * id] - (float)px, dy = xy[2 * id + 1] - (float)py;
+                        const float* con = conic_op + 4 * id;
+                        float q = fmaf(con[2] * dy, dy, (con[0] * dx) * dx);
+                        float power = fmaf(-0.5f, q, -((con[1] * dx) * dy));
+                        if (power > 0.0f) continue;
+                        float alpha = fminf(0.99f, con[3] * vr_exp(power));
+                        if (alpha < 1.0f / 255.0f) continue;
+                        any = 1;
+                        if (j - s < nc[l]) h |= 1ull << l;
+                    }
+                    if (any) { hit[nrel] = h; relj[nrel] = j - s; nrel++; }
+                }
+                if (!nrel) continue;
+                lo[12] += 1;
+                for (int sch = 0; sch < 3; ++sch) {
+                    int CH = sch == 0 ? 64 : 32, ngroups = sch == 0 ? 32 : 16;
+                    for (int c0 = 0; c0 < nrel; c0 += CH) {
+                        int c1 = c0 + CH < nrel ? c0 + CH : nrel;
+                        int chunk_lo = relj[c0];
+                        lo[9 + sch] += 1;
+                        if (!(chunk_lo < wmax)) continue;
+                        unsigned long long all = 0;
+                        for (int r = c0; r < c1; ++r) all |= hit[r];
+                        for (int g = 0; g < ngroups; ++g) {
+                            unsigned long long pm;
+                            if (sch == 0) pm = 3ull << (2 * g);
+                            else if (sch == 1) pm = (3ull << (2 * g)) | (3ull << (2 * (g + 16)));
+                            else pm = 15ull << (4 * g);
+                            int mnc = 0;
+                            for (int l = 0; l < 64; ++l) if ((pm >> l) & 1ull) if (nc[l] > mnc) mnc = nc[l];
+                            if (mnc <= chunk_lo) lo[3 * sch + 0] += 1;
+                            else if (!(all & pm)) lo[3 * sch + 1] += 1;
+                            else lo[3 * sch + 2] += 1;
+                        }
+                    }
+                }
+            }
+        }
+#pragma omp critical
+        { for (int k = 0; k < 13; ++k) o[k] += lo[k]; }
+    }
+    for (int k = 0; k < 13; ++k) out[k] = o[k];
+}

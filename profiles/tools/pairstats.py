@@ -25,8 +25,18 @@ cumn = np.cumsum(hn) / hn.sum()
 print("nrel percentiles:", {q: int(np.searchsorted(cumn, q)) for q in (0.25, 0.5, 0.75, 0.9, 0.99)})
 print("trips weighted hist (max_c bucket: share of sum max_c):", {k: round(float((hm[a:b] * np.arange(a, b)).sum() / o[2]), 3) for k, (a, b) in {"1-4": (1, 5), "5-8": (5, 9), "9-16": (9, 17), "17-32": (17, 33), "33-64": (33, 65)}.items()})
 
+import sys as _s
+if len(_s.argv) > 2 and _s.argv[2] == "chunks":
+    q = None
 q = np.zeros(10)
 L.quad_stats(376, 1376, p(st["ranges"]), p(st["point_list"]), p(st["xy"]), p(st["conic_op"]), p(st["n_contrib"]), p(q))
 print("bwd pixel-pair trips now", q[0], "rows-of-16-per-quadrant trips", q[1], "ratio", q[0] / q[1], "| sum n", q[2], "sum_q n_q", q[3], "quadrants per entry", q[3] / q[2])
 print("fwd needed segs: sum n", q[4], "sum max_q n_q", q[5], "ratio", q[4] / q[5])
 print("fwd all segs: sum n", q[6], "sum max_q n_q", q[7], "ratio", q[6] / q[7], "quadrants per entry", q[8] / q[6], "units", q[9])
+
+ch = np.zeros(13)
+L.chunk_stats(376, 1376, p(st["ranges"]), p(st["point_list"]), p(st["xy"]), p(st["conic_op"]), p(st["n_contrib"]), p(ch))
+for sname, k in (("64 entries x 2 pixels (now)", 0), ("32 entries x 4 pixels (pairs pp, pp+16)", 1), ("32 entries x 4 pixels (4 x 1 runs)", 2)):
+    cheap, rej, acc = ch[3 * k:3 * k + 3]
+    print(f"k_seg_bwd {sname}: chunks {ch[9 + k]:.0f} trips cheap {cheap:.0f} reject {rej:.0f} accepted {acc:.0f}  cost(4/25/116) {(4 * cheap + 25 * rej + 116 * acc) / 1e6:.1f} M")
+print("units", ch[12])

@@ -59,6 +59,8 @@ def test_random_configuration(seed, dev):  # noqa: F811
     gmask = tuple(int(v) for v in rng.integers(0, 2, 5))
     if not any(gmask):
         gmask = (1, 0, 0, 0, 0)
-    # VEGS_FUZZ_HIP_FLAGS (campaigns): e.g. 256 deterministic backward, 512 scan binning, 2048 segment rounds forced on
+    # VEGS_FUZZ_HIP_FLAGS (campaigns): e.g. 256 deterministic backward, 512 scan binning, 2048 segment rounds forced on;
+    # VEGS_FUZZ_FLAGS: switches that change WHAT is computed, set on both sides (e.g. 32768 = the reference's full tile lists)
     tp._check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=seed, gmask=gmask, M=M,
+                             flags=int(os.environ.get("VEGS_FUZZ_FLAGS", "0")),
                              hip_flags=int(os.environ.get("VEGS_FUZZ_HIP_FLAGS", "0")))

@@ -224,8 +224,11 @@ static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ?
 /* ---- TIGHT TILE LISTS (vegs_amd/csrc/vr_device.h: the same functions, operation for operation).  A (Gaussian, tile) pair
  * whose footprint ellipse -- alpha >= 1/255 -- cannot reach any pixel centre of the tile is a no-op for every pixel (the
  * per-pixel rule of or_render_fwd skips it), so it is left out of the tile list; images, radii and gradients are what the
- * full rectangles give.  Rectangles of more than 64 tiles are emitted whole.  IEEE basic operations only. */
+ * full rectangles give.  IEEE basic operations only. */
 #define TIGHT_MAX_TILES 64
+#ifndef TIGHT_BIG_CELLS
+#define TIGHT_BIG_CELLS 32
+#endif
 #define VR_LN2 0.693147180559945309f
 static float vr_ln_repro(float v)
 {
@@ -260,11 +263,12 @@ static float tile_edge_min(float a, float inv_a, float b, float c, float fixed, 
     const float t = fminf(hi, fmaxf(lo, -b * fixed * inv_a));
     return fmaf(fmaf(a, t, 2.0f * b * fixed), t, c * fixed * fixed);
 }
-static int tile_reachable(const TileTest* t, float sx, float sy, float A, float B, float C, int tx, int ty)
+/* can the splat reach alpha >= 1/255 at a pixel centre of the block of ntx x nty tiles whose first tile is (tx, ty)? */
+static int tile_reachable(const TileTest* t, float sx, float sy, float A, float B, float C, int tx, int ty, int ntx, int nty)
 {
     if (t->mode != 2) return t->mode == 1;
-    const float xl = (float)(tx * TILE) - sx, xh = xl + (float)(TILE - 1);
-    const float yl = (float)(ty * TILE) - sy, yh = yl + (float)(TILE - 1);
+    const float xl = (float)(tx * TILE) - sx, xh = xl + (float)(ntx * TILE - 1);
+    const float yl = (float)(ty * TILE) - sy, yh = yl + (float)(nty * TILE - 1);
     const int in_x = xl <= 0.0f && xh >= 0.0f, in_y = yl <= 0.0f && yh >= 0.0f;
     const float fy = yl > 0.0f ? yl : yh, fx = xl > 0.0f ? xl : xh;
     /* minimum over the rectangle of pixel centres: on the boundary FACING the centre (two edges at most) */
@@ -272,6 +276,16 @@ static int tile_reachable(const TileTest* t, float sx, float sy, float A, float 
     const float qx = tile_edge_min(C, t->inv_C, B, A, fx, yl, yh);
     const float q = in_y ? qx : (in_x ? qy : fminf(qx, qy));
     return (in_x && in_y) || q <= t->lim;
+}
+/* Rectangles of more than 64 tiles are tested in CELLS of k x k tiles, k the smallest size for which the rectangle has at
+ * most 32 cells (mask bit j = cell j, row-major over ceil(w / k) x ceil(h / k) cells; the cells of the last column / row may
+ * be narrower): a cell none of whose pixel centres can be reached drops all its tiles.  k = 1 up to 64 tiles. */
+static int tile_cell_size(int w, int h)
+{
+    int k = 1;
+    const int limit = w * h <= TIGHT_MAX_TILES ? TIGHT_MAX_TILES : TIGHT_BIG_CELLS;
+    while (((w + k - 1) / k) * ((h + k - 1) / k) > limit) ++k;
+    return k;
 }
 
 /* A.2. Per Gaussian outputs (dense [P]); radii==0 marks culled/invisible. rect = xmin,ymin,xmax,ymax */
@@ -342,19 +356,22 @@ void or_preprocess(const OrCam* cam, int P, const float* means3D, const float* s
         conic_op[4 * i + 2] = cv.a * det_inv;
         conic_op[4 * i + 3] = opacities[i];
         rect[4 * i + 0] = x0; rect[4 * i + 1] = y0; rect[4 * i + 2] = x1; rect[4 * i + 3] = y1;
-        {   /* tiles the Gaussian's list entries go to: the reachable ones of its rectangle (bit j = tile j, row-major) */
-            const int area = (x1 - x0) * (y1 - y0);
+        {   /* tiles the Gaussian's list entries go to: those of the reachable cells of its rectangle */
+            const int w = x1 - x0, h = y1 - y0, area = w * h;
             uint64_t mask = 0;
-            if (area > TIGHT_MAX_TILES || (cam->flags & FLAG_FULL_TILE_LISTS)) {
+            if (cam->flags & FLAG_FULL_TILE_LISTS) {
                 mask = area >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << area) - 1);
                 tiles_touched[i] = (uint32_t)area;
             } else {
                 const float A = conic_op[4 * i + 0], B = conic_op[4 * i + 1], Cc = conic_op[4 * i + 2];
                 const TileTest tt = tile_test_setup(A, B, Cc, opacities[i]);
+                const int k = tile_cell_size(w, h);
                 int j = 0, cnt = 0;
-                for (int y = y0; y < y1; ++y)
-                    for (int x = x0; x < x1; ++x, ++j)
-                        if (tile_reachable(&tt, px, py, A, B, Cc, x, y)) { mask |= (uint64_t)1 << j; ++cnt; }
+                for (int y = y0; y < y1; y += k)
+                    for (int x = x0; x < x1; x += k, ++j) {
+                        const int ntx = x + k < x1 ? k : x1 - x, nty = y + k < y1 ? k : y1 - y;
+                        if (tile_reachable(&tt, px, py, A, B, Cc, x, y, ntx, nty)) { mask |= (uint64_t)1 << j; cnt += ntx * nty; }
+                    }
                 tiles_touched[i] = (uint32_t)cnt;
             }
             tile_mask[i] = mask;
@@ -401,11 +418,12 @@ void or_binning(const OrCam* cam, int P, const float* depth, const int* rect,
         if (!tiles_touched[i]) continue;
         uint32_t dbits;
         memcpy(&dbits, depth + i, 4);
-        const int masked = (rect[4 * i + 2] - rect[4 * i + 0]) * (rect[4 * i + 3] - rect[4 * i + 1]) <= TIGHT_MAX_TILES;
-        int j = 0;
-        for (int y = rect[4 * i + 1]; y < rect[4 * i + 3]; ++y)
-            for (int x = rect[4 * i + 0]; x < rect[4 * i + 2]; ++x, ++j) {
-                if (masked && !((tile_mask[i] >> j) & 1)) continue;      /* (tight lists: this tile cannot be reached) */
+        const int x0 = rect[4 * i + 0], y0 = rect[4 * i + 1], x1 = rect[4 * i + 2], y1 = rect[4 * i + 3];
+        const int k = tile_cell_size(x1 - x0, y1 - y0), cw = (x1 - x0 + k - 1) / k;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                const int j = ((y - y0) / k) * cw + (x - x0) / k;
+                if (!((tile_mask[i] >> j) & 1)) continue;      /* (tight lists: no pixel of this tile's cell can be reached) */
                 kv[off].key = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
                 kv[off].id = (uint32_t)i;
                 ++off;

@@ -75,15 +75,15 @@ constexpr int HIST_WORDS = 4 * 512;   // digit totals of one sort: passes << dig
 
 // ---------------------------------------------------------------- generic 3-kernel scan
 
-// tiles a Gaussian's list entries go to: the reachable tiles of its rectangle (vr_device.h: TIGHT TILE LISTS; mask bit j =
-// tile j of the rectangle, row-major), or the whole rectangle when it has more than 64 tiles
+// tiles a Gaussian's list entries go to: the tiles of the reachable cells of its rectangle (vr_device.h: TIGHT TILE LISTS).
+// Up to 64 tiles a cell is a tile, both words are mask (bit j = tile j, row-major) and the count is its population count;
+// beyond, r.z is the mask of at most 32 cells and r.w the number of kept tiles.
+__device__ __forceinline__ unsigned long long rect_mask(uint4 r) { return ((unsigned long long)r.w << 32) | r.z; }
 __device__ __forceinline__ uint32_t rect_area(uint4 r)
 {
     const uint32_t area = (r.y & 0xFFFFu) * (r.y >> 16);
-    return area > (uint32_t)TIGHT_MAX_TILES ? area : (uint32_t)(__popc(r.z) + __popc(r.w));
+    return area > (uint32_t)TIGHT_MAX_TILES ? r.w : (uint32_t)(__popc(r.z) + __popc(r.w));
 }
-__device__ __forceinline__ unsigned long long rect_mask(uint4 r) { return ((unsigned long long)r.w << 32) | r.z; }
-__device__ __forceinline__ bool rect_masked(uint4 r) { return (r.y & 0xFFFFu) * (r.y >> 16) <= (uint32_t)TIGHT_MAX_TILES; }
 
 struct SrcFlagTiles {  // 1 for visible Gaussians; secondary value = tiles touched (summed only);
     const uint4* rect;  // also the min / max depth key of the visible ones (range of the depth sort)
@@ -612,7 +612,7 @@ __host__ __device__ inline StatusPlan status_plan(long V, long R, int key_bits, 
 {
     StatusPlan p;
     p.depth = (onesweep_status_words(V, key_bits) * 4 + 15) / 16 * 16;
-    p.emit = (emit_status_words(V) * 8 + 15) / 16 * 16;
+    p.emit = (emit_status_words(V) * 8 + 15) / 16 * 16 + 16;     // (+ the counter of the big-rectangle list, emit_rects)
     p.tile = (onesweep_status_words(R, tile_bits) * 4 + 15) / 16 * 16;
     return p;
 }
@@ -975,22 +975,32 @@ k_gather_rect(int V, const uint32_t* __restrict__ sorted_id, const uint4* __rest
 // rectangle is written by its whole wave, 64 entries per step.
 constexpr int EMIT_SMALL = 8;
 
+// Rectangles of more than 64 tiles are NOT emitted by the wave that owns them: the depth order puts the nearest Gaussians
+// -- the ones with screen-sized rectangles -- side by side, and the first wave of a street view walked 200 ... 300 64-tile
+// steps while the average wave has 0.2 (k_emit_scan waited for that one wave).  They are appended to a list, and
+// k_emit_big gives every one of them a wave of its own.
+struct BigRects {
+    uint32_t* count;     // entries so far (cleared with the status words of the view)
+    uint2* items;        // {first output position, Gaussian id}
+};
+
 // The (tile, id) pairs of one wave's 64 rectangles, `cnt` kept tiles each (rect_area) from output position `off` on.
-// Small ones (<= EMIT_SMALL kept tiles: the vast majority) are written by their own lane, a large one by the whole wave.
-// Within a rectangle the kept tiles go out in row-major order (the reference's emission order, minus the tiles the mask
-// drops).
+// Small ones (<= EMIT_SMALL kept tiles: the vast majority) are written by their own lane, one of 9 ... 64 tiles by the whole
+// wave, larger ones are listed for k_emit_big.  Within a rectangle the kept tiles go out in row-major order (the reference's
+// emission order, minus the tiles the mask drops).
 __device__ __forceinline__ void emit_rects(uint4 rc, uint32_t cnt, uint32_t off, uint32_t id, int gx, int lane,
-                                           uint32_t* __restrict__ tkeys, uint32_t* __restrict__ tvals)
+                                           uint32_t* __restrict__ tkeys, uint32_t* __restrict__ tvals, BigRects big_list)
 {
-    const int x0 = (int)(rc.x & 0xFFFFu), y0 = (int)(rc.x >> 16), w = max((int)(rc.y & 0xFFFFu), 1);
-    const uint32_t area = (rc.y & 0xFFFFu) * (rc.y >> 16);
-    const bool masked = area <= (uint32_t)TIGHT_MAX_TILES;
+    const int x0 = (int)(rc.x & 0xFFFFu), y0 = (int)(rc.x >> 16), w = max((int)(rc.y & 0xFFFFu), 1), h = (int)(rc.y >> 16);
+    const uint32_t area = (uint32_t)(w * h);
     const unsigned long long mask = rect_mask(rc);
-    if (cnt > 0 && cnt <= (uint32_t)EMIT_SMALL) {
+    const bool huge = cnt > 0 && area > (uint32_t)TIGHT_MAX_TILES;
+    const bool small = cnt > 0 && cnt <= (uint32_t)EMIT_SMALL && !huge;
+    if (small) {
         int rx = 0, ry = 0;
         uint32_t k = 0;
         for (uint32_t j = 0; k < cnt; ++j) {
-            if (!masked || ((mask >> j) & 1ull)) {
+            if ((mask >> j) & 1ull) {
                 tkeys[off + k] = (uint32_t)((y0 + ry) * gx + x0 + rx);
                 tvals[off + k] = id;
                 ++k;
@@ -998,27 +1008,68 @@ __device__ __forceinline__ void emit_rects(uint4 rc, uint32_t cnt, uint32_t off,
             if (++rx == w) { rx = 0; ++ry; }
         }
     }
-    // large ones: one at a time, all 64 lanes of the wave
-    for (unsigned long long big = __ballot(cnt > (uint32_t)EMIT_SMALL); big; big &= big - 1) {
+    {
+        const unsigned long long hm = __ballot(huge);
+        if (hm) {
+            uint32_t base = 0;
+            if (lane == __builtin_ctzll(hm)) base = atomicAdd(big_list.count, (uint32_t)__popcll(hm));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(hm));
+            if (huge) big_list.items[base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = make_uint2(off, id);
+        }
+    }
+    // 9 ... 64 tiles: one at a time, all 64 lanes of the wave (a cell is a tile: positions from the mask itself)
+    for (unsigned long long big = __ballot(cnt > 0 && !small && !huge); big; big &= big - 1) {
         const int src = __builtin_ctzll(big);
-        const uint32_t b_off = (uint32_t)__shfl((int)off, src, 64), b_area = (uint32_t)__shfl((int)area, src, 64);
-        const uint32_t b_id = (uint32_t)__shfl((int)id, src, 64);
-        const int b_x0 = __shfl(x0, src, 64), b_y0 = __shfl(y0, src, 64), b_w = __shfl(w, src, 64);
-        const unsigned long long b_mask = ((unsigned long long)(uint32_t)__shfl((int)rc.w, src, 64) << 32) |
-                                          (uint32_t)__shfl((int)rc.z, src, 64);
-        const bool b_masked = b_area <= (uint32_t)TIGHT_MAX_TILES;
-        for (uint32_t k = lane; k < b_area; k += 64) {
-            if (b_masked && !((b_mask >> k) & 1ull)) continue;
-            const uint32_t pos = b_masked ? (uint32_t)__popcll(b_mask & ((1ull << k) - 1ull)) : k;
+        const uint32_t b_off = (uint32_t)__builtin_amdgcn_readlane((int)off, src);
+        const uint32_t b_id = (uint32_t)__builtin_amdgcn_readlane((int)id, src);
+        const int b_x0 = __builtin_amdgcn_readlane(x0, src), b_y0 = __builtin_amdgcn_readlane(y0, src);
+        const int b_w = __builtin_amdgcn_readlane(w, src);
+        const uint32_t b_area = (uint32_t)__builtin_amdgcn_readlane((int)area, src);
+        const unsigned long long b_mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)rc.w, src) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)rc.z, src);
+        const uint32_t k = (uint32_t)lane;
+        if (k < b_area && ((b_mask >> k) & 1ull)) {
+            const uint32_t pos = b_off + (uint32_t)__popcll(b_mask & ((1ull << k) - 1ull));
             const int ry = (int)(k / (uint32_t)b_w), rx = (int)(k - (uint32_t)ry * (uint32_t)b_w);
-            tkeys[b_off + pos] = (uint32_t)((b_y0 + ry) * gx + b_x0 + rx);
-            tvals[b_off + pos] = b_id;
+            tkeys[pos] = (uint32_t)((b_y0 + ry) * gx + b_x0 + rx);
+            tvals[pos] = b_id;
+        }
+    }
+}
+// One wave per listed rectangle (more than 64 tiles): 64 tiles per step, those of the mask's kept cells written.
+constexpr int EMIT_BIG_GRID = 2048;
+__global__ void __launch_bounds__(64)
+k_emit_big(BigRects big_list, const uint4* __restrict__ rect, int gx, uint32_t* __restrict__ tkeys,
+           uint32_t* __restrict__ tvals)
+{
+    const uint32_t n = *big_list.count;
+    const int lane = threadIdx.x;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint2 it = big_list.items[i];
+        const uint4 rc = rect[it.y];
+        const int x0 = (int)(rc.x & 0xFFFFu), y0 = (int)(rc.x >> 16), w = max((int)(rc.y & 0xFFFFu), 1), h = (int)(rc.y >> 16);
+        const uint32_t area = (uint32_t)(w * h), mask = rc.z;
+        int kc, cw, ch;
+        tile_cells(w, h, kc, cw, ch);
+        uint32_t done = 0;
+        for (uint32_t base = 0; base < area; base += 64) {
+            const uint32_t k = base + (uint32_t)lane;
+            const int ry = (int)(k / (uint32_t)w), rx = (int)(k - (uint32_t)ry * (uint32_t)w);
+            const int cell = (ry / kc) * cw + rx / kc;
+            const bool keep = k < area && ((mask >> (cell & 31)) & 1u);
+            const unsigned long long km = __ballot(keep);
+            if (keep) {
+                const uint32_t pos = it.x + done + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+                tkeys[pos] = (uint32_t)((y0 + ry) * gx + x0 + rx);
+                tvals[pos] = it.y;
+            }
+            done += (uint32_t)__popcll(km);
         }
     }
 }
 __global__ void __launch_bounds__(256)
 k_emit(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ offs,
-       const uint4* __restrict__ rect_sorted, uint32_t* __restrict__ tkeys, uint32_t* __restrict__ tvals)
+       const uint4* __restrict__ rect_sorted, uint32_t* __restrict__ tkeys, uint32_t* __restrict__ tvals, BigRects big_list)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -1030,7 +1081,7 @@ k_emit(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint32_t* __
         cnt = rect_area(rc);
         id = sorted_id[r];
     }
-    emit_rects(rc, cnt, off, id, gx, lane, tkeys, tvals);
+    emit_rects(rc, cnt, off, id, gx, lane, tkeys, tvals, big_list);
 }
 
 // The same emission with the offset scan folded in: a workgroup sums its 256 rectangle areas, posts the sum and adds
@@ -1073,7 +1124,7 @@ __device__ __forceinline__ unsigned long long sum_posted_wave(const unsigned lon
 __global__ void __launch_bounds__(256)
 k_emit_scan(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint4* __restrict__ rect,
             unsigned long long* __restrict__ status, uint32_t* __restrict__ err, uint32_t* __restrict__ tkeys,
-            uint32_t* __restrict__ tvals)
+            uint32_t* __restrict__ tvals, BigRects big_list)
 {
     __shared__ uint32_t lds4[4];
     __shared__ unsigned long long s_before;
@@ -1111,7 +1162,7 @@ k_emit_scan(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint4* 
     }
     __syncthreads();
     const uint32_t off = (uint32_t)s_before + ex;
-    emit_rects(rc, cnt, off, id, gx, lane, tkeys, tvals);
+    emit_rects(rc, cnt, off, id, gx, lane, tkeys, tvals, big_list);
 }
 
 // Also (thread 0 of the launch): the look-back guard word as it stands after ALL waiting passes of this view, posted
@@ -1143,7 +1194,7 @@ k_tile_ranges(const uint32_t* __restrict__ tkeys, long R, int2* __restrict__ ran
 // ---------------------------------------------------------------- stage 2 driver
 
 struct Stage2Layout {
-    size_t status, tmp_key, tmp_id, offs, rect_sorted, tkeysA, tkeysB, tvalsB, hist, bsum, tpartial, total;
+    size_t status, tmp_key, tmp_id, offs, rect_sorted, tkeysA, tkeysB, tvalsB, hist, bsum, tpartial, big, total;
 };
 
 static inline int tile_bits_of(int ntiles)
@@ -1162,7 +1213,7 @@ static Stage2Layout stage2_layout(int V, long R, int ntiles)
     const int tbits = tile_bits_of(ntiles);
     // posted block sums of the depth sort | emission scan | tile sort, packed at run time (status_plan); FIRST, so
     // that the compaction kernel can clear it knowing only the scratch pointer.  Sized for any depth-key span.
-    L.status = take(onesweep_status_words((long)v, 27) * 4 + emit_status_words((long)v) * 8 +
+    L.status = take(onesweep_status_words((long)v, 27) * 4 + emit_status_words((long)v) * 8 + 16 +
                     onesweep_status_words((long)r, tbits) * 4 + 64);
     L.tmp_key = take(v * 4);
     L.tmp_id = take(v * 4);
@@ -1177,6 +1228,7 @@ static Stage2Layout stage2_layout(int V, long R, int ntiles)
     L.bsum = take(radix_bsum_words((long)nmax) * 4 + 256);
     // partial digit histograms of the tile keys
     L.tpartial = take((size_t)HIST_BLOCKS * HIST_WORDS * 4);
+    L.big = take(v * 8 + 16);       // rectangles of more than 64 tiles: {output position, id} (+ the list's counter, multi-launch path)
     L.total = o;
     return L;
 }
@@ -1231,8 +1283,13 @@ static int binning_multi_launch(const Camera& cam, int V, long R, uint32_t key_m
     uint32_t* va = (passes % 2 == 0) ? point_list : tvalsB;   // the last pass must land in point_list
     uint32_t* vb = (passes % 2 == 0) ? tvalsB : point_list;
     uint32_t *ka = tkeysA, *kb = tkeysB;
+    BigRects big_list;
+    big_list.items = (uint2*)(base + L.big);
+    big_list.count = (uint32_t*)(base + L.big + (size_t)(V > 0 ? V : 1) * 8);
+    VR_HIP(hipMemsetAsync(big_list.count, 0, 4, s));
     hipLaunchKernelGGL(k_emit, dim3(cdiv(V, 256)), dim3(256), 0, s, V, cam.gx, (const uint32_t*)sorted_id,
-                       (const uint32_t*)offs, (const uint4*)rect_sorted, ka, va);
+                       (const uint32_t*)offs, (const uint4*)rect_sorted, ka, va, big_list);
+    hipLaunchKernelGGL(k_emit_big, dim3(EMIT_BIG_GRID), dim3(64), 0, s, big_list, rect, cam.gx, ka, va);
     VR_KERNEL_CHECK("emit", s, debug);
     prof_end(VR_STAGE_EMIT, s);
     ProfScope ps(VR_STAGE_TILE_SORT, s);
@@ -1290,8 +1347,12 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
         const int passes = radix_passes(bits);
         uint32_t* va = (passes % 2 == 0) ? point_list : tvalsB;   // the last pass must land in point_list
         uint32_t* vb = (passes % 2 == 0) ? tvalsB : point_list;
+        BigRects big_list;
+        big_list.items = (uint2*)(base + L.big);
+        big_list.count = (uint32_t*)(st + sp.depth + sp.emit - 16);        // (cleared with the status words)
         hipLaunchKernelGGL(k_emit_scan, dim3(cdiv(V, 256)), dim3(256), 0, s, V, cam.gx, (const uint32_t*)sorted_id,
-                           rect, (unsigned long long*)(st + sp.depth), err, tkeysA, va);
+                           rect, (unsigned long long*)(st + sp.depth), err, tkeysA, va, big_list);
+        hipLaunchKernelGGL(k_emit_big, dim3(EMIT_BIG_GRID), dim3(64), 0, s, big_list, rect, cam.gx, tkeysA, va);
         VR_KERNEL_CHECK("emit_scan", s, debug);
         prof_end(VR_STAGE_EMIT, s);
         // 4. stable sort by tile id

@@ -117,12 +117,15 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
     unsigned long long tmask = 0ull;
     {
         const int area = vis ? rw * rh : 0;
-        const bool whole = area > TIGHT_MAX_TILES || (cam.flags & FLAG_FULL_TILE_LISTS);
-        if (area > 0 && whole) tmask = area >= 64 ? ~0ull : ((1ull << area) - 1ull);       // (beyond 64 tiles: the rectangle as it is)
-        const bool tested = area > 0 && !whole;
+        const bool full = (cam.flags & FLAG_FULL_TILE_LISTS) != 0u;
+        // the reference's lists: every tile (beyond 64 tiles: low word = the cell mask, high word = the number of kept tiles)
+        if (area > 0 && full)
+            tmask = area > TIGHT_MAX_TILES ? (((unsigned long long)(uint32_t)area << 32) | 0xFFFFFFFFull)
+                                           : (area == 64 ? ~0ull : ((1ull << area) - 1ull));
+        const bool tested = area > 0 && !full;
         TileTest tt = {0, 0.f, 0.f, 0.f};
         if (tested) tt = tile_test_setup(conA, conB, conC, opac);
-        // rectangles of up to 4 tiles (96 % of the Gaussians of a street view): by their own lane, four predicated steps
+        // rectangles of up to 4 tiles (91 % of the Gaussians of a street view): by their own lane, four predicated steps
         if (tested && area <= 4) {
             int cx = 0, cy = 0;
 #pragma unroll
@@ -131,20 +134,32 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
                 if (++cx == rw) { cx = 0; ++cy; }
             }
         }
-        // larger ones (5 ... 64 tiles; two or three per wave): one at a time by the whole wave, lane j = tile j -- a lane
-        // walking its own 64 tiles held its 63 neighbours up (k_preprocess 137 -> 183 us)
+        // larger ones (two or three per wave): one at a time by the whole wave, lane j = tile j -- beyond 64 tiles: cell j of
+        // k x k tiles, vr_device.h: tile_cells -- (a lane walking its own 64 tiles held its 63 neighbours up: k_preprocess 137 -> 183 us)
+        int kc_l = 1, cw_l = rw, ch_l = rh;
+        if (tested && area > TIGHT_MAX_TILES) tile_cells(rw, rh, kc_l, cw_l, ch_l);       // (rare: 0.02 % of a street view's Gaussians)
         for (unsigned long long big = __ballot(tested && area > 4); big; big &= big - 1) {
             const int src = __builtin_ctzll(big);
             auto bf = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
-            const int b_area = __builtin_amdgcn_readlane(area, src), b_w = __builtin_amdgcn_readlane(rw, src);
+            const int b_w = __builtin_amdgcn_readlane(rw, src), b_h = __builtin_amdgcn_readlane(rh, src);
             const int b_x0 = __builtin_amdgcn_readlane(rx0, src), b_y0 = __builtin_amdgcn_readlane(ry0, src);
+            const int kc = __builtin_amdgcn_readlane(kc_l, src), cw = __builtin_amdgcn_readlane(cw_l, src);
+            const int chh = __builtin_amdgcn_readlane(ch_l, src);
             TileTest bt;
             bt.mode = __builtin_amdgcn_readlane(tt.mode, src);
             bt.lim = bf(tt.lim); bt.inv_A = bf(tt.inv_A); bt.inv_C = bf(tt.inv_C);
             const float b_px = bf(px), b_py = bf(py), b_A = bf(conA), b_B = bf(conB), b_C = bf(conC);
-            const int cy = lane / b_w, cx = lane - cy * b_w;
-            const bool r = lane < b_area && tile_reachable(bt, b_px, b_py, b_A, b_B, b_C, b_x0 + cx, b_y0 + cy);
-            const unsigned long long bm = __ballot(r);
+            const int cy = lane / cw, cx = lane - cy * cw;
+            const int ntx = min(kc, b_w - cx * kc), nty = min(kc, b_h - cy * kc);
+            const bool r = lane < cw * chh &&
+                           tile_reachable(bt, b_px, b_py, b_A, b_B, b_C, b_x0 + cx * kc, b_y0 + cy * kc, ntx, nty);
+            unsigned long long bm = __ballot(r);
+            if (kc > 1) {        // (wave-uniform) the kept tiles are counted here, once: cells differ in size
+                int kept = r ? ntx * nty : 0;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) kept += __shfl_xor(kept, d, 64);
+                bm = (bm & 0xFFFFFFFFull) | ((unsigned long long)(uint32_t)kept << 32);
+            }
             if (lane == src) tmask = bm;
         }
     }

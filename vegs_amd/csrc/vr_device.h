@@ -272,8 +272,9 @@ __device__ __forceinline__ uint32_t strips_relevant_exact(float sx, float sy, fl
 // skips it -- so leaving it out of the tile list changes no radius and images / gradients by rounding only (the sums are
 // grouped by 256-entry list segments, which start at other entries: ~5e-7); it shortens the lists the
 // sorts, the compositing kernels and their per-segment buffers are sized by.  The preprocess kernel therefore tests every
-// tile of a rectangle of up to 64 tiles (the same conservative ellipse-vs-rectangle test as the strip masks, over the
-// tile's 16 x 16 pixel centres) and hands the binning a 64-bit tile mask with the rectangle.  The test is part of the
+// tile of a rectangle of up to 64 tiles -- every cell of k x k tiles of a larger one, tile_cells -- (the same
+// conservative ellipse-vs-rectangle test as the strip masks, over the tiles' 16 x 16 pixel centres) and hands the binning a
+// 64-bit mask with the rectangle.  The test is part of the
 // LIST DEFINITION -- the CPU checker builds the same lists -- so it is written with IEEE basic operations only (no rcp,
 // no hardware log): bit-identical on host and device.  VR_FLAG_FULL_TILE_LISTS restores the reference's full rectangles.
 constexpr int TIGHT_MAX_TILES = 64;
@@ -315,21 +316,39 @@ __host__ __device__ inline float tile_edge_min(float a, float inv_a, float b, fl
     const float t = fminf(hi, fmaxf(lo, -b * fixed * inv_a));
     return fmaf(fmaf(a, t, 2.0f * b * fixed), t, c * fixed * fixed);
 }
-// can the splat reach alpha >= 1/255 at a pixel centre of tile (tx, ty)?  (conservative: true when in doubt)
-// Minimum of the convex quadratic over the tile's rectangle of pixel centres: 0 when the centre lies inside; otherwise on
-// the boundary FACING the centre -- the horizontal edge on the centre's side when it lies above / below, the vertical one
-// when it lies left / right, the smaller of the two when both (two edge minimisations, not four).
-__host__ __device__ inline bool tile_reachable(const TileTest& t, float sx, float sy, float A, float B, float C, int tx, int ty)
+// can the splat reach alpha >= 1/255 at a pixel centre of the block of ntx x nty tiles whose first tile is (tx, ty)?
+// (conservative: true when in doubt).  Minimum of the convex quadratic over the block's rectangle of pixel centres: 0 when
+// the centre lies inside; otherwise on the boundary FACING the centre -- the horizontal edge on the centre's side when it
+// lies above / below, the vertical one when it lies left / right, the smaller of the two when both (two edge minimisations,
+// not four).
+__host__ __device__ inline bool tile_reachable(const TileTest& t, float sx, float sy, float A, float B, float C, int tx, int ty,
+                                               int ntx = 1, int nty = 1)
 {
     if (t.mode != 2) return t.mode == 1;
-    const float xl = (float)(tx * TILE) - sx, xh = xl + (float)(TILE - 1);
-    const float yl = (float)(ty * TILE) - sy, yh = yl + (float)(TILE - 1);
+    const float xl = (float)(tx * TILE) - sx, xh = xl + (float)(ntx * TILE - 1);
+    const float yl = (float)(ty * TILE) - sy, yh = yl + (float)(nty * TILE - 1);
     const bool in_x = xl <= 0.0f && xh >= 0.0f, in_y = yl <= 0.0f && yh >= 0.0f;
     const float fy = yl > 0.0f ? yl : yh, fx = xl > 0.0f ? xl : xh;
     const float qy = tile_edge_min(A, t.inv_A, B, C, fy, xl, xh);       // along the facing horizontal edge
     const float qx = tile_edge_min(C, t.inv_C, B, A, fx, yl, yh);       // along the facing vertical edge
     const float q = in_y ? qx : (in_x ? qy : fminf(qx, qy));
     return (in_x && in_y) || q <= t.lim;
+}
+// Rectangles of more than 64 tiles are tested in CELLS of k x k tiles, k the smallest size for which the rectangle has at
+// most 32 cells (mask bit j = cell j, row-major over cw x ch = ceil(w / k) x ceil(h / k) cells; the last column / row of
+// cells may be narrower): a cell none of whose pixel centres can be reached drops all its tiles.  Their mask needs one
+// word; the other one holds the number of kept tiles (up to 64 tiles it is the mask's population count), so that nobody has
+// to recount.  Without a division: cw = ceil(w / k) is the c with (c - 1) k < w <= c k, and it only shrinks as k grows.
+constexpr int TIGHT_BIG_CELLS = 32;
+__host__ __device__ inline void tile_cells(int w, int h, int& k, int& cw, int& ch)
+{
+    k = 1; cw = w; ch = h;
+    if (w * h <= TIGHT_MAX_TILES) return;
+    while (cw * ch > TIGHT_BIG_CELLS) {
+        ++k;
+        while ((cw - 1) * k >= w) --cw;
+        while ((ch - 1) * k >= h) --ch;
+    }
 }
 
 // The Gaussian exponent at a pixel in units of log2 e:  power2 = log2(e) (-1/2 (A dx^2 + C dy^2) - B dx dy)

@@ -147,11 +147,13 @@ def _check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=0, grad_rtol=GRAD
             if k in sens:
                 moved = sens[k]
                 ill_k = ill | (moved > 1.0)
-                # ... and such a row may miss by what the perturbation moves it -- x3 with the deterministic backward (its
-                # per-Gaussian sums are added in double: the rule of tests/test_gpu_fullsize.py), x8 with the atomic one (fp32
-                # sums in arbitrary order: the largest of three 1-sigma draws against a 3-sigma reality; a 31 M-entry view of
-                # profiles/tools/sweep_street.py has a row at 4.9 ... 13 x) --, at least by 10 allowances
-                quota = np.maximum(10.0, (3.0 if (flags | hip_flags) & 256 else 8.0) * moved)
+                # ... and such a row may miss by what the perturbation moves it -- x4 with the deterministic backward (its
+                # per-Gaussian sums are added in double; the full-size views of tests/test_gpu_fullsize.py stay within 2.7 x,
+                # a view of profiles/tools/sweep_street.py from inside the geometry -- median conic conditioning 22 instead
+                # of 3 -- has a row at 3.3 x: the measurement is the largest of three 1-sigma draws), x8 with the atomic one
+                # (fp32 sums in arbitrary order; a 31 M-entry view of the sweep has a row at 4.9 ... 13 x) --, at least by
+                # 10 allowances
+                quota = np.maximum(10.0, (4.0 if (flags | hip_flags) & 256 else 8.0) * moved)
                 explain_k = (lambda i, e=explain, m=moved: e(i) + f", measured summation sensitivity {m[i]:.3g} allowances")
         assert_grad_close(k, g, o_grads[k], rtol=grad_rtol, explain=explain_k, ill=ill_k, ill_quota=quota if per_gaussian else None)
     return h_out, h_grads, o_out, st

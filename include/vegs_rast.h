@@ -136,13 +136,14 @@ typedef enum VrFlags {
     /* ABI v8.  TILE LISTS.  The reference emits one list entry per tile of a Gaussian's rectangle, and the rectangle
      * comes from the 3-sigma radius of the LARGER axis: on a street scene a third of those (Gaussian, tile) pairs cannot
      * reach alpha >= 1/255 at any pixel centre of the tile -- for every pixel the blend rule skips them.  By default the
-     * library leaves such pairs out (rectangles of up to 64 tiles are tested tile by tile with a conservative
-     * ellipse-vs-rectangle test written in IEEE basic operations, which the CPU checker restates bit for bit): images,
-     * radii and gradients are what the full rectangles give -- images to rounding (~5e-7: the sums are grouped by
-     * 256-entry list segments, which start at other entries), radii exactly -- while the lists the sorts and the
-     * compositing kernels work on are a third shorter.  num_rendered, n_contrib and vr_count_fragments then refer to the
-     * shorter lists.  This flag restores the reference's full rectangles (for comparisons with the fork's internal
-     * buffers, or with BASELINE.md's definition of a fragment). */
+     * library leaves such pairs out (rectangles of up to 64 tiles are tested tile by tile, larger ones in cells of k x k
+     * tiles, with a conservative ellipse-vs-rectangle test written in IEEE basic operations, which the CPU checker restates
+     * bit for bit): images, radii and gradients are what the full rectangles give -- radii exactly, images to rounding
+     * (~5e-7: the sums are grouped by 256-entry list segments, which start at other entries; a pixel whose transmittance
+     * sits within an ulp of the 1e-4 stop test may take one fragment of weight < 1e-4 more or fewer) -- while the lists the
+     * sorts and the compositing kernels work on are a third shorter (more than half with large splats).  num_rendered,
+     * n_contrib and vr_count_fragments then refer to the shorter lists.  This flag restores the reference's full
+     * rectangles (for comparisons with the fork's internal buffers, or with BASELINE.md's definition of a fragment). */
     VR_FLAG_FULL_TILE_LISTS = 1u << 15
 } VrFlags;
 

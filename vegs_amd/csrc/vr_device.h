@@ -270,7 +270,8 @@ __device__ __forceinline__ uint32_t strips_relevant_exact(float sx, float sy, fl
 // street scene a third of the (Gaussian, tile) pairs it emits cannot reach alpha >= 1/255 at ANY pixel centre of the tile
 // (thin discs, faint splats; profiles/experiments/README.md).  Such a pair is a no-op for every pixel -- the per-pixel rule
 // skips it -- so leaving it out of the tile list changes no radius and images / gradients by rounding only (the sums are
-// grouped by 256-entry list segments, which start at other entries: ~5e-7); it shortens the lists the
+// grouped by 256-entry list segments, which start at other entries: ~5e-7, or one fragment of weight < 1e-4 in a pixel whose
+// transmittance sits within an ulp of the 1e-4 stop test); it shortens the lists the
 // sorts, the compositing kernels and their per-segment buffers are sized by.  The preprocess kernel therefore tests every
 // tile of a rectangle of up to 64 tiles -- every cell of k x k tiles of a larger one, tile_cells -- (the same
 // conservative ellipse-vs-rectangle test as the strip masks, over the tiles' 16 x 16 pixel centres) and hands the binning a

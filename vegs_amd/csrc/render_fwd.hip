@@ -199,6 +199,13 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
     return p;
 }
 
+// the forward's per-pixel outputs (what k_seg_combine writes; a tile with ONE list segment is finished by seg_first_body)
+struct FwdOut {
+    float *color, *depth, *quat, *scale, *alpha, *final_T;
+    uint32_t* n_contrib;
+    float* dsum;
+};
+
 // ---- A + C for a tile's FIRST segment in one pass.  Its boundary transmittance is 1 by definition, so nothing has to
 // wait for the chain: the workgroup builds the relevance masks and the local product like k_seg_alpha AND blends like
 // k_seg_blend (same expressions, same order: `part`, last contributor and the stop test are bit for bit what the two
@@ -214,10 +221,11 @@ __device__ __forceinline__ void seg_first_body(const Camera& cam, const int tile
                                                const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ point_list,
                                                const Splat* __restrict__ rec, float* __restrict__ Pbuf,
                                                unsigned long long* __restrict__ segmask, float* __restrict__ part,
-                                               float4 (*lds)[SEG], float2* lds_s, unsigned long long* masks)
+                                               float4 (*lds)[SEG], float2* lds_s, unsigned long long* masks, const FwdOut& o)
 {
     const uint32_t seg0 = seg_off[tile];
     if (seg_off[tile + 1] == seg0) return;                     // empty tile
+    const bool single = seg_off[tile + 1] - seg0 == 1u;        // (half of a street view's tiles: finished here, below)
     SegCtx c;
     if (!seg_setup_at(cam, ranges, seg_off, seg0, threadIdx.x >> 6, c)) return;
     {
@@ -306,13 +314,42 @@ __device__ __forceinline__ void seg_first_body(const Camera& cam, const int tile
     const bool stopped = c.inside && gx == GATED;
     Pbuf[(size_t)c.seg * SEG + threadIdx.x] = stopped ? pstop : p;
     if (c.inside) {
-        float* dst = part + (size_t)c.seg * (NPART * SEG) + threadIdx.x;
         const float Cs[NCH] = {Cp[0].x, Cp[0].y, Cp[1].x, Cd, Cp[1].y, Cp[2].x, Cp[2].y, Cp[3].x, Cp[3].y, Cp[4].x, Cp[4].y};
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) dst[k * SEG] = Cs[k];
-        dst[11 * SEG] = p;
         const uint32_t last = lastk >= 0 ? (uint32_t)(lastk + 1) : 0u;       // (sl = 0: tile-relative index + 1)
-        dst[12 * SEG] = __uint_as_float(last | (stopped ? 0x80000000u : 0u));
+        if (single) {
+            // The tile's ONLY segment: its sums are the pixel's sums -- the images are written here, with k_seg_combine's
+            // operations in k_seg_combine's order (0 + sum, Tb * product with Tb = 1), and the tile's 13 `part` planes
+            // are neither written nor read back (k_seg_combine skips the tile).
+            const size_t N = (size_t)cam.H * cam.W, pix = c.pix;
+            const float T = Tb * p;
+            float C[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) C[k] = 0.0f + Cs[k];
+            o.final_T[pix] = T;
+            o.n_contrib[pix] = last;
+            o.color[pix] = fmaf(T, cam.bg[0], C[0]);
+            o.color[N + pix] = fmaf(T, cam.bg[1], C[1]);
+            o.color[2 * N + pix] = fmaf(T, cam.bg[2], C[2]);
+            o.alpha[pix] = 1.0f - T;
+            float depth_out = C[3];
+            if (cam.flags & FLAG_DEPTH_NORMALIZED) {
+                const float A = 1.0f - T;
+                o.dsum[pix] = C[3];
+                depth_out = A > 0.0f ? C[3] / A : 0.0f;
+            }
+            o.depth[pix] = depth_out;
+            if (cam.flags & FLAG_FILL_EMPTY) C[4] += T;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o.quat[k * N + pix] = C[4 + k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o.scale[k * N + pix] = C[8 + k];
+        } else {
+            float* dst = part + (size_t)c.seg * (NPART * SEG) + threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) dst[k * SEG] = Cs[k];
+            dst[11 * SEG] = p;
+            dst[12 * SEG] = __uint_as_float(last | (stopped ? 0x80000000u : 0u));
+        }
     }
 }
 
@@ -333,7 +370,7 @@ template <int ROUND, bool FAST>
 __global__ void __launch_bounds__(256)
 k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off, uint32_t cap,
             const uint32_t* __restrict__ point_list, const Splat* __restrict__ rec, float* __restrict__ Pbuf,
-            unsigned long long* __restrict__ segmask, float* __restrict__ part, int first_fused)
+            unsigned long long* __restrict__ segmask, float* __restrict__ part, int first_fused, FwdOut fwd_out)
 {
     // (18.5 KB in round 0: eight workgroups per CU, as with the 8 KB of the plain path alone)
     __shared__ float4 lds[ROUND == 0 ? 4 : 2][SEG];
@@ -343,7 +380,7 @@ k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     // without a hint); the catch-up rounds a fixed grid striding over a list whose length only the device knows
     const int ntiles = cam.gx * cam.gy;
     if (ROUND == 0 && first_fused && (int)blockIdx.x < ntiles) {      // the tiles' FIRST segments: alpha and blend in one pass
-        seg_first_body<FAST>(cam, (int)blockIdx.x, ranges, seg_off, point_list, rec, Pbuf, segmask, part, lds, lds_s, masks);
+        seg_first_body<FAST>(cam, (int)blockIdx.x, ranges, seg_off, point_list, rec, Pbuf, segmask, part, lds, lds_s, masks, fwd_out);
         return;
     }
     const uint32_t count = seg_off[seg_counts_offset(ntiles, cap) + ROUND];
@@ -639,7 +676,7 @@ __device__ __forceinline__ void seg_combine_group(const Camera& cam, uint32_t ca
                                                   float* __restrict__ out_depth, float* __restrict__ out_quat,
                                                   float* __restrict__ out_scale, float* __restrict__ out_alpha,
                                                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                  float* __restrict__ dsum)
+                                                  float* __restrict__ dsum, int first_fused)
 {
     // planes of `part` this group loads: [P0, P0 + NP) channel sums, then (WITH_P) the local product and (GROUP 0) the
     // last-contributor word
@@ -665,6 +702,7 @@ __device__ __forceinline__ void seg_combine_group(const Camera& cam, uint32_t ca
     const int px = tx * TILE + region_x(w, lane), py = ty * TILE + region_y(w, lane);
     if (!(px < cam.W && py < cam.H)) return;
     const uint32_t s0 = seg_off[tile];
+    if (first_fused && seg_off[tile + 1] - s0 == 1u) return;      // a tile with ONE segment was finished by seg_first_body
     const uint32_t needed = seg_needed[tile];
     float C[NP];
 #pragma unroll
@@ -732,17 +770,17 @@ k_seg_combine(Camera cam, uint32_t cap, const uint32_t* __restrict__ seg_off, co
               const float* __restrict__ Tbuf, const float* __restrict__ part, float* __restrict__ out_color,
               float* __restrict__ out_depth, float* __restrict__ out_quat, float* __restrict__ out_scale,
               float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-              float* __restrict__ dsum)
+              float* __restrict__ dsum, int first_fused)
 {
     if (blockIdx.y == 0)
         seg_combine_group<0>(cam, cap, seg_off, seg_needed, Tbuf, part, out_color, out_depth, out_quat, out_scale, out_alpha,
-                             final_T, n_contrib, dsum);
+                             final_T, n_contrib, dsum, first_fused);
     else if (blockIdx.y == 1)
         seg_combine_group<1>(cam, cap, seg_off, seg_needed, Tbuf, part, out_color, out_depth, out_quat, out_scale, out_alpha,
-                             final_T, n_contrib, dsum);
+                             final_T, n_contrib, dsum, first_fused);
     else
         seg_combine_group<2>(cam, cap, seg_off, seg_needed, Tbuf, part, out_color, out_depth, out_quat, out_scale, out_alpha,
-                             final_T, n_contrib, dsum);
+                             final_T, n_contrib, dsum, first_fused);
 }
 
 __global__ void __launch_bounds__(256)
@@ -868,9 +906,10 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     const unsigned grid0 = (unsigned)(!auto_rounds || nseg < bound0 ? nseg : bound0);
     const unsigned gridc = (unsigned)(nseg < 4096 ? nseg : 4096);
     const bool fast = (cam.flags & FLAG_FAST_EXP) != 0u;
+    const FwdOut fwd_out{out_color, out_depth, out_quat, out_scale, out_alpha, final_T, n_contrib, dsum};
 #define VR_ALPHA(RD, FST, GRID)                                                                                           \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_alpha<RD, FST>), dim3(GRID), dim3(256), 0, s, cam, ranges,                   \
-                       (const uint32_t*)seg_off, (uint32_t)nseg, point_list, rec, Pbuf, segmask, part, first_fused)
+                       (const uint32_t*)seg_off, (uint32_t)nseg, point_list, rec, Pbuf, segmask, part, first_fused, fwd_out)
 #define VR_ROUND(RD, GRID)                                                                                                \
     if (R > 0) { if (fast) VR_ALPHA(RD, true, GRID); else VR_ALPHA(RD, false, GRID); }                                    \
     if (R > 0 || RD == 0) hipLaunchKernelGGL(k_seg_scan<RD>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (uint32_t)nseg, second, \
@@ -897,7 +936,7 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     }
     hipLaunchKernelGGL(k_seg_combine, dim3(2 * ntiles, 3), dim3(256), 0, s, cam, (uint32_t)nseg, (const uint32_t*)seg_off,
                        (const uint32_t*)seg_needed, (const float*)Tbuf, (const float*)part, out_color, out_depth,
-                       out_quat, out_scale, out_alpha, final_T, n_contrib, dsum);
+                       out_quat, out_scale, out_alpha, final_T, n_contrib, dsum, first_fused);
     VR_KERNEL_CHECK("seg_combine", s, debug);
     return 0;
 }

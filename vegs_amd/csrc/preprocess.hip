@@ -39,7 +39,10 @@ __device__ __forceinline__ void sh_dot(const float* bas, int K, const float* sh,
 
 // RAW (VR_FLAG_RAW_PARAMS) is a compile-time switch: the default instantiation is the kernel as it was
 template <bool RAW>
-__global__ void __launch_bounds__(256)
+#ifndef PRE_THREADS
+#define PRE_THREADS 128      // (two waves per workgroup: the same three waves per SIMD in finer grains, 159 -> 157.5 us; one wave: 170 VGPRs, 189 us)
+#endif
+__global__ void __launch_bounds__(PRE_THREADS)
 k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
              const float* __restrict__ shs_rest, const float* __restrict__ shs_tail, int tail_start,
              const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -48,7 +51,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
              uint4* __restrict__ rect, uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clampb,
              float* __restrict__ shd)
 {
-    __shared__ __attribute__((aligned(16))) float sh_lds[4][64 * SH_LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float sh_lds[PRE_THREADS / 64][64 * SH_LDS_STRIDE];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool in_range = i < P;
@@ -335,10 +338,10 @@ int launch_preprocess(const Camera& cam, int P, const float* means3D, const floa
 {
     if (P == 0) return 0;
     if (cam.flags & FLAG_RAW_PARAMS)
-        hipLaunchKernelGGL(k_preprocess<true>, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, means3D, shs, shs_rest, shs_tail,
+        hipLaunchKernelGGL(k_preprocess<true>, dim3(cdiv(P, PRE_THREADS)), dim3(PRE_THREADS), 0, s, cam, P, means3D, shs, shs_rest, shs_tail,
                            tail_start, colors_precomp, opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, clampb, shd);
     else
-        hipLaunchKernelGGL(k_preprocess<false>, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, means3D, shs, shs_rest, shs_tail,
+        hipLaunchKernelGGL(k_preprocess<false>, dim3(cdiv(P, PRE_THREADS)), dim3(PRE_THREADS), 0, s, cam, P, means3D, shs, shs_rest, shs_tail,
                            tail_start, colors_precomp, opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, clampb, shd);
     VR_KERNEL_CHECK("preprocess", s, debug);
     return 0;

@@ -105,11 +105,11 @@ typedef enum VrFlags {
     VR_FLAG_SCAN_BINNING = 1u << 9,
     /* The forward's segment rounds (ABI v6).  A tile's list is cut into 256-entry segments; most of them lie behind
      * the point where every pixel of the tile has stopped.  With ROUNDS the forward evaluates the first 6 segments of
-     * every tile, then -- only for tiles that still have a live pixel -- the next 24 ... 48 (by list density), then whatever is left; without,
+     * every tile (2 on dense lists), then -- only for tiles that still have a live pixel -- the next 64 (8), then whatever is left; without,
      * every segment at once.  Results are identical bit for bit either way; the time is not: rounds win when lists
-     * are long (discs three times larger than the street scene's: forward 0.65 -> 0.48 ms) and lose on short ones (the
-     * heavy tiles' later rounds run at low parallelism: +0.04 ms on the headline view).  Default: chosen per call from
-     * the number of list entries (rounds from 12 segments per tile on).  A needed-segment hint implies rounds. */
+     * are long (discs three times larger than the street scene's: forward 0.49 -> 0.27 ms) and lose on short ones (the
+     * deep tiles' later rounds run at low parallelism: +0.04 ms on the headline view).  Default: chosen per call from
+     * the number of list entries (rounds from 6.5 segments per tile on).  A needed-segment hint implies rounds. */
     VR_FLAG_ROUNDS_OFF = 1u << 10,
     VR_FLAG_ROUNDS_ON = 1u << 11,
     /* opacities / scales / rotations are the model's RAW parameters (scene/gaussian_model.py:_opacity, _scaling,

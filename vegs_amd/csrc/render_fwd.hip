@@ -31,12 +31,21 @@ namespace vr {
 
 constexpr int NPART = 13;      // planes of `part` per segment: 11 channel sums, the local product, the last contributor
 __device__ __forceinline__ uint32_t hinted_limit(uint32_t h) { return h + 2u + (h >> 3); }
-constexpr uint32_t AUTO_FIRST = 6u;    // segments of every tile computed in round 0 of a forward with automatic rounds
-// ... and at least this many more in round 1.  Swept 12 ... 48 at 13 and at 24 list segments per tile: the sparser scene wants
-// 48 (forward 0.44 -> 0.39 ms), the denser 12 ... 30 (its pixels saturate sooner although its lists are longer) -- the host
-// knows the density when it launches (launch_render_fwd)
-constexpr uint32_t AUTO_SECOND_SPARSE = 48u, AUTO_SECOND_DENSE = 24u, AUTO_SECOND_SPLIT = 18u;
-constexpr uint32_t AUTO_DENSITY = 12u; // ... which are used from this many list segments per tile on (launch_render_fwd)
+// Segment rounds without a hint ("auto").  Re-tuned in round 4 on the tight tile lists (profiles/tools/ab/rounds.sh: the street
+// scene with its discs x 1 / 1.5 / 2 / 3 / 5 = 5.0 / 5.9 / 7.0 / 10 / 20 list segments per tile; render forward, ms):
+//   x1    all at once 0.358   rounds 6 + 48: 0.400, 6 + 64: 0.401, 12 + 96: 0.383   (deep vanishing-point tiles need the third
+//                                                                                  round's whole rest: a tail)
+//   x1.5  all at once 0.370   6 + 48: 0.344   6 + 64: 0.320
+//   x2    all at once 0.398   6 + 48: 0.319   6 + 64: 0.317   4 + 32: 0.309
+//   x3    all at once 0.488   6 + 24: 0.347   3 + 8: 0.292    2 + 8: 0.272    2 + 16: 0.273
+//   x5    all at once 0.842   6 + 24: 0.336   3 + 8: 0.242    2 + 8: 0.219    2 + 4: 0.216
+// Large, opaque discs saturate a tile within one or two segments; the rounds are used from 6.5 segments per tile on
+// (between x1.5 and x2: the crossover sits near 5.4, the headline view at 5.0 and its 1408-wide variant at 5.25 stay clear
+// of it), with 6 + 64 below 8.5 segments per tile and 2 + 8 from there on.  The host knows the density when it launches.
+constexpr uint32_t AUTO_FIRST_SPARSE = 6u, AUTO_FIRST_DENSE = 2u;     // segments of every tile computed in round 0
+constexpr uint32_t AUTO_SECOND_SPARSE = 64u, AUTO_SECOND_DENSE = 8u;  // ... and at least this many more in round 1
+constexpr uint32_t AUTO_ON_X2 = 13u, AUTO_DENSE_X2 = 17u;             // thresholds in HALF segments per tile (6.5, 8.5)
+constexpr uint32_t AUTO_FIRST = AUTO_FIRST_SPARSE;                    // (grid bound of round 0: the larger of the two)
 
 // seg_off[t] = first global segment id of tile t; seg_off[T] = total.  Single workgroup.  (k_seg_tiles then
 // fills seg_tile[s] = tile of segment s, 0xFFFFFFFF beyond the total: the launch grids cover `cap` segments.)
@@ -884,16 +893,19 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     const size_t nseg = seg_capacity(R, ntiles);
     float* Pbuf = (float*)scratch;
     constexpr int first_fused = 1;     // (0 = the round-3 structure: every first segment through k_seg_alpha and k_seg_blend; A/B on one box: same time)
-    // Rounds without a hint ("auto"): worth it on dense lists only.  On the headline view (7 segments per tile on
-    // average) the heavy tiles' catch-up rounds run at low parallelism behind everybody else's round 0 and cost 40 us more
-    // than the 22 % fewer segments save; with discs three times larger (25 per tile, 70 % of them never needed) the forward
-    // drops from 0.645 to 0.49 ms.  The host knows R when it gets here; VR_FLAG_ROUNDS_OFF / _ON override.
+    // Rounds without a hint ("auto"): worth it from 6.5 list segments per tile on (the table at AUTO_FIRST_SPARSE above).  On
+    // the headline view (5 per tile) the deep tiles' catch-up rounds run at low parallelism behind everybody else's round 0
+    // and cost 40 us more than the skipped segments save.  The host knows R when it gets here; VR_FLAG_ROUNDS_OFF / _ON
+    // override.
+    const size_t half_segs = 2 * (size_t)R / SEG;            // list density in half segments per tile x tiles
+    const bool dense = half_segs >= (size_t)AUTO_DENSE_X2 * ntiles;
     const bool auto_rounds = !needed_hint && R > 0 && !(cam.flags & FLAG_ROUNDS_OFF) &&
-                             ((cam.flags & FLAG_ROUNDS_ON) || (size_t)R / SEG >= (size_t)AUTO_DENSITY * ntiles);
+                             ((cam.flags & FLAG_ROUNDS_ON) || half_segs >= (size_t)AUTO_ON_X2 * ntiles);
     const bool rounds = needed_hint || auto_rounds;
-    const uint32_t second = (size_t)R / SEG >= (size_t)AUTO_SECOND_SPLIT * ntiles ? AUTO_SECOND_DENSE : AUTO_SECOND_SPARSE;
+    const uint32_t first = dense ? AUTO_FIRST_DENSE : AUTO_FIRST_SPARSE;
+    const uint32_t second = dense ? AUTO_SECOND_DENSE : AUTO_SECOND_SPARSE;
     hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(SEGOFF_THREADS), 0, s, ranges, ntiles, seg_off,
-                       (const uint32_t*)needed_hint, seg_needed, (uint32_t)nseg, auto_rounds ? AUTO_FIRST : 0x3FFFFFFFu, first_fused);
+                       (const uint32_t*)needed_hint, seg_needed, (uint32_t)nseg, auto_rounds ? first : 0x3FFFFFFFu, first_fused);
     hipLaunchKernelGGL(k_seg_tiles, dim3(cdiv((long)nseg, 256)), dim3(256), 0, s, ntiles, ranges, seg_off,
                        (const uint32_t*)seg_needed, (uint32_t)nseg, first_fused);
     VR_KERNEL_CHECK("seg_offsets", s, debug);
@@ -902,7 +914,7 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     // and puts the next window of every tile that still has a live pixel on the next round's list; round 2 takes what is
     // left of the tiles that are short even then.  The catch-up rounds run a fixed grid over lists whose length only the
     // device knows.
-    const size_t bound0 = (size_t)AUTO_FIRST * ntiles;      // round 0 of the automatic rounds: at most AUTO_FIRST segments per tile
+    const size_t bound0 = (size_t)first * ntiles;      // round 0 of the automatic rounds: at most AUTO_FIRST segments per tile
     const unsigned grid0 = (unsigned)(!auto_rounds || nseg < bound0 ? nseg : bound0);
     const unsigned gridc = (unsigned)(nseg < 4096 ? nseg : 4096);
     const bool fast = (cam.flags & FLAG_FAST_EXP) != 0u;

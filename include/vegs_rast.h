@@ -109,7 +109,7 @@ typedef enum VrFlags {
      * every segment at once.  Results are identical bit for bit either way; the time is not: rounds win when lists
      * are long (discs three times larger than the street scene's: forward 0.49 -> 0.27 ms) and lose on short ones (the
      * deep tiles' later rounds run at low parallelism: +0.04 ms on the headline view).  Default: chosen per call from
-     * the number of list entries (rounds from 6.5 segments per tile on).  A needed-segment hint implies rounds. */
+     * the number of list entries (rounds from 8.5 segments per tile on).  A needed-segment hint implies rounds. */
     VR_FLAG_ROUNDS_OFF = 1u << 10,
     VR_FLAG_ROUNDS_ON = 1u << 11,
     /* opacities / scales / rotations are the model's RAW parameters (scene/gaussian_model.py:_opacity, _scaling,

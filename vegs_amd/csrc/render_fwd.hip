@@ -39,12 +39,14 @@ __device__ __forceinline__ uint32_t hinted_limit(uint32_t h) { return h + 2u + (
 //   x2    all at once 0.398   6 + 48: 0.319   6 + 64: 0.317   4 + 32: 0.309
 //   x3    all at once 0.488   6 + 24: 0.347   3 + 8: 0.292    2 + 8: 0.272    2 + 16: 0.273
 //   x5    all at once 0.842   6 + 24: 0.336   3 + 8: 0.242    2 + 8: 0.219    2 + 4: 0.216
-// Large, opaque discs saturate a tile within one or two segments; the rounds are used from 6.5 segments per tile on
-// (between x1.5 and x2: the crossover sits near 5.4, the headline view at 5.0 and its 1408-wide variant at 5.25 stay clear
-// of it), with 6 + 64 below 8.5 segments per tile and 2 + 8 from there on.  The host knows the density when it launches.
+// Large, opaque discs saturate a tile within one or two segments.  List density alone does not predict the outcome in
+// between: the x1 view on the reference's FULL rectangles (7.4 segments per tile, a third of them no-ops) loses 0.06 ms with
+// rounds, the x2 view (7.0) wins 0.08 -- so the rounds are used from 8.5 segments per tile on (x3 and denser: 2 + 8), with
+// the list length of a VR_FLAG_FULL_TILE_LISTS forward counted at two thirds; VR_FLAG_ROUNDS_ON below that: 6 + 64.  The host
+// knows the density when it launches.
 constexpr uint32_t AUTO_FIRST_SPARSE = 6u, AUTO_FIRST_DENSE = 2u;     // segments of every tile computed in round 0
 constexpr uint32_t AUTO_SECOND_SPARSE = 64u, AUTO_SECOND_DENSE = 8u;  // ... and at least this many more in round 1
-constexpr uint32_t AUTO_ON_X2 = 13u, AUTO_DENSE_X2 = 17u;             // thresholds in HALF segments per tile (6.5, 8.5)
+constexpr uint32_t AUTO_DENSE_X2 = 17u;                               // threshold in HALF segments per tile (8.5)
 constexpr uint32_t AUTO_FIRST = AUTO_FIRST_SPARSE;                    // (grid bound of round 0: the larger of the two)
 
 // seg_off[t] = first global segment id of tile t; seg_off[T] = total.  Single workgroup.  (k_seg_tiles then
@@ -893,14 +895,13 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     const size_t nseg = seg_capacity(R, ntiles);
     float* Pbuf = (float*)scratch;
     constexpr int first_fused = 1;     // (0 = the round-3 structure: every first segment through k_seg_alpha and k_seg_blend; A/B on one box: same time)
-    // Rounds without a hint ("auto"): worth it from 6.5 list segments per tile on (the table at AUTO_FIRST_SPARSE above).  On
+    // Rounds without a hint ("auto"): used from 8.5 list segments per tile on (the table at AUTO_FIRST_SPARSE above).  On
     // the headline view (5 per tile) the deep tiles' catch-up rounds run at low parallelism behind everybody else's round 0
     // and cost 40 us more than the skipped segments save.  The host knows R when it gets here; VR_FLAG_ROUNDS_OFF / _ON
     // override.
-    const size_t half_segs = 2 * (size_t)R / SEG;            // list density in half segments per tile x tiles
-    const bool dense = half_segs >= (size_t)AUTO_DENSE_X2 * ntiles;
-    const bool auto_rounds = !needed_hint && R > 0 && !(cam.flags & FLAG_ROUNDS_OFF) &&
-                             ((cam.flags & FLAG_ROUNDS_ON) || half_segs >= (size_t)AUTO_ON_X2 * ntiles);
+    const size_t r_eff = (cam.flags & FLAG_FULL_TILE_LISTS) ? (size_t)R * 2 / 3 : (size_t)R;   // (full rectangles: a third are no-ops)
+    const bool dense = 2 * r_eff / SEG >= (size_t)AUTO_DENSE_X2 * ntiles;
+    const bool auto_rounds = !needed_hint && R > 0 && !(cam.flags & FLAG_ROUNDS_OFF) && ((cam.flags & FLAG_ROUNDS_ON) || dense);
     const bool rounds = needed_hint || auto_rounds;
     const uint32_t first = dense ? AUTO_FIRST_DENSE : AUTO_FIRST_SPARSE;
     const uint32_t second = dense ? AUTO_SECOND_DENSE : AUTO_SECOND_SPARSE;

@@ -149,7 +149,7 @@ k_seg_tiles(int ntiles, const int2* __restrict__ ranges, uint32_t* __restrict__ 
 template <bool FAST>
 __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t* __restrict__ point_list,
                                                 const Splat* __restrict__ rec, float4 (*lds)[SEG],
-                                                unsigned long long* masks, unsigned long long* __restrict__ segmask)
+                                                unsigned long long* masks, unsigned long long* __restrict__ segmask, void* qspace)
 {
     {
         const bool have = (int)threadIdx.x < c.count;
@@ -168,9 +168,76 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
     }
     __syncthreads();
     if (threadIdx.x < 16) segmask[(size_t)c.seg * 16 + threadIdx.x] = masks[threadIdx.x];
-    const int w = threadIdx.x >> 6;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float pxf = (float)c.px, pyf = (float)c.py;
     float p = 1.0f;
+#ifdef VR_QUARTER_WAVE
+    // ---- QUARTER-WAVE LISTS (experiment).  An entry relevant to the 8 x 8 strip reaches 1.9 of its four 4 x 4 quadrants on
+    // average: every quadrant (16 lanes) walks its OWN list of relevant entries, the wave as many trips as the longest.
+    uint8_t* const ql = reinterpret_cast<uint8_t*>(qspace) + w * 1024;     // 4 lists of up to 256 entry indices
+    uint8_t* const rel = reinterpret_cast<uint8_t*>(qspace) + 4096 + w * 256; // the strip's relevant entries, compacted
+    int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+    {
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int nrel = 0;
+#pragma unroll
+        for (int part = 0; part < 4; ++part) {
+            const unsigned long long m = uniform64(masks[w * 4 + part]);
+            if ((m >> lane) & 1ull) rel[nrel + __popcll(m & lt)] = (uint8_t)(part * 64 + lane);
+            nrel += __popcll(m);
+        }
+        const float sx0 = c.x0 + (float)((w % REGIONS_X) * REGION_W), sy0 = c.y0 + (float)((w / REGIONS_X) * REGION_H);
+        for (int base = 0; base < nrel; base += 64) {
+            const bool have = base + lane < nrel;
+            const int j = have ? (int)rel[base + lane] : 0;
+            const float4 a = lds[0][j], b = lds[1][j];        // x y kA kB | kC opacity thr2 depth
+            // -power2 = A' dx^2 + 2 B' dx dy + C' dy^2 with A' = -kA, B' = -kB / 2, C' = -kC; the entry reaches a quadrant iff
+            // the minimum over the quadrant's pixel centres is <= -thr2 (with the strip test's slack)
+            const float A = -a.z, B = -0.5f * a.w, Cc = -b.x;
+            const float lim = (-b.z) * 1.001f + 0.001f;
+            const bool odd = !(A > 0.0f) || !(Cc > 0.0f) || !(A * Cc - B * B > 0.0f);
+            const float inv_A = __builtin_amdgcn_rcpf(A), inv_C = __builtin_amdgcn_rcpf(Cc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float xl = sx0 + (float)((q & 1) * 4) - a.x, xh = xl + 3.0f;
+                const float yl = sy0 + (float)((q >> 1) * 4) - a.y, yh = yl + 3.0f;
+                const bool r = have && (odd || rect_relevant_facing(A, inv_A, B, Cc, inv_C, lim, xl, xh, yl, yh));
+                const unsigned long long bm = __ballot(r);
+                int& n = q == 0 ? n0 : (q == 1 ? n1 : (q == 2 ? n2 : n3));
+                if (r) ql[q * 256 + n + __popcll(bm & lt)] = (uint8_t)j;
+                n += __popcll(bm);
+            }
+        }
+    }
+    {
+        const int myq = ((lane >> 5) & 1) * 2 + ((lane >> 2) & 1);
+        const int n_mine = myq == 0 ? n0 : (myq == 1 ? n1 : (myq == 2 ? n2 : n3));
+        const int trips = max(max(n0, n1), max(n2, n3));
+        const uint8_t* const myl = ql + myq * 256;
+        auto apply = [&](const float4 a, const float4 b, const bool act) {
+            float dx, dy;
+            const float power = splat_power2(a.x, a.y, a.z, a.w, b.x, pxf, pyf, dx, dy);
+            const bool pre = act && !(power > 0.0f) && power >= b.z;
+            const float alpha = fminf(ALPHA_MAX, b.y * exp2_sel<FAST>(power));
+            const bool valid = pre && !(alpha < ALPHA_MIN);
+            p = valid ? p * (1.0f - alpha) : p;
+        };
+        for (int t = 0; t < trips; t += 4) {
+            const uint32_t idx4 = *reinterpret_cast<const uint32_t*>(myl + t);
+            float4 av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = (int)((idx4 >> (8 * u)) & 255u);
+                av[u] = lds[0][k];
+                bv[u] = lds[1][k];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (t + u < trips) apply(av[u], bv[u], t + u < n_mine);
+        }
+    }
+    return p;
+#else
     // Four entries per trip: their LDS broadcasts are issued before any of them is used, so a wave pays the LDS
     // latency once per batch (s_waitcnt on LDS reads was 44 % of this kernel's wave cycles, SQ_WAIT_ANY).  The entries
     // are still applied strictly in list order.
@@ -208,6 +275,7 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
         }
     }
     return p;
+#endif
 }
 
 // the forward's per-pixel outputs (what k_seg_combine writes; a tile with ONE list segment is finished by seg_first_body)
@@ -387,6 +455,8 @@ k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     __shared__ float4 lds[ROUND == 0 ? 4 : 2][SEG];
     __shared__ float2 lds_s[ROUND == 0 ? SEG : 1];
     __shared__ unsigned long long masks[16];
+    __shared__ uint32_t qextra[ROUND == 0 ? 1 : 1280];                  // (quarter-wave lists: round 0 borrows the fused path's planes)
+    void* const qspace = ROUND == 0 ? (void*)&lds[ROUND == 0 ? 2 : 0][0] : (void*)qextra;
     // the round's work list: round 0 one workgroup per entry (the grid is sized for it: AUTO_FIRST segments per tile
     // without a hint); the catch-up rounds a fixed grid striding over a list whose length only the device knows
     const int ntiles = cam.gx * cam.gy;
@@ -399,7 +469,7 @@ k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     for (uint32_t item = blockIdx.x - (ROUND == 0 && first_fused ? (uint32_t)ntiles : 0u); item < count; item += gridDim.x) {
         SegCtx c;
         if (seg_setup_at(cam, ranges, seg_off, list[item], threadIdx.x >> 6, c)) {
-            const float p = seg_alpha_body<FAST>(c, point_list, rec, lds, masks, segmask);
+            const float p = seg_alpha_body<FAST>(c, point_list, rec, lds, masks, segmask, qspace);
             Pbuf[(size_t)c.seg * SEG + threadIdx.x] = p;
         }
         if (ROUND == 0) break;       // (grid >= count in round 0)

@@ -244,6 +244,19 @@ __device__ __forceinline__ bool rect_relevant(float A, float inv_A, float B, flo
     return in || q <= lim;
 }
 
+// the same with the two edges FACING the centre only (the minimum of a convex quadratic over a rectangle that does not hold
+// its centre lies on them): half the work of rect_relevant, equally conservative
+__device__ __forceinline__ bool rect_relevant_facing(float A, float inv_A, float B, float C, float inv_C, float lim, float xl,
+                                                     float xh, float yl, float yh)
+{
+    const bool in_x = xl <= 0.0f && xh >= 0.0f, in_y = yl <= 0.0f && yh >= 0.0f;
+    const float fy = yl > 0.0f ? yl : yh, fx = xl > 0.0f ? xl : xh;
+    const float qy = quad_edge_min(A, inv_A, B, C, fy, xl, xh);
+    const float qx = quad_edge_min(C, inv_C, B, A, fx, yl, yh);
+    const float q = in_y ? qx : (in_x ? qy : fminf(qx, qy));
+    return (in_x && in_y) || q <= lim;
+}
+
 // relevance of one splat for the four regions of a tile (bit s of the result = region s)
 __device__ __forceinline__ uint32_t strips_relevant_exact(float sx, float sy, float A, float B, float C, float thr,
                                                           float x0, float y0)

@@ -171,9 +171,15 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float pxf = (float)c.px, pyf = (float)c.py;
     float p = 1.0f;
-#ifdef VR_QUARTER_WAVE
-    // ---- QUARTER-WAVE LISTS (experiment).  An entry relevant to the 8 x 8 strip reaches 1.9 of its four 4 x 4 quadrants on
-    // average: every quadrant (16 lanes) walks its OWN list of relevant entries, the wave as many trips as the longest.
+    // ---- QUARTER-WAVE LISTS (round 4).  An entry relevant to the 8 x 8 strip reaches 1.9 of its four 4 x 4 quadrants on
+    // average: every quadrant (16 lanes) walks its OWN list of the entries that can reach it, the wave makes as many trips as
+    // the longest of the four lists -- 36 % fewer than with one list per strip (profiles/tools/pairstats.py), for three more
+    // instructions per trip and ~250 per wave to build the lists (the strip's entries compacted first, then four
+    // rectangle tests per entry, two facing edges each).  An entry left out of a quadrant's list has alpha < 1/255 at every
+    // one of its pixels: a no-op there, the products are bit for bit what they were.  Four entries per trip: their LDS
+    // reads are issued before any of them is used; the entries are still applied strictly in list order.
+    // (render forward 0.360 -> 0.340 ms.  Not in seg_first_body -- 5 KB more of LDS would cost it a workgroup per CU, and the
+    // near splats of a first segment reach most quadrants anyway -- nor in k_seg_blend, where per-chunk lists bought nothing.)
     uint8_t* const ql = reinterpret_cast<uint8_t*>(qspace) + w * 1024;     // 4 lists of up to 256 entry indices
     uint8_t* const rel = reinterpret_cast<uint8_t*>(qspace) + 4096 + w * 256; // the strip's relevant entries, compacted
     int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
@@ -237,45 +243,6 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
         }
     }
     return p;
-#else
-    // Four entries per trip: their LDS broadcasts are issued before any of them is used, so a wave pays the LDS
-    // latency once per batch (s_waitcnt on LDS reads was 44 % of this kernel's wave cycles, SQ_WAIT_ANY).  The entries
-    // are still applied strictly in list order.
-    auto apply = [&](const float4 a, const float4 b) {
-        float dx, dy;
-        const float power = splat_power2(a.x, a.y, a.z, a.w, b.x, pxf, pyf, dx, dy);
-        const bool pre = !(power > 0.0f) && power >= b.z;
-        if (__ballot(pre) == 0ull) return;  // cannot reach 1/255 anywhere in this strip
-        const float alpha = fminf(ALPHA_MAX, b.y * exp2_sel<FAST>(power));
-        const bool valid = pre && !(alpha < ALPHA_MIN);
-        p = valid ? p * (1.0f - alpha) : p;
-    };
-    for (int part = 0; part < 4; ++part) {
-        unsigned long long m = uniform64(masks[w * 4 + part]);
-        while (m) {
-            constexpr int NB = 4;
-            int kk[NB];
-            float4 av[NB], bv[NB];
-            int nb = 0;
-#pragma unroll
-            for (int t = 0; t < NB; ++t) {
-                if (m) {
-                    kk[t] = part * 64 + __builtin_ctzll(m);
-                    m &= m - 1;
-                    nb = t + 1;
-                } else {
-                    kk[t] = kk[0];
-                }
-                av[t] = lds[0][kk[t]];  // x y kA kB
-                bv[t] = lds[1][kk[t]];  // kC opacity thr2 depth
-            }
-#pragma unroll
-            for (int t = 0; t < NB; ++t)
-                if (t < nb) apply(av[t], bv[t]);
-        }
-    }
-    return p;
-#endif
 }
 
 // the forward's per-pixel outputs (what k_seg_combine writes; a tile with ONE list segment is finished by seg_first_body)

@@ -72,17 +72,18 @@ void pair_stats(int H, int W, const int* ranges, const uint32_t* point_list, con
  * number of contributing entries n and per 4x4 quadrant n_q.  out[0] = sum 32*ceil(n/64) (pixel-pair trips now),
  * out[1] = sum 8*max_q ceil(n_q/16) (rows of 16 entries per quadrant), out[2] = sum n, out[3] = sum_q n_q,
  * fwd (all segments up to the tile's needed count / all segments): out[4] = sum n_fwd (needed segs), out[5] = sum max_q n_q fwd (needed),
- * out[6] = sum n_fwd all segments, out[7] = sum max_q n_q all segments, out[8] = sum_q n_q fwd all, out[9] = units all */
+ * out[6] = sum n_fwd all segments, out[7] = sum max_q n_q all segments, out[8] = sum_q n_q fwd all, out[9] = units all,
+ * out[10], out[11] = the same two sums over the tiles' FIRST segments only */
 void quad_stats(int H, int W, const int* ranges, const uint32_t* point_list, const float* xy, const float* conic_op,
                 const uint32_t* n_contrib, double* out)
 {
     int gx = (W + 15) / 16, gy = (H + 15) / 16;
-    double o[10] = {0};
+    double o[12] = {0};
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gx * gy; ++tile) {
         int tx = tile % gx, ty = tile / gx;
         int s = ranges[2 * tile], e = ranges[2 * tile + 1];
-        double lo[10] = {0};
+        double lo[12] = {0};
         int maxnc = 0;
         for (int ly = 0; ly < 16; ++ly) for (int lx = 0; lx < 16; ++lx) {
             int px = tx * 16 + lx, py = ty * 16 + ly;
@@ -122,12 +123,13 @@ void quad_stats(int H, int W, const int* ranges, const uint32_t* point_list, con
                     lo[4] += nf; lo[5] += mqf;
                 }
                 lo[6] += nf; lo[7] += mqf; lo[8] += nfq[0] + nfq[1] + nfq[2] + nfq[3]; lo[9] += 1;
+                if (sb == s) { lo[10] += nf; lo[11] += mqf; }      /* first segments only */
             }
         }
 #pragma omp critical
-        { for (int k = 0; k < 10; ++k) o[k] += lo[k]; }
+        { for (int k = 0; k < 12; ++k) o[k] += lo[k]; }
     }
-    for (int k = 0; k < 10; ++k) out[k] = o[k];
+    for (int k = 0; k < 12; ++k) out[k] = o[k];
 }
 
 /* chunk statistics of k_seg_bwd's pixel loop (needed segments only).  The kernel compacts a region's relevant entries (any

@@ -28,11 +28,12 @@ print("trips weighted hist (max_c bucket: share of sum max_c):", {k: round(float
 import sys as _s
 if len(_s.argv) > 2 and _s.argv[2] == "chunks":
     q = None
-q = np.zeros(10)
+q = np.zeros(12)
 L.quad_stats(376, 1376, p(st["ranges"]), p(st["point_list"]), p(st["xy"]), p(st["conic_op"]), p(st["n_contrib"]), p(q))
 print("bwd pixel-pair trips now", q[0], "rows-of-16-per-quadrant trips", q[1], "ratio", q[0] / q[1], "| sum n", q[2], "sum_q n_q", q[3], "quadrants per entry", q[3] / q[2])
 print("fwd needed segs: sum n", q[4], "sum max_q n_q", q[5], "ratio", q[4] / q[5])
 print("fwd all segs: sum n", q[6], "sum max_q n_q", q[7], "ratio", q[6] / q[7], "quadrants per entry", q[8] / q[6], "units", q[9])
+print("fwd FIRST segs: sum n", q[10], "sum max_q n_q", q[11], "ratio", q[10] / max(q[11], 1))
 
 ch = np.zeros(13)
 L.chunk_stats(376, 1376, p(st["ranges"]), p(st["point_list"]), p(st["xy"]), p(st["conic_op"]), p(st["n_contrib"]), p(ch))

@@ -982,6 +982,7 @@ constexpr int EMIT_SMALL = 8;
 struct BigRects {
     uint32_t* count;     // entries so far (cleared with the status words of the view)
     uint2* items;        // {first output position, Gaussian id}
+    int inline_big;      // few such rectangles in the view: their own waves emit them, no list, no k_emit_big
 };
 
 // The (tile, id) pairs of one wave's 64 rectangles, `cnt` kept tiles each (rect_area) from output position `off` on.
@@ -1008,7 +1009,48 @@ __device__ __forceinline__ void emit_rects(uint4 rc, uint32_t cnt, uint32_t off,
             if (++rx == w) { rx = 0; ++ry; }
         }
     }
+    if (big_list.inline_big) {
+    // rectangles of more than 64 tiles by their own wave (few of them: emit_big_inline), with division-free index arithmetic:
+    // floor((k + 1/2) / w) in fp32 is exact for k < 2^22 -- used below 2^21 -- (the error of the product, (k / w) 2^-23, stays below the 1 / (2 w)
+    // that separates (k + 1/2) / w from the nearest integer)
     {
+        int kc_l = 1, cw_l = w, ch_l = h;
+        if (huge) tile_cells(w, h, kc_l, cw_l, ch_l);
+        for (unsigned long long hm = __ballot(huge); hm; hm &= hm - 1) {
+            const int src = __builtin_ctzll(hm);
+            const uint32_t b_off = (uint32_t)__builtin_amdgcn_readlane((int)off, src);
+            const uint32_t b_id = (uint32_t)__builtin_amdgcn_readlane((int)id, src);
+            const int b_x0 = __builtin_amdgcn_readlane(x0, src), b_y0 = __builtin_amdgcn_readlane(y0, src);
+            const int b_w = __builtin_amdgcn_readlane(w, src);
+            const uint32_t b_area = (uint32_t)__builtin_amdgcn_readlane((int)area, src);
+            const uint32_t b_mask = (uint32_t)__builtin_amdgcn_readlane((int)rc.z, src);
+            const int kc = __builtin_amdgcn_readlane(kc_l, src), cw = __builtin_amdgcn_readlane(cw_l, src);
+            const float inv_w = 1.0f / (float)b_w, inv_k = 1.0f / (float)kc;
+            uint32_t done = 0;
+            for (uint32_t base = 0; base < b_area; base += 64) {
+                const uint32_t k = base + (uint32_t)lane;
+                int ry, rx, cell;
+                if (b_area < (1u << 21)) {
+                    ry = (int)(((float)k + 0.5f) * inv_w);
+                    rx = (int)k - ry * b_w;
+                    cell = (int)(((float)ry + 0.5f) * inv_k) * cw + (int)(((float)rx + 0.5f) * inv_k);
+                } else {
+                    ry = (int)(k / (uint32_t)b_w);
+                    rx = (int)k - ry * b_w;
+                    cell = (ry / kc) * cw + rx / kc;
+                }
+                const bool keep = k < b_area && ((b_mask >> (cell & 31)) & 1u);
+                const unsigned long long km = __ballot(keep);
+                if (keep) {
+                    const uint32_t pos = b_off + done + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+                    tkeys[pos] = (uint32_t)((b_y0 + ry) * gx + b_x0 + rx);
+                    tvals[pos] = b_id;
+                }
+                done += (uint32_t)__popcll(km);
+            }
+        }
+    }
+    } else {
         const unsigned long long hm = __ballot(huge);
         if (hm) {
             uint32_t base = 0;
@@ -1036,6 +1078,12 @@ __device__ __forceinline__ void emit_rects(uint4 rc, uint32_t cnt, uint32_t off,
         }
     }
 }
+// Who emits the rectangles of more than 64 tiles?  Listed for k_emit_big they cost a launch (7 us); emitted by their own
+// waves they cost nothing while there are few of them (a street view: ~300, all in the first workgroups) and a lot when most
+// waves hold some (emit stage, us, inline / listed -- discs x1: 63 / 70, x1.5: 88 / 74, x2: 121 / 79, x3: 177 / 101).  The host
+// does not know their number when it launches; it knows the list entries per visible Gaussian (1.60 / 1.88 / 2.23 / 3.18 for
+// the four scenes): inline below 1.75.
+static inline int emit_big_inline(int V, long R) { return R * 100 < 175 * (long)(V > 0 ? V : 1); }
 // One wave per listed rectangle (more than 64 tiles): 64 tiles per step, those of the mask's kept cells written.
 constexpr int EMIT_BIG_GRID = 2048;
 __global__ void __launch_bounds__(64)
@@ -1286,10 +1334,12 @@ static int binning_multi_launch(const Camera& cam, int V, long R, uint32_t key_m
     BigRects big_list;
     big_list.items = (uint2*)(base + L.big);
     big_list.count = (uint32_t*)(base + L.big + (size_t)(V > 0 ? V : 1) * 8);
+    big_list.inline_big = emit_big_inline(V, R);
     VR_HIP(hipMemsetAsync(big_list.count, 0, 4, s));
     hipLaunchKernelGGL(k_emit, dim3(cdiv(V, 256)), dim3(256), 0, s, V, cam.gx, (const uint32_t*)sorted_id,
                        (const uint32_t*)offs, (const uint4*)rect_sorted, ka, va, big_list);
-    hipLaunchKernelGGL(k_emit_big, dim3(EMIT_BIG_GRID), dim3(64), 0, s, big_list, rect, cam.gx, ka, va);
+    if (!big_list.inline_big)
+        hipLaunchKernelGGL(k_emit_big, dim3(EMIT_BIG_GRID), dim3(64), 0, s, big_list, rect, cam.gx, ka, va);
     VR_KERNEL_CHECK("emit", s, debug);
     prof_end(VR_STAGE_EMIT, s);
     ProfScope ps(VR_STAGE_TILE_SORT, s);
@@ -1350,9 +1400,11 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
         BigRects big_list;
         big_list.items = (uint2*)(base + L.big);
         big_list.count = (uint32_t*)(st + sp.depth + sp.emit - 16);        // (cleared with the status words)
+        big_list.inline_big = emit_big_inline(V, R);
         hipLaunchKernelGGL(k_emit_scan, dim3(cdiv(V, 256)), dim3(256), 0, s, V, cam.gx, (const uint32_t*)sorted_id,
                            rect, (unsigned long long*)(st + sp.depth), err, tkeysA, va, big_list);
-        hipLaunchKernelGGL(k_emit_big, dim3(EMIT_BIG_GRID), dim3(64), 0, s, big_list, rect, cam.gx, tkeysA, va);
+        if (!big_list.inline_big)
+            hipLaunchKernelGGL(k_emit_big, dim3(EMIT_BIG_GRID), dim3(64), 0, s, big_list, rect, cam.gx, tkeysA, va);
         VR_KERNEL_CHECK("emit_scan", s, debug);
         prof_end(VR_STAGE_EMIT, s);
         // 4. stable sort by tile id

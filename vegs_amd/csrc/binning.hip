@@ -911,12 +911,13 @@ k_compact_apply(const uint4* __restrict__ rect, const uint32_t* __restrict__ dep
     const long base = (long)blockIdx.x * SCAN_BLOCK + threadIdx.x;
     uint32_t v[SCAN_ITEMS], key[SCAN_ITEMS], before[SCAN_ITEMS];
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
+    for (int k = 0; k < SCAN_ITEMS; ++k) {      // (who has list entries is in the key itself: 4 bytes per Gaussian, not the rectangle's 16)
         const long e = base + (long)k * 256;
-        v[k] = (e < n && rect_area(rect[e])) ? 1u : 0u;
+        key[k] = e < n ? depth_key[e] : DEPTH_KEY_NONE;
+        v[k] = key[k] != DEPTH_KEY_NONE ? 1u : 0u;
     }
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) key[k] = v[k] ? depth_key[base + (long)k * 256] : 0u;
+    for (int k = 0; k < SCAN_ITEMS; ++k) key[k] = v[k] ? key[k] : 0u;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         const unsigned long long m = __ballot(v[k] != 0u);

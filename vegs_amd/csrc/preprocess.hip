@@ -315,7 +315,10 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
         rect[i] = vis ? make_uint4((uint32_t)rx0 | ((uint32_t)ry0 << 16), (uint32_t)rw | ((uint32_t)rh << 16),
                                    (uint32_t)tmask, (uint32_t)(tmask >> 32))
                       : make_uint4(0u, 0u, 0u, 0u);
-        depth_key[i] = vis ? __float_as_uint(t2) : 0u;
+        // depth key (bits of a positive float); DEPTH_KEY_NONE for a Gaussian without list entries (culled, or no tile of its
+        // rectangle reachable): the compaction then needs only this array to know who is in (binning.hip: k_compact_apply)
+        const uint32_t kept = rw * rh > TIGHT_MAX_TILES ? (uint32_t)(tmask >> 32) : (uint32_t)__popcll(tmask);
+        depth_key[i] = vis && kept ? __float_as_uint(t2) : DEPTH_KEY_NONE;
         clampb[i] = (uint8_t)clampbits;   // dense copy for the backward (a 4-byte gather out of the 80-byte records costs a line each)
     }
 }

@@ -345,7 +345,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     // ---- transient, P-sized
     const size_t s1 = binning_stage1_scratch_bytes(P);
     const size_t arr = align_up(p1 * 4, 256);
-    void* scr = alloc(user, VR_BUF_SCRATCH, 7 * arr + s1 + 256);
+    void* scr = alloc(user, VR_BUF_SCRATCH, 8 * arr + s1 + 256);
     if (!geom || !image || !scr) return fail(VR_ERR_ALLOC, "allocator returned NULL");
     Splat* rec = (Splat*)geom;
     float* final_T = (float*)((char*)image + IL.final_T);
@@ -354,8 +354,9 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     uint32_t* depth_key = (uint32_t*)((char*)scr + 4 * arr);
     uint32_t* vis_key = (uint32_t*)((char*)scr + 5 * arr);
     uint32_t* vis_id = (uint32_t*)((char*)scr + 6 * arr);
-    void* scan_scr = (char*)scr + 7 * arr;
-    uint32_t* totals_dev = (uint32_t*)((char*)scr + 7 * arr + s1);
+    uint32_t* tile_count = (uint32_t*)((char*)scr + 7 * arr);      // list entries per Gaussian (what the rectangle + mask say, as one word)
+    void* scan_scr = (char*)scr + 8 * arr;
+    uint32_t* totals_dev = (uint32_t*)((char*)scr + 8 * arr + s1);
     bool ranges_zeroed = false, status_zeroed = false;
 
     uint32_t V = 0, R = 0, key_min = 0;
@@ -375,7 +376,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
         prof_begin(VR_STAGE_PREPROCESS, s);
         rc = launch_preprocess(cam, P, in->means3D, in->shs, in->shs_rest, in->shs_tail,
                                in->shs_tail ? (int)in->tail_start : P, in->colors_precomp, in->opacities, in->scales,
-                               in->rotations, in->cov3D_precomp, rec, out->radii, rect, depth_key,
+                               in->rotations, in->cov3D_precomp, rec, out->radii, rect, depth_key, tile_count,
                                (uint8_t*)geom + geom_clamp, (float*)((char*)geom + geom_shd), s, debug);
         prof_end(VR_STAGE_PREPROCESS, s);
         if (rc) return rc;
@@ -384,7 +385,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
         // writes them into the pinned mailbox itself; the host polls for this call's sequence number after it has
         // queued the compaction's apply kernel, so the round trip overlaps with that kernel instead of idling the GPU.
         const uint32_t seq = ++mail.seq ? mail.seq : ++mail.seq;   // never 0 (the mailbox's initial content)
-        rc = launch_compact_reduce(P, rect, depth_key, scan_scr, totals_dev, mail.guard, mail.pinned_dev, seq, s, debug);
+        rc = launch_compact_reduce(P, tile_count, depth_key, scan_scr, totals_dev, mail.guard, mail.pinned_dev, seq, s, debug);
         if (rc) return rc;
         // the apply kernel also clears the tile ranges (when the binning buffer already exists): no fill launch
         // and the status words of the binning passes (when their scratch exists)

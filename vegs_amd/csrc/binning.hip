@@ -85,12 +85,12 @@ __device__ __forceinline__ uint32_t rect_area(uint4 r)
     return area > (uint32_t)TIGHT_MAX_TILES ? r.w : (uint32_t)(__popc(r.z) + __popc(r.w));
 }
 
-struct SrcFlagTiles {  // 1 for visible Gaussians; secondary value = tiles touched (summed only);
-    const uint4* rect;  // also the min / max depth key of the visible ones (range of the depth sort)
+struct SrcFlagTiles {  // 1 for Gaussians with list entries; secondary value = their number (summed only);
+    const uint32_t* tile_count;  // also the min / max depth key of those Gaussians (range of the depth sort)
     const uint32_t* depth_key;
     static constexpr bool MINMAX = true;
-    __device__ uint32_t operator()(long i) const { return rect_area(rect[i]) ? 1u : 0u; }
-    __device__ uint32_t second(long i) const { return rect_area(rect[i]); }
+    __device__ uint32_t operator()(long i) const { return tile_count[i] ? 1u : 0u; }
+    __device__ uint32_t second(long i) const { return tile_count[i]; }
     __device__ uint32_t key(long i) const { return depth_key[i]; }
 };
 struct SrcRectSorted {  // tiles touched, in depth-sorted order (rectangles already gathered: coalesced reads)
@@ -263,13 +263,13 @@ size_t binning_stage1_scratch_bytes(int P)
 
 // Two halves: the totals {V, R, min key, max key} reach the host (host_mail, see k_scan_totals) while the apply kernel
 // runs, so the round trip overlaps with that kernel instead of idling the GPU.
-int launch_compact_reduce(int P, const uint4* rect, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,
+int launch_compact_reduce(int P, const uint32_t* tile_count, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,
                           const uint32_t* err_in, uint32_t* host_mail, uint32_t seq, hipStream_t s, bool debug)
 {
     int nb = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
     uint32_t* bsum = (uint32_t*)scratch;
     uint32_t* bsum2 = bsum + nb;
-    SrcFlagTiles src{rect, depth_key};
+    SrcFlagTiles src{tile_count, depth_key};
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_reduce<SrcFlagTiles>), dim3(nb), dim3(256), 0, s, src, (long)P, bsum, bsum2);
     VR_KERNEL_CHECK("compact_reduce", s, debug);
     hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(256), 0, s, (const uint32_t*)bsum, (const uint32_t*)bsum2, nb, totals_dev,

@@ -48,8 +48,8 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
              const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
              const float* __restrict__ scales, const float* __restrict__ rotations,
              const float* __restrict__ cov3D_precomp, Splat* __restrict__ rec, int* __restrict__ radii,
-             uint4* __restrict__ rect, uint32_t* __restrict__ depth_key, uint8_t* __restrict__ clampb,
-             float* __restrict__ shd)
+             uint4* __restrict__ rect, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tile_count,
+             uint8_t* __restrict__ clampb, float* __restrict__ shd)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[PRE_THREADS / 64][64 * SH_LDS_STRIDE];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -319,6 +319,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
         // rectangle reachable): the compaction then needs only this array to know who is in (binning.hip: k_compact_apply)
         const uint32_t kept = rw * rh > TIGHT_MAX_TILES ? (uint32_t)(tmask >> 32) : (uint32_t)__popcll(tmask);
         depth_key[i] = vis && kept ? __float_as_uint(t2) : DEPTH_KEY_NONE;
+        tile_count[i] = vis ? kept : 0u;          // (the same number rect_area reads off the rectangle: one word for the totals' pass)
         clampb[i] = (uint8_t)clampbits;   // dense copy for the backward (a 4-byte gather out of the 80-byte records costs a line each)
     }
 }
@@ -337,15 +338,15 @@ int launch_preprocess(const Camera& cam, int P, const float* means3D, const floa
                       const float* shs_tail, int tail_start, const float* colors_precomp,
                       const float* opacities, const float* scales, const float* rotations,
                       const float* cov3D_precomp, Splat* rec, int* radii, uint4* rect,
-                      uint32_t* depth_key, uint8_t* clampb, float* shd, hipStream_t s, bool debug)
+                      uint32_t* depth_key, uint32_t* tile_count, uint8_t* clampb, float* shd, hipStream_t s, bool debug)
 {
     if (P == 0) return 0;
     if (cam.flags & FLAG_RAW_PARAMS)
         hipLaunchKernelGGL(k_preprocess<true>, dim3(cdiv(P, PRE_THREADS)), dim3(PRE_THREADS), 0, s, cam, P, means3D, shs, shs_rest, shs_tail,
-                           tail_start, colors_precomp, opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, clampb, shd);
+                           tail_start, colors_precomp, opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, tile_count, clampb, shd);
     else
         hipLaunchKernelGGL(k_preprocess<false>, dim3(cdiv(P, PRE_THREADS)), dim3(PRE_THREADS), 0, s, cam, P, means3D, shs, shs_rest, shs_tail,
-                           tail_start, colors_precomp, opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, clampb, shd);
+                           tail_start, colors_precomp, opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, tile_count, clampb, shd);
     VR_KERNEL_CHECK("preprocess", s, debug);
     return 0;
 }

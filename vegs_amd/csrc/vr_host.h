@@ -47,7 +47,7 @@ int launch_preprocess(const Camera& cam, int P, const float* means3D, const floa
                       const float* shs_tail, int tail_start, const float* colors_precomp,
                       const float* opacities, const float* scales, const float* rotations,
                       const float* cov3D_precomp, Splat* rec, int* radii, uint4* rect,
-                      uint32_t* depth_key, uint8_t* clampb, float* shd, hipStream_t s, bool debug);
+                      uint32_t* depth_key, uint32_t* tile_count, uint8_t* clampb, float* shd, hipStream_t s, bool debug);
 int launch_mark_visible(const float* xyz, int P, const float* view, uint8_t* present, hipStream_t s);
 
 // ---- binning.hip
@@ -55,7 +55,7 @@ int launch_mark_visible(const float* xyz, int P, const float* view, uint8_t* pre
 // depth key, [4] = *err_in (the look-back guard word, see launch_binning).
 size_t binning_stage1_scratch_bytes(int P);
 // host_mail: device address of the caller's pinned, coherent mailbox; receives the five words, then host_mail[8] = seq.
-int launch_compact_reduce(int P, const uint4* rect, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,
+int launch_compact_reduce(int P, const uint32_t* tile_count, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,
                           const uint32_t* err_in, uint32_t* host_mail, uint32_t seq, hipStream_t s, bool debug);
 // Second half of the compaction.  Side duties: the partial digit histograms of the depth keys (into `scratch`, for
 // the depth sort), clearing zero_a (the tile ranges) and, when `status` = binning_stage2_status(stage-2 scratch) is

@@ -449,8 +449,9 @@ def bench_c5(args, rank, world, device):
                                                   "views' 3-float factors)", "achieved": round(achieved, 2),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                         "alg_bytes_per_launch": round(bytes_k), "avg_launch_ms": round(ms_k, 4),
-                     "alg_bytes_note": "72 R + 56 N + 68 V with R on the reference's full tile rectangles (SURVEY 8d)",
-                     "frac_on_own_lists": round(bytes_k_own / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms_k > 0 else 0.0, "launches_timed": len(events)},
+                        "alg_bytes_note": "(24 x 48 + 12 (views + 1)) bytes per Gaussian: parameter and both moments of the 48 SH "
+                                          "floats read and written, the views' factors and the means read",
+                        "launches_timed": len(events)},
            "cpu_baseline": None}
     print(json.dumps(res))
 

@@ -281,3 +281,20 @@ def test_bench_line_contract_single_gpu():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["unit"] == "views/s"
     assert d["blended_mfragments_per_s"] < d["mfragments_per_s"]
+
+
+def test_bench_c5_workload_line():
+    """bench.py --workload c5 (BASELINE C5's full training step: static model + box instances with optimised instance
+    models and BoxModels) prints its one JSON line (small sizes; N = 1)."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--gaussians", "120000", "--boxes", "2",
+           "--steps", "3", "--warmup", "2", "--repeats", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "views/s" and d["value"] > 0
+    assert d["config"]["workload"].startswith("c5") and d["config"]["boxes"] == 2
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and rf["launches_timed"] > 0

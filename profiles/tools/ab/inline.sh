@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs the EXPERIMENT build of profiles/experiments/r04_sweep_env_overrides.patch.txt (VEGS_EXP_* are not read by the tree's library)
 # emission of the rectangles of more than 64 tiles: inline (VEGS_EXP_INLINE=100000) or listed for k_emit_big (=0), per disc scale
 for sc in 1 1.5 2 3; do
 for thr in 100000 0; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs the EXPERIMENT build of profiles/experiments/r04_sweep_env_overrides.patch.txt (VEGS_EXP_* are not read by the tree's library)
 # sweep of the segment-round constants (experiment build with VEGS_EXP_* overrides): render_fwd per disc scale
 run() { sc=$1; cfg=$2
   if [ "$cfg" = "off" ]; then f=1024; a=6; b=0; else f=2048; set -- $cfg; a=$1; b=$2; fi

@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs the EXPERIMENT build of profiles/experiments/r04_sweep_env_overrides.patch.txt (VEGS_EXP_* are not read by the tree's library)
 run() { sc=$1; cfg=$2
   if [ "$cfg" = "off" ]; then f=1024; a=6; b=0; else f=2048; set -- $cfg; a=$1; b=$2; fi
   r=$(VEGS_RAST_FLAGS=$f VEGS_EXP_FIRST=$a VEGS_EXP_SECOND=$b python bench.py --stages --no-variants --no-cpu-baseline --disc-scale $sc --repeats 3 2>&1 | grep "stage breakdown" | sed "s/.*'render_fwd': \([0-9.]*\).*'render_bwd': \([0-9.]*\).*/fwd \1 bwd \2/" | tr '\n' ' ')

@@ -130,7 +130,7 @@ static int wait_mailbox(uint32_t* pinned, uint32_t seq, const uint32_t* totals_d
             if (q == hipSuccess || dt > std::chrono::milliseconds(20)) {
                 VR_HIP(hipStreamSynchronize(s));
                 if (__atomic_load_n(&pinned[8], __ATOMIC_ACQUIRE) == seq) return 0;
-                VR_HIP(hipMemcpy(pinned, totals_dev, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                VR_HIP(hipMemcpy(pinned, totals_dev, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
                 return 0;
             }
         }
@@ -359,7 +359,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     uint32_t* totals_dev = (uint32_t*)((char*)scr + 8 * arr + s1);
     bool ranges_zeroed = false, status_zeroed = false;
 
-    uint32_t V = 0, R = 0, key_min = 0;
+    uint32_t V = 0, R = 0, key_min = 0, n_huge = 0;
     int key_bits = 0;
     // R-sized buffers: requested up front when the caller supplied a capacity hint (see VrSaved)
     size_t Rcap = saved->binning_capacity > 0 ? (size_t)saved->binning_capacity : 0;
@@ -405,6 +405,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
         }
         V = g_pinned[0];
         R = g_pinned[1];
+        n_huge = g_pinned[5];
         if (V > 0) {
             key_min = g_pinned[2];
             uint32_t span = g_pinned[3] - g_pinned[2];
@@ -427,7 +428,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     g_raise_guard = false;
     rc = launch_binning(cam, P, (int)V, (long)R, key_min, key_bits, vis_key, vis_id, rect, scan_scr, scr2, point_list,
                         ranges, ranges_zeroed, status_zeroed, mail.guard,
-                        mail.pinned_dev + RING_AT + 2 * (mail.seq % RING_SLOTS), mail.seq, raise, s, debug);
+                        mail.pinned_dev + RING_AT + 2 * (mail.seq % RING_SLOTS), mail.seq, raise, n_huge, s, debug);
     if (rc) return rc;
     if ((st->flags & FLAG_VERIFY_BINNING) && lists && !(cam.flags & FLAG_SCAN_BINNING)) {
         // VR_FLAG_VERIFY_BINNING: the host waits for this view's guard word (posted by the last binning kernel) BEFORE it
@@ -452,7 +453,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
             again.flags |= FLAG_SCAN_BINNING;
             rc = launch_binning(again, P, (int)V, (long)R, key_min, key_bits, vis_key, vis_id, rect, scan_scr, scr2, point_list,
                                 ranges, false, false, mail.guard, mail.pinned_dev + RING_AT + 2 * (mail.seq % RING_SLOTS),
-                                mail.seq, false, s, debug);
+                                mail.seq, false, n_huge, s, debug);
             if (rc) return rc;
             ++g_rebinned;
         }

@@ -90,7 +90,8 @@ struct SrcFlagTiles {  // 1 for Gaussians with list entries; secondary value = t
     const uint32_t* depth_key;
     static constexpr bool MINMAX = true;
     __device__ uint32_t operator()(long i) const { return tile_count[i] ? 1u : 0u; }
-    __device__ uint32_t second(long i) const { return tile_count[i]; }
+    __device__ uint32_t second(long i) const { return tile_count[i] & TILE_COUNT_MASK; }
+    __device__ uint32_t third(long i) const { return tile_count[i] >> 31; }      // rectangles of more than 64 tiles (counted)
     __device__ uint32_t key(long i) const { return depth_key[i]; }
 };
 struct SrcRectSorted {  // tiles touched, in depth-sorted order (rectangles already gathered: coalesced reads)
@@ -98,6 +99,7 @@ struct SrcRectSorted {  // tiles touched, in depth-sorted order (rectangles alre
     static constexpr bool MINMAX = false;
     __device__ uint32_t operator()(long i) const { return rect_area(rect_sorted[i]); }
     __device__ uint32_t second(long) const { return 0; }
+    __device__ uint32_t third(long) const { return 0; }
     __device__ uint32_t key(long) const { return 0; }
 };
 struct SrcPlain {
@@ -105,6 +107,7 @@ struct SrcPlain {
     static constexpr bool MINMAX = false;
     __device__ uint32_t operator()(long i) const { return v[i]; }
     __device__ uint32_t second(long) const { return 0; }
+    __device__ uint32_t third(long) const { return 0; }
     __device__ uint32_t key(long) const { return 0; }
 };
 
@@ -118,12 +121,12 @@ struct SinkStore {
 template <class Src>
 __global__ void __launch_bounds__(256) k_scan_reduce(Src src, long n, uint32_t* bsum, uint32_t* bsum2)
 {
-    __shared__ uint32_t lds[16];
+    __shared__ uint32_t lds[20];
     // sums, minimum and maximum do not care which thread takes which element of the block: consecutive lanes take
     // consecutive elements (coalesced; with SCAN_ITEMS consecutive elements per thread, as the ordered apply kernels must,
     // every load instruction of a wave touches 64 lines: 70 -> 2x us at 5 M Gaussians, where the arrays no longer sit in L2)
     const long base = (long)blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    uint32_t a = 0, b = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+    uint32_t a = 0, b = 0, c3 = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         const long e = base + (long)k * 256;
@@ -131,7 +134,7 @@ __global__ void __launch_bounds__(256) k_scan_reduce(Src src, long n, uint32_t* 
             const uint32_t v = src(e);
             a += v;
             b += src.second(e);
-            if (Src::MINMAX && v) { const uint32_t key = src.key(e); kmin = min(kmin, key); kmax = max(kmax, key); }
+            if (Src::MINMAX && v) { const uint32_t key = src.key(e); kmin = min(kmin, key); kmax = max(kmax, key); c3 += src.third(e); }
         }
     }
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -142,9 +145,10 @@ __global__ void __launch_bounds__(256) k_scan_reduce(Src src, long n, uint32_t* 
         if (Src::MINMAX) {
             kmin = min(kmin, (uint32_t)__shfl_down((int)kmin, d, 64));
             kmax = max(kmax, (uint32_t)__shfl_down((int)kmax, d, 64));
+            c3 += __shfl_down(c3, d, 64);
         }
     }
-    if (lane == 0) { lds[w] = a; lds[4 + w] = b; lds[8 + w] = kmin; lds[12 + w] = kmax; }
+    if (lane == 0) { lds[w] = a; lds[4 + w] = b; lds[8 + w] = kmin; lds[12 + w] = kmax; lds[16 + w] = c3; }
     __syncthreads();
     if (threadIdx.x == 0) {
         bsum[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
@@ -153,6 +157,7 @@ __global__ void __launch_bounds__(256) k_scan_reduce(Src src, long n, uint32_t* 
             if (Src::MINMAX) {
                 bsum2[gridDim.x + blockIdx.x] = min(min(lds[8], lds[9]), min(lds[10], lds[11]));
                 bsum2[2 * gridDim.x + blockIdx.x] = max(max(lds[12], lds[13]), max(lds[14], lds[15]));
+                bsum2[3 * gridDim.x + blockIdx.x] = lds[16] + lds[17] + lds[18] + lds[19];
             }
         }
     }
@@ -205,15 +210,17 @@ k_scan_totals(const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ bs
 {
     __shared__ uint32_t lds4[4];
     __shared__ uint32_t mm[8];
-    uint32_t t0 = 0, t1 = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+    uint32_t t0 = 0, t1 = 0, t2 = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
     for (int j = threadIdx.x; j < nb; j += 256) {
         t0 += bsum[j];
         t1 += bsum2[j];
+        t2 += bsum2[3 * nb + j];
         kmin = min(kmin, bsum2[nb + j]);
         kmax = max(kmax, bsum2[2 * nb + j]);
     }
     t0 = block_sum(t0, lds4);
     t1 = block_sum(t1, lds4);
+    t2 = block_sum(t2, lds4);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d, 64));
@@ -228,12 +235,13 @@ k_scan_totals(const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ bs
         totals[3] = max(max(mm[4], mm[5]), max(mm[6], mm[7]));
         // the guard word of earlier calls rides along (see launch_binning)
         totals[4] = err_in ? __hip_atomic_load(err_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        totals[5] = t2;      // Gaussians whose rectangle has more than 64 tiles (who emits them: emit_big_inline)
         // The host's copy: written straight into its pinned, coherent mailbox, sequence number last (release at system
         // scope); the host polls that word.  No copy command and no event on the stream: the apply kernel follows
         // this one without the ~10 us the two used to put between them.
         if (host_mail) {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) __hip_atomic_store(&host_mail[k], totals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int k = 0; k < 6; ++k) __hip_atomic_store(&host_mail[k], totals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&host_mail[8], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -255,10 +263,13 @@ static int run_scan(Src src, Sink sink, long n, uint32_t* bsum, hipStream_t s, b
 // ---------------------------------------------------------------- stage 1: compaction
 
 // block sums of the compaction scan (4 words per block), then one partial digit histogram of the depth keys per block
+// stage-1 scratch: five per-block values of the compaction's reduce pass (count, list entries, min key, max key, large
+// rectangles), then the per-block digit histograms of the depth keys
+static inline size_t stage1_partial_offset(size_t nb) { return align_up(5 * nb * sizeof(uint32_t), 256); }
 size_t binning_stage1_scratch_bytes(int P)
 {
     size_t nb = (size_t)cdiv(P > 0 ? P : 1, SCAN_BLOCK);
-    return align_up(4 * nb * sizeof(uint32_t), 256) + align_up(nb * HIST_WORDS * sizeof(uint32_t), 256);
+    return stage1_partial_offset(nb) + align_up(nb * HIST_WORDS * sizeof(uint32_t), 256);
 }
 
 // Two halves: the totals {V, R, min key, max key} reach the host (host_mail, see k_scan_totals) while the apply kernel
@@ -949,7 +960,7 @@ int launch_compact_apply(int P, const uint4* rect, const uint32_t* depth_key, vo
 {
     int nb = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
     uint32_t* bsum = (uint32_t*)scratch;
-    uint32_t* partial = (uint32_t*)((char*)scratch + align_up(4 * (size_t)nb * sizeof(uint32_t), 256));
+    uint32_t* partial = (uint32_t*)((char*)scratch + stage1_partial_offset((size_t)nb));
     hipLaunchKernelGGL(k_compact_apply, dim3(nb), dim3(256), 0, s, rect, depth_key, (long)P, (const uint32_t*)bsum,
                        totals_dev, tile_bits, vis_key, vis_id, partial, zero_a, zero_na, (uint4*)status,
                        (long)status_bytes);
@@ -1081,10 +1092,10 @@ __device__ __forceinline__ void emit_rects(uint4 rc, uint32_t cnt, uint32_t off,
 }
 // Who emits the rectangles of more than 64 tiles?  Listed for k_emit_big they cost a launch (7 us); emitted by their own
 // waves they cost nothing while there are few of them (a street view: ~300, all in the first workgroups) and a lot when most
-// waves hold some (emit stage, us, inline / listed -- discs x1: 63 / 70, x1.5: 88 / 74, x2: 121 / 79, x3: 177 / 101).  The host
-// does not know their number when it launches; it knows the list entries per visible Gaussian (1.60 / 1.88 / 2.23 / 3.18 for
-// the four scenes): inline below 1.75.
-static inline int emit_big_inline(int V, long R) { return R * 100 < 175 * (long)(V > 0 ? V : 1); }
+// waves hold some (emit stage, us, inline / listed -- discs x1: 63 / 70, x1.5: 88 / 74, x2: 121 / 79, x3: 177 / 101; the four
+// views have 120 ... 290 / ~1.1 k / ~5.8 k / 26 k of them).  Their number comes back with the list sizes (k_scan_totals):
+// inline below 384.
+static inline int emit_big_inline(uint32_t n_huge) { return n_huge < 384u; }
 // One wave per listed rectangle (more than 64 tiles): 64 tiles per step, those of the mask's kept cells written.
 constexpr int EMIT_BIG_GRID = 2048;
 __global__ void __launch_bounds__(64)
@@ -1295,7 +1306,7 @@ int binning_tile_bits(int ntiles) { return tile_bits_of(ntiles); }
 // the generic launch_sort_pairs used by knn.hip and the deterministic backward).
 static int binning_multi_launch(const Camera& cam, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
                                 uint32_t* vis_id, const uint4* rect, char* base, const Stage2Layout& L,
-                                uint32_t* point_list, uint32_t** tile_keys, hipStream_t s, bool debug)
+                                uint32_t* point_list, uint32_t** tile_keys, uint32_t n_huge, hipStream_t s, bool debug)
 {
     uint32_t* tmp_key = (uint32_t*)(base + L.tmp_key);
     uint32_t* tmp_id = (uint32_t*)(base + L.tmp_id);
@@ -1335,7 +1346,7 @@ static int binning_multi_launch(const Camera& cam, int V, long R, uint32_t key_m
     BigRects big_list;
     big_list.items = (uint2*)(base + L.big);
     big_list.count = (uint32_t*)(base + L.big + (size_t)(V > 0 ? V : 1) * 8);
-    big_list.inline_big = emit_big_inline(V, R);
+    big_list.inline_big = emit_big_inline(n_huge);
     VR_HIP(hipMemsetAsync(big_list.count, 0, 4, s));
     hipLaunchKernelGGL(k_emit, dim3(cdiv(V, 256)), dim3(256), 0, s, V, cam.gx, (const uint32_t*)sorted_id,
                        (const uint32_t*)offs, (const uint4*)rect_sorted, ka, va, big_list);
@@ -1354,7 +1365,7 @@ static int binning_multi_launch(const Camera& cam, int V, long R, uint32_t key_m
 int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
                    uint32_t* vis_id, const uint4* rect, const void* stage1_scratch, void* scratch, uint32_t* point_list,
                    int2* ranges, bool ranges_zeroed, bool status_zeroed, uint32_t* err, uint32_t* guard_post,
-                   uint32_t guard_seq, bool debug_raise_guard, hipStream_t s, bool debug)
+                   uint32_t guard_seq, bool debug_raise_guard, uint32_t n_huge, hipStream_t s, bool debug)
 {
     int ntiles = cam.gx * cam.gy;
     if (!ranges_zeroed) VR_HIP(hipMemsetAsync(ranges, 0, sizeof(int2) * (size_t)ntiles, s));
@@ -1364,7 +1375,7 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
     uint32_t* tile_keys = nullptr;
     if ((cam.flags & FLAG_SCAN_BINNING) || (long)V > ONESWEEP_MAX_N || R > ONESWEEP_MAX_N || (long)V > EMIT_SCAN_MAX_V) {
         int rc = binning_multi_launch(cam, V, R, key_min, key_bits, vis_key, vis_id, rect, base, L, point_list,
-                                      &tile_keys, s, debug);
+                                      &tile_keys, n_huge, s, debug);
         if (rc) return rc;
     } else {
         uint32_t* tmp_key = (uint32_t*)(base + L.tmp_key);
@@ -1382,7 +1393,7 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
         // the compaction kernel's partial digit histograms of the depth keys, one row per scan block
         const int rows = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
         const uint32_t* dpartial =
-            (const uint32_t*)((const char*)stage1_scratch + align_up(4 * (size_t)rows * sizeof(uint32_t), 256));
+            (const uint32_t*)((const char*)stage1_scratch + stage1_partial_offset((size_t)rows));
         // 2. depth sort of the visible Gaussians on the bits of (key - kmin) that vary
         uint32_t* sorted_id = vis_id;
         {
@@ -1401,7 +1412,7 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
         BigRects big_list;
         big_list.items = (uint2*)(base + L.big);
         big_list.count = (uint32_t*)(st + sp.depth + sp.emit - 16);        // (cleared with the status words)
-        big_list.inline_big = emit_big_inline(V, R);
+        big_list.inline_big = emit_big_inline(n_huge);
         hipLaunchKernelGGL(k_emit_scan, dim3(cdiv(V, 256)), dim3(256), 0, s, V, cam.gx, (const uint32_t*)sorted_id,
                            rect, (unsigned long long*)(st + sp.depth), err, tkeysA, va, big_list);
         if (!big_list.inline_big)

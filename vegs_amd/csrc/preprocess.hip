@@ -319,7 +319,8 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
         // rectangle reachable): the compaction then needs only this array to know who is in (binning.hip: k_compact_apply)
         const uint32_t kept = rw * rh > TIGHT_MAX_TILES ? (uint32_t)(tmask >> 32) : (uint32_t)__popcll(tmask);
         depth_key[i] = vis && kept ? __float_as_uint(t2) : DEPTH_KEY_NONE;
-        tile_count[i] = vis ? kept : 0u;          // (the same number rect_area reads off the rectangle: one word for the totals' pass)
+        // (the same number rect_area reads off the rectangle -- one word for the totals' pass --, bit 31: more than 64 tiles)
+        tile_count[i] = vis && kept ? (kept | (rw * rh > TIGHT_MAX_TILES ? ~TILE_COUNT_MASK : 0u)) : 0u;
         clampb[i] = (uint8_t)clampbits;   // dense copy for the backward (a 4-byte gather out of the 80-byte records costs a line each)
     }
 }

@@ -292,6 +292,7 @@ __device__ __forceinline__ uint32_t strips_relevant_exact(float sx, float sy, fl
 // LIST DEFINITION -- the CPU checker builds the same lists -- so it is written with IEEE basic operations only (no rcp,
 // no hardware log): bit-identical on host and device.  VR_FLAG_FULL_TILE_LISTS restores the reference's full rectangles.
 constexpr int TIGHT_MAX_TILES = 64;
+constexpr uint32_t TILE_COUNT_MASK = 0x7FFFFFFFu;  // tile_count[i]: list entries of Gaussian i; bit 31: its rectangle has more than 64 tiles
 constexpr uint32_t DEPTH_KEY_NONE = 0xFFFFFFFFu;   // depth key of a Gaussian without list entries (real keys: bits of a positive float)
 constexpr float VR_LN2 = 0.693147180559945309f;
 // ln(v), v > 0: v = m 2^e with m in [sqrt(1/2), sqrt(2)), ln m = 2 atanh(s), s = (m - 1) / (m + 1), four odd terms

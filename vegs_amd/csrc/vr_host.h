@@ -77,7 +77,7 @@ int binning_tile_bits(int ntiles);
 int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
                    uint32_t* vis_id, const uint4* rect, const void* stage1_scratch, void* scratch, uint32_t* point_list,
                    int2* ranges, bool ranges_zeroed, bool status_zeroed, uint32_t* err, uint32_t* guard_post,
-                   uint32_t guard_seq, bool debug_raise_guard, hipStream_t s, bool debug);
+                   uint32_t guard_seq, bool debug_raise_guard, uint32_t n_huge, hipStream_t s, bool debug);
 
 // stable LSD radix sort of (key,val) u32 pairs on the low nbits of (key - kmin); ping-pongs between the two
 // pairs, *where = 0/1 tells which pair holds the result

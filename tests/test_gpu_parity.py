@@ -133,8 +133,10 @@ def _check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=0, grad_rtol=GRAD
             assert o_grads[k] is None, k
             continue
         assert g.shape == o_grads[k].shape, k
-        per_gaussian = g.shape[0] == len(ill) and k in ("means3D", "scales", "rotations", "cov3D_precomp", "means2D")
+        per_gaussian = g.shape[0] == len(ill) and k in ("means3D", "scales", "rotations", "cov3D_precomp", "means2D", "opacities")
         ill_k, explain_k = (ill, explain) if per_gaussian else (None, None)
+        if k == "opacities":
+            ill_k = np.zeros_like(ill)          # (an opacity gradient does not go through the conic: only a MEASURED sensitivity counts)
         quota = 10.0
         if per_gaussian and len(grad_mismatch(g, o_grads[k], grad_rtol, 1e-6)[0]):
             # offenders: MEASURE what fp32 summation can move each row by (helpers.summation_sensitivity: the oracle's own
@@ -143,17 +145,26 @@ def _check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=0, grad_rtol=GRAD
             # ones whose rotation gradient is pure cancellation) is ill-conditioned whatever its conic looks like.
             if sens is None:
                 og = orc.backward(oc, st, *gouts, abs_sums=True)
-                sens = summation_sensitivity(oc, st, og, names=("means3D", "scales", "rotations"), rtol=grad_rtol, floor=1e-6)
+                # (opacities too: with upstream gradients on depth / alpha only, a screen-filling splat's opacity gradient is a
+                # sum of thousands of terms that cancel to 1 / 4600 of their absolute sum -- fuzz seed 1325)
+                sens = summation_sensitivity(oc, st, og, names=("means3D", "scales", "rotations", "opacities"), rtol=grad_rtol, floor=1e-6)
             if k in sens:
                 moved = sens[k]
-                ill_k = ill | (moved > 1.0)
+                factor = 4.0 if (flags | hip_flags) & 256 else 8.0
+                # ill-conditioned: by its conic, by a movement of more than one allowance -- or by one whose multiple below
+                # exceeds the 3 allowances a well-conditioned row may miss by (fuzz seed 1325: an opacity gradient that moved
+                # 0.73 allowances in the measurement and missed by 3.2 with the atomic backward); the last kind is held to
+                # that multiple itself, not to 10
+                hard = ill_k | (moved > 1.0)
+                soft = ~hard & (factor * moved > 3.0)
+                ill_k = hard | soft
                 # ... and such a row may miss by what the perturbation moves it -- x4 with the deterministic backward (its
                 # per-Gaussian sums are added in double; the full-size views of tests/test_gpu_fullsize.py stay within 2.7 x,
                 # a view of profiles/tools/sweep_street.py from inside the geometry -- median conic conditioning 22 instead
                 # of 3 -- has a row at 3.3 x: the measurement is the largest of three 1-sigma draws), x8 with the atomic one
                 # (fp32 sums in arbitrary order; a 31 M-entry view of the sweep has a row at 4.9 ... 13 x) --, at least by
                 # 10 allowances
-                quota = np.maximum(10.0, (4.0 if (flags | hip_flags) & 256 else 8.0) * moved)
+                quota = np.where(soft, factor * moved, np.maximum(10.0, factor * moved))
                 explain_k = (lambda i, e=explain, m=moved: e(i) + f", measured summation sensitivity {m[i]:.3g} allowances")
         assert_grad_close(k, g, o_grads[k], rtol=grad_rtol, explain=explain_k, ill=ill_k, ill_quota=quota if per_gaussian else None)
     return h_out, h_grads, o_out, st

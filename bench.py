@@ -361,8 +361,8 @@ def variant(name, sc, deg, cams, device, steps, warmup, factored=False, hints="o
     nv = len(done)                      # steps x views per step
     res = {"workload": name, "views_per_s": round(nv / dt, 2), "ms_per_view": round(dt / nv * 1e3, 4),
            "ms_per_view_runs": [round(r / nv * 1e3, 4) for r in runs],
-           "mfragments_per_s": round(sum(cn[v]["F"] for v in done) / dt / 1e6, 1),
-           "mfragments_per_s_own_lists": round(sum(cn[v]["F_lists"] for v in done) / dt / 1e6, 1),
+           "mfragments_per_s": round(sum(cn[v]["F_lists"] for v in done) / dt / 1e6, 1),
+           "mfragments_per_s_reference_lists": round(sum(cn[v]["F"] for v in done) / dt / 1e6, 1),
            "blended_mfragments_per_s": round(sum(cn[v]["B"] for v in done) / dt / 1e6, 1),
            "mean_counters": {k: round(v, 1) for k, v in mean.items()}}
     res.update(extra)
@@ -562,16 +562,19 @@ def main():
     value = views / elapsed
     mean = {k: float(np.mean([counters[v][k] for v in views_done])) for k in ("Pz", "V", "R", "R_lists", "F", "F_lists", "B")}
     # algorithmic bytes per view, SURVEY.md section 8(d)
-    b_alg = 32 * P + 28 * mean["Pz"] + (294 + 24 * K) * mean["V"] + 188 * mean["R"] + 112 * N + (56 + 12 * K) * P
+    # (R term on the lists the kernels walk; `..._ref`: on the reference's full rectangles)
+    b_alg = 32 * P + 28 * mean["Pz"] + (294 + 24 * K) * mean["V"] + 188 * mean["R_lists"] + 112 * N + (56 + 12 * K) * P
+    b_alg_ref = b_alg + 188 * (mean["R"] - mean["R_lists"])
     # dominant kernel: k_seg_bwd (gradients of one (tile, segment)), timed with HIP events recorded by the
     # library on the stream it launches on, inside the timed region.  Its algorithmic bytes are those of the
-    # whole render-backward step (72R + 56N + 68V), of which it is the only heavy kernel.
+    # whole render-backward step (72R + 56N + 68V), of which it is the only heavy kernel --
+    # priced on the units the launch actually PROCESSES: R_lists, the entries of the build's own tile lists.  The
+    # reference's rectangles hold a third more entries (R: one per tile of the rectangle), which this
+    # kernel never touches; that figure is kept as `frac_on_reference_lists` for comparison with earlier rounds.
     kern = "k_seg_bwd"
     ms_k = stage[kern][0] / max(stage[kern][1], 1)
-    # R = list entries as SURVEY 8(d) counts them: one per tile of the REFERENCE's rectangles.  The build's own lists are a
-    # third shorter (tiles a splat cannot reach are not listed): `frac_on_own_lists` prices the kernel on those.
-    bytes_k = 72 * mean["R"] + 56 * N + 68 * mean["V"]
-    bytes_k_own = 72 * mean["R_lists"] + 56 * N + 68 * mean["V"]
+    bytes_k = 72 * mean["R_lists"] + 56 * N + 68 * mean["V"]
+    bytes_k_ref = 72 * mean["R"] + 56 * N + 68 * mean["V"]
     achieved = bytes_k / (ms_k * 1e-3) / 1e9 if ms_k > 0 else 0.0
     # (the kernel's own sources AND everything upstream that shapes its work: lists, masks, records)
     traffic, valu_insts, traffic_from = profile_figures(kern, ("render_bwd.hip", "vr_segment.h", "vr_device.h", "render_fwd.hip",
@@ -590,6 +593,24 @@ def main():
                      "achieved_gatomics_per_s": round(17 * flushes / (ms_k * 1e-3) / 1e9, 2) if ms_k > 0 else None,
                      "peak": None, "note": "fp32 global atomics (hardware, -munsafe-fp-atomics), 17 per (entry, region) flush; "
                                            "no published L2 atomic peak for gfx950"}}
+    # per-stage roofline fractions (level-2 stage timers of 8 views OUTSIDE the timed region): SURVEY 8(a)'s algorithmic
+    # bytes of every row on the units this build processes (R_lists) against the stage's time and the HBM peak
+    Rl, Vm, Pz = mean["R_lists"], mean["V"], mean["Pz"]
+    stage_bytes = {
+        "preprocess": 12 * P + 8 * P + 28 * Pz + (4 + 12 * K + 67) * Vm,                 # K1
+        "binning": 8 * P + (4 * P + 16 * Vm + 12 * Rl) + 24 * Rl + 8 * Rl,                 # K2 + K3 + K4 (floor) + K5
+        "render_fwd": 72 * Rl + 56 * N,                                                   # K6
+        "render_bwd": 72 * Rl + 56 * N + 68 * Vm,                                         # K7
+        "preprocess_bwd": (68 + 4 + 12 * K + 67) * Vm + (56 + 12 * K) * P,                # K8 (SURVEY's figure: incl. an SH re-read this build does not do)
+    }
+    stage_frac = {}
+    if stage_ms:
+        t_bin = sum(stage_ms.get(k, 0.0) for k in ("compact", "depth_sort", "emit", "tile_sort", "ranges"))
+        for k, by in stage_bytes.items():
+            t = t_bin if k == "binning" else stage_ms.get(k, 0.0)
+            if t > 0:
+                stage_frac[k] = {"ms": round(t, 4), "alg_bytes": round(by), "frac": round(by / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    t_view = elapsed / (args.steps * vps)
     res = {
         "metric": "rasterizer fwd+bwd views/sec + Mfragments/sec, 2M Gaussians @1376x376",
         "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -597,17 +618,18 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         # `repeats` regions of K steps each were timed; value / ms_per_step are those of the MEDIAN region
         "repeats": len(region_s), "ms_per_step_regions": [round(r / args.steps * 1e3, 4) for r in region_s],
-        # F = sum of n_contrib = list entries TRAVERSED by the forward blend loop (BASELINE.md's fragment definition);
-        # B = (pixel, splat) pairs actually BLENDED (alpha >= 1/255 before the stop) -- an order of magnitude fewer
-        # ... on the REFERENCE's tile rectangles (BASELINE.md's definition of a fragment); `..._own_lists`: entries of the
-        # build's tighter lists actually walked (a third of the reference's pairs cannot reach any pixel and are not listed)
-        "mfragments_per_s": round(frag_total / elapsed / 1e6, 2),
-        "mfragments_per_s_own_lists": round(frag_own_total / elapsed / 1e6, 2),
+        # Fragments = list entries TRAVERSED by the forward blend loop (sum of n_contrib).  `mfragments_per_s`: the entries of
+        # the build's own tile lists, i.e. what its loops actually walk; `..._reference_lists`: the same views counted on the
+        # REFERENCE's full tile rectangles (BASELINE.md's definition; a third of those pairs cannot reach any pixel and are
+        # not listed by default) -- multiplied by THIS build's view rate, so comparable with upstream's figure of merit but
+        # not a statement about work done; B = (pixel, splat) pairs actually BLENDED (alpha >= 1/255 before the stop)
+        "mfragments_per_s": round(frag_own_total / elapsed / 1e6, 2),
+        "mfragments_per_s_reference_lists": round(frag_total / elapsed / 1e6, 2),
         "blended_mfragments_per_s": round(blend_total / elapsed / 1e6, 2),
         "exchange": exchange,
         "config": {"workload": f"{args.workload}: {P} street Gaussians (VEGS disc init), SH deg {deg}, {W}x{H} "
                                f"KITTI-360 intrinsics, {n_views} views cycled, 12 output channels + colour/quat/scale grads; tile lists "
-                               f"without the (Gaussian, tile) pairs that cannot reach a pixel (R, F quoted on the reference's full rectangles); "
+                               f"without the (Gaussian, tile) pairs that cannot reach a pixel (R_lists, F_lists; R, F = the same views on the reference's full rectangles); "
                                + (f"EVERY DISC x{args.disc_scale} (--disc-scale: not the headline workload); " if args.disc_scale != 1.0 else "")
                                + "every view is rendered as a camera's first visit (no per-camera state carried between views)",
                    "hints": "off",
@@ -623,12 +645,15 @@ def main():
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "traffic_collected": traffic_from, "secondary": secondary,
                      "alg_bytes_per_launch": round(bytes_k), "avg_launch_ms": round(ms_k, 4),
-                     "alg_bytes_note": "72 R + 56 N + 68 V with R on the reference's full tile rectangles (SURVEY 8d)",
-                     "frac_on_own_lists": round(bytes_k_own / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms_k > 0 else 0.0,
+                     "alg_bytes_note": "72 R_lists + 56 N + 68 V: SURVEY 8(a) row K7 per unit x the units one launch processes "
+                                       "(R_lists = entries of the build's own tile lists, the ones the kernel walks)",
+                     "frac_on_reference_lists": round(bytes_k_ref / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms_k > 0 else 0.0,
                      "launches_timed": int(stage[kern][1]),
                      "stage_ms": stage_ms,
+                     "stages": stage_frac,
                      "whole_view_alg_bytes": round(b_alg),
-                     "whole_view_frac": round(b_alg / (elapsed / (args.steps * vps)) / 1e9 / HBM_PEAK_GBS, 5)},
+                     "whole_view_frac": round(b_alg / t_view / 1e9 / HBM_PEAK_GBS, 5),
+                     "whole_view_frac_on_reference_lists": round(b_alg_ref / t_view / 1e9 / HBM_PEAK_GBS, 5)},
     }
     if args.stages:
         print("hipMalloc calls inside the timed region:", mallocs1 - mallocs0, "reserved MB before/after:",
@@ -672,6 +697,11 @@ def main():
                     sc, deg, cams, device, 16, 4, flags=rasterizer.FLAG_FAST_EXP),
         ]
         noglue = [v for v in res["variants"] if "without the reference's render() glue" in v["workload"]][0]
+        full = [v for v in res["variants"] if "VR_FLAG_FULL_TILE_LISTS" in v["workload"]][0]
+        # the north star asks for the reference's tile / sort indices: the same views with the reference's full tile
+        # rectangles as the lists (VR_FLAG_FULL_TILE_LISTS) -- the headline `value` runs the default, tighter lists
+        res["views_per_s_reference_tile_lists"] = full["views_per_s"]
+        res["ms_per_view_reference_tile_lists"] = full["ms_per_view"]
         res["aten_glue_ms_per_view"] = round(res["ms_per_step"] / vps - noglue["ms_per_view"], 4)
     if world == 1 and not args.no_cpu_baseline:
         cpu_views = [0, 2, 4, 6, 8, 10, 12, 14]           # ~1.6 s each on the box's host cores: 10 ... 15 s of CPU work

@@ -16,7 +16,7 @@ json.dump({"c3": a, "c5_5M_8_boxes": b, "note": "profiles/tools/iteration_bench.
           open(f"profiles/{tag}_iteration.json", "w"), indent=1)
 d = json.loads(open(f"profiles/{tag}_bench_line.json").read().strip().splitlines()[-1])
 rf = d["roofline"]
-print(d["value"], d["ms_per_step"], d["ms_per_step_regions"], "frac", rf["frac"], "own", rf["frac_on_own_lists"], "traffic", rf["traffic"], rf["traffic_collected"], "valu", rf["secondary"]["valu"])
+print(d["value"], d["ms_per_step"], d["ms_per_step_regions"], "frac", rf["frac"], "ref", rf["frac_on_reference_lists"], "traffic", rf["traffic"], rf["traffic_collected"], "valu", rf["secondary"]["valu"])
 for v in d["variants"]:
     print(" ", v["ms_per_view"], v["workload"][:90])
 PY

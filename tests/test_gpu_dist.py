@@ -271,10 +271,17 @@ def test_bench_line_contract_single_gpu():
     assert "traffic_collected" in rf and (rf["traffic"] is None) == (isinstance(rf["traffic_collected"], str))
     sec = rf["secondary"]
     assert abs(sec["l2_atomics"]["atomics_per_view"] - 17 * sec["l2_atomics"]["flushes_per_view"]) <= 17 and sec["l2_atomics"]["flushes_per_view"] > 0
-    # fragments and list entries are quoted on the REFERENCE's full tile rectangles (BASELINE.md's definition); the build's
-    # own, tighter lists are reported beside them
+    # fragments, list entries and the roofline fraction are priced on the lists the kernels WALK (the build's own, tighter
+    # lists); the same views on the REFERENCE's full tile rectangles (BASELINE.md's definition) are reported beside them
     mc = d["config"]["mean_counters"]
-    assert mc["R_lists"] < mc["R"] and mc["F_lists"] < mc["F"] and d["mfragments_per_s_own_lists"] < d["mfragments_per_s"]
+    assert mc["R_lists"] < mc["R"] and mc["F_lists"] < mc["F"] and d["mfragments_per_s"] < d["mfragments_per_s_reference_lists"]
+    N = d["config"]["width"] * d["config"]["height"]
+    assert abs(rf["alg_bytes_per_launch"] - (72 * mc["R_lists"] + 56 * N + 68 * mc["V"])) <= 2
+    assert rf["frac"] < rf["frac_on_reference_lists"] < 1 and rf["whole_view_frac"] < rf["whole_view_frac_on_reference_lists"] < 1
+    # every stage's own fraction of the HBM peak (SURVEY 8a bytes on the build's lists / its HIP-event time)
+    assert set(("preprocess", "binning", "render_fwd", "render_bwd", "preprocess_bwd")) <= set(rf["stages"])
+    for st in rf["stages"].values():
+        assert st["ms"] > 0 and abs(st["frac"] - st["alg_bytes"] / (st["ms"] * 1e-3) / 8e12) < 2e-4
     if rf["traffic"] is not None:
         assert 0 < sec["valu"]["frac"] < 1 and sec["valu"]["peak_ginst_per_s"] == 1228.8
     assert set(("preprocess", "render_fwd", "render_bwd", "preprocess_bwd", "k_seg_bwd")) <= set(rf["stage_ms"])

@@ -27,7 +27,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from vegs_amd import _capi, dist as vdist, harness, scenes  # noqa: E402
+from vegs_amd import _capi, dist as vdist, harness, scenes, so3  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guide: MI355X_MICROARCH.md chip table)
 VALU_PEAK_GINST = 1228.8   # wave64 VALU instructions per ns: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles (same guide)
@@ -82,11 +82,7 @@ def upstream_grads(pkg, cam, rng, device):
     q = pkg["render_cov_quat"].detach().clone().requires_grad_(True)
     s = pkg["render_cov_scale"].detach().clone().requires_grad_(True)
     qs = torch.where((q * q).sum(0, keepdim=True) > 0, q, torch.ones_like(q))
-    r, i, j, k = torch.unbind(qs.permute(1, 2, 0).reshape(-1, 4), -1)
-    two_s = 2.0 / (r * r + i * i + j * j + k * k)
-    rot = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
-                       two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
-                       two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1).reshape(-1, 3, 3)
+    rot = so3.quaternion_to_matrix(qs.permute(1, 2, 0).reshape(-1, 4))
     cs = s.permute(1, 2, 0).reshape(-1, 1, 3)
     Rm = torch.tensor(cam.R, dtype=torch.float32, device=device)
     nw = (Rm @ normal.reshape(3, -1)).t()[:, :, None].expand(-1, 3, 3)

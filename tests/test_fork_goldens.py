@@ -21,6 +21,42 @@ from helpers import GOLDEN, OUT_NAMES, assert_grad_close, case_inputs, oracle_ca
 
 FORK_DIR = os.path.join(GOLDEN, "fork")
 FWD_ATOL = 1e-4            # BASELINE.json north_star: "outputs within 1e-4 abs"
+# ... EXCEPT threshold flips.  A fragment whose alpha sits within an ulp of 1/255 is classified one way by one correct exp()
+# and the other way by another (CUDA's expf, this build's polynomial, v_exp_f32 all differ in the last place): its pixel
+# then moves by up to alpha * |attribute| ~ 1/255 of a channel -- far above 1e-4 and no defect of either side.  The rule is
+# the one tests/test_gpu_parity.py applies to VR_FLAG_FAST_EXP against the checker: a BOUNDED number of such pixels
+# (<= max(2, 2e-5 H W) per case), each off by at most 1.01 / 255 x the channel's scale; they are printed.
+FLIP_FRACTION = 2e-5
+FLIP_BOUND = 1.01 / 255.0
+
+
+def forward_deviation(out, ref, atol=FWD_ATOL, report=None):
+    """Worst |out - ref| over the five images of one case OUTSIDE the pixels excused as threshold flips; inf when the
+    flips exceed their count or size bound.  `report` (a list) receives one line per excused pixel."""
+    H, W = out["color"].shape[-2:]
+    bad = np.zeros((H, W), bool)
+    worst = 0.0
+    per = {}
+    for n in OUT_NAMES:
+        a = out[n].astype(np.float64).reshape(-1, H, W)
+        b = ref[n].astype(np.float64).reshape(-1, H, W)
+        d = np.abs(a - b)
+        scale = max(1.0, float(np.abs(b).max()))
+        if float(d.max(initial=0.0)) > FLIP_BOUND * scale:
+            return float("inf")
+        off = (d > atol).any(axis=0)
+        bad |= off
+        per[n] = d
+        worst = max(worst, float(d[:, ~off].max(initial=0.0)))
+    if int(bad.sum()) > max(2, int(FLIP_FRACTION * H * W)):
+        return float("inf")
+    if report is not None:
+        for y, x in zip(*np.nonzero(bad)):
+            report.append(f"   threshold-flip pixel ({x}, {y}): " +
+                          ", ".join(f"{n} {float(per[n][:, y, x].max()):.2e}" for n in OUT_NAMES if per[n][:, y, x].max() > atol))
+    return worst
+
+
 GRAD_NAMES = ["means3D", "means2D", "shs", "colors_precomp", "opacities", "scales", "rotations", "cov3D_precomp"]
 
 
@@ -56,8 +92,11 @@ def matching_flag_sets(cases, atol=FWD_ATOL):
             if not np.array_equal(out["radii"], f["radii"]):
                 w = float("inf")
                 break
-            for n in OUT_NAMES:
-                w = max(w, float(np.abs(out[n].astype(np.float64) - f["out_" + n].reshape(out[n].shape)).max()))
+            notes = []
+            w = max(w, forward_deviation(out, {n: f["out_" + n].reshape(out[n].shape) for n in OUT_NAMES}, atol, notes))
+            if notes and w <= atol:
+                print(f"flags {flags}, {name}: {len(notes)} pixel(s) excused as threshold flips")
+                print("\n".join(notes))
         worst[flags] = w
     return [k for k, v in worst.items() if v <= atol], worst
 
@@ -132,6 +171,38 @@ def test_kit_identifies_a_known_flag_combination(tmp_path, flags):
         assert (w ^ flags) & ~1 == 0 or all(float(c["scale_modifier"]) == 1.0 for _, c, _ in cases) and (w ^ flags) & 0xE == 0
 
 
+def test_threshold_flip_pixels_are_excused_but_bounded(tmp_path):
+    """The forward comparison tolerates what two correct exp() implementations legitimately disagree on -- a fragment at
+    the 1/255 threshold classified the other way moves ONE pixel by up to ~1/255 of a channel -- and nothing else: more
+    such pixels than 2e-5 of the frame, a larger step, or a deviation spread over the image all fail the match."""
+    d = _standin_fork_files(tmp_path, 0)
+    f = os.path.join(d, "fork_case_sh3.npz")
+    base = {k: v for k, v in np.load(f).items()}
+
+    def winners_with(edit):
+        z = {k: v.copy() for k, v in base.items()}
+        edit(z)
+        np.savez_compressed(f, **z)
+        return matching_flag_sets(_cases(d))[0]
+
+    def one_flip(z):
+        z["out_color"][1, 7, 9] += 0.9 / 255.0
+        z["out_depth"].reshape(z["out_depth"].shape[-2:])[7, 9] += 0.9 / 255.0 * max(1.0, float(np.abs(z["out_depth"]).max()))
+    assert 0 in winners_with(one_flip)
+
+    def too_large(z):
+        z["out_color"][1, 7, 9] += 3.0 / 255.0
+    assert winners_with(too_large) == []
+
+    def too_many(z):
+        z["out_color"][0, 3, ::2] += 0.5 / 255.0
+    assert winners_with(too_many) == []
+
+    def everywhere(z):
+        z["out_color"] += 2e-4
+    assert winners_with(everywhere) == []
+
+
 def test_dump_script_is_standalone():
     """tools/fork_pin/dump_fork_goldens.py must run where this repository is not importable."""
     import ast
@@ -167,8 +238,10 @@ def test_hip_matches_the_fork():
         g = [c["gout_" + n] if n in ("color", "cov_quat", "cov_scale") else None for n in OUT_NAMES]
         out, grads, _ = _run_hip(_settings(c, None, None, None, dev), case_inputs(c), dev, g, flags=flags)
         assert np.array_equal(out["radii"], f["radii"])
-        for n in OUT_NAMES:
-            assert np.abs(out[n] - f["out_" + n].reshape(out[n].shape)).max() <= FWD_ATOL, (name, n)
+        notes = []
+        dev_ = forward_deviation(out, {n: f["out_" + n].reshape(out[n].shape) for n in OUT_NAMES}, FWD_ATOL, notes)
+        print("\n".join(notes))
+        assert dev_ <= FWD_ATOL, (name, dev_)
         for k in GRAD_NAMES:
             if grads.get(k) is not None and f"grad3_{k}" in f:
                 assert_grad_close(f"hip vs fork {name} {k}", grads[k], f[f"grad3_{k}"].reshape(grads[k].shape), rtol=2e-3, floor=1e-5)

@@ -31,16 +31,24 @@ def _inputs(sc):
                 scales=sc["scales"], rotations=sc["rotations"], cov3D_precomp=None)
 
 
-def test_c2_500k_forward_matches_oracle_bit_exact(dev):
+# Both list definitions at full size: 0 = the build's default, tight tile lists; FULL = the REFERENCE's emission rule, every
+# tile of a Gaussian's rectangle -- the north star's "tile/sort indices bit-exact" is a statement about those.
+FULL_LISTS = 32768          # VR_FLAG_FULL_TILE_LISTS
+LIST_MODES = pytest.mark.parametrize("list_flags", [0, FULL_LISTS], ids=["tight-lists", "reference-lists"])
+
+
+@LIST_MODES
+def test_c2_500k_forward_matches_oracle_bit_exact(dev, list_flags):
     from oracle import oracle as orc
     from vegs_amd import scenes
     sc, deg = scenes.scene_street(P=500_000, length=120.0, sh_degree=3, seed=1)
     cam = scenes.kitti_camera(0.0, 0.3, 1376, 376)
-    oc = oracle_cam(cam, [0, 0, 0], deg)
+    oc = oracle_cam(cam, [0, 0, 0], deg, flags=list_flags)
     o_out, st = orc.forward(oc, **_inputs(sc))
     gouts = [np.random.default_rng(5).normal(size=s).astype(np.float32) * 1e-3
              for s in [(3, 376, 1376), (1, 376, 1376), (4, 376, 1376), (3, 376, 1376), (1, 376, 1376)]]
-    h_out, h_grads, res = _run_hip(_settings(cam, [0, 0, 0], deg, 1.0, dev), _inputs(sc), dev, gouts)
+    h_out, h_grads, res = _run_hip(_settings(cam, [0, 0, 0], deg, 1.0, dev), _inputs(sc), dev, gouts, flags=list_flags)
+    assert res[0].grad_fn.num_rendered == st["R"]
     assert np.array_equal(h_out["radii"], o_out["radii"])
     pl, rg = _export_binning(res, 376, 1376, dev)
     assert np.array_equal(rg, st["ranges"]) and np.array_equal(pl, st["point_list"])
@@ -51,7 +59,7 @@ def test_c2_500k_forward_matches_oracle_bit_exact(dev):
     for k in ("means3D", "shs", "opacities", "scales", "rotations", "means2D"):
         # default (atomic) mode: no row beyond 10x unless its conic is ill-conditioned (printed)
         assert_grad_close(k, h_grads[k], o_grads[k], rtol=1e-3, explain=explain, ill=ill)
-    _oracle_parity("c2", _inputs(sc), deg, cam, dev)                     # deterministic mode: the tight comparison
+    _oracle_parity("c2", _inputs(sc), deg, cam, dev, flags=list_flags)                     # deterministic mode: the tight comparison
 
 
 @pytest.fixture(scope="module")
@@ -255,14 +263,14 @@ EXPLAIN_FACTOR = float(os.environ.get("VEGS_EXPLAIN_FACTOR", "3.0"))
 EXEMPT_FROM_CAP = float(os.environ.get("VEGS_EXEMPT_FROM_CAP", "1.0"))
 
 
-def _oracle_parity(name, sc_inputs, deg, cam, dev, hip_runs=1):
+def _oracle_parity(name, sc_inputs, deg, cam, dev, hip_runs=1, flags=0):
     """sc_inputs: op kwargs (numpy).  Renders `hip_runs` times through the operator (same camera tensors: with the hint
     cache on, the third run uses a warm needed-segment hint), checks every run bit-exact against the oracle's forward and
     the last run's deterministic-mode gradients per row against the oracle's backward."""
     from oracle import oracle as orc
     from vegs_amd import rasterizer
     H, W = cam.image_height, cam.image_width
-    oc = oracle_cam(cam, [0, 0, 0], deg)
+    oc = oracle_cam(cam, [0, 0, 0], deg, flags=flags)       # (`flags`: on BOTH sides -- the list definition, a fork switch)
     o_out, st = orc.forward(oc, **sc_inputs)
     rng = np.random.default_rng(31)
     gouts = [rng.normal(size=s).astype(np.float32) * 1e-3 if m else None
@@ -274,7 +282,7 @@ def _oracle_parity(name, sc_inputs, deg, cam, dev, hip_runs=1):
         for run in range(hip_runs):
             last = run == hip_runs - 1
             h_out, h_grads, res = _run_hip(settings, sc_inputs, dev, gouts if last else None,
-                                           flags=rasterizer.FLAG_DETERMINISTIC if last else 0)
+                                           flags=flags | (rasterizer.FLAG_DETERMINISTIC if last else 0))
             assert np.array_equal(h_out["radii"], o_out["radii"]), (name, run)
             pl, rg = _export_binning(res, H, W, dev)
             assert res[0].grad_fn.num_rendered == st["R"]
@@ -319,14 +327,17 @@ def _bench_cams():
     return cams
 
 
-def test_c3_headline_views_match_oracle(c3, dev):
+@LIST_MODES
+def test_c3_headline_views_match_oracle(c3, dev, list_flags):
     """BASELINE config C3 (2 M Gaussians, the headline): two of bench.py's 16 cameras under the oracle, one of them
-    rendered three times so that its last forward runs with a recorded needed-segment hint."""
+    rendered three times so that its last forward runs with a recorded needed-segment hint -- on the build's tight tile
+    lists and on the reference's full rectangles (radii / lists / ranges / images bit-exact in both)."""
     sc, deg, cam, T = c3
     cams = _bench_cams()
-    st = _oracle_parity("c3 cam5", _inputs(sc), deg, cams[5], dev, hip_runs=3)
-    assert st["R"] > 2_500_000          # (tight tile lists: about 4.2 M pairs with the reference's full rectangles)
-    _oracle_parity("c3 cam10", _inputs(sc), deg, cams[10], dev)
+    st = _oracle_parity("c3 cam5", _inputs(sc), deg, cams[5], dev, hip_runs=3, flags=list_flags)
+    # (tight tile lists: about 2.7 M entries; the reference's full rectangles: about 4.2 M)
+    assert st["R"] > (3_500_000 if list_flags else 2_500_000) and (list_flags or st["R"] < 3_200_000)
+    _oracle_parity("c3 cam10", _inputs(sc), deg, cams[10], dev, flags=list_flags)
 
 
 def test_c3_dense_13m_entries_matches_oracle(c3, dev):

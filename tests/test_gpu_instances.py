@@ -39,6 +39,42 @@ def test_instance_transform_matches_reference_outputs():
     assert kw["shs"].shape == (240, 4, 3) and kw["opacities"].shape == (240, 1)
 
 
+def test_render_dyn_op_by_op_equals_fused():
+    """render_dyn (gaussian_renderer/__init__.py:188-260: only the dynamic instances, no static model): the op-by-op
+    composition (harness.render_all(static=None, fused=False)) and the fused one render the same frame -- images equal to
+    the rounding of the transformed inputs, gradients of every instance leaf and pose equal per tensor."""
+    from vegs_amd import harness, scenes
+    rng = np.random.default_rng(16)
+    nb, n = 3, 4000
+    sc_boxes = [scenes.scene_random(P=n, sh_degree=1, seed=70 + i, extent=0.3, scale=0.03)[0] for i in range(nb)]
+    Bs = []
+    for i in range(nb):
+        B = np.eye(4)
+        B[:3, :3] = harness.quaternion_to_matrix(torch.tensor(rng.normal(size=4))).numpy() * rng.uniform(0.8, 1.3)
+        B[:3, 3] = rng.uniform(-0.3, 0.3, 3)
+        Bs.append(B.astype(np.float32))
+    cam = scenes.camera_c1(192, 128)
+    gouts = [torch.tensor(rng.normal(size=s).astype(np.float32), device=DEV) for s in [(3, 128, 192), (4, 128, 192), (3, 128, 192)]]
+    res = []
+    for fused in (False, True):
+        bx = [{k: torch.tensor(v, device=DEV, requires_grad=True) for k, v in b.items()} for b in sc_boxes]
+        bw = [torch.tensor(B, device=DEV, requires_grad=True) for B in Bs]
+        pkg = harness.render_all(cam, None, bx, bw, 1, torch.zeros(3, device=DEV), fused=fused)
+        torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], gouts)
+        res.append((pkg, bx, bw))
+    (pa, bxa, bwa), (pb, bxb, bwb) = res
+    assert pa["op_inputs"]["means3D"].shape[0] == nb * n and torch.equal(pa["radii"], pb["radii"])
+    for k in ("render", "render_depth", "render_cov_quat", "render_cov_scale", "alpha"):
+        assert rel_err(pb[k].detach().cpu().numpy(), pa[k].detach().cpu().numpy()) < 2e-5, k
+    for a, b in zip(bxa, bxb):
+        for k in ("means3D", "scales", "rotations", "opacities", "shs"):
+            assert rel_err(b[k].grad.cpu().numpy(), a[k].grad.cpu().numpy()) < 2e-3, k
+    for a, b in zip(bwa, bwb):
+        assert rel_err(b.grad.cpu().numpy(), a.grad.cpu().numpy()) < 2e-3
+    with pytest.raises(ValueError):
+        harness.render_all(cam, None, [], [], 1, torch.zeros(3, device=DEV), fused=False)
+
+
 def test_fused_render_all_equals_the_op_by_op_composition():
     """C5-shaped: a static model + 20 instances of 8196 Gaussians (more than one launch table), through the
     rasterizer; forward images bit-identical inputs apart, gradients of every leaf vs the float64 oracle."""

@@ -53,33 +53,7 @@ def render(cam, tensors, sh_degree, bg_color, scaling_modifier=1.0, debug=False,
 # model/boxmodel.py:30-42).  Device-agnostic on purpose: the tests run the same graph on the CPU to
 # carry the oracle's op-input gradients back to the parameters.
 
-def quaternion_to_matrix(q):
-    """(w,x,y,z) -> rotation matrix, normalising by |q|^2 (convention of utils/graphics_utils.py:204-248)."""
-    r, i, j, k = torch.unbind(q, -1)
-    two_s = 2.0 / (q * q).sum(-1)
-    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
-                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
-                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
-    return o.reshape(q.shape[:-1] + (3, 3))
-
-
-def matrix_to_quaternion(m):
-    """Rotation matrix -> (w,x,y,z): of the four algebraically equivalent candidates (each is the
-    quaternion scaled by one of its own components) take the best conditioned one, i.e. the one whose
-    defining component sqrt(1 +- m00 +- m11 +- m22)/2 is largest (utils/graphics_utils.py:140-201)."""
-    m00, m01, m02 = m[..., 0, 0], m[..., 0, 1], m[..., 0, 2]
-    m10, m11, m12 = m[..., 1, 0], m[..., 1, 1], m[..., 1, 2]
-    m20, m21, m22 = m[..., 2, 0], m[..., 2, 1], m[..., 2, 2]
-    sq = torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22, 1 - m00 - m11 + m22], -1)
-    q_abs = torch.sqrt(torch.clamp(sq, min=0.0) + (sq <= 0) * 1e-30) * (sq > 0)
-    cand = torch.stack([
-        torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], -1),
-        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], -1),
-        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], -1),
-        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], -1)], -2)
-    cand = cand / (2.0 * torch.clamp(q_abs, min=0.1)[..., None])
-    best = q_abs.argmax(-1)
-    return torch.gather(cand, -2, best[..., None, None].expand(best.shape + (1, 4))).squeeze(-2)
+from .so3 import matrix_to_quaternion, quaternion_to_matrix  # noqa: E402,F401  (re-exported: tests and tools use harness.*)
 
 
 def prepare_rasterization(t, box2world=None):
@@ -125,9 +99,13 @@ def render_all(cam, static, boxes, box2worlds, sh_degree, bg_color, scaling_modi
             static = {**static, "opacities": o, "scales": s_, "rotations": r}
         kw = instances.prepare_and_merge(static, boxes, box2worlds)
     else:
-        kw = prepare_rasterization(static)
+        # static=None: only the dynamic instances are in frame (the reference's render_dyn, gaussian_renderer/__init__.py:188-260)
+        kw = prepare_rasterization(static) if static is not None else None
         for t, b2w in zip(boxes, box2worlds):
-            kw = merge_kwargs(kw, prepare_rasterization(t, b2w))
+            one = prepare_rasterization(t, b2w)
+            kw = one if kw is None else merge_kwargs(kw, one)
+        if kw is None:
+            raise ValueError("render_all: neither a static model nor a box instance to render")
     pkg = render(cam, kw, sh_degree, bg_color, scaling_modifier, cam_t=cam_t, sh_color_grad=sh_color_grad)
     pkg["op_inputs"] = kw
     return pkg

@@ -345,7 +345,9 @@ int vr_debug_export_binning(const VrSaved* saved, int32_t image_height, int32_t 
  * that never gets a backward (eval under no_grad) is reported by the NEXT vr_forward of the host thread instead.
  * vr_debug_set_guard sets the word (value != 0) or clears it (0) by hand, as if an earlier view had raised it;
  * vr_debug_raise_guard(1) makes the NEXT vr_forward of the calling thread raise it in the middle of its own binning, as
- * a timed-out wait would. */
+ * a timed-out wait would -- after lists that are in fact valid; vr_debug_raise_guard(2) makes that forward LOSE the first
+ * workgroup of its depth sort (it never posts its counts): the waits of its successors run out for real (~2 s) and the
+ * lists behind them are built from short prefixes -- what VR_FLAG_VERIFY_BINNING has to recover from. */
 int vr_debug_set_guard(uint32_t value, void* stream);
 int vr_debug_raise_guard(int on);
 /* views of the calling thread that VR_FLAG_VERIFY_BINNING binned a second time (tests) */

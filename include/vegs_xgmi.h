@@ -67,8 +67,19 @@ typedef struct VrXgmiSegment {
 /* Mean (scale * sum over ranks, summed in rank order) of every segment, delivered on every rank at
  *     window + result_offset + result_floats_offset[i]      (result_floats_offset is an OUTPUT: segment i's place)
  * All ranks must call with the same segment lengths.  Kernels go onto `stream`; the call returns once they are
- * enqueued.  A peer that does not show up within the wait bound (2 s) raises the window's error word: the NEXT call on
- * this window (and vr_xgmi_check) returns VR_ERR_HIP instead of hanging the queue. */
+ * enqueued.
+ * FAILURE CONTRACT (ABI v9).  Every device-side wait for a peer is bounded (10 s of wall clock by default;
+ * vr_xgmi_set_wait_bound).  A wait that runs out raises the window's error word -- in the window and in a pinned host
+ * mirror -- instead of hanging the queue, and the error is STICKY:
+ *   * the reduce kernel whose wait ran out adds nothing, writes nothing into any rank's result[] and posts no epoch, so
+ *     the peers waiting for its shard run into their own bound: every rank of the job learns, within two bounds;
+ *   * vr_xgmi_allreduce / _allgather_begin / _allgather_wait read the host mirror FIRST (one host load, no
+ *     synchronisation) and return VR_ERR_HIP once it is set: the call after the failed exchange fails, on every rank;
+ *     vr_xgmi_failed() is the same test as a predicate, vr_xgmi_check() synchronises `stream` first.
+ * What the failed exchange itself left in result[] / gather[] is the PREVIOUS iteration's content or a partial one: a
+ * caller that must not consume it calls vr_xgmi_check() before it does; a caller that can afford to lose one step
+ * (the trainer: the exception ends the run, the last checkpoint is the recovery point) relies on the next call.  A window
+ * that has failed stays failed: destroy it and build a new one, collectively. */
 int vr_xgmi_allreduce(VrXgmi* x, const VrXgmiSegment* segs, int32_t count, float scale, int64_t* result_floats_offset,
                       void* stream);
 
@@ -80,8 +91,12 @@ int vr_xgmi_allgather_begin(VrXgmi* x, const VrXgmiSegment* segs, int32_t count,
                             int64_t* slot_floats_offset, void* stream);
 int vr_xgmi_allgather_wait(VrXgmi* x, int32_t parity, void* stream);
 
-/* Synchronises `stream` and reports a timed-out wait (VR_ERR_HIP) -- for tests and shutdown. */
+/* Synchronises `stream` and reports a timed-out wait (VR_ERR_HIP): for a caller that must not consume a failed result. */
 int vr_xgmi_check(VrXgmi* x, void* stream);
+/* 1 if a wait on this window has timed out (as far as the host can see without synchronising), else 0. */
+int vr_xgmi_failed(const VrXgmi* x);
+/* Bound of every device-side wait of the calls that follow, in seconds of wall clock (default 10; tests use less). */
+int vr_xgmi_set_wait_bound(VrXgmi* x, double seconds);
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,26 @@ def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(_capi.VrCounters) == 5 * 8
 
 
+def test_flag_values_agree_between_header_binding_and_kernels():
+    """VrFlags is defined three times -- include/vegs_rast.h (the contract), vegs_amd/_capi.py (the ctypes binding) and
+    csrc/vr_device.h (what the kernels test; tied to the header by a static_assert in api.hip) -- and a renumbering in one of
+    them would silently flip e.g. the default tile-list semantics.  The header's values are parsed and compared with both."""
+    from vegs_amd import _capi
+    hdr = open(os.path.join(ROOT, "include", "vegs_rast.h")).read()
+    header = {m.group(1): 1 << int(m.group(2)) for m in re.finditer(r"\bVR_(FLAG_[A-Z_]+)\s*=\s*1u\s*<<\s*(\d+)", hdr)}
+    assert len(header) >= 12 and len(set(header.values())) == len(header)          # distinct bits
+    dev = open(os.path.join(ROOT, "vegs_amd", "csrc", "vr_device.h")).read()
+    device = {m.group(1): 1 << int(m.group(2)) for m in re.finditer(r"constexpr uint32_t (FLAG_[A-Z_]+)\s*=\s*1u\s*<<\s*(\d+)", dev)}
+    api = open(os.path.join(ROOT, "vegs_amd", "csrc", "api.hip")).read()
+    for name, value in header.items():
+        assert getattr(_capi, name) == value, name
+        assert device.get(name) == value, name
+        assert f"{name} == VR_{name}" in api, f"{name} is missing from api.hip's static_assert"
+        assert re.search(rf"KNOWN_FLAGS\s*=[^;]*\b{name}\b", api, re.S), f"{name} is missing from KNOWN_FLAGS"
+    bits = [device[k] for k in re.findall(r"constexpr uint32_t (FLAG_[A-Z_]+)", dev)]
+    assert bits == sorted(bits)                                                      # listed in bit order
+
+
 def test_invalid_arguments_are_reported_without_a_gpu():
     from vegs_amd import _capi
     lib = _capi.load()

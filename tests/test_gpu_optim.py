@@ -148,3 +148,35 @@ def test_fused_adam_many_tensors_with_an_empty_one():
         if p.numel():
             assert rel_err(q.detach().cpu().numpy(), p.detach().numpy()) < 2e-6, i
             assert float(our_opt.state[q]["step"]) == 4.0
+
+
+def test_step_many_is_all_or_nothing():
+    """A batch of optimizers is validated BEFORE any of them is touched: when a later optimizer is rejected (weight decay,
+    a CPU parameter -- there is no CPU path --, state of another shape), the earlier ones keep their step counters, get no
+    freshly initialised state and no kernel runs (advisor finding, round 4: the counters used to advance first, which skews
+    the bias correction of a retry and desynchronises the ranks of a distributed job)."""
+    from vegs_amd import optim
+    dev = torch.device("cuda:0")
+
+    def fresh(cls=optim.Adam, device=dev, **kw):
+        p = torch.nn.Parameter(torch.ones(4, 3, device=device))
+        p.grad = torch.ones(4, 3, device=device)
+        return cls([p], lr=1e-2, eps=1e-15, **kw), p
+
+    good, pg = fresh()
+    good.step()
+    assert float(good.state[pg]["step"]) == 1.0
+    before = pg.detach().clone()
+    untouched, pu = fresh()                               # no state yet: must stay that way
+    mism, pm = fresh()
+    mism.state[pm] = {"step": torch.tensor(3.0), "exp_avg": torch.zeros(2, 3, device=dev), "exp_avg_sq": torch.zeros(4, 3, device=dev)}
+    for bad, exc in ((fresh(torch.optim.Adam, weight_decay=0.1)[0], NotImplementedError), (fresh(device="cpu")[0], ValueError),
+                     (mism, ValueError)):
+        with pytest.raises(exc):
+            optim.step_many([good, untouched, bad])
+        torch.cuda.synchronize()
+        assert float(good.state[pg]["step"]) == 1.0 and len(untouched.state.get(pu, {})) == 0
+        assert torch.equal(pg.detach(), before) and torch.equal(pu.detach(), torch.ones(4, 3, device=dev))
+    assert float(mism.state[pm]["step"]) == 3.0
+    optim.step_many([good, untouched])                    # and the valid batch goes through
+    assert float(good.state[pg]["step"]) == 2.0 and float(untouched.state[pu]["step"]) == 1.0

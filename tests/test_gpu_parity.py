@@ -518,6 +518,50 @@ def test_verify_binning_flag_rebins_a_tripped_view(dev):
     assert _capi.load().vr_debug_rebinned() == before + 1 and torch.equal(img0, img2) and torch.equal(g0, g2)
 
 
+def test_a_wait_that_really_times_out_is_recovered_or_reported(dev):
+    """vr_debug_raise_guard(2): workgroup 0 of the depth sort's first pass never posts its digit counts -- a lost workgroup.
+    Its successors' bounded waits run out FOR REAL (~2 s), they scatter from a short prefix (colliding slots, stale memory in
+    the sort's ping-pong buffers) and the guard word goes up.  With VR_FLAG_VERIFY_BINNING the forward must bin the view
+    again from the compaction's own data -- NOT from the buffers the failed sort scribbled over (round-4 advisor finding:
+    the re-run used to sort them) -- and render it bit-exact; without the flag the view is left empty and ITS backward
+    fails, nothing crashes, the next view is clean."""
+    from vegs_amd import _capi, harness, rasterizer, scenes
+    sc, deg = scenes.scene_street(P=60000, length=40.0, sh_degree=1, seed=19)     # ~12 blocks of 4096 depth keys
+    cam = scenes.kitti_camera(0.0, 0.0, 344, 94)
+    bg = torch.zeros(3, device=dev)
+
+    def run(trip, flags, backward=True):
+        T = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in sc.items()}
+        with rasterizer.flags(flags):
+            if trip:
+                _capi.check(_capi.load().vr_debug_raise_guard(2))
+            pkg = harness.render(cam, T, deg, bg)
+            H, W = cam.image_height, cam.image_width
+            lists = _export_binning((pkg["render"],), H, W, dev) if backward else None
+            if backward:
+                pkg["render"].sum().backward()
+        torch.cuda.synchronize()
+        return pkg, T, lists
+    DET, VERIFY = rasterizer.FLAG_DETERMINISTIC, rasterizer.FLAG_VERIFY_BINNING
+    p0, T0, l0 = run(False, DET)
+    assert int((p0["radii"] > 0).sum()) > 3 * 4096
+    before = _capi.load().vr_debug_rebinned()
+    p1, T1, l1 = run(True, DET | VERIFY)
+    assert _capi.load().vr_debug_rebinned() == before + 1
+    assert np.array_equal(l0[0], l1[0]) and np.array_equal(l0[1], l1[1])           # point list, ranges
+    for k in ("render", "render_depth", "render_cov_quat", "render_cov_scale", "alpha"):
+        assert torch.equal(p0[k], p1[k]), k
+    for k in T0:
+        assert torch.equal(T0[k].grad, T1[k].grad), k
+    # default mode: the same lost workgroup fails the view -- at its backward, with an error, without a fault
+    p2, T2, _ = run(True, DET, backward=False)
+    with pytest.raises(Exception, match="timed out"):
+        p2["render"].sum().backward()
+    assert T2["means3D"].grad is None
+    p3, T3, l3 = run(False, DET)
+    assert torch.equal(p0["render"], p3["render"]) and torch.equal(T0["means3D"].grad, T3["means3D"].grad)
+
+
 def test_binning_guard_of_a_forward_only_view_is_reported_by_the_next_forward(dev):
     """A view rendered under no_grad never gets a backward: its raised guard is reported by the next forward of the
     thread (which fails and clears the word), as before."""

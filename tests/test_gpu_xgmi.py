@@ -87,3 +87,69 @@ def test_direct_exchange_equals_fixed_order_sum(world):
                 q.kill()
             raise
     assert all(p.returncode == 0 for p in procs) and all("RANK_OK" in o for o in outs), "\n".join(o[-2500:] for o in outs)
+
+
+# ---- FAILURE CONTRACT (include/vegs_xgmi.h, ABI v9): a peer that does not show up.  Rank 1 sits one all-reduce out while
+# rank 0 issues it with a 0.5 s wait bound.  Rank 0's reduce gives up: it must write NOTHING (its result[] still holds the
+# previous exchange's mean), the failure must become visible on the host WITHOUT a synchronisation (the pinned mirror) and
+# the next exchange call must raise; rank 1, arriving late, finds rank 0's shard missing and fails the same way -- every
+# rank learns.  (Round-4 advisor finding: the error word was only read by vr_xgmi_check, which nothing called.)
+FAIL_WORKER = r"""
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, %(root)r)
+from vegs_amd import dist as vdist, xgmi
+rank, world, local = vdist.init_from_env()
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+ex = xgmi.DirectExchange(rank, world, dev)
+ex.set_wait_bound(0.5)
+n = 70001
+g = torch.full((n,), float(rank + 1), device=dev)
+(r1,) = ex.allreduce_mean([g], 1.0)
+ex.check()
+assert bool((r1 == 3.0).all()) and not ex.failed()
+torch.distributed.barrier()
+if rank == 1:
+    time.sleep(3.0)                      # ... while rank 0 waits for a push that does not come
+t0 = time.time()
+(r2,) = ex.allreduce_mean([g * 10.0], 1.0)
+while not ex.failed() and time.time() - t0 < 20.0:
+    time.sleep(0.01)                     # host-visible without any synchronisation
+assert ex.failed(), "the timed-out wait never reached the host mirror"
+waited = time.time() - t0
+assert waited < 10.0, waited
+torch.cuda.synchronize()
+if rank == 0:
+    # (rank 0's own shard of the result: the first half; the other half belongs to rank 1's reduce, which arrives later)
+    assert bool((r2[:35000] == 3.0).all()), "a reduce whose wait ran out must not write into result[]"
+for call in (lambda: ex.allreduce_mean([g], 1.0), lambda: ex.begin_gather([g[:12]]), ex.check):
+    try:
+        call()
+        raise SystemExit("a call on a failed window went through")
+    except RuntimeError as e:
+        assert "wait bound" in str(e), str(e)
+torch.distributed.barrier()
+ex._drop()
+torch.distributed.destroy_process_group()
+print("RANK_OK", rank, round(waited, 2))
+"""
+
+
+def test_a_missing_peer_fails_every_rank_and_no_result_is_written():
+    script = FAIL_WORKER % dict(root=ROOT)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), VEGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs) and all("RANK_OK" in o for o in outs), "\n".join(o[-2500:] for o in outs)

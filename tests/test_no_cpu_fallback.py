@@ -50,3 +50,15 @@ def test_instances_knn_and_rasterizer_refuse_cpu_tensors():
     with pytest.raises(ValueError):
         GaussianRasterizer(raster_settings=st)(means3D=t["means3D"], means2D=torch.zeros(4, 3), shs=t["shs"],
                                                opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+
+
+def test_trainer_rejects_a_factored_exchange_without_the_fused_operator():
+    """exchange='factored' / 'direct' move the 3-float SH factor, an output of the FUSED operator: with fused=False the
+    trainer used to arm an exchange that never got a factor (advisor finding, round 4)."""
+    import pytest
+    from vegs_amd import iteration
+    for ex in ("factored", "direct"):
+        with pytest.raises(ValueError, match="fused=True"):
+            iteration.Trainer({}, "cpu", fused=False, world=2, rank=0, exchange=ex)
+    with pytest.raises(ValueError, match="exchange must be"):
+        iteration.Trainer({}, "cpu", exchange="ring")

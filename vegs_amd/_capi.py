@@ -34,7 +34,7 @@ EXPORTS = ["vr_abi_version", "vr_last_error", "vr_forward", "vr_backward", "vr_b
            "vr_instances_forward", "vr_instances_backward", "vr_activations_forward", "vr_activations_backward",
            "vr_boxmodel_forward", "vr_boxmodel_backward", "vr_boxmodel_regularizer_grad",
            "vr_xgmi_create", "vr_xgmi_detach", "vr_xgmi_destroy", "vr_xgmi_layout", "vr_xgmi_window", "vr_xgmi_handle", "vr_xgmi_attach",
-           "vr_xgmi_allreduce", "vr_xgmi_allgather_begin", "vr_xgmi_allgather_wait", "vr_xgmi_check"]
+           "vr_xgmi_allreduce", "vr_xgmi_allgather_begin", "vr_xgmi_allgather_wait", "vr_xgmi_check", "vr_xgmi_failed", "vr_xgmi_set_wait_bound"]
 STAGES = ["preprocess", "compact", "depth_sort", "emit", "tile_sort", "ranges", "render_fwd", "bwd_zero",
           "render_bwd", "preprocess_bwd", "k_seg_bwd"]
 
@@ -251,6 +251,10 @@ def load():
     lib.vr_xgmi_allgather_wait.argtypes = [vp, i32, vp]
     lib.vr_xgmi_check.restype = C.c_int
     lib.vr_xgmi_check.argtypes = [vp, vp]
+    lib.vr_xgmi_failed.restype = C.c_int
+    lib.vr_xgmi_failed.argtypes = [vp]
+    lib.vr_xgmi_set_wait_bound.restype = C.c_int
+    lib.vr_xgmi_set_wait_bound.argtypes = [vp, C.c_double]
     lib.vr_profile_level.restype = C.c_int
     lib.vr_profile_level.argtypes = [C.c_int]
     lib.vr_profile_collect.restype = C.c_int

@@ -19,7 +19,9 @@ static_assert(FLAG_SCALE_MODIFIED == VR_FLAG_SCALE_MODIFIED && FLAG_DEPTH_NORMAL
               FLAG_EXTRA_NO_ALPHA_GRAD == VR_FLAG_EXTRA_NO_ALPHA_GRAD && FLAG_FILL_EMPTY == VR_FLAG_FILL_EMPTY &&
               FLAG_DETERMINISTIC == VR_FLAG_DETERMINISTIC && FLAG_SCAN_BINNING == VR_FLAG_SCAN_BINNING &&
               FLAG_ROUNDS_OFF == VR_FLAG_ROUNDS_OFF && FLAG_ROUNDS_ON == VR_FLAG_ROUNDS_ON &&
-              FLAG_RAW_PARAMS == VR_FLAG_RAW_PARAMS, "device-side flag constants must match include/vegs_rast.h");
+              FLAG_RAW_PARAMS == VR_FLAG_RAW_PARAMS && FLAG_FAST_EXP == VR_FLAG_FAST_EXP &&
+              FLAG_VERIFY_BINNING == VR_FLAG_VERIFY_BINNING && FLAG_FULL_TILE_LISTS == VR_FLAG_FULL_TILE_LISTS,
+              "device-side flag constants must match include/vegs_rast.h");
 constexpr uint32_t KNOWN_FLAGS = FLAG_SCALE_MODIFIED | FLAG_DEPTH_NORMALIZED | FLAG_EXTRA_NO_ALPHA_GRAD | FLAG_FILL_EMPTY |
                                  FLAG_DETERMINISTIC | FLAG_SCAN_BINNING | FLAG_ROUNDS_OFF | FLAG_ROUNDS_ON | FLAG_RAW_PARAMS | FLAG_FAST_EXP | FLAG_VERIFY_BINNING | FLAG_FULL_TILE_LISTS;
 
@@ -37,16 +39,28 @@ constexpr int MAX_DEVICES = 64;
 // saved buffers -- GBs at the headline size -- so 1024 outstanding forwards is beyond any batch; 8 KB of pinned memory).
 // Beyond that the slot has been reused: check_ticket then says so instead of guessing.
 constexpr int RING_AT = 64, RING_SLOTS = 1024, MAIL_BYTES = (RING_AT + 2 * RING_SLOTS) * 4;
-struct Mailbox { uint32_t* pinned; uint32_t* pinned_dev; uint32_t seq; uint32_t* guard; uint32_t id; };
+// DEVICE guard words: one per forward IN FLIGHT (ABI v9; until v8 one per thread and device, so that two views in flight on
+// two streams failed each other).  Forward `seq` owns word seq % GUARD_SLOTS: its totals kernel clears it, its binning
+// kernels raise it, its last binning kernel copies it into the forward's ring slot.  64 forwards of one thread cannot be
+// in their binning at once (each blocks its host thread once, behind its own compaction).
+constexpr int GUARD_SLOTS = 64;
+// ring slot word 1: 0 = clean, GUARD_RAISED = a wait of that forward's binning ran out, GUARD_REPORTED = ... and a later
+// forward of the thread has already reported it (the view's own backward still fails)
+constexpr uint32_t GUARD_RAISED = 1u, GUARD_REPORTED = 2u;
+struct Mailbox {
+    uint32_t* pinned; uint32_t* pinned_dev; uint32_t seq; uint32_t* guard; uint32_t id;
+    uint32_t unchecked;      // oldest forward whose ring slot no later forward has looked at yet (report_earlier)
+};
 static thread_local Mailbox g_mail[MAX_DEVICES] = {};
 struct MailRef { uint32_t* pinned; uint32_t* guard; int dev; };
 static std::mutex g_mail_mu;
 static std::vector<MailRef> g_mail_reg;
-static thread_local bool g_raise_guard = false;   // test hook: vr_debug_raise_guard
+static thread_local int g_raise_guard = 0;        // test hook: vr_debug_raise_guard (1 = raise the word, 2 = lose a workgroup)
 static thread_local int g_rebinned = 0;           // views re-binned under VR_FLAG_VERIFY_BINNING (vr_debug_rebinned)
 
 // the calling thread's mailbox for the current device, created on first use
 static int get_mailbox(int dev_id, hipStream_t s, Mailbox** out);
+static int fail(int code, const char* fmt, ...);
 
 void set_error(const char* fmt, ...)
 {
@@ -64,9 +78,9 @@ static int get_mailbox(int dev_id, hipStream_t s, Mailbox** out)
         memset(mail.pinned, 0, MAIL_BYTES);
         VR_HIP(hipHostGetDevicePointer((void**)&mail.pinned_dev, mail.pinned, 0));
     }
-    if (!mail.guard) {   // device word raised by a binning kernel whose bounded wait ran out (binning.hip)
-        VR_HIP(hipMalloc((void**)&mail.guard, 256));
-        VR_HIP(hipMemsetAsync(mail.guard, 0, 256, s));
+    if (!mail.guard) {   // device words raised by a binning kernel whose bounded wait ran out (binning.hip): GUARD_SLOTS of them
+        VR_HIP(hipMalloc((void**)&mail.guard, GUARD_SLOTS * sizeof(uint32_t)));
+        VR_HIP(hipMemsetAsync(mail.guard, 0, GUARD_SLOTS * sizeof(uint32_t), s));
         std::lock_guard<std::mutex> lk(g_mail_mu);
         g_mail_reg.push_back({mail.pinned, mail.guard, dev_id});
         mail.id = (uint32_t)g_mail_reg.size();   // 1-based
@@ -77,10 +91,16 @@ static int get_mailbox(int dev_id, hipStream_t s, Mailbox** out)
 
 // The guard word of the forward behind `ticket` (see Mailbox).  Returns VR_OK when that forward's binning finished
 // without a timed-out wait (or nothing can be said: no ticket, slot long overwritten), VR_ERR_HIP when one timed out --
-// the view's lists, images and everything derived from them are invalid.  Waits (normally not at all: the caller comes
-// after the forward's launches and the loss) until the slot is posted.
-static int check_ticket(uint64_t ticket, hipStream_t s)
+// the view's lists, images and everything derived from them are invalid.
+//   wait = true  (the calls that read the lists back and synchronise anyway): waits until the slot is posted -- normally
+//                not at all, the caller comes after the forward's launches --, with a stream synchronisation after 20 ms;
+//   wait = false (vr_backward, ABI v9): NEVER blocks the host.  A slot that is not posted yet says nothing: *pending is set
+//                and the caller asks again once it has queued its work (a tripped view's tile ranges are all empty, so the
+//                backward's kernels are harmless on it); if the answer is still missing then, the thread's next forward
+//                reports the view (report_earlier).
+static int check_ticket(uint64_t ticket, hipStream_t s, bool wait = true, bool* pending = nullptr)
 {
+    if (pending) *pending = false;
     if (ticket == 0) return VR_OK;
     const uint32_t id = (uint32_t)(ticket >> 32), seq = (uint32_t)ticket;
     MailRef ref;
@@ -101,6 +121,7 @@ static int check_ticket(uint64_t ticket, hipStream_t s)
                       "forward's binning guard is gone (run the backward closer to its forward)", RING_SLOTS);
             return VR_ERR_INVALID_ARGUMENT;
         }
+        if (!wait) { if (pending) *pending = true; return VR_OK; }
         __builtin_ia32_pause();
         if ((spins & 4095u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
             VR_HIP(hipStreamSynchronize(s));   // the forward ran on this stream (same-stream contract of the op)
@@ -108,10 +129,32 @@ static int check_ticket(uint64_t ticket, hipStream_t s)
         }
     }
     if (__atomic_load_n(&slot[1], __ATOMIC_RELAXED) == 0u) return VR_OK;
-    (void)hipMemsetAsync(ref.guard, 0, 4, s);   // reported: clear for the calls to come
+    __atomic_store_n(&slot[1], GUARD_REPORTED, __ATOMIC_RELAXED);   // (the device word is the forward's own: nothing to clear)
     set_error("a look-back wait in this view's binning timed out: its lists, images and gradients are invalid "
               "(re-render the view; VR_FLAG_SCAN_BINNING avoids inter-workgroup waits)");
     return VR_ERR_HIP;
+}
+
+// Forwards that never get a backward (evaluation under no_grad) cannot fail "their own" later call: every vr_forward first
+// looks at the ring slots of the thread's earlier forwards that nobody has looked at yet and reports the first one whose
+// binning tripped (once).  Host memory only; a slot that is not posted yet is left for the next call.
+static int report_earlier(Mailbox& mail)
+{
+    while ((int32_t)(mail.seq - mail.unchecked) >= 0 && mail.unchecked != 0u) {
+        const uint32_t q = mail.unchecked;
+        uint32_t* slot = mail.pinned + RING_AT + 2 * (q % RING_SLOTS);
+        const uint32_t got = __atomic_load_n(&slot[0], __ATOMIC_ACQUIRE);
+        if (got != q) {
+            // not posted (yet): still running, or a forward that returned an error before its binning.  Old ones are given up.
+            if ((int32_t)(got - q) > 0 || mail.seq - q >= 32u) { mail.unchecked = q + 1u ? q + 1u : 1u; continue; }
+            break;
+        }
+        mail.unchecked = q + 1u ? q + 1u : 1u;
+        uint32_t want = GUARD_RAISED;
+        if (__atomic_compare_exchange_n(&slot[1], &want, GUARD_REPORTED, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED))
+            return fail(VR_ERR_HIP, "a look-back wait in an earlier binning pass timed out; that view's output is invalid");
+    }
+    return VR_OK;
 }
 
 // Waits until the totals kernel has published this call's sequence number in the mailbox.  Polls host memory (the
@@ -334,6 +377,9 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     if (rc) return rc;
     Mailbox& mail = *mailp;
     uint32_t* const g_pinned = mail.pinned;
+    rc = report_earlier(mail);        // an EARLIER forward of this thread whose binning tripped and that nobody has reported
+    if (rc) return rc;
+    uint32_t* guard_word = mail.guard;       // this forward's device guard word (set with its sequence number below)
 
     // ---- buffers that survive until backward
     const size_t p1 = (size_t)(P > 0 ? P : 1);
@@ -385,7 +431,9 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
         // writes them into the pinned mailbox itself; the host polls for this call's sequence number after it has
         // queued the compaction's apply kernel, so the round trip overlaps with that kernel instead of idling the GPU.
         const uint32_t seq = ++mail.seq ? mail.seq : ++mail.seq;   // never 0 (the mailbox's initial content)
-        rc = launch_compact_reduce(P, tile_count, depth_key, scan_scr, totals_dev, mail.guard, mail.pinned_dev, seq, s, debug);
+        if (mail.unchecked == 0u) mail.unchecked = seq;
+        guard_word = mail.guard + (seq % GUARD_SLOTS);             // cleared by the totals kernel, ahead of the binning
+        rc = launch_compact_reduce(P, tile_count, depth_key, scan_scr, totals_dev, guard_word, mail.pinned_dev, seq, s, debug);
         if (rc) return rc;
         // the apply kernel also clears the tile ranges (when the binning buffer already exists): no fill launch
         // and the status words of the binning passes (when their scratch exists)
@@ -399,10 +447,6 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
         if (rc) return rc;
         rc = wait_mailbox(g_pinned, seq, totals_dev, s);
         if (rc) return rc;
-        if (g_pinned[4]) {   // raised by an EARLIER forward on this thread and device whose backward never ran (the
-            VR_HIP(hipMemsetAsync(mail.guard, 0, 4, s));   // backward reports it first, see check_ticket): eval / no_grad views
-            return fail(VR_ERR_HIP, "a look-back wait in an earlier binning pass timed out; that view's output is invalid");
-        }
         V = g_pinned[0];
         R = g_pinned[1];
         n_huge = g_pinned[5];
@@ -424,12 +468,17 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     int2* ranges = (int2*)((char*)binning + BL.ranges);
     uint32_t* point_list = (uint32_t*)((char*)binning + BL.point_list);
     const bool lists = V > 0 && R > 0;
-    const bool raise = g_raise_guard;
-    g_raise_guard = false;
+    const int raise = g_raise_guard;
+    g_raise_guard = 0;
     rc = launch_binning(cam, P, (int)V, (long)R, key_min, key_bits, vis_key, vis_id, rect, scan_scr, scr2, point_list,
-                        ranges, ranges_zeroed, status_zeroed, mail.guard,
+                        ranges, ranges_zeroed, status_zeroed, guard_word,
                         mail.pinned_dev + RING_AT + 2 * (mail.seq % RING_SLOTS), mail.seq, raise, n_huge, s, debug);
     if (rc) return rc;
+    if (!lists && P > 0) {   // no binning kernel will post this forward's slot: the host does (nothing can have tripped)
+        uint32_t* slot = g_pinned + RING_AT + 2 * (mail.seq % RING_SLOTS);
+        __atomic_store_n(&slot[1], 0u, __ATOMIC_RELAXED);
+        __atomic_store_n(&slot[0], mail.seq, __ATOMIC_RELEASE);
+    }
     if ((st->flags & FLAG_VERIFY_BINNING) && lists && !(cam.flags & FLAG_SCAN_BINNING)) {
         // VR_FLAG_VERIFY_BINNING: the host waits for this view's guard word (posted by the last binning kernel) BEFORE it
         // queues the render stage; a view whose look-back wait gave up is binned once more with the wait-free multi-launch
@@ -448,12 +497,19 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
             // the slot is posted a second time by the re-run's last kernel: until then it reads "not posted yet"
             __atomic_store_n(&slot[1], 0u, __ATOMIC_RELAXED);
             __atomic_store_n(&slot[0], 0u, __ATOMIC_RELEASE);
-            VR_HIP(hipMemsetAsync(mail.guard, 0, 4, s));
+            VR_HIP(hipMemsetAsync(guard_word, 0, 4, s));
+            // The first attempt's depth sort ping-pongs between (vis_key, vis_id) and its scratch pair, and after a wait that
+            // really ran out its passes scattered from a short prefix: slots collide, others keep stale memory -- the pairs
+            // the second attempt would sort are NOT the compaction's any more.  They are written again from what the first
+            // attempt only read: the depth keys, the compaction's block sums and the totals (round-4 advisor finding).
+            rc = launch_compact_apply(P, rect, depth_key, scan_scr, totals_dev, binning_tile_bits((int)T), vis_key, vis_id,
+                                      nullptr, 0L, nullptr, 0, s, debug);
+            if (rc) return rc;
             Camera again = cam;
             again.flags |= FLAG_SCAN_BINNING;
             rc = launch_binning(again, P, (int)V, (long)R, key_min, key_bits, vis_key, vis_id, rect, scan_scr, scr2, point_list,
-                                ranges, false, false, mail.guard, mail.pinned_dev + RING_AT + 2 * (mail.seq % RING_SLOTS),
-                                mail.seq, false, n_huge, s, debug);
+                                ranges, false, false, guard_word, mail.pinned_dev + RING_AT + 2 * (mail.seq % RING_SLOTS),
+                                mail.seq, 0, n_huge, s, debug);
             if (rc) return rc;
             ++g_rebinned;
         }
@@ -519,8 +575,10 @@ static int backward_first(const Camera& cam, const VrSettings* st, const VrInput
 {
     const bool debug = st->debug != 0;
     const int P = in->P;
-    // a timed-out wait in THIS view's binning fails its own backward, before any gradient is produced
-    int rc = check_ticket(saved->ticket, s);
+    // a timed-out wait in THIS view's binning fails its own backward.  Asked without blocking the host (ABI v9): when the
+    // forward's last binning kernel has not run yet the answer comes after this call's kernels are queued (below).
+    bool guard_pending = false;
+    int rc = check_ticket(saved->ticket, s, false, &guard_pending);
     if (rc) return rc;
     const size_t N = (size_t)cam.H * cam.W, T = (size_t)cam.gx * cam.gy;
     const ImageLayout IL = image_layout(N);
@@ -570,9 +628,13 @@ static int backward_first(const Camera& cam, const VrSettings* st, const VrInput
                                (const float*)((const char*)saved->image + IL.dsum), det_scr, P, zero_in_kernel, s, debug);
         if (rc) return rc;
     }
-    if (sh_factored && factor_now)
-        return launch_sh_factor(P, radii, (const uint8_t*)saved->geom + align_up((size_t)P * sizeof(Splat), 256), gacc,
-                                gin->dL_dcolors_sh, s, debug);
+    if (sh_factored && factor_now) {
+        rc = launch_sh_factor(P, radii, (const uint8_t*)saved->geom + align_up((size_t)P * sizeof(Splat), 256), gacc,
+                              gin->dL_dcolors_sh, s, debug);
+        if (rc) return rc;
+    }
+    // the second look at the guard (see above).  A tripped view's ranges are empty: what was queued computed zeros.
+    if (guard_pending) return check_ticket(saved->ticket, s, false, nullptr);
     return VR_OK;
 }
 
@@ -853,14 +915,20 @@ int vr_debug_set_guard(uint32_t value, void* stream)
     Mailbox* mail = nullptr;
     int rc = get_mailbox(dev_id, (hipStream_t)stream, &mail);
     if (rc) return rc;
-    VR_HIP(hipMemsetD32Async((hipDeviceptr_t)mail->guard, (int)value, 1, (hipStream_t)stream));
+    if (mail->seq == 0u) return fail(VR_ERR_INVALID_ARGUMENT, "vr_debug_set_guard: no forward has run on this thread and device");
+    // as if the thread's most recent forward had (value != 0) or had not (0) tripped: its ring slot, once its own post is in
+    VR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    uint32_t* slot = mail->pinned + RING_AT + 2 * (mail->seq % RING_SLOTS);
+    __atomic_store_n(&slot[1], value ? GUARD_RAISED : 0u, __ATOMIC_RELAXED);
+    __atomic_store_n(&slot[0], mail->seq, __ATOMIC_RELEASE);
+    if (mail->unchecked == 0u || (int32_t)(mail->unchecked - mail->seq) > 0) mail->unchecked = mail->seq;
     return VR_OK;
 }
 
 int vr_debug_raise_guard(int on)
 {
     g_err[0] = 0;
-    g_raise_guard = on != 0;
+    g_raise_guard = on == 2 ? 2 : (on != 0 ? 1 : 0);
     return VR_OK;
 }
 

@@ -206,7 +206,7 @@ k_scan_apply(Src src, Sink sink, long n, const uint32_t* __restrict__ bsum)
 // kernel is still running.  totals = {sum, secondary sum, min key, max key}.
 __global__ void __launch_bounds__(256)
 k_scan_totals(const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ bsum2, int nb, uint32_t* __restrict__ totals,
-              const uint32_t* __restrict__ err_in, uint32_t* __restrict__ host_mail, uint32_t seq)
+              uint32_t* __restrict__ err_clear, uint32_t* __restrict__ host_mail, uint32_t seq)
 {
     __shared__ uint32_t lds4[4];
     __shared__ uint32_t mm[8];
@@ -233,8 +233,10 @@ k_scan_totals(const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ bs
         totals[1] = t1;
         totals[2] = min(min(mm[0], mm[1]), min(mm[2], mm[3]));
         totals[3] = max(max(mm[4], mm[5]), max(mm[6], mm[7]));
-        // the guard word of earlier calls rides along (see launch_binning)
-        totals[4] = err_in ? __hip_atomic_load(err_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        // this forward's guard word (api.hip: one per forward in flight) starts clean: the binning kernels that may raise it
+        // are behind this kernel on the stream
+        if (err_clear) __hip_atomic_store(err_clear, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        totals[4] = 0u;
         totals[5] = t2;      // Gaussians whose rectangle has more than 64 tiles (who emits them: emit_big_inline)
         // The host's copy: written straight into its pinned, coherent mailbox, sequence number last (release at system
         // scope); the host polls that word.  No copy command and no event on the stream: the apply kernel follows
@@ -275,7 +277,7 @@ size_t binning_stage1_scratch_bytes(int P)
 // Two halves: the totals {V, R, min key, max key} reach the host (host_mail, see k_scan_totals) while the apply kernel
 // runs, so the round trip overlaps with that kernel instead of idling the GPU.
 int launch_compact_reduce(int P, const uint32_t* tile_count, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,
-                          const uint32_t* err_in, uint32_t* host_mail, uint32_t seq, hipStream_t s, bool debug)
+                          uint32_t* err_clear, uint32_t* host_mail, uint32_t seq, hipStream_t s, bool debug)
 {
     int nb = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
     uint32_t* bsum = (uint32_t*)scratch;
@@ -284,7 +286,7 @@ int launch_compact_reduce(int P, const uint32_t* tile_count, const uint32_t* dep
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_reduce<SrcFlagTiles>), dim3(nb), dim3(256), 0, s, src, (long)P, bsum, bsum2);
     VR_KERNEL_CHECK("compact_reduce", s, debug);
     hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(256), 0, s, (const uint32_t*)bsum, (const uint32_t*)bsum2, nb, totals_dev,
-                       err_in, host_mail, seq);
+                       err_clear, host_mail, seq);
     VR_KERNEL_CHECK("compact_totals", s, debug);
     return 0;
 }
@@ -714,7 +716,7 @@ template <int BITS>
 __global__ void __launch_bounds__(256)
 k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
            uint32_t* __restrict__ vals_out, long n, uint32_t kmin, int pass,
-           const uint32_t* __restrict__ totals, uint32_t* __restrict__ status, uint32_t* __restrict__ err)
+           const uint32_t* __restrict__ totals, uint32_t* __restrict__ status, uint32_t* __restrict__ err, int lose_block0)
 {
     constexpr int SIZE = 1 << BITS;
     constexpr int BPT = (SIZE + 255) / 256;   // digits per thread in the per-digit phases
@@ -765,7 +767,9 @@ k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
         if (d < SIZE) {
             const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
             mine[k] = c0 + c1 + c2 + c3;
-            st_store(&status[b * SIZE + d], mine[k] | ST_POSTED);
+            // (lose_block0: test hook -- workgroup 0 never posts, as a lost workgroup would not: its successors' waits run
+            // out FOR REAL, vr_debug_raise_guard(2))
+            if (!(lose_block0 && b == 0)) st_store(&status[b * SIZE + d], mine[k] | ST_POSTED);
             off[0][d] = 0;
             off[1][d] = c0;
             off[2][d] = c0 + c1;
@@ -852,7 +856,7 @@ k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
 // onesweep_status_words(n, nbits) words, all zero.
 static int onesweep_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long n, uint32_t kmin, int nbits,
                          const uint32_t* partial, int rows, uint32_t* status, uint32_t* err, hipStream_t s, bool debug,
-                         int* res)
+                         int* res, bool lose_block0 = false)
 {
     const int digit = radix_digit(nbits);
     const int passes = radix_passes(nbits);
@@ -870,7 +874,8 @@ static int onesweep_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
         uint32_t* st = status + (size_t)pass * per_pass;
 #define VR_SWEEP(B)                                                                                           \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_onesweep<B>), dim3(nblk), dim3(256), 0, s, (const uint32_t*)ka,      \
-                       (const uint32_t*)va, kb, vb, n, kmin, pass, (const uint32_t*)totals, st, err)
+                       (const uint32_t*)va, kb, vb, n, kmin, pass, (const uint32_t*)totals, st, err,        \
+                       (lose_block0 && pass == 0) ? 1 : 0)
         if (digit == 6) VR_SWEEP(6);
         else if (digit == 9) VR_SWEEP(9);
         else VR_SWEEP(8);
@@ -1365,8 +1370,10 @@ static int binning_multi_launch(const Camera& cam, int V, long R, uint32_t key_m
 int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
                    uint32_t* vis_id, const uint4* rect, const void* stage1_scratch, void* scratch, uint32_t* point_list,
                    int2* ranges, bool ranges_zeroed, bool status_zeroed, uint32_t* err, uint32_t* guard_post,
-                   uint32_t guard_seq, bool debug_raise_guard, uint32_t n_huge, hipStream_t s, bool debug)
+                   uint32_t guard_seq, int debug_raise_guard, uint32_t n_huge, hipStream_t s, bool debug)
 {
+    // debug_raise_guard (tests): 1 = raise the guard word by hand after a VALID binning; 2 = lose workgroup 0 of the depth
+    // sort's first pass, so that real waits run out and the lists that follow are built from a short prefix
     int ntiles = cam.gx * cam.gy;
     if (!ranges_zeroed) VR_HIP(hipMemsetAsync(ranges, 0, sizeof(int2) * (size_t)ntiles, s));
     if (V == 0 || R == 0) return 0;
@@ -1400,7 +1407,7 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
             ProfScope ps(VR_STAGE_DEPTH_SORT, s);
             int where = 0;
             int rc = onesweep_sort(vis_key, vis_id, tmp_key, tmp_id, V, key_min, key_bits, dpartial, rows, (uint32_t*)st,
-                                   err, s, debug, &where);
+                                   err, s, debug, &where, debug_raise_guard == 2);
             if (rc) return rc;
             sorted_id = where ? tmp_id : vis_id;
         }
@@ -1433,7 +1440,7 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
     }
     // 5. ranges
     prof_begin(VR_STAGE_RANGES, s);
-    if (debug_raise_guard) VR_HIP(hipMemsetD32Async((hipDeviceptr_t)err, 1, 1, s));   // test hook: "a wait of THIS view timed out"
+    if (debug_raise_guard == 1) VR_HIP(hipMemsetD32Async((hipDeviceptr_t)err, 1, 1, s));   // test hook: "a wait of THIS view timed out"
     hipLaunchKernelGGL(k_tile_ranges, dim3(cdiv(R, 256)), dim3(256), 0, s, (const uint32_t*)tile_keys, R, ranges,
                        (const uint32_t*)err, guard_post, guard_seq);
     VR_KERNEL_CHECK("tile_ranges", s, debug);

@@ -40,9 +40,9 @@ constexpr uint32_t FLAG_SCAN_BINNING = 1u << 9;         // binning with the scan
 constexpr uint32_t FLAG_ROUNDS_OFF = 1u << 10;          // forward: all list segments at once
 constexpr uint32_t FLAG_ROUNDS_ON = 1u << 11;           // forward: segment rounds whatever the list density
 constexpr uint32_t FLAG_RAW_PARAMS = 1u << 12;          // opacities / scales / rotations are raw parameters (activated here)
-constexpr uint32_t FLAG_FULL_TILE_LISTS = 1u << 15;     // tile lists hold the reference's full rectangles (no tile test)
-constexpr uint32_t FLAG_VERIFY_BINNING = 1u << 14;      // forward: wait for the binning's guard word; a tripped view is re-binned without waits
 constexpr uint32_t FLAG_FAST_EXP = 1u << 13;            // the compositing's 2^x by the hardware's v_exp_f32 (forward AND backward)
+constexpr uint32_t FLAG_VERIFY_BINNING = 1u << 14;      // forward: wait for the binning's guard word; a tripped view is re-binned without waits
+constexpr uint32_t FLAG_FULL_TILE_LISTS = 1u << 15;     // tile lists hold the reference's full rectangles (no tile test)
 
 // The model's activations (scene/gaussian_model.py:37-45), shared by vr_activations_* and the VR_FLAG_RAW_PARAMS path
 constexpr float NORMALIZE_EPS = 1e-12f;   // F.normalize's default eps

@@ -56,7 +56,7 @@ int launch_mark_visible(const float* xyz, int P, const float* view, uint8_t* pre
 size_t binning_stage1_scratch_bytes(int P);
 // host_mail: device address of the caller's pinned, coherent mailbox; receives the five words, then host_mail[8] = seq.
 int launch_compact_reduce(int P, const uint32_t* tile_count, const uint32_t* depth_key, void* scratch, uint32_t* totals_dev,
-                          const uint32_t* err_in, uint32_t* host_mail, uint32_t seq, hipStream_t s, bool debug);
+                          uint32_t* err_clear, uint32_t* host_mail, uint32_t seq, hipStream_t s, bool debug);
 // Second half of the compaction.  Side duties: the partial digit histograms of the depth keys (into `scratch`, for
 // the depth sort), clearing zero_a (the tile ranges) and, when `status` = binning_stage2_status(stage-2 scratch) is
 // given, the posted-sum status region of this view (else launch_binning clears it with a fill).
@@ -77,7 +77,7 @@ int binning_tile_bits(int ntiles);
 int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
                    uint32_t* vis_id, const uint4* rect, const void* stage1_scratch, void* scratch, uint32_t* point_list,
                    int2* ranges, bool ranges_zeroed, bool status_zeroed, uint32_t* err, uint32_t* guard_post,
-                   uint32_t guard_seq, bool debug_raise_guard, uint32_t n_huge, hipStream_t s, bool debug);
+                   uint32_t guard_seq, int debug_raise_guard, uint32_t n_huge, hipStream_t s, bool debug);
 
 // stable LSD radix sort of (key,val) u32 pairs on the low nbits of (key - kmin); ping-pongs between the two
 // pairs, *where = 0/1 tells which pair holds the result

@@ -11,8 +11,12 @@
 //
 // Synchronisation is three arrays of epoch words per window (written by the peer with a system-scope release store after a
 // system-scope fence behind its data stores; polled with system-scope acquire loads).  A kernel's LAST workgroup (device
-// counter) posts the epoch to all peers.  Every wait is wall-clock bounded and raises the window's error word instead of
-// hanging the queue.  Buffers are reused every iteration without further handshakes:
+// counter) posts the epoch to all peers.  Every wait is wall-clock bounded (10 s by default, vr_xgmi_set_wait_bound) and
+// raises the window's error word instead of hanging the queue -- the word in the window AND its mirror in pinned host
+// memory, which every vr_xgmi_* call reads first (no synchronisation): the call after a timed-out exchange fails.  The
+// error is sticky: a reduce whose wait ran out writes NOTHING into the peers' result buffers and posts nothing (the peers'
+// own waits then run out as well -- every rank learns), and so does every later one on this window.
+// Buffers are reused every iteration without further handshakes:
 //   recv[]    is written by a peer's push k+1 only after that peer has seen my flag_b(k), which I post after my reduce(k)
 //             has read recv[] completely;
 //   result[]  is written by a peer's reduce k+1 only after my flag_a(k+1), which my push k+1 posts -- stream-ordered behind
@@ -32,7 +36,8 @@ constexpr int XG_MAXR = VR_XGMI_MAX_RANKS;
 constexpr int XG_MAXS = VR_XGMI_MAX_SEGMENTS;
 constexpr int XG_FLAG_STRIDE = 8;                       // uint64 words per flag: one 64-byte line each
 constexpr size_t XG_FLAG_BYTES = 16384;                 // flags + counters + error word, at the start of the window
-constexpr unsigned long long XG_WAIT_TICKS = 1000000000ull;   // 10 s at 100 MHz (ranks may be far apart at start-up)
+constexpr unsigned long long XG_TICKS_PER_S = 100000000ull;    // s_memrealtime: 100 MHz
+constexpr double XG_WAIT_SECONDS = 10.0;                       // default bound of a wait (ranks may be far apart at start-up)
 // word indices (uint64) inside the flag region
 constexpr int XG_FLAG_A = 0;                            // [N] all-reduce: peer j's push has landed
 constexpr int XG_FLAG_B = XG_MAXR * XG_FLAG_STRIDE;     // [N] all-reduce: peer j's reduced shard has landed
@@ -49,6 +54,8 @@ struct XgArgs {
     long recv_offset, result_offset, slot_stride;      // floats; slot_stride = sum of the segments' shard lengths
     unsigned long long epoch;
     float scale;
+    unsigned long long wait_ticks;                     // bound of every wait of this launch
+    unsigned long long* err_host;                      // mirror of the window's error word in pinned host memory
 };
 
 __device__ __forceinline__ unsigned long long* flags_of(float* window) { return reinterpret_cast<unsigned long long*>(window); }
@@ -58,9 +65,10 @@ __device__ __forceinline__ void post(unsigned long long* word, unsigned long lon
     __hip_atomic_store(word, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// thread j < world of the calling workgroup waits for word[j * stride] >= epoch; raises *err after the bound
-__device__ __forceinline__ void wait_all(const unsigned long long* words, int world, unsigned long long epoch,
-                                         unsigned long long* err)
+// thread j < world of the calling workgroup waits for word[j * stride] >= epoch; raises *err (and its host mirror) after
+// the bound.  Returns (to every thread of the workgroup) whether the window's error word is set -- by this wait or earlier.
+__device__ __forceinline__ bool wait_all(const unsigned long long* words, int world, unsigned long long epoch,
+                                         unsigned long long* err, unsigned long long* err_host, unsigned long long ticks)
 {
     if ((int)threadIdx.x < world) {
         const unsigned long long* w = words + (size_t)threadIdx.x * XG_FLAG_STRIDE;
@@ -70,12 +78,17 @@ __device__ __forceinline__ void wait_all(const unsigned long long* words, int wo
             if ((polls & 255) == 255) {
                 const unsigned long long now = __builtin_amdgcn_s_memrealtime();
                 if (t0 == 0) t0 = now | 1ull;
-                else if (now - t0 > XG_WAIT_TICKS) { __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                else if (now - t0 > ticks) {
+                    __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (err_host) __hip_atomic_store(err_host, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(8);
             }
         }
     }
     __syncthreads();
+    return __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull;
 }
 
 // all stores of this workgroup are visible system-wide; the LAST workgroup to get here posts `epoch` into word
@@ -129,7 +142,9 @@ __global__ void __launch_bounds__(XG_THREADS) k_xg_push(XgArgs a)
 __global__ void __launch_bounds__(XG_THREADS) k_xg_reduce(XgArgs a)
 {
     unsigned long long* mine = flags_of(a.peer[a.rank]);
-    wait_all(mine + XG_FLAG_A, a.world, a.epoch, mine + XG_ERR);
+    // a push that never arrived (or an earlier failure on this window): recv[] is not the peers' data -- nothing is summed,
+    // nothing is written into anybody's result[], no epoch is posted
+    if (wait_all(mine + XG_FLAG_A, a.world, a.epoch, mine + XG_ERR, a.err_host, a.wait_ticks)) return;
     const float* recv = a.peer[a.rank] + a.recv_offset;
     for (int t = 0; t < a.nseg; ++t) {
         const XgSeg s = a.seg[t];
@@ -158,10 +173,11 @@ __global__ void __launch_bounds__(XG_THREADS) k_xg_reduce(XgArgs a)
 }
 
 // ---- waits (one workgroup): every peer's word has reached `epoch`
-__global__ void __launch_bounds__(64) k_xg_wait(float* window, int flag_base, int world, unsigned long long epoch)
+__global__ void __launch_bounds__(64) k_xg_wait(float* window, int flag_base, int world, unsigned long long epoch,
+                                                unsigned long long* err_host, unsigned long long ticks)
 {
     unsigned long long* mine = flags_of(window);
-    wait_all(mine + flag_base, world, epoch, mine + XG_ERR);
+    (void)wait_all(mine + flag_base, world, epoch, mine + XG_ERR, err_host, ticks);
 }
 
 // ---- all-gather: my block into slot `rank` of every peer's gather buffer
@@ -214,17 +230,22 @@ struct VrXgmi {
     bool attached = false;
     unsigned long long epoch_r = 0, epoch_g[2] = {0, 0};
     unsigned long long nonce = 0;
+    unsigned long long wait_ticks = (unsigned long long)(XG_WAIT_SECONDS * (double)XG_TICKS_PER_S);
+    unsigned long long* err_host = nullptr;       // pinned, coherent mirror of the error word (host pointer) ...
+    unsigned long long* err_host_dev = nullptr;   // ... and its device address
 };
 
-static int xg_error_pending(VrXgmi* x, hipStream_t s, bool sync)
+// a timed-out wait of an EARLIER call on this window, read from the pinned mirror: no synchronisation
+static int xg_failed(const VrXgmi* x)
 {
-    if (!sync) return 0;
-    VR_HIP(hipStreamSynchronize(s));
-    unsigned long long err = 0;
-    VR_HIP(hipMemcpy(&err, reinterpret_cast<unsigned long long*>(x->window) + XG_ERR, sizeof(err), hipMemcpyDeviceToHost));
-    if (err) { set_error("xgmi: a peer did not arrive within the wait bound (rank %d of %d)", x->rank, x->world); return VR_ERR_HIP; }
+    if (x->err_host && __atomic_load_n(x->err_host, __ATOMIC_ACQUIRE) != 0ull) {
+        set_error("xgmi: a peer did not arrive within the wait bound in an earlier exchange on this window (rank %d of %d): "
+                  "its results are invalid and the window is unusable", x->rank, x->world);
+        return VR_ERR_HIP;
+    }
     return 0;
 }
+
 
 extern "C" int vr_xgmi_create(int32_t rank, int32_t world, int64_t reduce_floats, int64_t gather_floats, VrXgmi** out)
 {
@@ -262,6 +283,15 @@ extern "C" int vr_xgmi_create(int32_t rank, int32_t world, int64_t reduce_floats
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();      // the clear must have HAPPENED before any peer can post into this window
     if (e != hipSuccess) { (void)hipFree(p); delete x; set_error("xgmi: hipDeviceSynchronize failed: %s", hipGetErrorString(e)); return VR_ERR_HIP; }
+    if (hipHostMalloc((void**)&x->err_host, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&x->err_host_dev, x->err_host, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (x->err_host) (void)hipHostFree(x->err_host);
+        (void)hipFree(p); delete x;
+        set_error("xgmi: pinned error word could not be allocated");
+        return VR_ERR_HIP;
+    }
+    *x->err_host = 0ull;
     x->peer[rank] = x->window;
     x->attached = (world == 1);
     *out = x;
@@ -283,6 +313,7 @@ extern "C" int vr_xgmi_destroy(VrXgmi* x)
     if (!x) return VR_OK;
     vr_xgmi_detach(x);
     if (x->window) (void)hipFree(x->window);
+    if (x->err_host) (void)hipHostFree(x->err_host);
     delete x;
     return VR_OK;
 }
@@ -343,6 +374,7 @@ extern "C" int vr_xgmi_allreduce(VrXgmi* x, const VrXgmiSegment* segs, int32_t c
 {
     if (!x || !x->attached) { set_error("xgmi: window not attached"); return VR_ERR_INVALID_ARGUMENT; }
     if (count < 1 || count > XG_MAXS || !segs || !result_floats_offset) { set_error("xgmi: 1 .. %d segments", XG_MAXS); return VR_ERR_INVALID_ARGUMENT; }
+    if (int rf = xg_failed(x)) return rf;
     XgArgs a;
     memset(&a, 0, sizeof(a));
     long total = 0, slot = 0, res = 0, most = 0;
@@ -362,10 +394,12 @@ extern "C" int vr_xgmi_allreduce(VrXgmi* x, const VrXgmiSegment* segs, int32_t c
     a.recv_offset = x->lay.recv_offset; a.result_offset = x->lay.result_offset; a.slot_stride = slot;
     a.epoch = ++x->epoch_r;
     a.scale = scale;
+    a.wait_ticks = x->wait_ticks;
+    a.err_host = x->err_host_dev;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_xg_push, dim3(xg_grid(most)), dim3(XG_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_xg_reduce, dim3(xg_grid(most / x->world)), dim3(XG_THREADS), 0, s, a);
-    hipLaunchKernelGGL(k_xg_wait, dim3(1), dim3(64), 0, s, x->window, XG_FLAG_B, x->world, a.epoch);
+    hipLaunchKernelGGL(k_xg_wait, dim3(1), dim3(64), 0, s, x->window, XG_FLAG_B, x->world, a.epoch, x->err_host_dev, x->wait_ticks);
     if (hipGetLastError() != hipSuccess) { set_error("xgmi: all-reduce launch failed"); return VR_ERR_HIP; }
     return VR_OK;
 }
@@ -376,6 +410,7 @@ extern "C" int vr_xgmi_allgather_begin(VrXgmi* x, const VrXgmiSegment* segs, int
     if (!x || !x->attached) { set_error("xgmi: window not attached"); return VR_ERR_INVALID_ARGUMENT; }
     if (count < 1 || count > XG_MAXS || !segs || !slot_floats_offset || (parity != 0 && parity != 1))
         { set_error("xgmi: 1 .. %d segments, parity 0 or 1", XG_MAXS); return VR_ERR_INVALID_ARGUMENT; }
+    if (int rf = xg_failed(x)) return rf;
     XgGatherArgs g;
     memset(&g, 0, sizeof(g));
     long off = 0;
@@ -398,8 +433,9 @@ extern "C" int vr_xgmi_allgather_begin(VrXgmi* x, const VrXgmiSegment* segs, int
 extern "C" int vr_xgmi_allgather_wait(VrXgmi* x, int32_t parity, void* stream)
 {
     if (!x || !x->attached || (parity != 0 && parity != 1)) { set_error("xgmi: window not attached / bad parity"); return VR_ERR_INVALID_ARGUMENT; }
+    if (int rf = xg_failed(x)) return rf;
     hipLaunchKernelGGL(k_xg_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, x->window,
-                       XG_FLAG_G + parity * XG_MAXR * XG_FLAG_STRIDE, x->world, x->epoch_g[parity]);
+                       XG_FLAG_G + parity * XG_MAXR * XG_FLAG_STRIDE, x->world, x->epoch_g[parity], x->err_host_dev, x->wait_ticks);
     if (hipGetLastError() != hipSuccess) { set_error("xgmi: wait launch failed"); return VR_ERR_HIP; }
     return VR_OK;
 }
@@ -407,5 +443,22 @@ extern "C" int vr_xgmi_allgather_wait(VrXgmi* x, int32_t parity, void* stream)
 extern "C" int vr_xgmi_check(VrXgmi* x, void* stream)
 {
     if (!x) { set_error("xgmi: NULL argument"); return VR_ERR_INVALID_ARGUMENT; }
-    return xg_error_pending(x, (hipStream_t)stream, true);
+    VR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    unsigned long long err = 0;
+    VR_HIP(hipMemcpy(&err, reinterpret_cast<unsigned long long*>(x->window) + XG_ERR, sizeof(err), hipMemcpyDeviceToHost));
+    if (err && x->err_host) __atomic_store_n(x->err_host, 1ull, __ATOMIC_RELEASE);
+    return xg_failed(x);
+}
+
+extern "C" int vr_xgmi_failed(const VrXgmi* x)
+{
+    return x && x->err_host && __atomic_load_n(x->err_host, __ATOMIC_ACQUIRE) != 0ull ? 1 : 0;
+}
+
+extern "C" int vr_xgmi_set_wait_bound(VrXgmi* x, double seconds)
+{
+    if (!x || !(seconds > 0.0) || seconds > 3600.0) { set_error("xgmi: the wait bound must lie in (0, 3600] seconds"); return VR_ERR_INVALID_ARGUMENT; }
+    x->wait_ticks = (unsigned long long)(seconds * (double)XG_TICKS_PER_S);
+    if (x->wait_ticks == 0ull) x->wait_ticks = 1ull;
+    return VR_OK;
 }

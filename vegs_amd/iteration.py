@@ -216,7 +216,14 @@ class Trainer:
         from . import optim
         self.device, self.fused = device, fused
         self.world, self.rank, self.group, self.exchange = int(world), int(rank), group, exchange
+        if exchange not in ("factored", "dense", "direct"):
+            raise ValueError(f"exchange must be 'factored', 'dense' or 'direct' (got {exchange!r})")
         if self.world > 1 and exchange in ("factored", "direct"):
+            # both schemes exchange the 3-float SH factor the FUSED operator returns; the op-by-op reference composition
+            # (fused=False) has no such output -- it would arm an exchange that never receives a factor
+            if not fused:
+                raise ValueError(f"exchange={exchange!r} needs fused=True (the factored SH gradient is an output of the fused "
+                                 "operator); use exchange='dense' with the op-by-op composition")
             factored_sh = True
         self.factored_sh = bool(factored_sh and fused)
         self.p, groups = make_model(sc, device, lrs)
@@ -464,6 +471,12 @@ class Trainer:
                         self.boxes[i][0]["shs"].grad = g_all[row:row + n]
                     row += n
 
+            # A timed-out wait of the direct exchange makes the NEXT exchange call raise (include/vegs_xgmi.h, FAILURE
+            # CONTRACT); on iterations that densify -- the ranks must not plan a different model from diverged statistics --
+            # the trainer synchronises and asks before it acts (one host sync per densification interval).
+            if self.direct is not None and world > 1 and self.schedule is not None and \
+                    self.schedule.actions(self.iteration, box=False)[1]:
+                self.direct.check()
             # ---- densification / opacity reset on schedule, then the optimizers (train.py:283-320, :254-275)
             replaced = self._scheduled()
             if self.factored_sh and "static" not in replaced:

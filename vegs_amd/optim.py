@@ -40,11 +40,11 @@ class Adam(torch.optim.Optimizer):
         return loss
 
 
-def _collect(optimizer, by_cfg, keep):
-    """The VrAdamTensor entries of one optimizer (vegs_amd.optim.Adam or torch.optim.Adam: same state layout), its step
-    counters advanced as torch.optim.Adam.step does; parameters without a gradient are skipped."""
+def _validate(optimizer):
+    """Everything _collect would raise for, checked WITHOUT touching the optimizer: step_many validates every optimizer of
+    its batch before the first step counter moves, so an exception leaves all of them exactly as they were (a half-advanced
+    batch would skew the bias correction of a retry and desynchronise the ranks of a distributed job)."""
     for group in optimizer.param_groups:
-        b1, b2 = group["betas"]
         if group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or group.get("maximize", False):
             raise NotImplementedError("the fused Adam covers the reference's configuration: no weight decay, no amsgrad")
         for p in group["params"]:
@@ -56,14 +56,28 @@ def _collect(optimizer, by_cfg, keep):
                 raise ValueError("fused Adam expects dense float32 parameters and gradients")
             if not p.is_contiguous():
                 raise ValueError("fused Adam expects contiguous parameters")
+            st = optimizer.state.get(p) or {}
+            if len(st):
+                m, v = st.get("exp_avg"), st.get("exp_avg_sq")
+                if (m is None or v is None or "step" not in st or m.shape != p.shape or v.shape != p.shape
+                        or not m.is_contiguous() or not v.is_contiguous()):
+                    raise ValueError("optimizer state does not match its parameter")
+
+
+def _collect(optimizer, by_cfg, keep):
+    """The VrAdamTensor entries of one VALIDATED optimizer (vegs_amd.optim.Adam or torch.optim.Adam: same state layout), its
+    step counters advanced as torch.optim.Adam.step does; parameters without a gradient are skipped."""
+    for group in optimizer.param_groups:
+        b1, b2 = group["betas"]
+        for p in group["params"]:
+            if p.grad is None:
+                continue
             st = optimizer.state[p]
             if len(st) == 0:
                 st["step"] = torch.tensor(0.0, dtype=torch.float32)
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             m, v = st["exp_avg"], st["exp_avg_sq"]
-            if m.shape != p.shape or v.shape != p.shape or not m.is_contiguous() or not v.is_contiguous():
-                raise ValueError("optimizer state does not match its parameter")
             st["step"] += 1
             g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
             keep.append(g)
@@ -78,8 +92,12 @@ def step_many(optimizers):
     after the other when dynamic objects are in frame -- the static model's six groups, six more per instance model
     (densification_and_optimization(..., box=True)) and the three pose corrections of every BoxModel
     (box_model.optimizer.step(), model/boxmodel.py:13) -- with every tensor's own learning rate, step count and eps in
-    the kernel's block->tensor table.  Optimizers may be vegs_amd.optim.Adam or torch.optim.Adam (same state layout)."""
+    the kernel's block->tensor table.  Optimizers may be vegs_amd.optim.Adam or torch.optim.Adam (same state layout).
+    All-or-nothing: every optimizer is validated before any state (step counters, fresh moments) is touched."""
     lib = _capi.load()
+    optimizers = list(optimizers)
+    for opt in optimizers:
+        _validate(opt)
     by_cfg, keep = {}, []
     for opt in optimizers:
         _collect(opt, by_cfg, keep)

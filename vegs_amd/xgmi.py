@@ -37,6 +37,19 @@ class DirectExchange:
         self.parity = 0
         self._pending = None
         self._side = None
+        self.wait_bound = None          # seconds; None = the library's default (10 s)
+
+    def set_wait_bound(self, seconds):
+        """Bound of every device-side wait for a peer (include/vegs_xgmi.h: FAILURE CONTRACT); applies to this and every
+        later window of the object."""
+        self.wait_bound = float(seconds)
+        if self.ctx is not None:
+            _capi.check(_capi.load().vr_xgmi_set_wait_bound(self.ctx, self.wait_bound))
+
+    def failed(self):
+        """True once a wait on the current window has timed out, as far as the host can see WITHOUT synchronising (the
+        pinned mirror of the window's error word).  Every exchange call tests the same word first and raises."""
+        return self.ctx is not None and bool(_capi.load().vr_xgmi_failed(self.ctx))
 
     # ---- window management (collective: every rank must make the same calls with the same sizes)
     def _ensure(self, reduce_floats, gather_floats, agree=False):
@@ -106,6 +119,8 @@ class DirectExchange:
                 dist.barrier(group=self.group)          # nobody frees a window that a peer still has mapped
             _capi.check(lib.vr_xgmi_destroy(old))
         self.ctx = ctx
+        if self.wait_bound is not None:
+            _capi.check(lib.vr_xgmi_set_wait_bound(ctx, self.wait_bound))
         lay = _capi.VrXgmiLayout()
         _capi.check(lib.vr_xgmi_layout(ctx, C.byref(lay)))
         self.lay = lay

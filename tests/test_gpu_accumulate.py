@@ -1,0 +1,188 @@
+"""GPU (-m gpu): in-place gradient accumulation over the views of a step (include/vegs_rast.h: VR_FLAG_ACCUMULATE_GRADS;
+vegs_amd.rasterizer.accumulate_grads).  From a step's second view on the backward ADDS its rows into the leaves' existing
+`.grad` tensors -- the rows the view renders, nothing else -- instead of writing dense arrays that autograd then adds out of
+place.  The sums must be what autograd's own accumulation gives: bit-equal in the deterministic mode (same fp32 adds in the
+same order), on one stream and with two views in flight, for every input layout of the op."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DET = 256
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from vegs_amd import _capi
+    _capi.load()
+    return torch.device("cuda", 0)
+
+
+def _scene(dev, P=90000, deg=2):
+    from vegs_amd import harness, scenes
+    sc, deg = scenes.scene_street(P=P, length=60.0, sh_degree=deg, seed=43)
+    cams = [scenes.kitti_camera(7.0 * s, y, 688, 188) for s in range(3) for y in (0.3, -0.3)]
+    cam_ts = [harness.cam_tensors(c, dev) for c in cams]
+    return sc, deg, cams, cam_ts
+
+
+def _gouts(dev, n, H=188, W=688, seed=5):
+    rng = np.random.default_rng(seed)
+    return [[torch.tensor(rng.normal(size=s).astype(np.float32), device=dev) for s in [(3, H, W), (4, H, W), (3, H, W)]]
+            for _ in range(n)]
+
+
+def _batch(leaves, one_view, n, dev, accumulate, streams=1):
+    """n views forward + backward into the shared leaves; returns ({name: grad}, [per-view means2D grads])."""
+    from vegs_amd import rasterizer, views
+    for t in leaves.values():
+        t.grad = None
+    old = rasterizer.accumulate_grads(accumulate)
+    try:
+        with rasterizer.flags(rasterizer.get_flags() | DET):
+            m2d = views.view_batch(range(n), one_view, dev, streams=streams)
+    finally:
+        rasterizer.accumulate_grads(old)
+    torch.cuda.synchronize()
+    return {k: t.grad.detach().clone() for k, t in leaves.items()}, [m.clone() for m in m2d]
+
+
+@pytest.mark.parametrize("streams", [1, 2])
+def test_accumulated_in_place_equals_autograd_accumulation_bit_for_bit(dev, streams):
+    from vegs_amd import harness
+    sc, deg, cams, cam_ts = _scene(dev)
+    T = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in sc.items()}
+    bg = torch.zeros(3, device=dev)
+    gouts = _gouts(dev, 6)
+
+    def one(v):
+        pkg = harness.render(cams[v], T, deg, bg, cam_t=cam_ts[v])
+        torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], gouts[v])
+        return pkg["viewspace_points"].grad
+    want, m_want = _batch(T, one, 6, dev, False, streams)
+    ptrs = {}
+
+    def one_spy(v):
+        out = one(v)
+        ptrs.setdefault(v, T["shs"].grad.data_ptr())
+        return out
+    got, m_got = _batch(T, one_spy, 6, dev, True, streams)
+    for k in want:
+        assert torch.equal(want[k], got[k]), (k, float((want[k] - got[k]).abs().max()))
+        assert float(got[k].abs().max()) > 0
+    for a, b in zip(m_want, m_got):                    # the per-view screen-space gradient is returned as always
+        assert torch.equal(a, b) and float(a[:, 2].abs().max()) == 0.0
+    # in place: the dense array of the FIRST view is the .grad every later view added into
+    assert len(set(ptrs.values())) == 1
+
+
+def test_rows_a_view_does_not_render_are_not_touched(dev):
+    """The accumulate call reads and writes the rows with radii > 0 only: a sentinel in a culled row's .grad survives it
+    (NaN + 0 would not), visible rows receive exactly this view's gradient."""
+    from vegs_amd import harness, rasterizer
+    sc, deg, cams, cam_ts = _scene(dev, P=40000)
+    T = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in sc.items()}
+    bg = torch.zeros(3, device=dev)
+    g = _gouts(dev, 1)[0]
+
+    def run():
+        pkg = harness.render(cams[0], T, deg, bg, cam_t=cam_ts[0])
+        torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], g)
+        return pkg["radii"]
+    with rasterizer.flags(DET):
+        radii = run()
+        plain = {k: t.grad.clone() for k, t in T.items()}
+        culled = radii == 0
+        assert int(culled.sum()) > 100 and int((~culled).sum()) > 1000
+        for k, t in T.items():
+            t.grad = torch.zeros_like(t)
+            t.grad[culled] = float("nan")
+        old = rasterizer.accumulate_grads(True)
+        try:
+            run()
+        finally:
+            rasterizer.accumulate_grads(old)
+    for k, t in T.items():
+        assert torch.isnan(t.grad[culled]).all(), k
+        assert torch.equal(t.grad[~culled], plain[k][~culled]), k
+
+
+def test_split_sh_precomputed_colours_and_covariances(dev):
+    """The other input layouts of the op: shs as the model's pair (features_dc, features_rest); colors_precomp and
+    cov3D_precomp instead of shs / (scales, rotations)."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc, deg, cams, cam_ts = _scene(dev, P=50000, deg=3)
+    gouts = _gouts(dev, 3, seed=9)
+    bg = torch.zeros(3, device=dev)
+
+    def settings(v):
+        c, ct = cams[v], cam_ts[v]
+        return GaussianRasterizationSettings(188, 688, c.tanfovx, c.tanfovy, bg, 1.0, ct["viewmatrix"], ct["projmatrix"], deg,
+                                             ct["campos"], False, False)
+    shs = torch.tensor(sc["shs"], device=dev)
+    L1 = dict(means3D=torch.tensor(sc["means3D"], device=dev), dc=shs[:, :1].contiguous(), rest=shs[:, 1:].contiguous(),
+              opacities=torch.tensor(sc["opacities"], device=dev), scales=torch.tensor(sc["scales"], device=dev),
+              rotations=torch.tensor(sc["rotations"], device=dev))
+    for t in L1.values():
+        t.requires_grad_(True)
+
+    def one_split(v):
+        m2d = torch.zeros_like(L1["means3D"], requires_grad=True)
+        out = GaussianRasterizer(settings(v))(means3D=L1["means3D"], means2D=m2d, shs=(L1["dc"], L1["rest"]),
+                                              opacities=L1["opacities"], scales=L1["scales"], rotations=L1["rotations"])
+        torch.autograd.backward([out[0], out[2], out[3]], gouts[v])
+        return m2d.grad
+    want, _ = _batch(L1, one_split, 3, dev, False)
+    got, _ = _batch(L1, one_split, 3, dev, True)
+    for k in want:
+        assert torch.equal(want[k], got[k]), k
+    # precomputed colours + covariances (cov_quat / cov_scale are zeros then: only the colour gradient is fed back)
+    rng = np.random.default_rng(2)
+    P = sc["means3D"].shape[0]
+    A = rng.normal(size=(P, 3, 3)).astype(np.float32) * 0.05
+    cov = np.einsum("pij,pkj->pik", A, A)
+    L2 = dict(means3D=torch.tensor(sc["means3D"], device=dev), colors=torch.tensor(rng.uniform(0, 1, (P, 3)).astype(np.float32), device=dev),
+              opacities=torch.tensor(sc["opacities"], device=dev),
+              cov=torch.tensor(np.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1), device=dev))
+    for t in L2.values():
+        t.requires_grad_(True)
+
+    def one_pre(v):
+        m2d = torch.zeros_like(L2["means3D"], requires_grad=True)
+        out = GaussianRasterizer(settings(v))(means3D=L2["means3D"], means2D=m2d, colors_precomp=L2["colors"],
+                                              opacities=L2["opacities"], cov3D_precomp=L2["cov"])
+        torch.autograd.backward([out[0]], [gouts[v][0]])
+        return m2d.grad
+    want, _ = _batch(L2, one_pre, 3, dev, False)
+    got, _ = _batch(L2, one_pre, 3, dev, True)
+    for k in want:
+        assert torch.equal(want[k], got[k]) and float(got[k].abs().max()) > 0, k
+
+
+def test_non_leaf_inputs_take_the_plain_path(dev):
+    """The reference's own call pattern feeds ACTIVATIONS of the parameters (non-leaf tensors): nothing to add into, the
+    backward returns dense gradients to autograd as always -- accumulate_grads(True) changes nothing."""
+    from vegs_amd import harness, rasterizer
+    sc, deg, cams, cam_ts = _scene(dev, P=30000)
+    raw = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in sc.items()}
+    bg = torch.zeros(3, device=dev)
+    gouts = _gouts(dev, 2)
+
+    def batch(acc):
+        for t in raw.values():
+            t.grad = None
+        old = rasterizer.accumulate_grads(acc)
+        try:
+            with rasterizer.flags(DET):
+                for v in range(2):
+                    T = {k: t * 1.0 for k, t in raw.items()}          # non-leaf op inputs
+                    pkg = harness.render(cams[v], T, deg, bg, cam_t=cam_ts[v])
+                    torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], gouts[v])
+        finally:
+            rasterizer.accumulate_grads(old)
+        return {k: t.grad.clone() for k, t in raw.items()}
+    a, b = batch(False), batch(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

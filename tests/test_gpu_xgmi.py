@@ -104,8 +104,11 @@ torch.cuda.set_device(dev)
 ex = xgmi.DirectExchange(rank, world, dev)
 ex.set_wait_bound(0.5)
 n = 70001
+ex.reserve(n, 64)                    # both regions up front: a window that has failed must not be replaced by a fresh one
 g = torch.full((n,), float(rank + 1), device=dev)
+ex.begin_gather([g[:12]])
 (r1,) = ex.allreduce_mean([g], 1.0)
+ex.finish_gather()
 ex.check()
 assert bool((r1 == 3.0).all()) and not ex.failed()
 torch.distributed.barrier()

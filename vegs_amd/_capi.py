@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libvegsrast.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # VrSettings.flags (include/vegs_rast.h, VrFlags)
 FLAG_SCALE_MODIFIED, FLAG_DEPTH_NORMALIZED, FLAG_EXTRA_NO_ALPHA_GRAD, FLAG_FILL_EMPTY, FLAG_DETERMINISTIC = 1, 2, 4, 8, 256
@@ -21,6 +21,7 @@ FLAG_RAW_PARAMS = 4096
 FLAG_FAST_EXP = 8192
 FLAG_VERIFY_BINNING = 16384
 FLAG_FULL_TILE_LISTS = 32768
+FLAG_ACCUMULATE_GRADS = 65536
 
 VR_BUF_GEOM, VR_BUF_BINNING, VR_BUF_IMAGE, VR_BUF_SCRATCH, VR_BUF_BACKWARD = 0, 1, 2, 3, 4
 

@@ -20,10 +20,11 @@ static_assert(FLAG_SCALE_MODIFIED == VR_FLAG_SCALE_MODIFIED && FLAG_DEPTH_NORMAL
               FLAG_DETERMINISTIC == VR_FLAG_DETERMINISTIC && FLAG_SCAN_BINNING == VR_FLAG_SCAN_BINNING &&
               FLAG_ROUNDS_OFF == VR_FLAG_ROUNDS_OFF && FLAG_ROUNDS_ON == VR_FLAG_ROUNDS_ON &&
               FLAG_RAW_PARAMS == VR_FLAG_RAW_PARAMS && FLAG_FAST_EXP == VR_FLAG_FAST_EXP &&
-              FLAG_VERIFY_BINNING == VR_FLAG_VERIFY_BINNING && FLAG_FULL_TILE_LISTS == VR_FLAG_FULL_TILE_LISTS,
+              FLAG_VERIFY_BINNING == VR_FLAG_VERIFY_BINNING && FLAG_FULL_TILE_LISTS == VR_FLAG_FULL_TILE_LISTS &&
+              FLAG_ACCUMULATE_GRADS == VR_FLAG_ACCUMULATE_GRADS,
               "device-side flag constants must match include/vegs_rast.h");
 constexpr uint32_t KNOWN_FLAGS = FLAG_SCALE_MODIFIED | FLAG_DEPTH_NORMALIZED | FLAG_EXTRA_NO_ALPHA_GRAD | FLAG_FILL_EMPTY |
-                                 FLAG_DETERMINISTIC | FLAG_SCAN_BINNING | FLAG_ROUNDS_OFF | FLAG_ROUNDS_ON | FLAG_RAW_PARAMS | FLAG_FAST_EXP | FLAG_VERIFY_BINNING | FLAG_FULL_TILE_LISTS;
+                                 FLAG_DETERMINISTIC | FLAG_SCAN_BINNING | FLAG_ROUNDS_OFF | FLAG_ROUNDS_ON | FLAG_RAW_PARAMS | FLAG_FAST_EXP | FLAG_VERIFY_BINNING | FLAG_FULL_TILE_LISTS | FLAG_ACCUMULATE_GRADS;
 
 static thread_local char g_err[512] = "";
 static thread_local VrCounters g_counters = {0, 0, 0, 0, 0};
@@ -603,6 +604,8 @@ static int backward_first(const Camera& cam, const VrSettings* st, const VrInput
         // split SH storage: the kernel writes every row of both gradient arrays
     } else if (in->shs_tail) {
         // SH tail: validated for the staged paths, which write every row of all the SH gradient arrays
+    } else if (cam.flags & FLAG_ACCUMULATE_GRADS) {
+        // accumulate mode: the caller's arrays hold the sum so far; nothing is cleared
     } else if (gin->dL_dshs && !preprocess_bwd_writes_all_sh(in->M, in->shs, gin->dL_dshs)) {
         VR_HIP(hipMemsetAsync(gin->dL_dshs, 0, (size_t)P * in->M * 3 * sizeof(float), s));
     }

@@ -727,10 +727,16 @@ k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int shift = pass * BITS;
     const long b = blockIdx.x;
+    // A wait that ran out in an EARLIER launch of this view (a pass before this one, visible in stream order) left keys and
+    // values that are not a permutation of the input any more -- slots written twice, others holding stale or uninitialised
+    // memory.  This pass would rank keys whose digit counts no longer add up to the totals it scatters by: destinations
+    // beyond the buffers.  The view is lost either way (k_tile_ranges leaves it empty and reports it): nothing is touched.
+    const uint32_t tripped = st_load(err);
     for (int d = threadIdx.x; d < SIZE; d += 256) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) cnt[k][d] = 0;
     }
+    if (tripped) return;
     __syncthreads();
     const long wbase = b * RADIX_BLOCK + (long)w * (64 * RADIX_ITEMS);
     uint32_t key[RADIX_ITEMS], val[RADIX_ITEMS], rank[RADIX_ITEMS];
@@ -1197,6 +1203,8 @@ k_emit_scan(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint4* 
     const int lane = threadIdx.x & 63;
     uint32_t cnt = 0, id = 0;
     uint4 rc = make_uint4(0u, 0u, 0u, 0u);
+    // (a wait of this view's depth sort ran out: `sorted_id` may hold anything -- it is not used as an index; see k_onesweep)
+    if (st_load(err) != 0u) return;
     if (r < V) {
         // the packed rectangle + tile mask is gathered by id HERE (1.65 M random 16-byte reads): this kernel is bound by
         // the latency of its waits, not by bandwidth, and hides them; in the last depth-sort pass they cost 22 us

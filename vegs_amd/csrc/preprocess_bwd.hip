@@ -70,7 +70,38 @@ __device__ __forceinline__ void sh_backward_factor(const Camera& cam, float px3,
     for (int k = 0; k < 3; ++k) dmean[k] += (ddir[k] - dir[k] * dot) * il;
 }
 
-template <bool RAW>      // VR_FLAG_RAW_PARAMS, compile-time: the default instantiation is the kernel as it was
+// dst[e] += lds[e] for e < n (the wave's contiguous block of gradient rows): VR_FLAG_ACCUMULATE_GRADS
+template <int MAXV>
+__device__ __forceinline__ void wave_add_from_lds(float* __restrict__ dst, const float* __restrict__ lds, int n, int lane)
+{
+    if ((reinterpret_cast<size_t>(dst) & 15) == 0) {
+        const int nv = n >> 2;
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        const float4* s4 = reinterpret_cast<const float4*>(lds);
+        float4 old[MAXV];
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j)
+            if (lane + 64 * j < nv) old[j] = d4[lane + 64 * j];
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            if (lane + 64 * j < nv) {
+                const float4 v = s4[lane + 64 * j];
+                d4[lane + 64 * j] = make_float4(old[j].x + v.x, old[j].y + v.y, old[j].z + v.z, old[j].w + v.w);
+            }
+        }
+        if (lane < (n & 3)) dst[(nv << 2) + lane] += lds[(nv << 2) + lane];
+    } else {
+        for (int e = lane; e < n; e += 64) dst[e] += lds[e];
+    }
+}
+
+// RAW: VR_FLAG_RAW_PARAMS, ACC: VR_FLAG_ACCUMULATE_GRADS -- compile-time: the default instantiation is the kernel as it was.
+// ACC: every gradient array except dL_dmeans2D (written by the render backward) and the SH factor RECEIVES this view's
+// gradient, grad[i] += g_view[i] in fp32, for rows with radii > 0 only; culled rows are neither read nor written (their
+// contribution is an exact zero: in a partly visible wave of the SH paths they get "+ 0" with their neighbours).  What a
+// multi-view step otherwise pays per view -- this kernel's dense write of (56 + 12 K) bytes per Gaussian plus autograd's
+// read-read-write accumulation of the same arrays -- becomes one read-modify-write of the visible rows.
+template <bool RAW, bool ACC>
 __global__ void __launch_bounds__(256)
 k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ means3D, const float* __restrict__ shs,
                  const float* __restrict__ shs_rest, float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dshs_tail,
@@ -133,11 +164,21 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
             float* head = mine_tail ? dL_dshs_tail + (size_t)(i - tail_start) * row
                                     : (shs_rest ? dL_dshs + 3 * (size_t)i : dL_dshs + (size_t)i * row);
             float* rest = (!mine_tail && shs_rest) ? dL_dshs_rest + (size_t)i * (row - 3) : head + 3;
+            if (ACC) {
+                if (vis) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) head[c] = srow[c];
+                    for (int c = 0; c < 3; ++c) head[c] += srow[c];
 #pragma unroll
-            for (int k = 0; k < SH_ROW_MAX - 3; ++k)
-                if (k < row - 3) rest[k] = srow[3 + k];
+                    for (int k = 0; k < SH_ROW_MAX - 3; ++k)
+                        if (k < row - 3) rest[k] += srow[3 + k];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) head[c] = srow[c];
+#pragma unroll
+                for (int k = 0; k < SH_ROW_MAX - 3; ++k)
+                    if (k < row - 3) rest[k] = srow[3 + k];
+            }
         }
     } else if (shs && shs_rest && !(dL_dshs_tail && (long)(blockIdx.x * blockDim.x + w * 64) >= (long)tail_start)) {
         // split storage: dL_dshs = [P,1,3] DC rows (written by their own lane: 12 contiguous bytes per lane),
@@ -168,11 +209,19 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (in_range) {
+        if (ACC) {
+            if (vis) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) dL_dshs[3 * (size_t)i + c] = dc[c];
+                for (int c = 0; c < 3; ++c) dL_dshs[3 * (size_t)i + c] += dc[c];
+            }
+            if (any) wave_add_from_lds<SH_ROW_MAX / 4>(dL_dshs_rest + wave_first * rowr, sh_lds[w], rows_here * rowr, lane);
+        } else {
+            if (in_range) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dL_dshs[3 * (size_t)i + c] = dc[c];
+            }
+            wave_copy_from_lds<SH_ROW_MAX / 4>(dL_dshs_rest + wave_first * rowr, sh_lds[w], rows_here * rowr, lane, !any);
         }
-        wave_copy_from_lds<SH_ROW_MAX / 4>(dL_dshs_rest + wave_first * rowr, sh_lds[w], rows_here * rowr, lane, !any);
     } else if (shs && (sh_staged || dL_dshs_tail)) {
         // whole rows: the only SH tensor, the static part in front of a tail, or the tail itself (indexed by Gaussian id)
         const int row = cam.M * 3;
@@ -203,14 +252,32 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
         }
         float4* dst4 = reinterpret_cast<float4*>(whole_out + wave_first * row);
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ACC) {
+            if (any) {      // (a wave without a visible Gaussian adds nothing: its rows are not touched)
+                float4 old[SH_ROW_MAX / 4];
 #pragma unroll
-        for (int j = 0; j < SH_ROW_MAX / 4; ++j) {
-            const int v = lane + 64 * j;
-            if (v < nvec) {
-                const int r = row4 == 12 ? v / 12 : v / row4;
-                float4 val = zero4;
-                if (any) val = lds4[r * (SH_LDS_STRIDE / 4) + (v - r * row4)];
-                nt_store4(val, &dst4[v]);
+                for (int j = 0; j < SH_ROW_MAX / 4; ++j)
+                    if (lane + 64 * j < nvec) old[j] = dst4[lane + 64 * j];
+#pragma unroll
+                for (int j = 0; j < SH_ROW_MAX / 4; ++j) {
+                    const int v = lane + 64 * j;
+                    if (v < nvec) {
+                        const int r = row4 == 12 ? v / 12 : v / row4;
+                        const float4 val = lds4[r * (SH_LDS_STRIDE / 4) + (v - r * row4)];
+                        dst4[v] = make_float4(old[j].x + val.x, old[j].y + val.y, old[j].z + val.z, old[j].w + val.w);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SH_ROW_MAX / 4; ++j) {
+                const int v = lane + 64 * j;
+                if (v < nvec) {
+                    const int r = row4 == 12 ? v / 12 : v / row4;
+                    float4 val = zero4;
+                    if (any) val = lds4[r * (SH_LDS_STRIDE / 4) + (v - r * row4)];
+                    nt_store4(val, &dst4[v]);
+                }
             }
         }
     } else if (shs && vis) {
@@ -220,7 +287,16 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
         float D[9];
 #pragma unroll
         for (int q = 0; q < 9; ++q) D[q] = shd[9 * (size_t)i + q];
-        sh_backward_row(cam, px3, py3, pz3, (uint32_t)clampb[i], a1.x, a1.y, a1.z, D, dL_dshs + (size_t)i * cam.M * 3, dmean);
+        if (ACC) {
+            float srow[SH_ROW_MAX];
+            sh_backward_row(cam, px3, py3, pz3, (uint32_t)clampb[i], a1.x, a1.y, a1.z, D, srow, dmean);
+            float* out = dL_dshs + (size_t)i * cam.M * 3;
+#pragma unroll
+            for (int k = 0; k < SH_ROW_MAX; ++k)
+                if (k < cam.M * 3) out[k] += srow[k];
+        } else {
+            sh_backward_row(cam, px3, py3, pz3, (uint32_t)clampb[i], a1.x, a1.y, a1.z, D, dL_dshs + (size_t)i * cam.M * 3, dmean);
+        }
     }
 
     if (vis) {
@@ -359,6 +435,29 @@ k_preprocess_bwd(Camera cam, int P, int sh_staged, const float* __restrict__ mea
         }
     }
     if (!in_range) return;
+    if (ACC) {
+        if (!vis) return;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * (size_t)i + k] += dmean[k];
+        dL_dopacities[i] += dop;
+        if (dL_dcolors) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dL_dcolors[3 * (size_t)i + k] += dcol[k];
+        }
+        if (dL_dscales) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dL_dscales[3 * (size_t)i + k] += dsc[k];
+        }
+        if (dL_drots) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dL_drots[4 * (size_t)i + k] += drot[k];
+        }
+        if (dL_dcov3D) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] += dcov[k];
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * (size_t)i + k] = dmean[k];
     dL_dopacities[i] = dop;
@@ -399,16 +498,15 @@ int launch_preprocess_bwd(const Camera& cam, int P, const float* means3D, const 
 {
     if (P == 0) return 0;
     const int sh_staged = preprocess_bwd_writes_all_sh(cam.M, shs, dL_dshs) ? 1 : 0;
-    if (cam.flags & FLAG_RAW_PARAMS)
-        hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, sh_staged, means3D, shs, shs_rest,
-                       dL_dshs_rest, dL_dshs_tail, tail_start, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, clampb, shd, gacc, gmean2D, dL_dmeans3D,
-                       dL_dshs, dL_dcolors,
-                       dL_dopacities, dL_dscales, dL_drots, dL_dcov3D, dL_dcolors_sh, store_factor ? 1 : 0);
-    else
-        hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, sh_staged, means3D, shs, shs_rest,
-                       dL_dshs_rest, dL_dshs_tail, tail_start, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, clampb, shd, gacc, gmean2D, dL_dmeans3D,
-                       dL_dshs, dL_dcolors,
-                       dL_dopacities, dL_dscales, dL_drots, dL_dcov3D, dL_dcolors_sh, store_factor ? 1 : 0);
+#define VR_PBWD(RAWP, ACCP)                                                                                                   \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_preprocess_bwd<RAWP, ACCP>), dim3(cdiv(P, 256)), dim3(256), 0, s, cam, P, sh_staged, \
+                       means3D, shs, shs_rest, dL_dshs_rest, dL_dshs_tail, tail_start, colors_precomp, opacities, scales,     \
+                       rotations, cov3D_precomp, radii, clampb, shd, gacc, gmean2D, dL_dmeans3D, dL_dshs, dL_dcolors,         \
+                       dL_dopacities, dL_dscales, dL_drots, dL_dcov3D, dL_dcolors_sh, store_factor ? 1 : 0)
+    const bool raw = (cam.flags & FLAG_RAW_PARAMS) != 0u, acc = (cam.flags & FLAG_ACCUMULATE_GRADS) != 0u;
+    if (raw) { if (acc) VR_PBWD(true, true); else VR_PBWD(true, false); }
+    else { if (acc) VR_PBWD(false, true); else VR_PBWD(false, false); }
+#undef VR_PBWD
     VR_KERNEL_CHECK("preprocess_bwd", s, debug);
     return 0;
 }

@@ -43,6 +43,7 @@ constexpr uint32_t FLAG_RAW_PARAMS = 1u << 12;          // opacities / scales / 
 constexpr uint32_t FLAG_FAST_EXP = 1u << 13;            // the compositing's 2^x by the hardware's v_exp_f32 (forward AND backward)
 constexpr uint32_t FLAG_VERIFY_BINNING = 1u << 14;      // forward: wait for the binning's guard word; a tripped view is re-binned without waits
 constexpr uint32_t FLAG_FULL_TILE_LISTS = 1u << 15;     // tile lists hold the reference's full rectangles (no tile test)
+constexpr uint32_t FLAG_ACCUMULATE_GRADS = 1u << 16;    // backward ADDS the view's gradients into the caller's arrays (visible rows only)
 
 // The model's activations (scene/gaussian_model.py:37-45), shared by vr_activations_* and the VR_FLAG_RAW_PARAMS path
 constexpr float NORMALIZE_EPS = 1e-12f;   // F.normalize's default eps

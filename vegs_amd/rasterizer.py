@@ -54,6 +54,7 @@ FLAG_RAW_PARAMS = _capi.FLAG_RAW_PARAMS                    # opacities / scales 
 FLAG_FULL_TILE_LISTS = _capi.FLAG_FULL_TILE_LISTS          # tile lists hold the reference's full rectangles (default: tiles a splat cannot reach are left out)
 FLAG_VERIFY_BINNING = _capi.FLAG_VERIFY_BINNING            # forward waits for the binning guard; a tripped view is re-binned without waits (opt-in)
 FLAG_FAST_EXP = _capi.FLAG_FAST_EXP                        # 2^x by v_exp_f32 in the compositing kernels, forward and backward (images ~1e-6 off the bit-exact mode)
+FLAG_ACCUMULATE_GRADS = _capi.FLAG_ACCUMULATE_GRADS        # backward adds into the caller's gradient arrays (set per call by accumulate_grads(), not by hand)
 _flags = int(os.environ.get("VEGS_RAST_FLAGS", "0"), 0)
 
 
@@ -172,6 +173,39 @@ def set_backward_split_hook(fn):
     global _split_hook
     old, _split_hook = _split_hook, fn
     return old
+
+
+# ---- gradient accumulation IN PLACE for steps that render several views of one model (include/vegs_rast.h:
+# VR_FLAG_ACCUMULATE_GRADS).  PyTorch adds the gradients of a leaf's second, third ... use out of place: per view the op
+# writes (56 + 12 K) bytes per Gaussian of dense gradients and autograd then reads them and the running sums and writes the
+# new sums -- 0.22 ms per view at 2 M Gaussians.  With accumulate_grads(True) the backward of a view whose op inputs are
+# LEAVES that already hold a `.grad` (i.e. from the step's second view on; the first one takes the plain path and its dense
+# arrays BECOME the `.grad`s) adds its rows straight into those `.grad` tensors -- only the rows the view renders -- and
+# returns None for these inputs.  Same numbers as autograd's own accumulation, in the same order (bit-equal in the
+# deterministic mode); what differs is what autograd SEES: no gradient arrives at the leaf's AccumulateGrad node for those
+# views, so hooks on the leaves (DDP-style post-accumulate hooks) do not fire for them.  Off by default; means2D (a
+# per-view tensor) and the SH factor are returned as always.  Views whose backwards run on different streams
+# (vegs_amd.views.ViewStreams) are ordered by an event between consecutive accumulations.
+_accumulate = False
+_acc_last = {}          # device -> (event recorded after the last accumulating backward, the stream it ran on)
+
+
+def accumulate_grads(enabled):
+    """In-place accumulation of the op's input gradients into existing leaf `.grad`s (see above); returns the previous
+    setting."""
+    global _accumulate
+    old, _accumulate = _accumulate, bool(enabled)
+    return old
+
+
+def _acc_target(t):
+    """The `.grad` tensor the backward may add into for op input `t`, or None."""
+    if t is None or not t.requires_grad or not t.is_leaf:
+        return None
+    g = t.grad
+    if g is None or g.dtype != torch.float32 or g.shape != t.shape or not g.is_contiguous() or g.device != t.device:
+        return None
+    return g
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -305,22 +339,38 @@ class _RasterizeGaussians(torch.autograd.Function):
             return None if t is None else _dev_f32(t, device)
         g_color, g_depth, g_quat, g_scale, g_alpha = g(g_color), g(g_depth), g(g_quat), g(g_scale), g(g_alpha)
         with torch.cuda.device(device):
-            st = _settings_struct(rs, device, keep, ctx.flag_bits)
-            inp = _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, sh_rest, sh_tail)
-            d_means3D = torch.empty_like(means3D)
-            d_means2D = torch.empty((P, 3), dtype=torch.float32, device=device)
-            d_opac = torch.empty_like(opacities) if opacities is not None else None
             # factored SH gradient: only the clamp-masked dL/d(colour) [P,3] is produced (it lands on the caller's
             # `sh_color_grad` tensor); shs / features_rest receive no gradient from this op
             factored = ctx.sh_factored
+            # accumulate mode (accumulate_grads): ALL the gradient arrays this call would allocate must have a leaf `.grad`
+            # to add into -- one flag for the call; otherwise (a step's first view, non-leaf inputs) the plain path
+            wanted = [t for t in (means3D, opacities, colors_precomp, scales, rotations, cov3Ds_precomp) if t is not None]
+            if not factored:
+                wanted += [t for t in (sh, sh_rest, sh_tail) if t is not None]
+            targets = {id(t): _acc_target(t) for t in wanted} if (_accumulate and P > 0) else {}
+            acc = bool(targets) and all(g is not None for g in targets.values())
+            flag_bits = ctx.flag_bits | (FLAG_ACCUMULATE_GRADS if acc else 0)
+
+            def out(t):
+                return None if t is None else (targets[id(t)] if acc else torch.empty_like(t))
+            st = _settings_struct(rs, device, keep, flag_bits)
+            inp = _inputs_struct(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, sh_rest, sh_tail)
+            d_means3D = out(means3D)
+            d_means2D = torch.empty((P, 3), dtype=torch.float32, device=device)
+            d_opac = out(opacities)
             d_sink = torch.empty((P, 3), dtype=torch.float32, device=device) if factored else None
-            d_sh = torch.empty_like(sh) if sh is not None and not factored else None
-            d_sh_rest = torch.empty_like(sh_rest) if sh_rest is not None and not factored else None
-            d_sh_tail = torch.empty_like(sh_tail) if sh_tail is not None and not factored else None
-            d_col = torch.empty_like(colors_precomp) if colors_precomp is not None else None
-            d_scales = torch.empty_like(scales) if scales is not None else None
-            d_rot = torch.empty_like(rotations) if rotations is not None else None
-            d_cov = torch.empty_like(cov3Ds_precomp) if cov3Ds_precomp is not None else None
+            d_sh = out(sh) if not factored else None
+            d_sh_rest = out(sh_rest) if not factored else None
+            d_sh_tail = out(sh_tail) if not factored else None
+            d_col = out(colors_precomp)
+            d_scales = out(scales)
+            d_rot = out(rotations)
+            d_cov = out(cov3Ds_precomp)
+            if acc:      # order this accumulation behind the previous one if that ran on another stream
+                cur = torch.cuda.current_stream(device)
+                last = _acc_last.get(device)
+                if last is not None and last[1] != cur:
+                    cur.wait_event(last[0])
             gout = _capi.VrOutGrads(_capi.ptr(g_color), _capi.ptr(g_depth), _capi.ptr(g_quat), _capi.ptr(g_scale),
                                     _capi.ptr(g_alpha))
             gin = _capi.VrInGrads(_capi.ptr(d_means3D), _capi.ptr(d_means2D), _capi.ptr(d_sh), _capi.ptr(d_col),
@@ -354,7 +404,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                 if arena.error is not None:
                     raise arena.error
                 _capi.check(rc)
+            if _accumulate and P > 0:
+                # the next accumulating backward (possibly on another stream) must come after this call's writes -- also
+                # after a PLAIN call's: its dense arrays become the `.grad`s the next view adds into
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(device))
+                _acc_last[device] = (ev, torch.cuda.current_stream(device))
         # input order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings
+        if acc:          # added in place: nothing for autograd to accumulate
+            return None, d_means2D, None, None, None, None, None, None, None, None, d_sink, None
         if ctx.tail_is_whole:        # the tail stood in for the whole tensor (empty head): its gradient goes back as the tail's
             d_sh, d_sh_tail = None, d_sh
         return d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, d_sh_rest, d_sink, d_sh_tail

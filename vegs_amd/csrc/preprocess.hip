@@ -11,6 +11,8 @@
 // reading its own row would stride 192 B across the wave and over-fetch 2.5x (measured with
 // FETCH_SIZE), so each wave stages the 64 contiguous rows of its Gaussians through LDS with fully
 // coalesced dwordx4 loads and every lane then reads its row back from LDS.
+#include <stdlib.h>
+
 #include "vr_host.h"
 
 namespace vr {
@@ -37,8 +39,18 @@ __device__ __forceinline__ void sh_dot(const float* bas, int K, const float* sh,
     acc[0] = a0; acc[1] = a1; acc[2] = a2;
 }
 
-// RAW (VR_FLAG_RAW_PARAMS) is a compile-time switch: the default instantiation is the kernel as it was
-template <bool RAW>
+// LDS row stride of the HALF path: half an SH row (8 coefficients = 24 floats) + one float4 of padding = 7 x 16 bytes
+// (odd: the per-lane float4 row reads are conflict-free, as with 13 above)
+constexpr int SH_HALF_STRIDE = 28;
+
+// RAW (VR_FLAG_RAW_PARAMS) is a compile-time switch: the default instantiation is the kernel as it was.
+// HALF (round 5): the whole-tensor, 16-coefficient SH layout (the op's plain `shs` argument: the headline path) staged
+// through LDS in two HALVES of 8 coefficients and evaluated coefficient by coefficient (sh_accumulate: the operations of
+// sh_dot / sh_ddir9 in their order, bit for bit) instead of 48-float rows against whole basis tables: 7 instead of 13 KB
+// of LDS per wave and ~60 registers fewer -- the kernel is bound by the latency of its three dependent memory round trips
+// per wave (means -> scales / rotations -> SH rows) at whatever occupancy it gets, and both resources held it to 3 waves
+// per SIMD.
+template <bool RAW, bool HALF>
 #ifndef PRE_THREADS
 #define PRE_THREADS 128      // (two waves per workgroup: the same three waves per SIMD in finer grains, 159 -> 157.5 us; one wave: 170 VGPRs, 189 us)
 #endif
@@ -51,7 +63,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
              uint4* __restrict__ rect, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tile_count,
              uint8_t* __restrict__ clampb, float* __restrict__ shd)
 {
-    __shared__ __attribute__((aligned(16))) float sh_lds[PRE_THREADS / 64][64 * SH_LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float sh_lds[PRE_THREADS / 64][64 * (HALF ? SH_HALF_STRIDE : SH_LDS_STRIDE)];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool in_range = i < P;
@@ -61,12 +73,34 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
     float px = 0.f, py = 0.f, t2 = 0.f, conA = 0.f, conB = 0.f, conC = 0.f;
     float q[4] = {0.f, 0.f, 0.f, 0.f}, sc[3] = {0.f, 0.f, 0.f};
     float px3 = 0.f, py3 = 0.f, pz3 = 0.f;
+    float t0 = 0.f, t1 = 0.f;
     if (in_range) {
         px3 = means3D[3 * (size_t)i];
         py3 = means3D[3 * (size_t)i + 1];
         pz3 = means3D[3 * (size_t)i + 2];
-        float t0, t1;
         xform43(cam.view, px3, py3, pz3, t0, t1, t2);
+    }
+    // HALF: the SH rows of the Gaussians in front of the near plane are requested HERE -- one memory round trip earlier
+    // than "once the lane knows it is visible": the loads travel while the covariance, the radius and the tile test are
+    // computed (the 4 % of rows that fail those tests are fetched for nothing).  Both halves of a row, 12 loads per lane.
+    float4 tA[HALF ? 6 : 1], tB[HALF ? 6 : 1];
+    unsigned long long front_rows = 0ull;
+    if (HALF && shs) {
+        front_rows = __ballot(in_range && t2 > NEAR_Z);
+        if (front_rows != 0ull) {
+            const size_t wave_first = (size_t)(blockIdx.x * blockDim.x + w * 64);
+            const float4* src4 = reinterpret_cast<const float4*>(shs + wave_first * 48);
+#pragma unroll
+            for (int j = 0; j < (HALF ? 6 : 1); ++j) {
+                const int v = lane + 64 * j, r = v / 6, c = v - r * 6;
+                if ((front_rows >> r) & 1ull) {           // (rows beyond P are not `front`)
+                    tA[j] = nt_load4(&src4[r * 12 + c]);
+                    tB[j] = nt_load4(&src4[r * 12 + 6 + c]);
+                }
+            }
+        }
+    }
+    if (in_range) {
         if (t2 > NEAR_Z) {
             float h0, h1, h2;
             xform43(cam.proj, px3, py3, pz3, h0, h1, h2);
@@ -174,6 +208,72 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
         if (vis) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) rgb[c] = colors_precomp[3 * (size_t)i + c];
+        }
+    } else if (HALF) {
+        // (host-checked: shs is the whole [P,16,3] tensor, 16-byte aligned; no split storage, no tail)
+        const unsigned long long vis_rows = __ballot(vis);
+        if (vis_rows != 0ull) {
+            const size_t wave_first = (size_t)(blockIdx.x * blockDim.x + w * 64);
+            const int rows_here = min(64, P - (int)wave_first);
+            float4* dst4 = reinterpret_cast<float4*>(sh_lds[w]);
+            // (the rows were requested above, both halves; the second half waits in registers while the first is evaluated)
+            int at[6];
+            bool ok[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int v = lane + 64 * j, r = v / 6, c = v - r * 6;
+                ok[j] = ((vis_rows & front_rows) >> r) & 1ull;
+                at[j] = r * (SH_HALF_STRIDE / 4) + c;
+            }
+            float x = 0.f, y = 0.f, z = 0.f;
+            if (vis) {
+                x = px3 - cam.campos[0]; y = py3 - cam.campos[1]; z = pz3 - cam.campos[2];
+                const float len = sqrtf(fmaf(z, z, fmaf(y, y, x * x)));
+                x = x / len; y = y / len; z = z / len;
+            }
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            const int K = (cam.deg + 1) * (cam.deg + 1);
+            float acc[3] = {0.f, 0.f, 0.f}, D[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float4* my4 = dst4 + lane * (SH_HALF_STRIDE / 4);
+#define VR_SH_K(KK, F) if (KK < K) sh_accumulate<KK>(x, y, z, xx, yy, zz, xy, yz, xz, &F[3 * ((KK) & 7)], acc, D)
+#define VR_SH_HALF(BASE)                                                                                                  \
+            if (vis) {                                                                                                    \
+                float f[24];                                                                                              \
+                _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                                           \
+                    const float4 t = my4[j];                                                                              \
+                    f[4 * j] = t.x; f[4 * j + 1] = t.y; f[4 * j + 2] = t.z; f[4 * j + 3] = t.w;                           \
+                }                                                                                                         \
+                VR_SH_K(BASE + 0, f); VR_SH_K(BASE + 1, f); VR_SH_K(BASE + 2, f); VR_SH_K(BASE + 3, f);                   \
+                VR_SH_K(BASE + 4, f); VR_SH_K(BASE + 5, f); VR_SH_K(BASE + 6, f); VR_SH_K(BASE + 7, f);                   \
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (ok[j]) dst4[at[j]] = tA[j];
+            __builtin_amdgcn_wave_barrier();
+            VR_SH_HALF(0)
+            __builtin_amdgcn_wave_barrier();
+            if (K > 8) {                                         // (wave-uniform: degree 0 and 1 need the first half only)
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    if (ok[j]) dst4[at[j]] = tB[j];
+                __builtin_amdgcn_wave_barrier();
+                VR_SH_HALF(8)
+                __builtin_amdgcn_wave_barrier();
+            }
+#undef VR_SH_HALF
+#undef VR_SH_K
+            {   // the wave's 64 D rows, one contiguous 2304-byte block: through LDS (row stride 9), out as float4s
+                float* myd = sh_lds[w] + lane * 9;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) myd[q] = vis ? D[q] : 0.0f;
+                __builtin_amdgcn_wave_barrier();
+                wave_copy_from_lds<3>(shd + wave_first * 9, sh_lds[w], rows_here * 9, lane, false);
+            }
+            if (vis) {
+                acc[0] += 0.5f; acc[1] += 0.5f; acc[2] += 0.5f;
+                clampbits = (acc[0] < 0.0f ? 1u : 0u) | (acc[1] < 0.0f ? 2u : 0u) | (acc[2] < 0.0f ? 4u : 0u);
+                rgb[0] = fmaxf(acc[0], 0.0f); rgb[1] = fmaxf(acc[1], 0.0f); rgb[2] = fmaxf(acc[2], 0.0f);
+            }
         }
     } else if (__ballot(vis) != 0ull) {
         // stage this wave's 64 SH rows (contiguous in memory) through LDS, coalesced
@@ -342,12 +442,18 @@ int launch_preprocess(const Camera& cam, int P, const float* means3D, const floa
                       uint32_t* depth_key, uint32_t* tile_count, uint8_t* clampb, float* shd, hipStream_t s, bool debug)
 {
     if (P == 0) return 0;
-    if (cam.flags & FLAG_RAW_PARAMS)
-        hipLaunchKernelGGL(k_preprocess<true>, dim3(cdiv(P, PRE_THREADS)), dim3(PRE_THREADS), 0, s, cam, P, means3D, shs, shs_rest, shs_tail,
-                           tail_start, colors_precomp, opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, tile_count, clampb, shd);
-    else
-        hipLaunchKernelGGL(k_preprocess<false>, dim3(cdiv(P, PRE_THREADS)), dim3(PRE_THREADS), 0, s, cam, P, means3D, shs, shs_rest, shs_tail,
-                           tail_start, colors_precomp, opacities, scales, rotations, cov3D_precomp, rec, radii, rect, depth_key, tile_count, clampb, shd);
+    // HALF: the plain whole-tensor SH layout with all 16 coefficients stored (see k_preprocess); VEGS_PRE_HALF=0 keeps the
+    // 48-float rows (A/B measurements)
+    static const bool half_ok = [] { const char* e = getenv("VEGS_PRE_HALF"); return !(e && e[0] == '0'); }();
+    const bool half = half_ok && shs && !colors_precomp && !shs_rest && !shs_tail && cam.M == 16 &&
+                      (reinterpret_cast<size_t>(shs) & 15) == 0;
+#define VR_PRE(RAWP, HALFP)                                                                                               \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_preprocess<RAWP, HALFP>), dim3(cdiv(P, PRE_THREADS)), dim3(PRE_THREADS), 0, s, cam, P, \
+                       means3D, shs, shs_rest, shs_tail, tail_start, colors_precomp, opacities, scales, rotations,         \
+                       cov3D_precomp, rec, radii, rect, depth_key, tile_count, clampb, shd)
+    if (cam.flags & FLAG_RAW_PARAMS) { if (half) VR_PRE(true, true); else VR_PRE(true, false); }
+    else { if (half) VR_PRE(false, true); else VR_PRE(false, false); }
+#undef VR_PRE
     VR_KERNEL_CHECK("preprocess", s, debug);
     return 0;
 }

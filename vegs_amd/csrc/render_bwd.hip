@@ -213,7 +213,7 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     __shared__ float stage[64 * NACC];            // one chunk's per-entry sums, entry-major, for the coalesced flush
     __shared__ uint32_t rel_gid[SEG];             // the strip's relevant entries, ascending: Gaussian id ...
     __shared__ unsigned short rel_j[SEG];         // ... and entry index inside the segment
-    __shared__ float4 pixrec[32][8];              // per PIXEL PAIR: coords, bg term, 11 upstream grads, carries
+    __shared__ float4 pix[8][32];                 // per PIXEL PAIR [slot][pair]: coords, bg term, 11 upstream grads, carries
     SegCtx c;
     const int w = (int)(blockIdx.x & 3u);
     const int ntiles = cam.gx * cam.gy;
@@ -277,12 +277,25 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     // gets every quantity as a ready-made (a,b) register pair for packed fp32 math.  float4 slots:
     //   0 {px_a px_b py_a py_b}  1 {bg_a bg_b g0_a g0_b}  2 {g1 g2}  3 {g3 g4}  4 {g5 g6}  5 {g7 g8}
     //   6 {g9 g10}  7 {Tcar_a Tcar_b Scar_a Scar_b} -- the two carries, updated in place by lane 63.
+    // SLOT-MAJOR, pix[slot][pair], and written as whole float4s by the EVEN lanes (the odd pixel's values come over DPP):
+    // eight ds_write_b128 at 32 consecutive addresses.  Round 4 had every lane store its 16 scalars into pixrec[pair][.] +
+    // (lane & 1): a lane stride of 32 floats per pair put 32 lanes on each of two banks -- 16 stores of ~32 cycles per
+    // workgroup, and that, not the loop's broadcast reads, was the kernel's SQ_LDS_BANK_CONFLICT count (0.71 of its
+    // SQ_ACTIVE_INST_LDS; profiles/tools/ubench/lds_pixrec.hip measures both patterns).
     {
-        float* rec2 = reinterpret_cast<float*>(&pixrec[lane >> 1][0]) + (lane & 1);
-        rec2[0] = v_pxf; rec2[2] = v_pyf; rec2[4] = v_bgterm;
+        float mine[16];
+        mine[0] = v_pxf; mine[1] = v_pyf; mine[2] = v_bgterm;
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) rec2[6 + 2 * k] = pg.g[k];
-        rec2[28] = v_Tcar; rec2[30] = v_Scar;
+        for (int k = 0; k < NCH; ++k) mine[3 + k] = pg.g[k];
+        mine[14] = v_Tcar; mine[15] = v_Scar;
+        float other[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) other[k] = __shfl_xor(mine[k], 1, 64);
+        if ((lane & 1) == 0) {
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl)
+                pix[sl][lane >> 1] = make_float4(mine[2 * sl], other[2 * sl], mine[2 * sl + 1], other[2 * sl + 1]);
+        }
     }
     __syncthreads();
 
@@ -327,7 +340,7 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
             for (int pp = 0; pp < 32; ++pp) {
                 const int nc0 = __builtin_amdgcn_readlane(v_nc, 2 * pp), nc1 = __builtin_amdgcn_readlane(v_nc, 2 * pp + 1);
                 if (max(nc0, nc1) <= chunk_lo) continue;  // neither pixel has a contributor in this chunk (wave-uniform)
-                const float4 r0 = pixrec[pp][0];
+                const float4 r0 = pix[0][pp];
                 const f2 pxf = {r0.x, r0.y}, pyf = {r0.z, r0.w};
                 f2 dx, dy;
                 const f2 power = splat_power2_x2(sx, sy, kA, kB, kC, pxf, pyf, dx, dy);    // in units of log2 e, as the forward
@@ -363,8 +376,8 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                 const f2 a_eff = {contrib0 ? alpha.x : 0.0f, contrib1 ? alpha.y : 0.0f};
                 G.x = contrib0 ? G.x : 0.0f;              // (exp of a positive exponent may be inf: keep it out of 0*inf)
                 G.y = contrib1 ? G.y : 0.0f;
-                const float4 r1 = pixrec[pp][1], r2 = pixrec[pp][2], r3 = pixrec[pp][3], r4 = pixrec[pp][4],
-                             r5 = pixrec[pp][5], r6 = pixrec[pp][6], r7 = pixrec[pp][7];
+                const float4 r1 = pix[1][pp], r2 = pix[2][pp], r3 = pix[3][pp], r4 = pix[4][pp],
+                             r5 = pix[5][pp], r6 = pix[6][pp], r7 = pix[7][pp];
                 const f2 bgterm = {r1.x, r1.y}, Tc = {r7.x, r7.y}, Sc = {r7.z, r7.w};
                 const f2 g[NCH] = {{r1.z, r1.w}, {r2.x, r2.y}, {r2.z, r2.w}, {r3.x, r3.y}, {r3.z, r3.w}, {r4.x, r4.y},
                                    {r4.z, r4.w}, {r5.x, r5.y}, {r5.z, r5.w}, {r6.x, r6.y}, {r6.z, r6.w}};
@@ -394,7 +407,7 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                 // carries for the next (nearer) chunk: values at the chunk's first entry = lane 63
                 if (lane == 63) {
                     const f2 Sn = Sc + psum;
-                    pixrec[pp][7] = make_float4(Tl.x, Tl.y, Sn.x, Sn.y);
+                    pix[7][pp] = make_float4(Tl.x, Tl.y, Sn.x, Sn.y);
                 }
                 if (contrib0 || contrib1) {
                     // Per-fragment work kept to what depends on the pixel.  With a = dL/dG * G (zero for a lane that does

@@ -457,6 +457,49 @@ __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z
 // D[3*c + a] = d colour_c / d direction_a = sum_k grad_a basis_k(dir) * sh[k][c]  (before normalisation of the
 // direction and before the clamp).  Computed in the FORWARD, next to the colour itself, and kept (9 floats per
 // visible Gaussian): the backward then needs neither the 192-byte SH row nor the basis gradients again.
+// One basis function and its gradient at a time (index K known at compile time): b = basis_K(x, y, z) and (bx, by, bz) its
+// partial derivatives, with the SAME expressions as sh_basis / sh_basis_grad above (bit-identical values) -- for callers
+// that consume the coefficients in order and cannot afford the 64 registers the whole tables take (k_preprocess, HALF path).
+// xx, yy, zz, xy, yz, xz: the products sh_basis forms (x * x ...).
+template <int K>
+__device__ __forceinline__ void sh_term(float x, float y, float z, float xx, float yy, float zz, float xy, float yz, float xz,
+                                        float& b, float& bx, float& by, float& bz)
+{
+    bx = 0.f; by = 0.f; bz = 0.f;
+    if (K == 0) { b = SH_C0; }
+    else if (K == 1) { b = -SH_C1 * y; by = -SH_C1; }
+    else if (K == 2) { b = SH_C1 * z; bz = SH_C1; }
+    else if (K == 3) { b = -SH_C1 * x; bx = -SH_C1; }
+    else if (K == 4) { b = SH_C2[0] * xy; bx = SH_C2[0] * y; by = SH_C2[0] * x; }
+    else if (K == 5) { b = SH_C2[1] * yz; by = SH_C2[1] * z; bz = SH_C2[1] * y; }
+    else if (K == 6) { b = SH_C2[2] * (2.0f * zz - xx - yy); bx = SH_C2[2] * -2.0f * x; by = SH_C2[2] * -2.0f * y; bz = SH_C2[2] * 4.0f * z; }
+    else if (K == 7) { b = SH_C2[3] * xz; bx = SH_C2[3] * z; bz = SH_C2[3] * x; }
+    else if (K == 8) { b = SH_C2[4] * (xx - yy); bx = SH_C2[4] * 2.0f * x; by = SH_C2[4] * -2.0f * y; }
+    else if (K == 9) { b = SH_C3[0] * y * (3.0f * xx - yy); bx = SH_C3[0] * 6.0f * x * y; by = SH_C3[0] * (3.0f * xx - 3.0f * yy); }
+    else if (K == 10) { b = SH_C3[1] * xy * z; bx = SH_C3[1] * y * z; by = SH_C3[1] * x * z; bz = SH_C3[1] * x * y; }
+    else if (K == 11) { b = SH_C3[2] * y * (4.0f * zz - xx - yy); bx = SH_C3[2] * -2.0f * x * y; by = SH_C3[2] * (4.0f * zz - xx - 3.0f * yy); bz = SH_C3[2] * 8.0f * y * z; }
+    else if (K == 12) { b = SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy); bx = SH_C3[3] * -6.0f * x * z; by = SH_C3[3] * -6.0f * y * z; bz = SH_C3[3] * (6.0f * zz - 3.0f * xx - 3.0f * yy); }
+    else if (K == 13) { b = SH_C3[4] * x * (4.0f * zz - xx - yy); bx = SH_C3[4] * (4.0f * zz - 3.0f * xx - yy); by = SH_C3[4] * -2.0f * x * y; bz = SH_C3[4] * 8.0f * x * z; }
+    else if (K == 14) { b = SH_C3[5] * z * (xx - yy); bx = SH_C3[5] * 2.0f * x * z; by = SH_C3[5] * -2.0f * y * z; bz = SH_C3[5] * (xx - yy); }
+    else { b = SH_C3[6] * x * (xx - 3.0f * yy); bx = SH_C3[6] * (3.0f * xx - 3.0f * yy); by = SH_C3[6] * -6.0f * x * y; }
+}
+// acc / D of sh_dot / sh_ddir9 advanced by coefficient K (sv = the coefficient's three channels): the same operations in
+// the same order as those two loops, including the fmas whose basis gradient is an exact zero
+template <int K>
+__device__ __forceinline__ void sh_accumulate(float x, float y, float z, float xx, float yy, float zz, float xy, float yz,
+                                              float xz, const float* sv, float* acc, float* D)
+{
+    float b, bx, by, bz;
+    sh_term<K>(x, y, z, xx, yy, zz, xy, yz, xz, b, bx, by, bz);
+    if (K == 0) { acc[0] = b * sv[0]; acc[1] = b * sv[1]; acc[2] = b * sv[2]; }
+    else { acc[0] = fmaf(b, sv[0], acc[0]); acc[1] = fmaf(b, sv[1], acc[1]); acc[2] = fmaf(b, sv[2], acc[2]); }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        D[3 * c + 0] = fmaf(bx, sv[c], D[3 * c + 0]);
+        D[3 * c + 1] = fmaf(by, sv[c], D[3 * c + 1]);
+        D[3 * c + 2] = fmaf(bz, sv[c], D[3 * c + 2]);
+    }
+}
 __device__ __forceinline__ void sh_ddir9(const float* bx, const float* by, const float* bz, int K, const float* sh, float* D)
 {
 #pragma unroll

@@ -33,6 +33,13 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guide: MI355X_MICROARCH.md chi
 VALU_PEAK_GINST = 1228.8   # wave64 VALU instructions per ns: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles (same guide)
 
 
+def _trace(msg):
+    """Progress markers on stderr (VEGS_BENCH_TRACE=1): where a run was when something outside Python ended it."""
+    if os.environ.get("VEGS_BENCH_TRACE") == "1":
+        torch.cuda.synchronize()
+        print(f"[bench trace] {msg}", file=sys.stderr, flush=True)
+
+
 def profile_figures(kern, sources):
     """(HBM traffic bytes per launch, VALU wave-instructions per launch, provenance) of `kern` from the committed PMC
     profile (profiles/pmc_traffic.json) -- or (None, None, reason) when a source file of that kernel has changed since
@@ -562,7 +569,9 @@ def main():
     n_views = len(cams)
     from vegs_amd import rasterizer
     rasterizer.needed_hints(False)
+    _trace("workload built")
     wl = prepare(sc, deg, cams, device, np.random.default_rng(1234))
+    _trace("prepared")
     counters, gouts = wl["counters"], wl["gouts"]
     vps = max(1, args.views_per_step)
     # --exchange auto (the default): THIS process times the headline regions with the RCCL exchange (factored, overlapped)
@@ -604,6 +613,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    _trace("warm")
     _capi.profile_level(1)          # level 1: HIP events around the roofline kernel only (one launch in four), inside the timed region
     _capi.profile_collect()
     mallocs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
@@ -613,6 +623,7 @@ def main():
     elapsed, views_done, region_s = timed_median(step, args.steps, world, args.repeats, first=args.warmup)
     stage = _capi.profile_collect()
     _capi.profile_level(0)
+    _trace("timed")
     mallocs1 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
 
     frag_local = float(sum(counters[v]["F"] for v in views_done))
@@ -660,6 +671,7 @@ def main():
     if rank != 0:
         return
     stage_ms = stage_profile(step, 8) if world == 1 else {}
+    _trace("stages profiled")
     views = args.steps * world * vps
     value = views / elapsed
     mean = {k: float(np.mean([counters[v][k] for v in views_done])) for k in ("Pz", "V", "R", "R_lists", "F", "F_lists", "B")}

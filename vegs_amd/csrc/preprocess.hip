@@ -80,26 +80,6 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
         pz3 = means3D[3 * (size_t)i + 2];
         xform43(cam.view, px3, py3, pz3, t0, t1, t2);
     }
-    // HALF: the SH rows of the Gaussians in front of the near plane are requested HERE -- one memory round trip earlier
-    // than "once the lane knows it is visible": the loads travel while the covariance, the radius and the tile test are
-    // computed (the 4 % of rows that fail those tests are fetched for nothing).  Both halves of a row, 12 loads per lane.
-    float4 tA[HALF ? 6 : 1], tB[HALF ? 6 : 1];
-    unsigned long long front_rows = 0ull;
-    if (HALF && shs) {
-        front_rows = __ballot(in_range && t2 > NEAR_Z);
-        if (front_rows != 0ull) {
-            const size_t wave_first = (size_t)(blockIdx.x * blockDim.x + w * 64);
-            const float4* src4 = reinterpret_cast<const float4*>(shs + wave_first * 48);
-#pragma unroll
-            for (int j = 0; j < (HALF ? 6 : 1); ++j) {
-                const int v = lane + 64 * j, r = v / 6, c = v - r * 6;
-                if ((front_rows >> r) & 1ull) {           // (rows beyond P are not `front`)
-                    tA[j] = nt_load4(&src4[r * 12 + c]);
-                    tB[j] = nt_load4(&src4[r * 12 + 6 + c]);
-                }
-            }
-        }
-    }
     if (in_range) {
         if (t2 > NEAR_Z) {
             float h0, h1, h2;
@@ -216,14 +196,25 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
             const size_t wave_first = (size_t)(blockIdx.x * blockDim.x + w * 64);
             const int rows_here = min(64, P - (int)wave_first);
             float4* dst4 = reinterpret_cast<float4*>(sh_lds[w]);
-            // (the rows were requested above, both halves; the second half waits in registers while the first is evaluated)
+            // Both halves of the wave's rows are requested at once (12 loads per lane in flight, rows of culled Gaussians left
+            // out); the second half waits in registers while the first is evaluated.  (Requesting them a round trip EARLIER --
+            // for every Gaussian in front of the near plane, before the covariance and the tile test -- measured slower,
+            // 0.152 against 0.148 ms, AND three bench runs of four with that build ended in a memory fault in k_emit_scan
+            // (garbage ids out of the depth sort; never with this one, same sources otherwise).  The cause was not found;
+            // the variant is gone: profiles/experiments/README.md.)
+            const float4* src4 = reinterpret_cast<const float4*>(shs + wave_first * 48);
+            float4 tA[6], tB[6];
             int at[6];
             bool ok[6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const int v = lane + 64 * j, r = v / 6, c = v - r * 6;
-                ok[j] = ((vis_rows & front_rows) >> r) & 1ull;
+                ok[j] = (vis_rows >> r) & 1ull;
                 at[j] = r * (SH_HALF_STRIDE / 4) + c;
+                if (ok[j]) {
+                    tA[j] = nt_load4(&src4[r * 12 + c]);
+                    tB[j] = nt_load4(&src4[r * 12 + 6 + c]);
+                }
             }
             float x = 0.f, y = 0.f, z = 0.f;
             if (vis) {

@@ -210,6 +210,8 @@ def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="trai
             m2d.grad = None
             return
         sink = torch.zeros_like(T["means3D"], requires_grad=True) if factored else None
+        if factored and not fact_x and vps > 1:
+            sinks.append((sink, cam_ts[v]["campos"]))
         pkg = harness.render(cams[v], T, deg, bg, cam_t=cam_ts[v], sh_color_grad=sink)
         if fact_x:          # overlapped exchange: the factors start travelling between the backward's two halves
             with xch.armed(cam_ts[v]["campos"]):
@@ -217,8 +219,11 @@ def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="trai
         else:
             torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], [gc, gq, gs])
 
+    sinks = []
+
     def step(i):
         done = []
+        sinks.clear()
         for k in range(vps):
             v = vdist.view_for_rank(i * vps + k, rank, world, n_views)
             vs.run(one_view, v)
@@ -232,6 +237,13 @@ def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="trai
             T["shs"].grad = optim.sh_grad_from_factors(T["means3D"].detach(), Cc, F, deg, T["shs"].shape[1], 1.0 / world)
         elif world > 1 and exchange_on:
             vdist.allreduce_grads(params, world)
+        if sinks:
+            # a multi-view step with the factored SH gradient: the dense [P,16,3] gradient of the STEP is rebuilt once from
+            # the views' 3-float factors (inside the timed region: the step ends with the same tensors as the dense batch)
+            from vegs_amd import optim
+            F = torch.stack([s_.grad for s_, _ in sinks])
+            Cc = torch.stack([c.reshape(3) for _, c in sinks]).to(F.device, torch.float32)
+            T["shs"].grad = optim.sh_grad_from_factors(T["means3D"].detach(), Cc, F, deg, T["shs"].shape[1], 1.0)
         for p in params:
             p.grad = None
         return done
@@ -547,6 +559,9 @@ def main():
                     help="multiply every Gaussian's scales (3.0 = the 'dense' variant's scene); a profiling aid, changes the workload")
     ap.add_argument("--streams", type=int, default=1,
                     help="with --views-per-step > 1: HIP streams the views of a step alternate between (2 = two views in flight)")
+    ap.add_argument("--accumulate", action="store_true",
+                    help="with --views-per-step > 1: accumulate the views' gradients IN PLACE (rasterizer.accumulate_grads; "
+                         "not the headline configuration)")
     ap.add_argument("--views-per-step", type=int, default=1,
                     help="views each rank renders per step; their gradients accumulate locally and are exchanged once")
     args = ap.parse_args()
@@ -569,6 +584,7 @@ def main():
     n_views = len(cams)
     from vegs_amd import rasterizer
     rasterizer.needed_hints(False)
+    rasterizer.accumulate_grads(bool(args.accumulate))
     _trace("workload built")
     wl = prepare(sc, deg, cams, device, np.random.default_rng(1234))
     _trace("prepared")
@@ -747,7 +763,7 @@ def main():
                                + (f"EVERY DISC x{args.disc_scale} (--disc-scale: not the headline workload); " if args.disc_scale != 1.0 else "")
                                + "every view is rendered as a camera's first visit (no per-camera state carried between views)",
                    "hints": "off",
-                   "gaussians": P, "width": W, "height": H, "views_per_step_per_gpu": vps,
+                   "gaussians": P, "width": W, "height": H, "views_per_step_per_gpu": vps, "accumulate_in_place": bool(args.accumulate),
                    "parallelism": f"view-sharded x{world}" + ("" if world == 1 else
                                                               " + direct hipIpc all-gather of SH factors (3 f32) + reduce-scatter/all-gather (11 f32) per Gaussian"
                                                               if args.exchange == "direct" and vps == 1 else
@@ -809,6 +825,11 @@ def main():
                     device, 4, 1, vps=8, accumulate=True),
             variant("headline scene, a batch of 8 views per iteration, gradients accumulated in place, TWO VIEWS IN FLIGHT "
                     "on two HIP streams", sc, deg, cams, device, 4, 1, vps=8, streams=2, accumulate=True),
+            variant("headline scene, a batch of 8 views per iteration on ONE stream, the 11 non-SH floats accumulated in place "
+                    "and the SH gradient kept FACTORED per view (3 floats), the step's dense [P,16,3] gradient rebuilt once "
+                    "from the 8 factors inside the timed region", sc, deg, cams, device, 4, 1, vps=8, accumulate=True, factored=True),
+            variant("headline scene, a batch of 8 views, in-place accumulation + factored SH, TWO VIEWS IN FLIGHT", sc, deg,
+                    cams, device, 4, 1, vps=8, streams=2, accumulate=True, factored=True),
             variant("headline scene with VR_FLAG_FULL_TILE_LISTS: every tile of the reference's rectangles a list entry (the "
                     "build's default leaves out the third of them whose tile the splat cannot reach: same radii, images and "
                     "gradients to rounding) -- what the tight lists buy", sc, deg, cams, device, 16, 4, flags=rasterizer.FLAG_FULL_TILE_LISTS),

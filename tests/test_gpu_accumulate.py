@@ -186,3 +186,40 @@ def test_non_leaf_inputs_take_the_plain_path(dev):
     a, b = batch(False), batch(True)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_factored_sh_plus_in_place_accumulation_equals_the_dense_batch(dev):
+    """The cheapest multi-view step on one GPU: the 11 non-SH floats accumulate in place, the SH gradient stays FACTORED per
+    view (the op's sh_color_grad: 3 floats) and the step's dense [P,16,3] gradient is rebuilt ONCE from the views' factors
+    (vegs_amd.optim.sh_grad_from_factors).  Same gradients as the dense batch: the in-place sums bit for bit, the rebuilt SH
+    gradient to fp32 re-association (the sum over views is taken inside the rebuild)."""
+    from helpers import assert_grad_close
+    from vegs_amd import harness, optim
+    sc, deg, cams, cam_ts = _scene(dev, P=60000, deg=3)
+    T = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in sc.items()}
+    bg = torch.zeros(3, device=dev)
+    gouts = _gouts(dev, 4)
+
+    def dense(v):
+        pkg = harness.render(cams[v], T, deg, bg, cam_t=cam_ts[v])
+        torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], gouts[v])
+        return pkg["viewspace_points"].grad
+    want, _ = _batch(T, dense, 4, dev, False)
+    sinks = []
+
+    def factored(v):
+        sink = torch.zeros_like(T["means3D"], requires_grad=True)
+        pkg = harness.render(cams[v], T, deg, bg, cam_t=cam_ts[v], sh_color_grad=sink)
+        torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], gouts[v])
+        sinks.append(sink)
+        return pkg["viewspace_points"].grad
+    others = {k: T[k] for k in ("means3D", "opacities", "scales", "rotations")}
+    T["shs"].grad = None
+    got, _ = _batch(others, factored, 4, dev, True)
+    assert T["shs"].grad is None and len(sinks) == 4            # the op produced no dense SH gradient at all
+    for k in others:
+        assert torch.equal(want[k], got[k]), k
+    F = torch.stack([s.grad for s in sinks])
+    C = torch.stack([cam_ts[v]["campos"].reshape(3) for v in range(4)]).to(dev, torch.float32)
+    g_sh = optim.sh_grad_from_factors(T["means3D"].detach(), C, F, deg, 16, 1.0)
+    assert_grad_close("rebuilt SH gradient of the step", g_sh.cpu().numpy(), want["shs"].cpu().numpy(), rtol=1e-4, floor=1e-6)

@@ -14,6 +14,8 @@
 // R-sized traffic is 2 passes of 8-byte pairs instead of upstream's 6 passes of 12-byte pairs.
 // Ranking inside a pass uses wave64 ballots (match-by-digit), no per-element atomics.
 #include "../../include/vegs_rast.h"
+#include <stdlib.h>
+
 #include "vr_host.h"
 
 namespace vr {
@@ -1192,6 +1194,12 @@ __device__ __forceinline__ unsigned long long sum_posted_wave(const unsigned lon
     }
 }
 
+// ITEMS batches of 256 depth-sorted Gaussians per workgroup (round 5).  The kernel is bound by the latency of its dependent
+// round trips -- id -> rectangle gather -> posted sums of the workgroups before it -- and a view's 6.4 k workgroups of 256
+// came in three resident sets; with 2 batches per workgroup the gathers of both are in flight together, half as many
+// workgroups post and look back, and the sets go from three to two.  Emission order and positions are what they were: batch
+// k of the workgroup lies behind batch k - 1.
+template <int ITEMS>
 __global__ void __launch_bounds__(256)
 k_emit_scan(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint4* __restrict__ rect,
             unsigned long long* __restrict__ status, uint32_t* __restrict__ err, uint32_t* __restrict__ tkeys,
@@ -1199,21 +1207,32 @@ k_emit_scan(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint4* 
 {
     __shared__ uint32_t lds4[4];
     __shared__ unsigned long long s_before;
-    const int r = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    uint32_t cnt = 0, id = 0;
-    uint4 rc = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t cnt[ITEMS], id[ITEMS];
+    uint4 rc[ITEMS];
     // (a wait of this view's depth sort ran out: `sorted_id` may hold anything -- it is not used as an index; see k_onesweep)
     if (st_load(err) != 0u) return;
-    if (r < V) {
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const int r = (blockIdx.x * ITEMS + k) * 256 + threadIdx.x;
+        cnt[k] = 0; id[k] = 0;
+        if (r < V) id[k] = sorted_id[r];
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const int r = (blockIdx.x * ITEMS + k) * 256 + threadIdx.x;
+        rc[k] = make_uint4(0u, 0u, 0u, 0u);
         // the packed rectangle + tile mask is gathered by id HERE (1.65 M random 16-byte reads): this kernel is bound by
         // the latency of its waits, not by bandwidth, and hides them; in the last depth-sort pass they cost 22 us
-        id = sorted_id[r];
-        rc = rect[id];
-        cnt = rect_area(rc);
+        if (r < V) { rc[k] = rect[id[k]]; cnt[k] = rect_area(rc[k]); }
     }
-    uint32_t total;
-    const uint32_t ex = block_excl_scan(cnt, total, lds4);
+    uint32_t ex[ITEMS], total = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        uint32_t t;
+        ex[k] = block_excl_scan(cnt[k], t, lds4) + total;
+        total += t;
+    }
     if (threadIdx.x < 64) {
         const long b = blockIdx.x, nblk = gridDim.x, n2 = (nblk + EFAN - 1) / EFAN;
         unsigned long long* const level2 = status + nblk;
@@ -1234,8 +1253,9 @@ k_emit_scan(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint4* 
         if (lane == 0) s_before = within + upper;
     }
     __syncthreads();
-    const uint32_t off = (uint32_t)s_before + ex;
-    emit_rects(rc, cnt, off, id, gx, lane, tkeys, tvals, big_list);
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k)
+        emit_rects(rc[k], cnt[k], (uint32_t)s_before + ex[k], id[k], gx, lane, tkeys, tvals, big_list);
 }
 
 // Also (thread 0 of the launch): the look-back guard word as it stands after ALL waiting passes of this view, posted
@@ -1428,7 +1448,10 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
         big_list.items = (uint2*)(base + L.big);
         big_list.count = (uint32_t*)(st + sp.depth + sp.emit - 16);        // (cleared with the status words)
         big_list.inline_big = emit_big_inline(n_huge);
-        hipLaunchKernelGGL(k_emit_scan, dim3(cdiv(V, 256)), dim3(256), 0, s, V, cam.gx, (const uint32_t*)sorted_id,
+        // (one batch of 256 Gaussians per workgroup: with 2 / 4 batches -- half / a quarter of the posted sums and look-backs,
+        // the gathers of all batches in flight together -- the stage went 66 -> 81 / 93 us: the serial emission of a
+        // workgroup's batches outweighs what the shorter look-back saves; round 5, profiles/experiments/README.md)
+        hipLaunchKernelGGL(k_emit_scan<1>, dim3(cdiv(V, 256)), dim3(256), 0, s, V, cam.gx, (const uint32_t*)sorted_id,
                            rect, (unsigned long long*)(st + sp.depth), err, tkeysA, va, big_list);
         if (!big_list.inline_big)
             hipLaunchKernelGGL(k_emit_big, dim3(EMIT_BIG_GRID), dim3(64), 0, s, big_list, rect, cam.gx, tkeysA, va);

@@ -388,7 +388,7 @@ class Trainer:
 
     def step_views(self, views, deg, bg, keep_grads=False):
         """One iteration over `views` (dicts cam, cam_t, gt, normal): this process's share of the iteration's view batch."""
-        from . import boxmodel, optim
+        from . import boxmodel, optim, rasterizer
         from . import dist as vdist
         self.iteration += 1
         world, n_local = self.world, len(views)
@@ -407,11 +407,18 @@ class Trainer:
         for v in views:
             ct = v.get("cam_t") or harness.cam_tensors(v["cam"], self.device)
             loss, pkg = self.forward_loss(v["cam"], ct, deg, bg, v["gt"], v["normal"])
-            if overlap:          # the factors start travelling between the backward's two halves
-                with (self.xch if self.xch is not None else self.direct).armed(ct["campos"]):
+            # several local views: from the second one on the fused operator adds its rows straight into the leaves' .grad
+            # (rasterizer.accumulate_grads: the same fp32 adds autograd would make, in the same order, without the dense
+            # write + read-read-write per view; applies where the op's inputs ARE the leaf parameters -- no instances in frame)
+            old_acc = rasterizer.accumulate_grads(self.fused and n_local > 1)
+            try:
+                if overlap:          # the factors start travelling between the backward's two halves
+                    with (self.xch if self.xch is not None else self.direct).armed(ct["campos"]):
+                        loss.backward()
+                else:
                     loss.backward()
-            else:
-                loss.backward()
+            finally:
+                rasterizer.accumulate_grads(old_acc)
             with torch.no_grad():
                 if collect:
                     self._view_stats(pkg, (self.accum, self.denom, self.max_radii) if single else

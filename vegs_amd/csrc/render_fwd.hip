@@ -131,6 +131,82 @@ k_seg_tiles(int ntiles, const int2* __restrict__ ranges, uint32_t* __restrict__ 
     if (up_front && sl >= first_fused) seg_off[seg_list_offset(ntiles, cap, 0) + seg_off[seg_actoff_offset(ntiles, cap) + lo] + sl - first_fused] = b;
 }
 
+// k_seg_offsets + k_seg_tiles in ONE launch (round 5): every workgroup of the table kernel repeats the two prefix sums over
+// the tiles in LDS -- a view has ~2 k tiles: 8 per thread, ~2 us, against a launch of its own for a single workgroup (6 us)
+// plus the dispatch gap -- and then fills its 256 segment slots from the LDS copies; workgroup 0 also writes the global
+// arrays the later kernels read.  Same values in the same places as the two kernels (which remain: frames of more than
+// SEGTAB_MAX_TILES tiles, 3.1 Mpixel).  Render forward -6 us.
+constexpr int SEGTAB_MAX_TILES = 3072;
+__global__ void __launch_bounds__(256)
+k_seg_table(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ hint,
+            uint32_t* __restrict__ limit, uint32_t cap, uint32_t auto_first, int first_fused)
+{
+    __shared__ uint32_t so[SEGTAB_MAX_TILES + 1], ao[SEGTAB_MAX_TILES + 1], lim[SEGTAB_MAX_TILES];
+    __shared__ uint32_t wsum[4], wsum_a[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int per = (ntiles + 255) / 256;                    // consecutive tiles per thread
+    const int t0 = min(ntiles, (int)threadIdx.x * per), t1 = min(ntiles, t0 + per);
+    uint32_t sum_n = 0, sum_a = 0;
+    for (int t = t0; t < t1; ++t) {
+        const int2 r = ranges[t];
+        const uint32_t n = (uint32_t)((r.y - r.x + SEG - 1) / SEG);
+        uint32_t a = hint ? min(n, hinted_limit(min(hint[t], 0x3FFFFFFFu))) : min(n, auto_first);
+        lim[t] = a;
+        if (first_fused) a -= a > 0u ? 1u : 0u;
+        so[t] = sum_n;                                       // thread-local exclusive prefixes, rebased below
+        ao[t] = sum_a;
+        sum_n += n;
+        sum_a += a;
+    }
+    uint32_t incl = sum_n, incl_a = sum_a;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64), oa = __shfl_up(incl_a, d, 64);
+        if (lane >= d) { incl += o; incl_a += oa; }
+    }
+    if (lane == 63) { wsum[w] = incl; wsum_a[w] = incl_a; }
+    __syncthreads();
+    uint32_t base = incl - sum_n, base_a = incl_a - sum_a;
+    for (int k = 0; k < w; ++k) { base += wsum[k]; base_a += wsum_a[k]; }
+    for (int t = t0; t < t1; ++t) { so[t] += base; ao[t] += base_a; }
+    const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3], total_a = wsum_a[0] + wsum_a[1] + wsum_a[2] + wsum_a[3];
+    if (threadIdx.x == 0) { so[ntiles] = total; ao[ntiles] = total_a; }
+    __syncthreads();
+    if (blockIdx.x == 0) {                                   // the global copies (k_seg_offsets' outputs)
+        uint32_t* const counts = seg_off + seg_counts_offset(ntiles, cap);
+        uint32_t* const act_off = seg_off + seg_actoff_offset(ntiles, cap);
+        for (int t = threadIdx.x; t <= ntiles; t += 256) {
+            seg_off[t] = so[t];
+            act_off[t] = ao[t];
+            if (t < ntiles) limit[t] = lim[t];
+        }
+        if (threadIdx.x == 0) {
+            counts[0] = total_a;
+            counts[1] = 0;
+            counts[2] = 0;
+            counts[SEG_LIST_NEEDED] = 0;
+            counts[SEG_COUNT_HEAVY] = 0;
+            for (int q = 0; q < SEG_QUEUES; ++q) seg_off[seg_qcount_offset(ntiles, cap, q)] = 0;
+        }
+    }
+    // ---- k_seg_tiles' part: one segment slot per thread
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= cap) return;
+    int4* __restrict__ seg_info = reinterpret_cast<int4*>(seg_off + seg_tile_offset(ntiles));
+    if (b >= total) { seg_info[b] = make_int4(-1, 0, 0, 0); return; }
+    int lo = 0, hi = ntiles;       // largest t with so[t] <= b
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (so[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    const int sl = (int)(b - so[lo]);
+    const int2 r = ranges[lo];
+    const int first = r.x + sl * SEG;
+    const bool up_front = (uint32_t)sl < lim[lo];
+    seg_info[b] = make_int4(lo, first, min(SEG, r.y - first), sl | (up_front ? 0 : (int)(3u << 30)));
+    if (up_front && sl >= first_fused) seg_off[seg_list_offset(ntiles, cap, 0) + ao[lo] + sl - first_fused] = b;
+}
+
 // ---- NEEDED-SEGMENT HINT.  Half of the segments lie behind the point where every pixel of their tile has stopped
 // (a few vanishing-point tiles have up to ~950 segments and need at most ~200): k_seg_alpha computes their products
 // for nothing, because which segments are needed is only known after the chain.  Training revisits every camera
@@ -942,10 +1018,16 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     const bool rounds = needed_hint || auto_rounds;
     const uint32_t first = dense ? AUTO_FIRST_DENSE : AUTO_FIRST_SPARSE;
     const uint32_t second = dense ? AUTO_SECOND_DENSE : AUTO_SECOND_SPARSE;
-    hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(SEGOFF_THREADS), 0, s, ranges, ntiles, seg_off,
-                       (const uint32_t*)needed_hint, seg_needed, (uint32_t)nseg, auto_rounds ? first : 0x3FFFFFFFu, first_fused);
-    hipLaunchKernelGGL(k_seg_tiles, dim3(cdiv((long)nseg, 256)), dim3(256), 0, s, ntiles, ranges, seg_off,
-                       (const uint32_t*)seg_needed, (uint32_t)nseg, first_fused);
+    static const bool one_table = [] { const char* e = getenv("VEGS_SEG_TABLE"); return !(e && e[0] == '0'); }();   // (A/B switch)
+    if (one_table && ntiles <= SEGTAB_MAX_TILES && nseg > 0) {
+        hipLaunchKernelGGL(k_seg_table, dim3(cdiv((long)nseg, 256)), dim3(256), 0, s, ranges, ntiles, seg_off,
+                           (const uint32_t*)needed_hint, seg_needed, (uint32_t)nseg, auto_rounds ? first : 0x3FFFFFFFu, first_fused);
+    } else {
+        hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(SEGOFF_THREADS), 0, s, ranges, ntiles, seg_off,
+                           (const uint32_t*)needed_hint, seg_needed, (uint32_t)nseg, auto_rounds ? first : 0x3FFFFFFFu, first_fused);
+        hipLaunchKernelGGL(k_seg_tiles, dim3(cdiv((long)nseg, 256)), dim3(256), 0, s, ntiles, ranges, seg_off,
+                           (const uint32_t*)seg_needed, (uint32_t)nseg, first_fused);
+    }
     VR_KERNEL_CHECK("seg_offsets", s, debug);
     // Three rounds over work lists (vr_segment.h).  Round 0: the first AUTO_FIRST segments of every tile (with a hint:
     // the hinted prefix -- its length is only known on the device, so the grid covers every slot); k_seg_scan walks them

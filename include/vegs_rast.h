@@ -221,7 +221,12 @@ typedef struct VrSaved {
                                  single-launch binning passes bound every wait for another workgroup's posted sum; the
                                  last binning kernel posts whether one ran out, and vr_backward / vr_count_* /
                                  vr_export_needed / vr_debug_export_binning called with this VrSaved return VR_ERR_HIP
-                                 for exactly this view (0 = nothing to check).  Pass it on unchanged. */
+                                 for exactly this view (0 = nothing to check).  Pass it on unchanged.
+                                 ABI v9: every forward in flight has its OWN device guard word (views on different
+                                 streams cannot fail each other), and vr_backward never blocks the host on the slot:
+                                 not posted yet = it queues its kernels (a tripped view's tile ranges are empty: they
+                                 compute zeros), asks once more, and leaves a still-missing answer to the thread's
+                                 next vr_forward, which reports "an earlier view's binning timed out". */
 } VrSaved;
 
 /* Incoming gradients, one per differentiable output (NULL = zero). */

@@ -346,9 +346,9 @@ def direct_in_children(args, rank, world, local):
             out, err = proc.communicate()
             rc = -998
             rec["timed_out"] = True
-    rec["child_rc"] = rc if rc >= -900 or rc in (-998, -999) else rc
-    if rc < 0 and rc > -900:
-        rec["child_signal"] = -rc
+    rec["child_rc"] = rc                 # (-998: killed at the time limit, -999: could not be started)
+    if -900 < rc < 0:
+        rec["child_signal"] = -rc        # ended by a signal: 11 = SIGSEGV, 6 = SIGABRT (a GPU memory fault aborts the process)
     ok = _agree_min(1 if rc == 0 else 0, world) == 1
     rec["ok"] = ok
     rec["elapsed_s"] = round(time.perf_counter() - t0, 1)

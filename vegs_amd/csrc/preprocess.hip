@@ -42,6 +42,9 @@ __device__ __forceinline__ void sh_dot(const float* bas, int K, const float* sh,
 // LDS row stride of the HALF path: half an SH row (8 coefficients = 24 floats) + one float4 of padding = 7 x 16 bytes
 // (odd: the per-lane float4 row reads are conflict-free, as with 13 above)
 constexpr int SH_HALF_STRIDE = 28;
+#ifndef VR_REC_LDS
+#define VR_REC_LDS 1
+#endif
 
 // RAW (VR_FLAG_RAW_PARAMS) is a compile-time switch: the default instantiation is the kernel as it was.
 // HALF (round 5): the whole-tensor, 16-coefficient SH layout (the op's plain `shs` argument: the headline path) staged
@@ -385,6 +388,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
         }
     }
 
+    if (HALF && VR_REC_LDS) __builtin_amdgcn_wave_barrier();     // (the D rows have been read out of sh_lds[w])
     if (vis) {
         Splat s;
         s.x = px; s.y = py; s.conA = conA; s.conB = conB;
@@ -394,10 +398,31 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
         const float sm = (cam.flags & FLAG_SCALE_MODIFIED) ? cam.mod : 1.0f;
         s.qx = q[1]; s.qy = q[2]; s.qz = q[3]; s.s0 = sc[0] * sm;
         s.s1 = sc[1] * sm; s.s2 = sc[2] * sm; s.clamped = clampbits; s.pad0 = 0;
-        float4* dst = reinterpret_cast<float4*>(rec + i);
         const float4* src = reinterpret_cast<const float4*>(&s);
+        if (HALF && VR_REC_LDS) {
+            float4* l4 = reinterpret_cast<float4*>(sh_lds[w]);     // (free: the SH rows and the D rows have left)
 #pragma unroll
-        for (int k = 0; k < 5; ++k) dst[k] = src[k];
+            for (int k = 0; k < 5; ++k) l4[lane * 5 + k] = src[k];
+        } else {
+            float4* dst = reinterpret_cast<float4*>(rec + i);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) dst[k] = src[k];
+        }
+    }
+    if (HALF && VR_REC_LDS) {
+        // the wave's 64 records are one contiguous 5 KB block: out of LDS as whole float4 runs (a lane writing its own 80-byte
+        // record made every store instruction touch 64 different lines); rows of culled Gaussians are left alone
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long vrows = __ballot(vis);
+        if (vrows != 0ull) {
+            const float4* l4 = reinterpret_cast<const float4*>(sh_lds[w]);
+            float4* dst4 = reinterpret_cast<float4*>(rec + (size_t)(blockIdx.x * blockDim.x + w * 64));
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int v = lane + 64 * j, r = v / 5;
+                if ((vrows >> r) & 1ull) dst4[v] = l4[v];
+            }
+        }
     }
     if (in_range) {
         radii[i] = vis ? rad : 0;

@@ -53,7 +53,7 @@ constexpr int SH_HALF_STRIDE = 28;
 // of LDS per wave and ~60 registers fewer -- the kernel is bound by the latency of its three dependent memory round trips
 // per wave (means -> scales / rotations -> SH rows) at whatever occupancy it gets, and both resources held it to 3 waves
 // per SIMD.
-template <bool RAW, bool HALF>
+template <bool RAW, int HALF>      // HALF: 0 = rows of up to 48 floats, 1 = whole [P,16,3] tensor in coefficient halves, 2 = split storage in row halves
 #ifndef PRE_THREADS
 #define PRE_THREADS 128      // (two waves per workgroup: the same three waves per SIMD in finer grains, 159 -> 157.5 us; one wave: 170 VGPRs, 189 us)
 #endif
@@ -192,7 +192,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
 #pragma unroll
             for (int c = 0; c < 3; ++c) rgb[c] = colors_precomp[3 * (size_t)i + c];
         }
-    } else if (HALF) {
+    } else if (HALF == 1) {
         // (host-checked: shs is the whole [P,16,3] tensor, 16-byte aligned; no split storage, no tail)
         const unsigned long long vis_rows = __ballot(vis);
         if (vis_rows != 0ull) {
@@ -256,6 +256,71 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
             }
 #undef VR_SH_HALF
 #undef VR_SH_K
+            {   // the wave's 64 D rows, one contiguous 2304-byte block: through LDS (row stride 9), out as float4s
+                float* myd = sh_lds[w] + lane * 9;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) myd[q] = vis ? D[q] : 0.0f;
+                __builtin_amdgcn_wave_barrier();
+                wave_copy_from_lds<3>(shd + wave_first * 9, sh_lds[w], rows_here * 9, lane, false);
+            }
+            if (vis) {
+                acc[0] += 0.5f; acc[1] += 0.5f; acc[2] += 0.5f;
+                clampbits = (acc[0] < 0.0f ? 1u : 0u) | (acc[1] < 0.0f ? 2u : 0u) | (acc[2] < 0.0f ? 4u : 0u);
+                rgb[0] = fmaxf(acc[0], 0.0f); rgb[1] = fmaxf(acc[1], 0.0f); rgb[2] = fmaxf(acc[2], 0.0f);
+            }
+        }
+    } else if (HALF == 2) {
+        // SPLIT storage, the model's own two tensors (host-checked: shs = [P,1,3] DC rows, shs_rest = [P,15,3], no tail).  The
+        // wave's 64 rest rows are ONE linear block of 64 x 45 floats; a row is 180 bytes -- no float4 boundary inside it
+        // to cut coefficient halves at -- so the halves are ROW halves: rows 0..31 are staged (1440 floats) and evaluated by
+        // lanes 0..31, then rows 32..63 by lanes 32..63, coefficient by coefficient straight from LDS (row stride 45 floats:
+        // odd, the per-lane reads are conflict-free).  Half the lanes idle during the evaluation -- 350 instructions twice
+        // in a kernel that waits for memory -- for 5.6 instead of 11.3 KB of LDS per wave and the register budget of the
+        // whole-tensor path.
+        const unsigned long long vis_rows = __ballot(vis);
+        if (vis_rows != 0ull) {
+            const size_t wave_first = (size_t)(blockIdx.x * blockDim.x + w * 64);
+            const int rows_here = min(64, P - (int)wave_first);
+            float dc[3] = {0.f, 0.f, 0.f};
+            if (vis) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dc[c] = shs[3 * (size_t)i + c];
+            }
+            float x = 0.f, y = 0.f, z = 0.f;
+            if (vis) {
+                x = px3 - cam.campos[0]; y = py3 - cam.campos[1]; z = pz3 - cam.campos[2];
+                const float len = sqrtf(fmaf(z, z, fmaf(y, y, x * x)));
+                x = x / len; y = y / len; z = z / len;
+            }
+            const int K = (cam.deg + 1) * (cam.deg + 1);
+            float acc[3] = {0.f, 0.f, 0.f}, D[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                if (vis) sh_accumulate<0>(x, y, z, xx, yy, zz, xy, yz, xz, dc, acc, D);
+            }
+            if (K > 1) {
+                const float* my = sh_lds[w] + (lane & 31) * 45;
+#define VR_SH_R(KK) if (KK < K) sh_accumulate<KK>(x, y, z, xx, yy, zz, xy, yz, xz, my + 3 * ((KK) - 1), acc, D)
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) {
+                    const int first = 32 * h, nrows = max(0, min(32, rows_here - first));
+                    const unsigned long long hrows = (vis_rows >> first) & 0xFFFFFFFFull;
+                    if (hrows != 0ull) {      // (wave-uniform)
+                        wave_copy_to_lds<6>(shs_rest + (wave_first + first) * 45, sh_lds[w], nrows * 45, lane, hrows, 45);
+                        __builtin_amdgcn_wave_barrier();
+                        if (vis && (lane >> 5) == h) {
+                            // (the direction goes through an opaque move: otherwise the 15 basis values and their 45 partial
+                            // derivatives are loop invariants and are kept in registers across both halves -- 211 VGPRs)
+                            asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
+                            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                            VR_SH_R(1); VR_SH_R(2); VR_SH_R(3); VR_SH_R(4); VR_SH_R(5); VR_SH_R(6); VR_SH_R(7);
+                            VR_SH_R(8); VR_SH_R(9); VR_SH_R(10); VR_SH_R(11); VR_SH_R(12); VR_SH_R(13); VR_SH_R(14); VR_SH_R(15);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+#undef VR_SH_R
+            }
             {   // the wave's 64 D rows, one contiguous 2304-byte block: through LDS (row stride 9), out as float4s
                 float* myd = sh_lds[w] + lane * 9;
 #pragma unroll
@@ -461,14 +526,15 @@ int launch_preprocess(const Camera& cam, int P, const float* means3D, const floa
     // HALF: the plain whole-tensor SH layout with all 16 coefficients stored (see k_preprocess); VEGS_PRE_HALF=0 keeps the
     // 48-float rows (A/B measurements)
     static const bool half_ok = [] { const char* e = getenv("VEGS_PRE_HALF"); return !(e && e[0] == '0'); }();
-    const bool half = half_ok && shs && !colors_precomp && !shs_rest && !shs_tail && cam.M == 16 &&
-                      (reinterpret_cast<size_t>(shs) & 15) == 0;
+    const bool plain = half_ok && shs && !colors_precomp && !shs_tail && cam.M == 16;
+    const bool half = plain && !shs_rest && (reinterpret_cast<size_t>(shs) & 15) == 0;              // whole [P,16,3] tensor
+    const bool split = plain && shs_rest && (reinterpret_cast<size_t>(shs_rest) & 15) == 0;         // (features_dc, features_rest)
 #define VR_PRE(RAWP, HALFP)                                                                                               \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_preprocess<RAWP, HALFP>), dim3(cdiv(P, PRE_THREADS)), dim3(PRE_THREADS), 0, s, cam, P, \
                        means3D, shs, shs_rest, shs_tail, tail_start, colors_precomp, opacities, scales, rotations,         \
                        cov3D_precomp, rec, radii, rect, depth_key, tile_count, clampb, shd)
-    if (cam.flags & FLAG_RAW_PARAMS) { if (half) VR_PRE(true, true); else VR_PRE(true, false); }
-    else { if (half) VR_PRE(false, true); else VR_PRE(false, false); }
+    if (cam.flags & FLAG_RAW_PARAMS) { if (half) VR_PRE(true, 1); else if (split) VR_PRE(true, 2); else VR_PRE(true, 0); }
+    else { if (half) VR_PRE(false, 1); else if (split) VR_PRE(false, 2); else VR_PRE(false, 0); }
 #undef VR_PRE
     VR_KERNEL_CHECK("preprocess", s, debug);
     return 0;

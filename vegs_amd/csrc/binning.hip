@@ -1201,7 +1201,7 @@ __device__ __forceinline__ unsigned long long sum_posted_wave(const unsigned lon
 // k of the workgroup lies behind batch k - 1.
 template <int ITEMS>
 __global__ void __launch_bounds__(256)
-k_emit_scan(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint4* __restrict__ rect,
+k_emit_scan(int V, int P, int gx, const uint32_t* __restrict__ sorted_id, const uint4* __restrict__ rect,
             unsigned long long* __restrict__ status, uint32_t* __restrict__ err, uint32_t* __restrict__ tkeys,
             uint32_t* __restrict__ tvals, BigRects big_list)
 {
@@ -1224,7 +1224,10 @@ k_emit_scan(int V, int gx, const uint32_t* __restrict__ sorted_id, const uint4* 
         rc[k] = make_uint4(0u, 0u, 0u, 0u);
         // the packed rectangle + tile mask is gathered by id HERE (1.65 M random 16-byte reads): this kernel is bound by
         // the latency of its waits, not by bandwidth, and hides them; in the last depth-sort pass they cost 22 us
-        if (r < V) { rc[k] = rect[id[k]]; cnt[k] = rect_area(rc[k]); }
+        // An id beyond the model cannot come out of a sound depth sort: it is not used as an index (the gather would
+        // fault the process) but raises the view's guard word -- the view is reported as failed, like a timed-out wait.
+        if (r < V && id[k] >= (uint32_t)P) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); id[k] = 0u; }
+        else if (r < V) { rc[k] = rect[id[k]]; cnt[k] = rect_area(rc[k]); }
     }
     uint32_t ex[ITEMS], total = 0;
 #pragma unroll
@@ -1451,7 +1454,7 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
         // (one batch of 256 Gaussians per workgroup: with 2 / 4 batches -- half / a quarter of the posted sums and look-backs,
         // the gathers of all batches in flight together -- the stage went 66 -> 81 / 93 us: the serial emission of a
         // workgroup's batches outweighs what the shorter look-back saves; round 5, profiles/experiments/README.md)
-        hipLaunchKernelGGL(k_emit_scan<1>, dim3(cdiv(V, 256)), dim3(256), 0, s, V, cam.gx, (const uint32_t*)sorted_id,
+        hipLaunchKernelGGL(k_emit_scan<1>, dim3(cdiv(V, 256)), dim3(256), 0, s, V, P, cam.gx, (const uint32_t*)sorted_id,
                            rect, (unsigned long long*)(st + sp.depth), err, tkeysA, va, big_list);
         if (!big_list.inline_big)
             hipLaunchKernelGGL(k_emit_big, dim3(EMIT_BIG_GRID), dim3(64), 0, s, big_list, rect, cam.gx, tkeysA, va);

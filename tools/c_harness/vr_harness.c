@@ -10,6 +10,9 @@
  * opacities[P], scales[P*3], rotations[P*4]; if has_gouts: float dL_dcolor[3HW], dL_dquat[4HW], dL_dscale[3HW].
  * out.bin: float color[3HW], depth[HW], quat[4HW], scale[3HW], alpha[HW]; int32 radii[P]; int64 {R, V};
  * if has_gouts: float dmeans3D[3P], dmeans2D[3P], dshs[3MP], dopac[P], dscales[3P], drot[4P].
+ * has_gouts == 2: both backward calls run with VR_FLAG_DETERMINISTIC, and the six arrays follow a SECOND time, after a
+ * second vr_backward of the same view with VR_FLAG_ACCUMULATE_GRADS on the same arrays (ABI v9: the view's gradient is
+ * added to the rows with radii > 0; dmeans2D is overwritten as always).
  * tests/test_gpu_c_harness.py writes the case, runs this program and compares with the oracle.
  */
 #define __HIP_PLATFORM_AMD__ 1
@@ -115,11 +118,18 @@ int main(int argc, char** argv)
             gi.dL_dmeans3D = (float*)dev(12 * (size_t)P); gi.dL_dmeans2D = (float*)dev(12 * (size_t)P);
             gi.dL_dshs = (float*)dev(12 * (size_t)P * M); gi.dL_dopacities = (float*)dev(4 * (size_t)P);
             gi.dL_dscales = (float*)dev(12 * (size_t)P); gi.dL_drotations = (float*)dev(16 * (size_t)P);
-            CHECK_VR(vr_backward(&st, &in, out.radii, &saved, &go, &gi, alloc_cb, NULL, stream));
-            CHECK_HIP(hipStreamSynchronize(stream));
-            download(fo, gi.dL_dmeans3D, 12 * (size_t)P); download(fo, gi.dL_dmeans2D, 12 * (size_t)P);
-            download(fo, gi.dL_dshs, 12 * (size_t)P * M); download(fo, gi.dL_dopacities, 4 * (size_t)P);
-            download(fo, gi.dL_dscales, 12 * (size_t)P); download(fo, gi.dL_drotations, 16 * (size_t)P);
+            {
+                int pass, passes = hdr[5] == 2 ? 2 : 1;
+                if (passes == 2) st.flags |= VR_FLAG_DETERMINISTIC;
+                for (pass = 0; pass < passes; ++pass) {
+                    if (pass == 1) st.flags |= VR_FLAG_ACCUMULATE_GRADS;     /* the same view once more, added in place */
+                    CHECK_VR(vr_backward(&st, &in, out.radii, &saved, &go, &gi, alloc_cb, NULL, stream));
+                    CHECK_HIP(hipStreamSynchronize(stream));
+                    download(fo, gi.dL_dmeans3D, 12 * (size_t)P); download(fo, gi.dL_dmeans2D, 12 * (size_t)P);
+                    download(fo, gi.dL_dshs, 12 * (size_t)P * M); download(fo, gi.dL_dopacities, 4 * (size_t)P);
+                    download(fo, gi.dL_dscales, 12 * (size_t)P); download(fo, gi.dL_drotations, 16 * (size_t)P);
+                }
+            }
         }
         fclose(fo);
         fclose(fi);

@@ -31,6 +31,8 @@ from vegs_amd import _capi, dist as vdist, harness, scenes, so3  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guide: MI355X_MICROARCH.md chip table)
 VALU_PEAK_GINST = 1228.8   # wave64 VALU instructions per ns: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles (same guide)
+VALU_MEASURED_GINST = 924.0   # ... what a stream of independent v_fma_f32 reaches at 8 waves per SIMD (2.66 cycles each;
+                              # profiles/r05_ubench_pk_rate.txt) -- v_pk_fma_f32 takes two such slots, v_rcp / v_exp ~3.5
 
 
 def _trace(msg):
@@ -717,7 +719,11 @@ def main():
                      "kernel": kern, "wave_instructions_per_launch": valu_insts,
                      "achieved_ginst_per_s": round(valu_insts / (ms_k * 1e-3) / 1e9, 1), "peak_ginst_per_s": VALU_PEAK_GINST,
                      "frac": round(valu_insts / (ms_k * 1e-3) / 1e9 / VALU_PEAK_GINST, 4),
-                     "note": "issue slots only: packed fp32 and transcendental instructions take more than one"},
+                     "measured_issue_peak_ginst_per_s": VALU_MEASURED_GINST,
+                     "frac_of_measured_issue_peak": round(valu_insts / (ms_k * 1e-3) / 1e9 / VALU_MEASURED_GINST, 4),
+                     "note": "instructions, not issue slots: a packed fp32 instruction takes two slots and a transcendental "
+                             "~3.5 (profiles/tools/ubench/pk_rate.hip); with ~40 % of this kernel's instructions packed and four "
+                             "reciprocals per trip its stream is ~230 us of pure issue (DESIGN section 14)"},
                  "l2_atomics": None if flushes is None else {
                      "kernel": kern, "flushes_per_view": round(flushes), "atomics_per_view": round(17 * flushes),
                      "achieved_gatomics_per_s": round(17 * flushes / (ms_k * 1e-3) / 1e9, 2) if ms_k > 0 else None,

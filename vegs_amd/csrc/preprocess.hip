@@ -194,100 +194,18 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
 #pragma unroll
             for (int c = 0; c < 3; ++c) rgb[c] = colors_precomp[3 * (size_t)i + c];
         }
-    } else if (HALF == 1) {
-        // (host-checked: shs is the whole [P,16,3] tensor, 16-byte aligned; no split storage, no tail)
+    } else if (HALF) {
+        // HALF == 1 (host-checked): shs is the whole [P,16,3] tensor, 16-byte aligned; no split storage, no tail.
+        // HALF == 2: split storage (shs = [P0,1,3] DC rows, shs_rest = [P0,15,3]), optionally with an SH TAIL (the box instances'
+        // rows behind the static model, a whole [P - P0,16,3] tensor): a wave reads the split static rows, or -- behind
+        // tail_start -- the tail tensor like HALF == 1 reads shs, or -- the one wave across the boundary -- its rows per lane.
         const unsigned long long vis_rows = __ballot(vis);
         if (vis_rows != 0ull) {
             const size_t wave_first = (size_t)(blockIdx.x * blockDim.x + w * 64);
             const int rows_here = min(64, P - (int)wave_first);
-            float4* dst4 = reinterpret_cast<float4*>(sh_lds[w]);
-            // Both halves of the wave's rows are requested at once (12 loads per lane in flight, rows of culled Gaussians left
-            // out); the second half waits in registers while the first is evaluated.  (Requesting them a round trip EARLIER --
-            // for every Gaussian in front of the near plane, before the covariance and the tile test -- measured slower,
-            // 0.152 against 0.148 ms, AND three bench runs of four with that build ended in a memory fault in k_emit_scan
-            // (garbage ids out of the depth sort; never with this one, same sources otherwise).  The cause was not found;
-            // the variant is gone: profiles/experiments/README.md.)
-            const float4* src4 = reinterpret_cast<const float4*>(shs + wave_first * 48);
-            float4 tA[6], tB[6];
-            int at[6];
-            bool ok[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int v = lane + 64 * j, r = v / 6, c = v - r * 6;
-                ok[j] = (vis_rows >> r) & 1ull;
-                at[j] = r * (SH_HALF_STRIDE / 4) + c;
-                if (ok[j]) {
-                    tA[j] = nt_load4(&src4[r * 12 + c]);
-                    tB[j] = nt_load4(&src4[r * 12 + 6 + c]);
-                }
-            }
-            float x = 0.f, y = 0.f, z = 0.f;
-            if (vis) {
-                x = px3 - cam.campos[0]; y = py3 - cam.campos[1]; z = pz3 - cam.campos[2];
-                const float len = sqrtf(fmaf(z, z, fmaf(y, y, x * x)));
-                x = x / len; y = y / len; z = z / len;
-            }
-            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-            const int K = (cam.deg + 1) * (cam.deg + 1);
-            float acc[3] = {0.f, 0.f, 0.f}, D[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const float4* my4 = dst4 + lane * (SH_HALF_STRIDE / 4);
-#define VR_SH_K(KK, F) if (KK < K) sh_accumulate<KK>(x, y, z, xx, yy, zz, xy, yz, xz, &F[3 * ((KK) & 7)], acc, D)
-#define VR_SH_HALF(BASE)                                                                                                  \
-            if (vis) {                                                                                                    \
-                float f[24];                                                                                              \
-                _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                                           \
-                    const float4 t = my4[j];                                                                              \
-                    f[4 * j] = t.x; f[4 * j + 1] = t.y; f[4 * j + 2] = t.z; f[4 * j + 3] = t.w;                           \
-                }                                                                                                         \
-                VR_SH_K(BASE + 0, f); VR_SH_K(BASE + 1, f); VR_SH_K(BASE + 2, f); VR_SH_K(BASE + 3, f);                   \
-                VR_SH_K(BASE + 4, f); VR_SH_K(BASE + 5, f); VR_SH_K(BASE + 6, f); VR_SH_K(BASE + 7, f);                   \
-            }
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-                if (ok[j]) dst4[at[j]] = tA[j];
-            __builtin_amdgcn_wave_barrier();
-            VR_SH_HALF(0)
-            __builtin_amdgcn_wave_barrier();
-            if (K > 8) {                                         // (wave-uniform: degree 0 and 1 need the first half only)
-#pragma unroll
-                for (int j = 0; j < 6; ++j)
-                    if (ok[j]) dst4[at[j]] = tB[j];
-                __builtin_amdgcn_wave_barrier();
-                VR_SH_HALF(8)
-                __builtin_amdgcn_wave_barrier();
-            }
-#undef VR_SH_HALF
-#undef VR_SH_K
-            {   // the wave's 64 D rows, one contiguous 2304-byte block: through LDS (row stride 9), out as float4s
-                float* myd = sh_lds[w] + lane * 9;
-#pragma unroll
-                for (int q = 0; q < 9; ++q) myd[q] = vis ? D[q] : 0.0f;
-                __builtin_amdgcn_wave_barrier();
-                wave_copy_from_lds<3>(shd + wave_first * 9, sh_lds[w], rows_here * 9, lane, false);
-            }
-            if (vis) {
-                acc[0] += 0.5f; acc[1] += 0.5f; acc[2] += 0.5f;
-                clampbits = (acc[0] < 0.0f ? 1u : 0u) | (acc[1] < 0.0f ? 2u : 0u) | (acc[2] < 0.0f ? 4u : 0u);
-                rgb[0] = fmaxf(acc[0], 0.0f); rgb[1] = fmaxf(acc[1], 0.0f); rgb[2] = fmaxf(acc[2], 0.0f);
-            }
-        }
-    } else if (HALF == 2) {
-        // SPLIT storage, the model's own two tensors (host-checked: shs = [P,1,3] DC rows, shs_rest = [P,15,3], no tail).  The
-        // wave's 64 rest rows are ONE linear block of 64 x 45 floats; a row is 180 bytes -- no float4 boundary inside it
-        // to cut coefficient halves at -- so the halves are ROW halves: rows 0..31 are staged (1440 floats) and evaluated by
-        // lanes 0..31, then rows 32..63 by lanes 32..63, coefficient by coefficient straight from LDS (row stride 45 floats:
-        // odd, the per-lane reads are conflict-free).  Half the lanes idle during the evaluation -- 350 instructions twice
-        // in a kernel that waits for memory -- for 5.6 instead of 11.3 KB of LDS per wave and the register budget of the
-        // whole-tensor path.
-        const unsigned long long vis_rows = __ballot(vis);
-        if (vis_rows != 0ull) {
-            const size_t wave_first = (size_t)(blockIdx.x * blockDim.x + w * 64);
-            const int rows_here = min(64, P - (int)wave_first);
-            float dc[3] = {0.f, 0.f, 0.f};
-            if (vis) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) dc[c] = shs[3 * (size_t)i + c];
-            }
+            const bool tailed = HALF == 2 && shs_tail != nullptr;
+            const bool in_tail = tailed && (long)wave_first >= (long)tail_start;
+            const bool straddle = tailed && !in_tail && (long)wave_first + 64 > (long)tail_start;
             float x = 0.f, y = 0.f, z = 0.f;
             if (vis) {
                 x = px3 - cam.campos[0]; y = py3 - cam.campos[1]; z = pz3 - cam.campos[2];
@@ -296,35 +214,116 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
             }
             const int K = (cam.deg + 1) * (cam.deg + 1);
             float acc[3] = {0.f, 0.f, 0.f}, D[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            {
-                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                if (vis) sh_accumulate<0>(x, y, z, xx, yy, zz, xy, yz, xz, dc, acc, D);
-            }
-            if (K > 1) {
-                const float* my = sh_lds[w] + (lane & 31) * 45;
-#define VR_SH_R(KK) if (KK < K) sh_accumulate<KK>(x, y, z, xx, yy, zz, xy, yz, xz, my + 3 * ((KK) - 1), acc, D)
-#pragma unroll 1
-                for (int h = 0; h < 2; ++h) {
-                    const int first = 32 * h, nrows = max(0, min(32, rows_here - first));
-                    const unsigned long long hrows = (vis_rows >> first) & 0xFFFFFFFFull;
-                    if (hrows != 0ull) {      // (wave-uniform)
-                        wave_copy_to_lds<6>(shs_rest + (wave_first + first) * 45, sh_lds[w], nrows * 45, lane, hrows, 45);
-                        __builtin_amdgcn_wave_barrier();
-                        if (vis && (lane >> 5) == h) {
-                            // (the direction goes through an opaque move: otherwise the 15 basis values and their 45 partial
-                            // derivatives are loop invariants and are kept in registers across both halves -- 211 VGPRs)
-                            asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
-                            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                            VR_SH_R(1); VR_SH_R(2); VR_SH_R(3); VR_SH_R(4); VR_SH_R(5); VR_SH_R(6); VR_SH_R(7);
-                            VR_SH_R(8); VR_SH_R(9); VR_SH_R(10); VR_SH_R(11); VR_SH_R(12); VR_SH_R(13); VR_SH_R(14); VR_SH_R(15);
-                        }
-                        __builtin_amdgcn_wave_barrier();
+            if (HALF == 1 || in_tail) {
+                // ---- whole 48-float rows in two coefficient HALVES
+                float4* dst4 = reinterpret_cast<float4*>(sh_lds[w]);
+                // Both halves of the wave's rows are requested at once (12 loads per lane in flight, rows of culled Gaussians
+                // left out); the second half waits in registers while the first is evaluated.  (Requesting them a round trip
+                // EARLIER -- for every Gaussian in front of the near plane, before the covariance and the tile test -- measured
+                // slower, 0.152 against 0.148 ms, AND three bench runs of four with that build ended in a memory fault in
+                // k_emit_scan (garbage ids out of the depth sort; never with this one, same sources otherwise).  The cause was
+                // not found; the variant is gone: profiles/experiments/README.md.)
+                const float* rows = HALF == 1 ? shs + wave_first * 48 : shs_tail + (wave_first - (size_t)tail_start) * 48;
+                const float4* src4 = reinterpret_cast<const float4*>(rows);
+                float4 tA[6], tB[6];
+                int at[6];
+                bool ok[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int v = lane + 64 * j, r = v / 6, c = v - r * 6;
+                    ok[j] = (vis_rows >> r) & 1ull;
+                    at[j] = r * (SH_HALF_STRIDE / 4) + c;
+                    if (ok[j]) {
+                        tA[j] = nt_load4(&src4[r * 12 + c]);
+                        tB[j] = nt_load4(&src4[r * 12 + 6 + c]);
                     }
                 }
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                const float4* my4 = dst4 + lane * (SH_HALF_STRIDE / 4);
+#define VR_SH_K(KK, F) if (KK < K) sh_accumulate<KK>(x, y, z, xx, yy, zz, xy, yz, xz, &F[3 * ((KK) & 7)], acc, D)
+#define VR_SH_HALF(BASE)                                                                                                  \
+                if (vis) {                                                                                                \
+                    float f[24];                                                                                          \
+                    _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                                       \
+                        const float4 t = my4[j];                                                                          \
+                        f[4 * j] = t.x; f[4 * j + 1] = t.y; f[4 * j + 2] = t.z; f[4 * j + 3] = t.w;                       \
+                    }                                                                                                     \
+                    VR_SH_K(BASE + 0, f); VR_SH_K(BASE + 1, f); VR_SH_K(BASE + 2, f); VR_SH_K(BASE + 3, f);               \
+                    VR_SH_K(BASE + 4, f); VR_SH_K(BASE + 5, f); VR_SH_K(BASE + 6, f); VR_SH_K(BASE + 7, f);               \
+                }
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    if (ok[j]) dst4[at[j]] = tA[j];
+                __builtin_amdgcn_wave_barrier();
+                VR_SH_HALF(0)
+                __builtin_amdgcn_wave_barrier();
+                if (K > 8) {                                     // (wave-uniform: degree 0 and 1 need the first half only)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j)
+                        if (ok[j]) dst4[at[j]] = tB[j];
+                    __builtin_amdgcn_wave_barrier();
+                    VR_SH_HALF(8)
+                    __builtin_amdgcn_wave_barrier();
+                }
+#undef VR_SH_HALF
+#undef VR_SH_K
+            } else if (HALF == 2 && straddle) {
+                // ---- the one wave across tail_start: every lane reads its own coefficients from memory, one at a time
+                if (vis) {
+                    const bool mine_tail = i >= tail_start;
+                    const float* p0 = mine_tail ? shs_tail + (size_t)(i - tail_start) * 48 : shs + 3 * (size_t)i;
+                    const float* pr = mine_tail ? p0 + 3 : shs_rest + (size_t)i * 45;
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    sh_accumulate<0>(x, y, z, xx, yy, zz, xy, yz, xz, p0, acc, D);
+#define VR_SH_G(KK) if (KK < K) sh_accumulate<KK>(x, y, z, xx, yy, zz, xy, yz, xz, pr + 3 * ((KK) - 1), acc, D)
+                    VR_SH_G(1); VR_SH_G(2); VR_SH_G(3); VR_SH_G(4); VR_SH_G(5); VR_SH_G(6); VR_SH_G(7); VR_SH_G(8);
+                    VR_SH_G(9); VR_SH_G(10); VR_SH_G(11); VR_SH_G(12); VR_SH_G(13); VR_SH_G(14); VR_SH_G(15);
+#undef VR_SH_G
+                }
+            } else if (HALF == 2) {
+                // ---- SPLIT storage, the model's own two tensors.  The wave's 64 rest rows are ONE linear block of 64 x 45
+                // floats; a row is 180 bytes -- no float4 boundary inside it to cut coefficient halves at -- so the halves are
+                // ROW halves: rows 0..31 are staged (1440 floats) and evaluated by lanes 0..31, then rows 32..63 by lanes
+                // 32..63, coefficient by coefficient straight from LDS (row stride 45 floats: odd, the per-lane reads are
+                // conflict-free).  Half the lanes idle during the evaluation -- 350 instructions twice in a kernel that waits
+                // for memory -- for 5.6 instead of 11.3 KB of LDS per wave and the register budget of the whole-tensor path.
+                const int rows_split = min(rows_here, (tailed ? tail_start : P) - (int)wave_first);
+                float dc[3] = {0.f, 0.f, 0.f};
+                if (vis) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) dc[c] = shs[3 * (size_t)i + c];
+                }
+                {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    if (vis) sh_accumulate<0>(x, y, z, xx, yy, zz, xy, yz, xz, dc, acc, D);
+                }
+                if (K > 1) {
+                    const float* my = sh_lds[w] + (lane & 31) * 45;
+#define VR_SH_R(KK) if (KK < K) sh_accumulate<KK>(x, y, z, xx, yy, zz, xy, yz, xz, my + 3 * ((KK) - 1), acc, D)
+#pragma unroll 1
+                    for (int h = 0; h < 2; ++h) {
+                        const int first = 32 * h, nrows = max(0, min(32, rows_split - first));
+                        const unsigned long long hrows = (vis_rows >> first) & 0xFFFFFFFFull;
+                        if (hrows != 0ull) {      // (wave-uniform)
+                            wave_copy_to_lds<6>(shs_rest + (wave_first + first) * 45, sh_lds[w], nrows * 45, lane, hrows, 45);
+                            __builtin_amdgcn_wave_barrier();
+                            if (vis && (lane >> 5) == h) {
+                                // (the direction goes through an opaque move: otherwise the 15 basis values and their 45
+                                // partial derivatives are loop invariants and are kept in registers across both halves -- 211 VGPRs)
+                                asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
+                                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                                VR_SH_R(1); VR_SH_R(2); VR_SH_R(3); VR_SH_R(4); VR_SH_R(5); VR_SH_R(6); VR_SH_R(7);
+                                VR_SH_R(8); VR_SH_R(9); VR_SH_R(10); VR_SH_R(11); VR_SH_R(12); VR_SH_R(13); VR_SH_R(14); VR_SH_R(15);
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
 #undef VR_SH_R
+                }
             }
             {   // the wave's 64 D rows, one contiguous 2304-byte block: through LDS (row stride 9), out as float4s
                 float* myd = sh_lds[w] + lane * 9;
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int q = 0; q < 9; ++q) myd[q] = vis ? D[q] : 0.0f;
                 __builtin_amdgcn_wave_barrier();
@@ -528,9 +527,11 @@ int launch_preprocess(const Camera& cam, int P, const float* means3D, const floa
     // HALF: the plain whole-tensor SH layout with all 16 coefficients stored (see k_preprocess); VEGS_PRE_HALF=0 keeps the
     // 48-float rows (A/B measurements)
     static const bool half_ok = [] { const char* e = getenv("VEGS_PRE_HALF"); return !(e && e[0] == '0'); }();
-    const bool plain = half_ok && shs && !colors_precomp && !shs_tail && cam.M == 16;
-    const bool half = plain && !shs_rest && (reinterpret_cast<size_t>(shs) & 15) == 0;              // whole [P,16,3] tensor
-    const bool split = plain && shs_rest && (reinterpret_cast<size_t>(shs_rest) & 15) == 0;         // (features_dc, features_rest)
+    const bool plain = half_ok && shs && !colors_precomp && cam.M == 16;
+    const bool half = plain && !shs_rest && !shs_tail && (reinterpret_cast<size_t>(shs) & 15) == 0;   // whole [P,16,3] tensor
+    // (features_dc, features_rest), with or without the instances' rows as an SH tail (16-byte aligned: check_inputs)
+    const bool split = plain && shs_rest && (reinterpret_cast<size_t>(shs_rest) & 15) == 0 &&
+                       (!shs_tail || (reinterpret_cast<size_t>(shs_tail) & 15) == 0);
 #define VR_PRE(RAWP, HALFP)                                                                                               \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_preprocess<RAWP, HALFP>), dim3(cdiv(P, PRE_WG(HALFP))), dim3(PRE_WG(HALFP)), 0, s, cam, P, \
                        means3D, shs, shs_rest, shs_tail, tail_start, colors_precomp, opacities, scales, rotations,         \

@@ -89,3 +89,47 @@ def test_two_views_in_flight_do_not_disturb_each_other(dev):  # noqa: F811
                 pl, rg = _lists(r, st, dev)
                 assert np.array_equal(rg, rg0) and np.array_equal(pl, pl0), f"round {it}: lists differ"
                 assert torch.equal(r[0], img0), f"round {it}: image differs"
+
+
+def test_chain_mode_and_rounds_agree_on_a_view_with_deep_tiles(dev):  # noqa: F811
+    """A street view with vanishing-point tiles of hundreds of list segments: the default forward walks their chains inside
+    k_seg_alpha's launch and skips the segments behind each chain's end (chain mode, vegs_amd/csrc/render_fwd.hip);
+    VR_FLAG_ROUNDS_ON takes the three-round path without walkers.  Images, needed-segment counts and the deterministic
+    backward's gradients must be bit-identical -- and stay so when the forward is repeated (which segments get skipped
+    depends on timing; the result may not)."""
+    import ctypes as C
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from vegs_amd import _capi, rasterizer
+    W, H = 1376, 376
+    st, t = _view(1000000, W, H, 11, 30.0, dev)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    gouts = [torch.randn(s, generator=g).to(dev) for s in [(3, H, W), (4, H, W), (3, H, W)]]
+
+    def run(flags):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+        m2d = torch.zeros(leaves["means3D"].shape[0], 3, device=dev, requires_grad=True)
+        old = rasterizer.needed_hints(False)
+        try:
+            with rasterizer.flags(flags | rasterizer.FLAG_DETERMINISTIC):
+                res = GaussianRasterizer(raster_settings=st)(means3D=leaves["means3D"], means2D=m2d, shs=leaves["shs"],
+                                                            opacities=leaves["opacities"], scales=leaves["scales"],
+                                                            rotations=leaves["rotations"])
+                need = torch.zeros(T, dtype=torch.int32, device=dev)
+                saved = _capi.saved_of(res[0].grad_fn)
+                _capi.check(_capi.load().vr_export_needed(C.byref(saved), H, W, need.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+                torch.autograd.backward([res[0], res[2], res[3]], gouts)
+        finally:
+            rasterizer.needed_hints(old)
+        return [r.detach().clone() for r in res[:5]], need, {k: v.grad.clone() for k, v in leaves.items()}, m2d.grad.clone()
+
+    img_r, need_r, grads_r, m2d_r = run(rasterizer.FLAG_ROUNDS_ON)
+    assert int(need_r.max()) > 40          # (a chain longer than the prefix every tile computes up front)
+    for rep in range(4):
+        img_c, need_c, grads_c, m2d_c = run(0)
+        assert torch.equal(need_c, need_r), rep
+        for a, b in zip(img_c, img_r):
+            assert torch.equal(a, b), rep
+        assert torch.equal(m2d_c, m2d_r)
+        for k in grads_r:
+            assert torch.equal(grads_c[k], grads_r[k]), (rep, k)

@@ -137,16 +137,44 @@ k_seg_tiles(int ntiles, const int2* __restrict__ ranges, uint32_t* __restrict__ 
 // arrays the later kernels read.  Same values in the same places as the two kernels (which remain: frames of more than
 // SEGTAB_MAX_TILES tiles, 3.1 Mpixel).  Render forward -6 us.
 constexpr int SEGTAB_MAX_TILES = 3072;
+
+// ---- CHAIN MODE (round 5; a forward without rounds).  Half of a street view's list segments are DEAD -- behind the point
+// where every pixel of their tile has stopped -- and nearly all of those lie in the few dozen deepest (vanishing-point)
+// tiles: up to ~950 segments of which at most ~200 are needed.  Which ones is the RESULT of the chain k_seg_scan walks
+// after k_seg_alpha.  In chain mode the chains of the HEAVY tiles (more than CHAIN_PREFIX segments) are walked INSIDE the
+// k_seg_alpha launch, by one WALKER workgroup per heavy tile that follows the tile's segment products as they are
+// published (a flag per segment) and, when the chain ends, publishes the number of needed segments (`dead`): a workgroup
+// whose segment lies behind it returns at once.  It only pays if the walkers know before the dead segments are dispatched,
+// so the launch's work is ordered for them:
+//   [ the heavy tiles' first segments (fused) | A: their levels 1 .. CHAIN_PREFIX-1 | the walkers |
+//     the other tiles' first segments | B: their other segments   (the bulk: ~40 us during which the walkers get through A) |
+//     C: the heavy tiles' levels >= CHAIN_PREFIX, LEVEL-major (all tiles' level k before any tile's level k + 1) ]
+// Nothing waits but the walkers (bounded; a walker that runs out of patience leaves its tile to k_seg_scan), the same
+// segment products feed the same chain arithmetic, and a skipped segment is one no pixel needs: results bit for bit.
+constexpr int CHAIN_PREFIX = 32;               // (16 and 48 measured the same)
+constexpr int CHAIN_MAX_HEAVY = 128;           // more heavy tiles than this: the view runs without walkers (classic order)
+constexpr int SEG_COUNT_CHAIN_HEAVY = 8;       // counts[]: heavy tiles of this view (0 = no chain mode)
+constexpr int SEG_COUNT_CHAIN_A = 9;           //           list entries of region A
+constexpr int SEG_COUNT_CHAIN_B = 10;          //           ... of region B
+constexpr uint32_t CHAIN_OPEN = 0xFFFFFFFFu;   // dead[tile]: the chain has not ended yet
+// chain mode's arrays live in the lists of the catch-up rounds it excludes: flags [cap] | dead [ntiles], heavy tile ids
+__host__ __device__ inline size_t chain_flags_offset(int ntiles, size_t cap) { return seg_list_offset(ntiles, cap, 1); }
+__host__ __device__ inline size_t chain_dead_offset(int ntiles, size_t cap) { return seg_list_offset(ntiles, cap, 2); }
+// (the tiles in launch order: the heavy ones, ascending, then the others: [ntiles])
+__host__ __device__ inline size_t chain_heavy_offset(int ntiles, size_t cap) { return seg_list_offset(ntiles, cap, 2) + (size_t)seg_tile_offset(ntiles); }
+
 __global__ void __launch_bounds__(256)
 k_seg_table(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ hint,
-            uint32_t* __restrict__ limit, uint32_t cap, uint32_t auto_first, int first_fused)
+            uint32_t* __restrict__ limit, uint32_t cap, uint32_t auto_first, int first_fused, int chain)
 {
     __shared__ uint32_t so[SEGTAB_MAX_TILES + 1], ao[SEGTAB_MAX_TILES + 1], lim[SEGTAB_MAX_TILES];
-    __shared__ uint32_t wsum[4], wsum_a[4];
+    __shared__ uint32_t ha[SEGTAB_MAX_TILES + 1];      // chain mode: list entries of the HEAVY tiles before tile t
+    __shared__ uint32_t hv_t[CHAIN_MAX_HEAVY], hv_n[CHAIN_MAX_HEAVY];
+    __shared__ uint32_t wsum[4], wsum_a[4], wsum_h[4], wsum_ha[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int per = (ntiles + 255) / 256;                    // consecutive tiles per thread
     const int t0 = min(ntiles, (int)threadIdx.x * per), t1 = min(ntiles, t0 + per);
-    uint32_t sum_n = 0, sum_a = 0;
+    uint32_t sum_n = 0, sum_a = 0, sum_h = 0, sum_ha = 0;
     for (int t = t0; t < t1; ++t) {
         const int2 r = ranges[t];
         const uint32_t n = (uint32_t)((r.y - r.x + SEG - 1) / SEG);
@@ -155,23 +183,46 @@ k_seg_table(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict__ 
         if (first_fused) a -= a > 0u ? 1u : 0u;
         so[t] = sum_n;                                       // thread-local exclusive prefixes, rebased below
         ao[t] = sum_a;
+        ha[t] = sum_ha;
         sum_n += n;
         sum_a += a;
+        if (chain && n > (uint32_t)CHAIN_PREFIX) { sum_h += 1u; sum_ha += a; }
     }
-    uint32_t incl = sum_n, incl_a = sum_a;
+    uint32_t incl = sum_n, incl_a = sum_a, incl_h = sum_h, incl_ha = sum_ha;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t o = __shfl_up(incl, d, 64), oa = __shfl_up(incl_a, d, 64);
-        if (lane >= d) { incl += o; incl_a += oa; }
+        const uint32_t oh = __shfl_up(incl_h, d, 64), oha = __shfl_up(incl_ha, d, 64);
+        if (lane >= d) { incl += o; incl_a += oa; incl_h += oh; incl_ha += oha; }
     }
-    if (lane == 63) { wsum[w] = incl; wsum_a[w] = incl_a; }
+    if (lane == 63) { wsum[w] = incl; wsum_a[w] = incl_a; wsum_h[w] = incl_h; wsum_ha[w] = incl_ha; }
     __syncthreads();
-    uint32_t base = incl - sum_n, base_a = incl_a - sum_a;
-    for (int k = 0; k < w; ++k) { base += wsum[k]; base_a += wsum_a[k]; }
-    for (int t = t0; t < t1; ++t) { so[t] += base; ao[t] += base_a; }
+    uint32_t base = incl - sum_n, base_a = incl_a - sum_a, base_h = incl_h - sum_h, base_ha = incl_ha - sum_ha;
+    for (int k = 0; k < w; ++k) { base += wsum[k]; base_a += wsum_a[k]; base_h += wsum_h[k]; base_ha += wsum_ha[k]; }
     const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3], total_a = wsum_a[0] + wsum_a[1] + wsum_a[2] + wsum_a[3];
-    if (threadIdx.x == 0) { so[ntiles] = total; ao[ntiles] = total_a; }
+    const uint32_t nheavy_all = wsum_h[0] + wsum_h[1] + wsum_h[2] + wsum_h[3];
+    const uint32_t total_ha = wsum_ha[0] + wsum_ha[1] + wsum_ha[2] + wsum_ha[3];
+    // chain mode for THIS view: some heavy tile, and no more of them than there are walkers
+    const uint32_t nheavy = (chain && nheavy_all <= (uint32_t)CHAIN_MAX_HEAVY) ? nheavy_all : 0u;
+    {
+        uint32_t h = base_h;
+        for (int t = t0; t < t1; ++t) {
+            const uint32_t n = (t + 1 < t1 ? so[t + 1] : sum_n) - so[t];
+            so[t] += base; ao[t] += base_a; ha[t] += base_ha;
+            if (nheavy && n > (uint32_t)CHAIN_PREFIX) {
+                hv_t[h] = (uint32_t)t; hv_n[h] = n;
+                if (blockIdx.x == 0) seg_off[chain_heavy_offset(ntiles, cap) + h] = (uint32_t)t;
+                ++h;
+            } else if (nheavy && blockIdx.x == 0) {
+                seg_off[chain_heavy_offset(ntiles, cap) + nheavy + ((uint32_t)t - h)] = (uint32_t)t;     // (h = heavy tiles before t)
+            }
+        }
+    }
+    if (threadIdx.x == 0) { so[ntiles] = total; ao[ntiles] = total_a; ha[ntiles] = total_ha; }
     __syncthreads();
+    // region sizes of the chain order (every heavy tile has all of the levels 1 .. CHAIN_PREFIX-1)
+    const uint32_t size_a = nheavy * (uint32_t)(CHAIN_PREFIX - 1);
+    const uint32_t size_b = total_a - total_ha;
     if (blockIdx.x == 0) {                                   // the global copies (k_seg_offsets' outputs)
         uint32_t* const counts = seg_off + seg_counts_offset(ntiles, cap);
         uint32_t* const act_off = seg_off + seg_actoff_offset(ntiles, cap);
@@ -179,6 +230,7 @@ k_seg_table(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict__ 
             seg_off[t] = so[t];
             act_off[t] = ao[t];
             if (t < ntiles) limit[t] = lim[t];
+            if (chain && t < ntiles) seg_off[chain_dead_offset(ntiles, cap) + t] = CHAIN_OPEN;
         }
         if (threadIdx.x == 0) {
             counts[0] = total_a;
@@ -186,12 +238,16 @@ k_seg_table(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict__ 
             counts[2] = 0;
             counts[SEG_LIST_NEEDED] = 0;
             counts[SEG_COUNT_HEAVY] = 0;
+            counts[SEG_COUNT_CHAIN_HEAVY] = nheavy;
+            counts[SEG_COUNT_CHAIN_A] = size_a;
+            counts[SEG_COUNT_CHAIN_B] = size_b;
             for (int q = 0; q < SEG_QUEUES; ++q) seg_off[seg_qcount_offset(ntiles, cap, q)] = 0;
         }
     }
     // ---- k_seg_tiles' part: one segment slot per thread
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= cap) return;
+    if (chain) seg_off[chain_flags_offset(ntiles, cap) + b] = 0u;       // "product published" flag of the slot
     int4* __restrict__ seg_info = reinterpret_cast<int4*>(seg_off + seg_tile_offset(ntiles));
     if (b >= total) { seg_info[b] = make_int4(-1, 0, 0, 0); return; }
     int lo = 0, hi = ntiles;       // largest t with so[t] <= b
@@ -204,7 +260,31 @@ k_seg_table(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict__ 
     const int first = r.x + sl * SEG;
     const bool up_front = (uint32_t)sl < lim[lo];
     seg_info[b] = make_int4(lo, first, min(SEG, r.y - first), sl | (up_front ? 0 : (int)(3u << 30)));
-    if (up_front && sl >= first_fused) seg_off[seg_list_offset(ntiles, cap, 0) + ao[lo] + sl - first_fused] = b;
+    if (!(up_front && sl >= first_fused)) return;
+    uint32_t pos = ao[lo] + (uint32_t)(sl - first_fused);                  // classic: tile-major
+    if (nheavy) {
+        const uint32_t n_lo = so[lo + 1] - so[lo];
+        if (n_lo <= (uint32_t)CHAIN_PREFIX) {
+            pos = size_a + (ao[lo] - ha[lo]) + (uint32_t)(sl - first_fused);               // B
+        } else {
+            int hl = 0, hh = (int)nheavy - 1;      // the tile's index among the heavy ones (ascending tile ids)
+            while (hl < hh) {
+                const int mid = (hl + hh) >> 1;
+                if (hv_t[mid] < (uint32_t)lo) hl = mid + 1; else hh = mid;
+            }
+            if (sl < CHAIN_PREFIX) {
+                pos = (uint32_t)hl * (uint32_t)(CHAIN_PREFIX - 1) + (uint32_t)(sl - 1);    // A
+            } else {
+                uint32_t before = 0;               // C, level-major: the deeper levels of all heavy tiles below `sl`, then the
+                for (uint32_t h = 0; h < nheavy; ++h) {                                    // tiles before this one on level `sl`
+                    before += min(hv_n[h], (uint32_t)sl) - (uint32_t)CHAIN_PREFIX;
+                    before += (h < (uint32_t)hl && hv_n[h] > (uint32_t)sl) ? 1u : 0u;
+                }
+                pos = size_a + size_b + before;
+            }
+        }
+    }
+    seg_off[seg_list_offset(ntiles, cap, 0) + pos] = b;
 }
 
 // ---- NEEDED-SEGMENT HINT.  Half of the segments lie behind the point where every pixel of their tile has stopped
@@ -219,6 +299,24 @@ k_seg_table(const int2* __restrict__ ranges, int ntiles, uint32_t* __restrict__ 
 // tests/test_gpu_parity.py::test_needed_hint_*).  Margin: 2 segments + 12 %: 4.6 k instead of 2.1 k of the 9.5 k dead
 // segments of the headline view are still computed, and a model drifting by 2 cm / +-0.3 opacity logits / +-5 % scales
 // misses in 3-5 of 2064 tiles (profiles/tools/staleness.py).
+
+// ---- chain mode (the segment table's comment): device-scope accesses of what workgroups of ONE launch hand each other.  The
+// 8 XCD L2s are not coherent with each other: payload AND flag go through device-scope (sc1) stores / loads, which are
+// performed at the level all XCDs share -- so no cache maintenance is needed, only ORDER: every wave waits for its own
+// stores (s_waitcnt vmcnt(0): a written-through store is acknowledged from that level) before the workgroup's barrier, the
+// flag is stored behind the barrier; the reader uses the payload only after it has seen the flag.  (The fences that say the
+// same in the memory model -- release: buffer_wbl2, acquire: buffer_inv -- write back / drop the WHOLE L2 of the XCD, with
+// every other workgroup's records and lists in it: 7 k of them per launch took k_seg_alpha from 170 to 364 us.)
+__device__ __forceinline__ void chain_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float chain_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t chain_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// every thread of the workgroup has stored its pixel's product: raise the segment's flag (all 256 threads call this)
+__device__ __forceinline__ void chain_publish(uint32_t* __restrict__ flags, uint32_t seg)
+{
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): this wave's device-scope stores have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&flags[seg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Product of (1 - alpha) over one segment for the calling thread's pixel; also builds the segment's strip-relevance
 // masks and stores them.  Called by all 256 threads of a workgroup (contains block barriers).
@@ -343,11 +441,14 @@ __device__ __forceinline__ void seg_first_body(const Camera& cam, const int tile
                                                const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ point_list,
                                                const Splat* __restrict__ rec, float* __restrict__ Pbuf,
                                                unsigned long long* __restrict__ segmask, float* __restrict__ part,
-                                               float4 (*lds)[SEG], float2* lds_s, unsigned long long* masks, const FwdOut& o)
+                                               float4 (*lds)[SEG], float2* lds_s, unsigned long long* masks, const FwdOut& o,
+                                               uint32_t* __restrict__ chain_flags)
 {
     const uint32_t seg0 = seg_off[tile];
     if (seg_off[tile + 1] == seg0) return;                     // empty tile
     const bool single = seg_off[tile + 1] - seg0 == 1u;        // (half of a street view's tiles: finished here, below)
+    // chain mode, heavy tile: the product is published for the tile's walker (chain_flags: this view's flags, or null)
+    const bool publish = chain_flags != nullptr && seg_off[tile + 1] - seg0 > (uint32_t)CHAIN_PREFIX;
     SegCtx c;
     if (!seg_setup_at(cam, ranges, seg_off, seg0, threadIdx.x >> 6, c)) return;
     {
@@ -434,7 +535,8 @@ __device__ __forceinline__ void seg_first_body(const Camera& cam, const int tile
         if (__builtin_amdgcn_ballot_w64(gx != GATED) == 0ull) break;     // every pixel of the strip is finished
     }
     const bool stopped = c.inside && gx == GATED;
-    Pbuf[(size_t)c.seg * SEG + threadIdx.x] = stopped ? pstop : p;
+    if (publish) chain_store(&Pbuf[(size_t)c.seg * SEG + threadIdx.x], stopped ? pstop : p);
+    else Pbuf[(size_t)c.seg * SEG + threadIdx.x] = stopped ? pstop : p;
     if (c.inside) {
         const float Cs[NCH] = {Cp[0].x, Cp[0].y, Cp[1].x, Cd, Cp[1].y, Cp[2].x, Cp[2].y, Cp[3].x, Cp[3].y, Cp[4].x, Cp[4].y};
         const uint32_t last = lastk >= 0 ? (uint32_t)(lastk + 1) : 0u;       // (sl = 0: tile-relative index + 1)
@@ -473,6 +575,7 @@ __device__ __forceinline__ void seg_first_body(const Camera& cam, const int tile
             dst[12 * SEG] = __uint_as_float(last | (stopped ? 0x80000000u : 0u));
         }
     }
+    if (publish) chain_publish(chain_flags, c.seg);
 }
 
 // Window of a short tile's list that catch-up round ROUND (1, 2) of a hinted forward covers, given where the previous
@@ -485,14 +588,113 @@ __device__ __forceinline__ uint32_t catchup_end(int round, uint32_t lo, uint32_t
     return round == 1 ? min(nseg, lo + max(8u + (lo >> 1), second)) : nseg;
 }
 
+// The tile's chain has ended: `needed` segments are needed by some pixel, the calling wave's pixels by `mine` of them.
+// (k_seg_scan's last step, also taken by the walkers of chain mode; all 256 threads; wbase: one word of LDS.)
+__device__ __forceinline__ void seg_tile_finish(const Camera& cam, uint32_t* __restrict__ seg_off, uint32_t cap, int tile,
+                                                uint32_t s0, uint32_t s1, uint32_t mine, uint32_t needed, float* __restrict__ Tbuf,
+                                                uint32_t* __restrict__ seg_needed, uint32_t* __restrict__ hint, uint32_t* wbase,
+                                                const bool enqueue = true)
+{
+    for (uint32_t s = s0 + mine; s < s0 + needed; ++s) Tbuf[(size_t)s * SEG + threadIdx.x] = -1.0f;
+    // the tile's needed segments go onto the list of its dispatch queue, in the order in which tiles finish (vr_segment.h)
+    // (enqueue = false, a walker of chain mode: k_seg_merge puts the walked tiles' segments BEHIND the queues' -- where the
+    // heavy tiles end up when k_seg_scan walks them, being the last to finish: the order k_seg_blend / k_seg_bwd want)
+    const int ntiles_all = cam.gx * cam.gy, queue = (int)(blockIdx.x % SEG_QUEUES);
+    if (threadIdx.x == 0) {
+        seg_needed[tile] = needed;
+        if (hint) hint[tile] = needed;     // in/out: what this forward needed is the hint of the camera's next visit
+        *wbase = enqueue ? atomicAdd(&seg_off[seg_qcount_offset(ntiles_all, cap, queue)], needed) : 0u;
+        if (needed >= HEAVY_TILE) {      // long chains start first in the per-tile kernels that follow (vr_segment.h)
+            const uint32_t hp = atomicAdd(&seg_off[seg_counts_offset(ntiles_all, cap) + SEG_COUNT_HEAVY], 1u);
+            seg_off[seg_actoff_offset(ntiles_all, cap) + hp] = (uint32_t)tile;     // (act_off's space: free after k_seg_tiles)
+        }
+    }
+    __syncthreads();
+    if (enqueue) {
+        uint32_t* const ql = seg_off + seg_qlist_offset(ntiles_all, cap, queue) + *wbase;
+        for (uint32_t k = threadIdx.x; k < needed; k += 256) ql[k] = s0 + k;
+    }
+    // per-segment flag for the segment kernels (vr_segment.h): 0 not needed / 1 needed, last / 2 needed, next too
+    int4* seg_info = reinterpret_cast<int4*>(seg_off + seg_tile_offset(ntiles_all));
+    for (uint32_t k = threadIdx.x; k < s1 - s0; k += 256) {
+        const uint32_t flag = k >= needed ? 0u : (k + 1 < needed ? 2u : 1u);
+        seg_info[s0 + k].w = (int)(k | (flag << 30));
+    }
+}
+
+// ---- chain mode: the WALKER of one heavy tile (one workgroup of k_seg_alpha<0>'s launch; the segment table's comment).
+// k_seg_scan<0>'s walk -- the same multiplications in the same order, the same Tbuf rows -- over products that are still
+// being computed: each wave polls the flags of the next WALK segments and takes as many as are published in a row.  When
+// the chain ends it publishes the tile's needed-segment count first (`dead`: workgroups of segments behind it return at
+// once), then finishes the tile like k_seg_scan.  The wait is bounded: after CHAIN_MAX_POLLS polls without a new segment
+// (a producer that is not scheduled: another process holding the GPU) the walker leaves and k_seg_scan walks the tile
+// behind the launch, as without chain mode (nothing has been skipped then: `dead` was never set).
+constexpr int CHAIN_MAX_POLLS = 20000;         // x (~1 us sleep + a device-scope load): tens of milliseconds
+__device__ __forceinline__ void seg_chain_walk(const Camera& cam, int tile, uint32_t* __restrict__ seg_off, uint32_t cap,
+                                               const float* __restrict__ Pbuf, float* __restrict__ Tbuf,
+                                               uint32_t* __restrict__ seg_needed, uint32_t* wsh)
+{
+    constexpr int WALK = 16;
+    uint32_t* const wneed = wsh, * const wgave = wsh + 4, * const wbase = wsh + 8;
+    const int ntiles = cam.gx * cam.gy;
+    const uint32_t* const flags = seg_off + chain_flags_offset(ntiles, cap);
+    const int tx = tile % cam.gx, ty = tile / cam.gx;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int px = tx * TILE + region_x(w, lane), py = ty * TILE + region_y(w, lane);
+    const uint32_t s0 = seg_off[tile], s1 = seg_off[tile + 1];
+    bool alive = px < cam.W && py < cam.H;
+    float Tb = 1.0f;
+    uint32_t mine = 0;
+    bool wave_alive = __ballot(alive) != 0ull, gave_up = false;
+    uint32_t s = s0;
+    while (s < s1 && wave_alive) {
+        int r = 0;
+        for (int polls = 0;; ++polls) {
+            uint32_t f = 1u;
+            if (lane < WALK && s + lane < s1) f = chain_load(&flags[s + lane]);
+            const unsigned long long missing = __ballot(f == 0u);
+            r = missing ? (int)__builtin_ctzll(missing) : WALK;
+            if (r > 0) break;
+            if (polls >= CHAIN_MAX_POLLS) { gave_up = true; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (gave_up) break;
+        r = min(min(r, WALK), (int)(s1 - s));
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);       // (compiler only: the products are loaded after the flags were seen)
+        float Pv[WALK];
+#pragma unroll
+        for (int k = 0; k < WALK; ++k) Pv[k] = k < r ? chain_load(&Pbuf[(size_t)(s + k) * SEG + threadIdx.x]) : 1.0f;
+#pragma unroll
+        for (int k = 0; k < WALK; ++k) {
+            if (k < r && wave_alive) {
+                mine = s + k - s0 + 1;
+                Tbuf[(size_t)(s + k) * SEG + threadIdx.x] = alive ? Tb : -1.0f;
+                const float Tn = Tb * Pv[k];
+                if (alive && Tn < T_EPS) alive = false;  // the stop test fires inside this segment
+                else if (alive) Tb = Tn;
+                wave_alive = __ballot(alive) != 0ull;
+            }
+        }
+        s += (uint32_t)r;
+    }
+    if (lane == 0) { wneed[w] = mine; wgave[w] = gave_up ? 1u : 0u; }
+    __syncthreads();
+    if ((wgave[0] | wgave[1] | wgave[2] | wgave[3]) != 0u) return;
+    const uint32_t needed = max(max(wneed[0], wneed[1]), max(wneed[2], wneed[3]));
+    if (threadIdx.x == 0)
+        __hip_atomic_store(seg_off + chain_dead_offset(ntiles, cap) + tile, needed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    seg_tile_finish(cam, seg_off, cap, tile, s0, s1, mine, needed, Tbuf, seg_needed, nullptr, wbase, false);
+}
+
 // ---- A: per (tile, segment, pixel) product of (1 - alpha).  ROUND 0 = the segments inside the hinted prefix of their
 // tile (all of them without a hint); ROUND 1, 2 = the catch-up rounds for the short tiles of a hinted forward (see
 // k_seg_scan): the segments still flagged 3 that fall into the round's window.
-template <int ROUND, bool FAST>
-__global__ void __launch_bounds__(256)
-k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off, uint32_t cap,
+template <int ROUND, bool FAST, bool CHAIN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))      // (chain mode: 102 SGPRs without it, 7 waves)
+k_seg_alpha(Camera cam, const int2* __restrict__ ranges, uint32_t* __restrict__ seg_off, uint32_t cap,
             const uint32_t* __restrict__ point_list, const Splat* __restrict__ rec, float* __restrict__ Pbuf,
-            unsigned long long* __restrict__ segmask, float* __restrict__ part, int first_fused, FwdOut fwd_out)
+            unsigned long long* __restrict__ segmask, float* __restrict__ part, int first_fused, FwdOut fwd_out,
+            float* __restrict__ Tbuf, uint32_t* __restrict__ seg_needed)
 {
     // (18.5 KB in round 0: eight workgroups per CU, as with the 8 KB of the plain path alone)
     __shared__ float4 lds[ROUND == 0 ? 4 : 2][SEG];
@@ -503,17 +705,63 @@ k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     // the round's work list: round 0 one workgroup per entry (the grid is sized for it: AUTO_FIRST segments per tile
     // without a hint); the catch-up rounds a fixed grid striding over a list whose length only the device knows
     const int ntiles = cam.gx * cam.gy;
-    if (ROUND == 0 && first_fused && (int)blockIdx.x < ntiles) {      // the tiles' FIRST segments: alpha and blend in one pass
-        seg_first_body<FAST>(cam, (int)blockIdx.x, ranges, seg_off, point_list, rec, Pbuf, segmask, part, lds, lds_s, masks, fwd_out);
-        return;
-    }
+    // chain mode (CHAIN: round 0 of a forward without rounds; the segment table's comment): this view's heavy tiles
+    const uint32_t nheavy = CHAIN ? seg_off[seg_counts_offset(ntiles, cap) + SEG_COUNT_CHAIN_HEAVY] : 0u;
+    uint32_t* const chain_flags = (CHAIN && nheavy) ? seg_off + chain_flags_offset(ntiles, cap) : nullptr;
     const uint32_t count = seg_off[seg_counts_offset(ntiles, cap) + ROUND];
     const uint32_t* const list = seg_off + seg_list_offset(ntiles, cap, ROUND);
-    for (uint32_t item = blockIdx.x - (ROUND == 0 && first_fused ? (uint32_t)ntiles : 0u); item < count; item += gridDim.x) {
+    uint32_t item0 = blockIdx.x - (ROUND == 0 && first_fused ? (uint32_t)ntiles : 0u);
+    bool publish = false;
+    if (CHAIN && nheavy) {
+        // the launch (the segment table's comment): heavy tiles' first segments | region A | CHAIN_MAX_HEAVY walkers | the other
+        // tiles' first segments | regions B, C
+        const uint32_t size_a = seg_off[seg_counts_offset(ntiles, cap) + SEG_COUNT_CHAIN_A];
+        const uint32_t size_b = seg_off[seg_counts_offset(ntiles, cap) + SEG_COUNT_CHAIN_B];
+        const uint32_t* const order = seg_off + chain_heavy_offset(ntiles, cap);
+        uint32_t b = blockIdx.x;
+        int first_of = -1;
+        if (b < nheavy) first_of = (int)order[b];
+        else if ((b -= nheavy) < size_a) item0 = b;
+        else if ((b -= size_a) < (uint32_t)CHAIN_MAX_HEAVY) {
+            if (b < nheavy) {
+                uint32_t* const wsh = reinterpret_cast<uint32_t*>(masks);      // (16 x u64 of LDS nobody else uses here)
+                seg_chain_walk(cam, (int)order[b], seg_off, cap, Pbuf, Tbuf, seg_needed, wsh);
+            }
+            return;
+        }
+        else if ((b -= (uint32_t)CHAIN_MAX_HEAVY) < (uint32_t)ntiles - nheavy) first_of = (int)order[nheavy + b];
+        else item0 = size_a + (b - ((uint32_t)ntiles - nheavy));
+        if (first_of >= 0) {
+            seg_first_body<FAST>(cam, first_of, ranges, seg_off, point_list, rec, Pbuf, segmask, part, lds, lds_s, masks, fwd_out, chain_flags);
+            return;
+        }
+        publish = item0 < size_a || item0 >= size_a + size_b;
+    } else if (ROUND == 0 && first_fused && (int)blockIdx.x < ntiles) {      // the tiles' FIRST segments: alpha and blend in one pass
+        seg_first_body<FAST>(cam, (int)blockIdx.x, ranges, seg_off, point_list, rec, Pbuf, segmask, part, lds, lds_s, masks, fwd_out,
+                             chain_flags);
+        return;
+    }
+    for (uint32_t item = item0; item < count; item += gridDim.x) {
         SegCtx c;
         if (seg_setup_at(cam, ranges, seg_off, list[item], threadIdx.x >> 6, c)) {
+            if (CHAIN && publish) {
+                // a segment behind the end of its tile's chain: nobody needs it (all four waves take the same decision)
+                uint32_t* const dsh = reinterpret_cast<uint32_t*>(masks);          // (free until seg_build_masks)
+                if (threadIdx.x == 0) dsh[0] = chain_load(seg_off + chain_dead_offset(ntiles, cap) + c.tile);
+                __syncthreads();
+                const uint32_t dead = dsh[0];
+                __syncthreads();
+                // (NOT counted in a word next to the launch's counts: one atomic per skipped workgroup on the line that every
+                // workgroup reads first took the kernel from 161 to 234 us)
+                if ((uint32_t)c.sl >= dead) return;
+            }
             const float p = seg_alpha_body<FAST>(c, point_list, rec, lds, masks, segmask, qspace);
-            Pbuf[(size_t)c.seg * SEG + threadIdx.x] = p;
+            if (CHAIN && publish) {
+                chain_store(&Pbuf[(size_t)c.seg * SEG + threadIdx.x], p);
+                chain_publish(chain_flags, c.seg);
+            } else {
+                Pbuf[(size_t)c.seg * SEG + threadIdx.x] = p;
+            }
         }
         if (ROUND == 0) break;       // (grid >= count in round 0)
         __syncthreads();             // the staging buffers are reused by the next entry
@@ -536,13 +784,15 @@ k_seg_alpha(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
 template <int ROUND>
 __global__ void __launch_bounds__(256)
 k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, uint32_t cap, uint32_t second, const float* __restrict__ Pbuf,
-           float* __restrict__ Tbuf, uint32_t* __restrict__ seg_needed, uint32_t* __restrict__ hint)
+           float* __restrict__ Tbuf, uint32_t* __restrict__ seg_needed, uint32_t* __restrict__ hint, int chain)
 {
     constexpr bool PASS2 = ROUND > 0;
     __shared__ uint32_t wneed[4];
     __shared__ uint32_t walive[4];
     __shared__ uint32_t wbase;
     const int tile = blockIdx.x;
+    // chain mode: the tile's walker has done all of this inside k_seg_alpha's launch
+    if (ROUND == 0 && chain && seg_off[chain_dead_offset(cam.gx * cam.gy, cap) + tile] != CHAIN_OPEN) return;
     const uint32_t lim_word = seg_needed[tile];   // k_seg_offsets' snapshot (ROUND > 0: what the previous round left)
     if (PASS2 && !(lim_word & TILE_SHORT)) return;
     const int tx = tile % cam.gx, ty = tile / cam.gx;
@@ -601,42 +851,55 @@ k_seg_scan(Camera cam, uint32_t* __restrict__ seg_off, uint32_t cap, uint32_t se
         return;   // the segment flags of this tile stay as they are (3 behind the prefix)
     }
     const uint32_t needed = max(max(wneed[0], wneed[1]), max(wneed[2], wneed[3]));
-    for (uint32_t s = s0 + mine; s < s0 + needed; ++s) Tbuf[(size_t)s * SEG + threadIdx.x] = -1.0f;
-    // the tile's needed segments go onto the list of its dispatch queue, in the order in which tiles finish (vr_segment.h)
-    const int ntiles_all = cam.gx * cam.gy, queue = (int)(blockIdx.x % SEG_QUEUES);
-    if (threadIdx.x == 0) {
-        seg_needed[tile] = needed;
-        if (hint) hint[tile] = needed;     // in/out: what this forward needed is the hint of the camera's next visit
-        wbase = atomicAdd(&seg_off[seg_qcount_offset(ntiles_all, cap, queue)], needed);
-        if (needed >= HEAVY_TILE) {      // long chains start first in the per-tile kernels that follow (vr_segment.h)
-            const uint32_t hp = atomicAdd(&seg_off[seg_counts_offset(ntiles_all, cap) + SEG_COUNT_HEAVY], 1u);
-            seg_off[seg_actoff_offset(ntiles_all, cap) + hp] = (uint32_t)tile;     // (act_off's space: free after k_seg_tiles)
-        }
-    }
-    __syncthreads();
-    {
-        uint32_t* const ql = seg_off + seg_qlist_offset(ntiles_all, cap, queue) + wbase;
-        for (uint32_t k = threadIdx.x; k < needed; k += 256) ql[k] = s0 + k;
-    }
-    // per-segment flag for the segment kernels (vr_segment.h): 0 not needed / 1 needed, last / 2 needed, next too
-    int4* seg_info = reinterpret_cast<int4*>(seg_off + seg_tile_offset(cam.gx * cam.gy));
-    for (uint32_t k = threadIdx.x; k < s1 - s0; k += 256) {
-        const uint32_t flag = k >= needed ? 0u : (k + 1 < needed ? 2u : 1u);
-        seg_info[s0 + k].w = (int)(k | (flag << 30));
-    }
+    seg_tile_finish(cam, seg_off, cap, tile, s0, s1, mine, needed, Tbuf, seg_needed, hint, &wbase);
 }
 
 // The eight queue lists dealt round-robin into the needed list: entry k of queue q goes behind the entries < k of every
 // queue and the entries k of the queues before q.  One thread per (queue, k) slot.
+// Chain mode (slice SEG_QUEUES of the grid): the needed segments of the tiles whose walkers finished go BEHIND the queues'
+// entries, level-major (every walked tile's segment k before any tile's segment k + 1: a tile's front segments -- every pixel
+// alive, the expensive ones -- first, consecutive workgroups on different tiles; vr_segment.h on why the order matters).
 __global__ void __launch_bounds__(256)
-k_seg_merge(int ntiles, uint32_t* __restrict__ seg_off, uint32_t cap)
+k_seg_merge(int ntiles, uint32_t* __restrict__ seg_off, uint32_t cap, const uint32_t* __restrict__ seg_needed, int chain)
 {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     const int q = (int)blockIdx.y;
     uint32_t len[SEG_QUEUES], total = 0;
 #pragma unroll
     for (int i = 0; i < SEG_QUEUES; ++i) { len[i] = seg_off[seg_qcount_offset(ntiles, cap, i)]; total += len[i]; }
-    if (k == 0 && q == 0) seg_off[seg_counts_offset(ntiles, cap) + SEG_LIST_NEEDED] = total;
+    const uint32_t nheavy = chain ? seg_off[seg_counts_offset(ntiles, cap) + SEG_COUNT_CHAIN_HEAVY] : 0u;
+    if (q == SEG_QUEUES) {
+        __shared__ uint32_t wn[CHAIN_MAX_HEAVY], wfirst[CHAIN_MAX_HEAVY], wpre[CHAIN_MAX_HEAVY + 1];
+        if (nheavy == 0u) return;
+        if (threadIdx.x < CHAIN_MAX_HEAVY) {
+            uint32_t n = 0, f = 0;
+            if (threadIdx.x < nheavy) {
+                const uint32_t t = seg_off[chain_heavy_offset(ntiles, cap) + threadIdx.x];
+                if (seg_off[chain_dead_offset(ntiles, cap) + t] != CHAIN_OPEN) n = seg_needed[t];    // (else: k_seg_scan walked and enqueued it)
+                f = seg_off[t];
+            }
+            wn[threadIdx.x] = n;
+            wfirst[threadIdx.x] = f;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (uint32_t h = 0; h < nheavy; ++h) { wpre[h] = run; run += wn[h]; }
+            wpre[nheavy] = run;
+        }
+        __syncthreads();
+        const uint32_t late = wpre[nheavy];
+        if (k == 0) seg_off[seg_counts_offset(ntiles, cap) + SEG_LIST_NEEDED] = total + late;
+        if (k >= late) return;
+        uint32_t h = 0;                              // entry k in tile-major order: walked tile h, its segment `lvl`
+        while (h + 1 < nheavy && wpre[h + 1] <= k) ++h;
+        const uint32_t lvl = k - wpre[h];
+        uint32_t before = 0;
+        for (uint32_t j = 0; j < nheavy; ++j) before += min(wn[j], lvl) + ((j < h && wn[j] > lvl) ? 1u : 0u);
+        seg_off[seg_list_offset(ntiles, cap, SEG_LIST_NEEDED) + total + before] = wfirst[h] + lvl;
+        return;
+    }
+    if (k == 0 && q == 0 && nheavy == 0u) seg_off[seg_counts_offset(ntiles, cap) + SEG_LIST_NEEDED] = total;
     if (k >= len[q]) return;
     uint32_t pos = 0;
 #pragma unroll
@@ -1019,9 +1282,14 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     const uint32_t first = dense ? AUTO_FIRST_DENSE : AUTO_FIRST_SPARSE;
     const uint32_t second = dense ? AUTO_SECOND_DENSE : AUTO_SECOND_SPARSE;
     static const bool one_table = [] { const char* e = getenv("VEGS_SEG_TABLE"); return !(e && e[0] == '0'); }();   // (A/B switch)
+    static const bool chain_env = [] { const char* e = getenv("VEGS_SEG_CHAIN"); return !(e && e[0] == '0'); }();   // (A/B switch)
+    // chain mode (the segment table's comment): a forward without rounds whose table comes from k_seg_table; its arrays
+    // (flags [cap] | dead and launch order [2 x tiles, padded]) live in the lists of the rounds
+    const bool chain = chain_env && !rounds && first_fused && one_table && ntiles <= SEGTAB_MAX_TILES && R / SEG >= ntiles + 256;
     if (one_table && ntiles <= SEGTAB_MAX_TILES && nseg > 0) {
         hipLaunchKernelGGL(k_seg_table, dim3(cdiv((long)nseg, 256)), dim3(256), 0, s, ranges, ntiles, seg_off,
-                           (const uint32_t*)needed_hint, seg_needed, (uint32_t)nseg, auto_rounds ? first : 0x3FFFFFFFu, first_fused);
+                           (const uint32_t*)needed_hint, seg_needed, (uint32_t)nseg, auto_rounds ? first : 0x3FFFFFFFu, first_fused,
+                           chain ? 1 : 0);
     } else {
         hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(SEGOFF_THREADS), 0, s, ranges, ntiles, seg_off,
                            (const uint32_t*)needed_hint, seg_needed, (uint32_t)nseg, auto_rounds ? first : 0x3FFFFFFFu, first_fused);
@@ -1039,22 +1307,25 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     const unsigned gridc = (unsigned)(nseg < 4096 ? nseg : 4096);
     const bool fast = (cam.flags & FLAG_FAST_EXP) != 0u;
     const FwdOut fwd_out{out_color, out_depth, out_quat, out_scale, out_alpha, final_T, n_contrib, dsum};
-#define VR_ALPHA(RD, FST, GRID)                                                                                           \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_alpha<RD, FST>), dim3(GRID), dim3(256), 0, s, cam, ranges,                   \
-                       (const uint32_t*)seg_off, (uint32_t)nseg, point_list, rec, Pbuf, segmask, part, first_fused, fwd_out)
-#define VR_ROUND(RD, GRID)                                                                                                \
-    if (R > 0) { if (fast) VR_ALPHA(RD, true, GRID); else VR_ALPHA(RD, false, GRID); }                                    \
+#define VR_ALPHA(RD, FST, CHN, GRID)                                                                                      \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_alpha<RD, FST, CHN>), dim3(GRID), dim3(256), 0, s, cam, ranges,              \
+                       seg_off, (uint32_t)nseg, point_list, rec, Pbuf, segmask, part, first_fused, fwd_out, Tbuf, seg_needed)
+#define VR_ROUND(RD, CHN, GRID)                                                                                           \
+    if (R > 0) { if (fast) VR_ALPHA(RD, true, CHN, GRID); else VR_ALPHA(RD, false, CHN, GRID); }                          \
     if (R > 0 || RD == 0) hipLaunchKernelGGL(k_seg_scan<RD>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (uint32_t)nseg, second, \
-                                             (const float*)Pbuf, Tbuf, seg_needed, needed_hint)
-    VR_ROUND(0, grid0 + (first_fused ? (unsigned)ntiles : 0u));        // (+ the tiles' first segments: the launch's first `ntiles` workgroups)
+                                             (const float*)Pbuf, Tbuf, seg_needed, needed_hint, (RD == 0 && CHN) ? 1 : 0)
+    // (+ the tiles' first segments: the launch's first `ntiles` workgroups; chain mode: + the walkers)
+    if (chain) { VR_ROUND(0, true, grid0 + (unsigned)ntiles + (unsigned)CHAIN_MAX_HEAVY); }
+    else { VR_ROUND(0, false, grid0 + (first_fused ? (unsigned)ntiles : 0u)); }
     if (rounds) {
-        VR_ROUND(1, gridc);
-        VR_ROUND(2, gridc);
+        VR_ROUND(1, false, gridc);
+        VR_ROUND(2, false, gridc);
     }
 #undef VR_ROUND
 #undef VR_ALPHA
     VR_KERNEL_CHECK("seg_alpha / seg_scan rounds", s, debug);
-    hipLaunchKernelGGL(k_seg_merge, dim3(cdiv((long)nseg, 256), SEG_QUEUES), dim3(256), 0, s, ntiles, seg_off, (uint32_t)nseg);
+    hipLaunchKernelGGL(k_seg_merge, dim3(cdiv((long)nseg, 256), SEG_QUEUES + (chain ? 1 : 0)), dim3(256), 0, s, ntiles, seg_off,
+                       (uint32_t)nseg, (const uint32_t*)seg_needed, chain ? 1 : 0);
     if (R > 0) {
         if (fast)
             hipLaunchKernelGGL(k_seg_blend<true>, dim3((unsigned)nseg * 4), dim3(64), 0, s, cam, ranges, (const uint32_t*)seg_off,

@@ -3,6 +3,9 @@ wait for sums posted by the workgroups before them (vegs_amd/csrc/binning.hip): 
 depends on WHO runs WHEN.  The parity tests run on a quiet GPU; here the same view is binned again and again while
 another stream keeps the CUs, the L2s and the memory system busy, and while a second view is in flight on a second
 stream -- the lists must come out bit for bit what the quiet run produced, every time, and no guard word may go up.
+The same for the render forward's chain mode (walker workgroups that follow segment products published by other workgroups
+of the same launch, render_fwd.hip): the images of the disturbed runs equal the quiet run's, and the walkers' result
+equals the three-round path's.
 VEGS_STRESS_ROUNDS widens the loop for a campaign (default: what a round's test run can afford)."""
 import os
 

@@ -362,7 +362,11 @@ int vr_debug_export_binning(const VrSaved* saved, int32_t image_height, int32_t 
  * vr_debug_raise_guard(1) makes the NEXT vr_forward of the calling thread raise it in the middle of its own binning, as
  * a timed-out wait would -- after lists that are in fact valid; vr_debug_raise_guard(2) makes that forward LOSE the first
  * workgroup of its depth sort (it never posts its counts): the waits of its successors run out for real (~2 s) and the
- * lists behind them are built from short prefixes -- what VR_FLAG_VERIFY_BINNING has to recover from. */
+ * lists behind them are built from short prefixes -- what VR_FLAG_VERIFY_BINNING has to recover from.
+ * vr_debug_raise_guard(3) has nothing to do with the guard word: the walker workgroups of that forward's render stage (they
+ * follow the deep tiles' segment chains inside the alpha launch) give up at their first empty poll, as they would after
+ * their bounded wait on a GPU that does not schedule the producers -- the tiles must then be finished by the kernel behind
+ * the launch, with the same result. */
 int vr_debug_set_guard(uint32_t value, void* stream);
 int vr_debug_raise_guard(int on);
 /* views of the calling thread that VR_FLAG_VERIFY_BINNING binned a second time (tests) */

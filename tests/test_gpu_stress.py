@@ -136,3 +136,14 @@ def test_chain_mode_and_rounds_agree_on_a_view_with_deep_tiles(dev):  # noqa: F8
         assert torch.equal(m2d_c, m2d_r)
         for k in grads_r:
             assert torch.equal(grads_c[k], grads_r[k]), (rep, k)
+    # walkers without patience (vr_debug_raise_guard(3): they leave at their first empty poll, as after their bounded wait on
+    # a GPU that does not schedule the producers): k_seg_scan finishes their tiles behind the launch -- same result
+    for rep in range(3):
+        _capi.check(_capi.load().vr_debug_raise_guard(3))
+        img_i, need_i, grads_i, m2d_i = run(0)
+        assert torch.equal(need_i, need_r), rep
+        for a, b in zip(img_i, img_r):
+            assert torch.equal(a, b), rep
+        assert torch.equal(m2d_i, m2d_r)
+        for k in grads_r:
+            assert torch.equal(grads_i[k], grads_r[k]), (rep, k)

@@ -56,7 +56,7 @@ static thread_local Mailbox g_mail[MAX_DEVICES] = {};
 struct MailRef { uint32_t* pinned; uint32_t* guard; int dev; };
 static std::mutex g_mail_mu;
 static std::vector<MailRef> g_mail_reg;
-static thread_local int g_raise_guard = 0;        // test hook: vr_debug_raise_guard (1 = raise the word, 2 = lose a workgroup)
+static thread_local int g_raise_guard = 0;        // test hook: vr_debug_raise_guard (1 = raise the word, 2 = lose a workgroup, 3 = impatient walkers)
 static thread_local int g_rebinned = 0;           // views re-binned under VR_FLAG_VERIFY_BINNING (vr_debug_rebinned)
 
 // the calling thread's mailbox for the current device, created on first use
@@ -473,7 +473,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     g_raise_guard = 0;
     rc = launch_binning(cam, P, (int)V, (long)R, key_min, key_bits, vis_key, vis_id, rect, scan_scr, scr2, point_list,
                         ranges, ranges_zeroed, status_zeroed, guard_word,
-                        mail.pinned_dev + RING_AT + 2 * (mail.seq % RING_SLOTS), mail.seq, raise, n_huge, s, debug);
+                        mail.pinned_dev + RING_AT + 2 * (mail.seq % RING_SLOTS), mail.seq, raise == 3 ? 0 : raise, n_huge, s, debug);
     if (rc) return rc;
     if (!lists && P > 0) {   // no binning kernel will post this forward's slot: the host does (nothing can have tripped)
         uint32_t* slot = g_pinned + RING_AT + 2 * (mail.seq % RING_SLOTS);
@@ -521,7 +521,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
                            (float*)((char*)binning + BL.part),
                            (unsigned long long*)((char*)binning + BL.segmask), scr3,
                            out->color, out->depth, out->cov_quat, out->cov_scale, out->alpha, final_T, n_contrib,
-                           (float*)((char*)image + IL.dsum), saved->needed_hint, s, debug);
+                           (float*)((char*)image + IL.dsum), saved->needed_hint, s, debug, raise == 3 ? 0 : -1);
     prof_end(VR_STAGE_RENDER_FWD, s);
     if (rc) return rc;
 
@@ -931,7 +931,7 @@ int vr_debug_set_guard(uint32_t value, void* stream)
 int vr_debug_raise_guard(int on)
 {
     g_err[0] = 0;
-    g_raise_guard = on == 2 ? 2 : (on != 0 ? 1 : 0);
+    g_raise_guard = (on == 2 || on == 3) ? on : (on != 0 ? 1 : 0);
     return VR_OK;
 }
 

@@ -632,7 +632,7 @@ __device__ __forceinline__ void seg_tile_finish(const Camera& cam, uint32_t* __r
 constexpr int CHAIN_MAX_POLLS = 20000;         // x (~1 us sleep + a device-scope load): tens of milliseconds
 __device__ __forceinline__ void seg_chain_walk(const Camera& cam, int tile, uint32_t* __restrict__ seg_off, uint32_t cap,
                                                const float* __restrict__ Pbuf, float* __restrict__ Tbuf,
-                                               uint32_t* __restrict__ seg_needed, uint32_t* wsh)
+                                               uint32_t* __restrict__ seg_needed, uint32_t* wsh, const int patience)
 {
     constexpr int WALK = 16;
     uint32_t* const wneed = wsh, * const wgave = wsh + 4, * const wbase = wsh + 8;
@@ -655,7 +655,7 @@ __device__ __forceinline__ void seg_chain_walk(const Camera& cam, int tile, uint
             const unsigned long long missing = __ballot(f == 0u);
             r = missing ? (int)__builtin_ctzll(missing) : WALK;
             if (r > 0) break;
-            if (polls >= CHAIN_MAX_POLLS) { gave_up = true; break; }
+            if (polls >= patience) { gave_up = true; break; }
             __builtin_amdgcn_s_sleep(8);
         }
         if (gave_up) break;
@@ -694,7 +694,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 k_seg_alpha(Camera cam, const int2* __restrict__ ranges, uint32_t* __restrict__ seg_off, uint32_t cap,
             const uint32_t* __restrict__ point_list, const Splat* __restrict__ rec, float* __restrict__ Pbuf,
             unsigned long long* __restrict__ segmask, float* __restrict__ part, int first_fused, FwdOut fwd_out,
-            float* __restrict__ Tbuf, uint32_t* __restrict__ seg_needed)
+            float* __restrict__ Tbuf, uint32_t* __restrict__ seg_needed, int chain_patience)
 {
     // (18.5 KB in round 0: eight workgroups per CU, as with the 8 KB of the plain path alone)
     __shared__ float4 lds[ROUND == 0 ? 4 : 2][SEG];
@@ -725,7 +725,7 @@ k_seg_alpha(Camera cam, const int2* __restrict__ ranges, uint32_t* __restrict__ 
         else if ((b -= size_a) < (uint32_t)CHAIN_MAX_HEAVY) {
             if (b < nheavy) {
                 uint32_t* const wsh = reinterpret_cast<uint32_t*>(masks);      // (16 x u64 of LDS nobody else uses here)
-                seg_chain_walk(cam, (int)order[b], seg_off, cap, Pbuf, Tbuf, seg_needed, wsh);
+                seg_chain_walk(cam, (int)order[b], seg_off, cap, Pbuf, Tbuf, seg_needed, wsh, chain_patience);
             }
             return;
         }
@@ -1264,7 +1264,7 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
                       uint32_t* seg_off, uint32_t* seg_needed, float* Tbuf, float* part, unsigned long long* segmask,
                       void* scratch, float* out_color,
                       float* out_depth, float* out_quat, float* out_scale, float* out_alpha, float* final_T,
-                      uint32_t* n_contrib, float* dsum, uint32_t* needed_hint, hipStream_t s, bool debug)
+                      uint32_t* n_contrib, float* dsum, uint32_t* needed_hint, hipStream_t s, bool debug, int chain_patience)
 {
     const int ntiles = cam.gx * cam.gy;
     if (ntiles == 0) return 0;
@@ -1309,7 +1309,8 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     const FwdOut fwd_out{out_color, out_depth, out_quat, out_scale, out_alpha, final_T, n_contrib, dsum};
 #define VR_ALPHA(RD, FST, CHN, GRID)                                                                                      \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_alpha<RD, FST, CHN>), dim3(GRID), dim3(256), 0, s, cam, ranges,              \
-                       seg_off, (uint32_t)nseg, point_list, rec, Pbuf, segmask, part, first_fused, fwd_out, Tbuf, seg_needed)
+                       seg_off, (uint32_t)nseg, point_list, rec, Pbuf, segmask, part, first_fused, fwd_out, Tbuf, seg_needed,  \
+                       chain_patience < 0 ? CHAIN_MAX_POLLS : chain_patience)
 #define VR_ROUND(RD, CHN, GRID)                                                                                           \
     if (R > 0) { if (fast) VR_ALPHA(RD, true, CHN, GRID); else VR_ALPHA(RD, false, CHN, GRID); }                          \
     if (R > 0 || RD == 0) hipLaunchKernelGGL(k_seg_scan<RD>, dim3(ntiles), dim3(256), 0, s, cam, seg_off, (uint32_t)nseg, second, \

@@ -118,7 +118,8 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
                       uint32_t* seg_off, uint32_t* seg_needed, float* Tbuf, float* part, unsigned long long* segmask,
                       void* scratch, float* out_color,
                       float* out_depth, float* out_quat, float* out_scale, float* out_alpha, float* final_T,
-                      uint32_t* n_contrib, float* dsum, uint32_t* needed_hint, hipStream_t s, bool debug);
+                      uint32_t* n_contrib, float* dsum, uint32_t* needed_hint, hipStream_t s, bool debug,
+                      int chain_patience = -1);      // (polls a chain-mode walker waits for a segment; < 0: the default.  0: test hook)
 int launch_count_fragments(const uint32_t* n_contrib, long N, unsigned long long* out_dev, hipStream_t s);
 
 // gacc: [P][16] floats = conic dA,dB,dC | opacity | attr[11] | pad ; gmean2D: [P][3] (x,y used)

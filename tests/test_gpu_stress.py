@@ -75,7 +75,8 @@ def test_lists_do_not_depend_on_what_else_the_gpu_is_doing(dev):  # noqa: F811
 def test_two_views_in_flight_do_not_disturb_each_other(dev):  # noqa: F811
     """Two streams, two different views, no synchronisation between the forwards: each view's lists and image equal its
     quiet run's (separate guard words and status regions per forward in flight, ABI v9)."""
-    views = [_view(300000, 1376, 376, 7, 5.0, dev), _view(200000, 1024, 320, 8, 25.0, dev)]
+    # (the first view is large enough for the render forward's chain mode: walkers of one launch beside the other view's kernels)
+    views = [_view(1000000, 1376, 376, 7, 5.0, dev), _view(200000, 1024, 320, 8, 25.0, dev)]
     quiet = []
     for st, t in views:
         r = _forward(st, t, dev)
@@ -147,3 +148,49 @@ def test_chain_mode_and_rounds_agree_on_a_view_with_deep_tiles(dev):  # noqa: F8
         assert torch.equal(m2d_i, m2d_r)
         for k in grads_r:
             assert torch.equal(grads_i[k], grads_r[k]), (rep, k)
+
+
+_SWEEP = range(int(os.environ.get("VEGS_STRESS_ROUNDS", "60")) // 10)
+
+
+@pytest.mark.parametrize("case", _SWEEP)
+def test_chain_mode_sweep_against_the_rounds(case, dev):  # noqa: F811
+    """Random street views around the sizes at which chain mode switches on (enough list segments, some tile deeper than the
+    prefix, not more heavy tiles than walkers): the default forward against VR_FLAG_ROUNDS_ON -- five images and per-tile
+    needed-segment counts bit-identical, whichever of the two the default turns out to be for the view."""
+    import ctypes as C
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from vegs_amd import _capi, rasterizer, scenes
+    rng = np.random.default_rng(4100 + case)
+    P = int(rng.choice([300000, 600000, 1000000, 1500000]))
+    W, H = [(1376, 376), (1408, 376), (1000, 300), (704, 188)][int(rng.integers(0, 4))]
+    disc = float(rng.choice([0.6, 1.0, 1.6, 2.5]))
+    sc, _ = scenes.scene_street(P=P, length=float(rng.choice([60.0, 120.0, 250.0])), sh_degree=1, seed=500 + case)
+    sc["scales"] = (sc["scales"] * disc).astype(np.float32)
+    if case % 3 == 0:
+        sc["opacities"] = np.clip(sc["opacities"] * 0.5, 0.0, 1.0).astype(np.float32)      # (long chains: more needed segments)
+    cam = scenes.kitti_camera(x_forward=float(rng.uniform(0.0, 40.0)), y_left=float(rng.uniform(-2.0, 2.0)), width=W, height=H)
+    st = tp._settings(cam, rng.uniform(0, 1, 3).astype(np.float32), 1, 1.0, dev)
+    t = {k: torch.tensor(v, device=dev) for k, v in sc.items()}
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+
+    def run(flags):
+        m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
+        old = rasterizer.needed_hints(False)
+        try:
+            with rasterizer.flags(flags):
+                res = GaussianRasterizer(raster_settings=st)(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"],
+                                                            scales=t["scales"], rotations=t["rotations"])
+                need = torch.zeros(T, dtype=torch.int32, device=dev)
+                saved = _capi.saved_of(res[0].grad_fn)
+                _capi.check(_capi.load().vr_export_needed(C.byref(saved), H, W, need.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        finally:
+            rasterizer.needed_hints(old)
+        return [r.detach() for r in res[:5]], need
+
+    img_r, need_r = run(rasterizer.FLAG_ROUNDS_ON)
+    for rep in range(2):
+        img_c, need_c = run(0)
+        assert torch.equal(need_c, need_r), (case, rep)
+        for a, b in zip(img_c, img_r):
+            assert torch.equal(a, b), (case, rep)

@@ -73,8 +73,11 @@ __device__ __forceinline__ bool wait_all(const unsigned long long* words, int wo
     if ((int)threadIdx.x < world) {
         const unsigned long long* w = words + (size_t)threadIdx.x * XG_FLAG_STRIDE;
         unsigned long long t0 = 0;
+        // (polled RELAXED, ONE acquire fence behind the loop: an acquire at system scope is a `buffer_inv` -- every poll of
+        // every waiting workgroup would drop the XCD's L2 under the backward kernels this exchange is overlapped with; what
+        // that costs was measured on the render forward's walkers in round 5)
         for (int polls = 0;; ++polls) {
-            if (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= epoch) break;
+            if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= epoch) break;
             if ((polls & 255) == 255) {
                 const unsigned long long now = __builtin_amdgcn_s_memrealtime();
                 if (t0 == 0) t0 = now | 1ull;
@@ -86,6 +89,7 @@ __device__ __forceinline__ bool wait_all(const unsigned long long* words, int wo
                 __builtin_amdgcn_s_sleep(8);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system scope: what the peers wrote before posting is visible from here on
     }
     __syncthreads();
     return __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull;

@@ -1287,10 +1287,195 @@ k_tile_ranges(const uint32_t* __restrict__ tkeys, long R, int2* __restrict__ ran
     if (j == R - 1) ranges[k].y = (int)R;
 }
 
+// ---------------------------------------------------------------- tile split: the stable sort by tile id in ONE scatter
+//
+// Until round 5 the (tile, id) pairs were sorted by two 6-bit onesweep passes (+ the digit histogram of the keys, its sum, and
+// k_tile_ranges over the sorted keys: 10 + 5 + 2 x 19 + 6.5 us on the headline view, all of it latency per launch).  A frame
+// has at most a few thousand tiles, so the whole key fits ONE digit -- too many bins for posted per-bin sums (4,096 words per
+// workgroup and level), but not for a count table:
+//   k_split_count    workgroup b counts the tiles of its SPLIT_BLOCK consecutive pairs in LDS -> table[b][tile]
+//   k_split_scan     per strip of 16 tiles, down the table: table[b][t] <- pairs of tile t in the workgroups before b; totals[t]
+//   k_split_base     one workgroup: base[t] = pairs of the tiles before t; ranges[t] = [base, base + total) -- k_tile_ranges'
+//                    output without the sorted keys, which nobody else reads -- and the view's guard word for the host
+//   k_split_scatter  workgroup b ranks its pairs again (per-wave counters in LDS, ballot matches on the 12 bits) and writes
+//                    each id to base[t] + table[b][t] + (pairs of t in the waves before) + (rank in the wave): stable.
+// No workgroup waits for another.  Used for frames of up to SPLIT_MAX_TILES tiles; larger ones keep the two passes.
+constexpr int SPLIT_BLOCK = 4096;                 // pairs per workgroup (16 per thread)
+constexpr int SPLIT_ITEMS = SPLIT_BLOCK / 256;
+constexpr int SPLIT_MAX_TILES = 3264;             // (k_split_scatter: 5 x 4 bytes of LDS per tile, 64 KB)
+__host__ __device__ inline int split_stride(int ntiles) { return (ntiles + 63) & ~63; }      // table row length (words)
+
+__global__ void __launch_bounds__(256)
+k_split_count(const uint32_t* __restrict__ tkeys, long R, int ntiles, int stride, uint32_t* __restrict__ table,
+              uint32_t* __restrict__ err)
+{
+    extern __shared__ uint32_t split_lds[];
+    uint32_t* const h = split_lds;                 // [stride]
+    if (st_load(err) != 0u) return;                // (a wait of this view's depth sort / emission ran out: the keys may be anything)
+    for (int d = threadIdx.x; d < stride; d += 256) h[d] = 0u;
+    __syncthreads();
+    const long base = (long)blockIdx.x * SPLIT_BLOCK;
+    uint32_t k[SPLIT_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SPLIT_ITEMS; ++i) {
+        const long idx = base + i * 256 + threadIdx.x;
+        k[i] = idx < R ? tkeys[idx] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int i = 0; i < SPLIT_ITEMS; ++i) {
+        if (k[i] < (uint32_t)ntiles) atomicAdd(&h[k[i]], 1u);
+        else if (k[i] != 0xFFFFFFFFu) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // not a tile: fail the view
+    }
+    __syncthreads();
+    uint32_t* const row = table + (size_t)blockIdx.x * stride;
+    for (int d = threadIdx.x; d < stride; d += 256) row[d] = h[d];
+}
+
+// 16 tiles x 16 row-lanes per step: thread (r, c) takes SCAN_U consecutive rows of column c, the 16 row-lanes are scanned
+// through LDS, the column's running total carries over to the next step.  In place: counts -> exclusive prefixes.
+// (16 rows per thread and step instead of 8: the same 9 us.  k_split_base run by the LAST workgroup of this launch -- a
+// counter, device-scope totals -- instead of a launch of its own: 13.6 against 9.2 + 4.9 us; two launches it stays.)
+constexpr int SPLIT_SCAN_U = 8;
+__global__ void __launch_bounds__(256)
+k_split_scan(uint32_t* __restrict__ table, int nblk, int stride, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t part[16][17];
+    const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + c;
+    uint32_t carry = 0;
+    for (int row0 = 0; row0 < nblk; row0 += 16 * SPLIT_SCAN_U) {
+        const int mine = row0 + r * SPLIT_SCAN_U;
+        uint32_t v[SPLIT_SCAN_U], sum = 0;
+#pragma unroll
+        for (int u = 0; u < SPLIT_SCAN_U; ++u) {
+            v[u] = (mine + u < nblk) ? table[(size_t)(mine + u) * stride + col] : 0u;
+            sum += v[u];
+        }
+        part[r][c] = sum;
+        __syncthreads();
+        uint32_t before = carry, all = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t t = part[q][c];
+            if (q < r) before += t;
+            all += t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < SPLIT_SCAN_U; ++u) {
+            if (mine + u < nblk) table[(size_t)(mine + u) * stride + col] = before;
+            before += v[u];
+        }
+        carry += all;
+    }
+    if (r == 0) totals[col] = carry;
+}
+
+// base[t] = pairs of the tiles before t; ranges[t] = [base, base + total) for the tiles that have pairs (the others stay
+// cleared) -- and (thread 0) the look-back guard word as it stands after ALL waiting passes of this view, posted with this
+// forward's sequence number into the host's pinned ring slot (what k_tile_ranges does on the two-pass path).
+__global__ void __launch_bounds__(1024)
+k_split_base(const uint32_t* __restrict__ totals, int ntiles, uint32_t* __restrict__ base, int2* __restrict__ ranges,
+             const uint32_t* __restrict__ err, uint32_t* __restrict__ post, uint32_t seq)
+{
+    __shared__ uint32_t wsum[16];
+    uint32_t tripped = 0u;
+    if (err) tripped = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && post) {
+        __hip_atomic_store(&post[1], tripped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&post[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // A timed-out wait left the lists of THIS view invalid: every tile stays empty (the ranges were cleared by the compaction)
+    if (tripped) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int PER = 4;                         // (1024 threads: up to 4096 tiles)
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int t = threadIdx.x * PER + k;
+        v[k] = t < ntiles ? totals[t] : 0u;
+        sum += v[k];
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int q = 0; q < w; ++q) run += wsum[q];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int t = threadIdx.x * PER + k;
+        if (t < ntiles) {
+            base[t] = run;
+            if (v[k]) ranges[t] = make_int2((int)run, (int)(run + v[k]));
+        }
+        run += v[k];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_split_scatter(const uint32_t* __restrict__ tkeys, const uint32_t* __restrict__ tvals, long R, int ntiles, int stride,
+                const uint32_t* __restrict__ table, const uint32_t* __restrict__ base, uint32_t* __restrict__ out,
+                const uint32_t* __restrict__ err)
+{
+    extern __shared__ uint32_t split_lds[];
+    uint32_t* const cnt = split_lds;                    // [4][stride]: per wave, pairs of each tile so far -> pairs in the waves before
+    uint32_t* const rowoff = split_lds + 4 * stride;    // [stride]: base[t] + pairs of t in the workgroups before this one
+    if (st_load(err) != 0u) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t* const row = table + (size_t)blockIdx.x * stride;
+    for (int d = threadIdx.x; d < stride; d += 256) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cnt[q * stride + d] = 0u;
+        rowoff[d] = (d < ntiles ? base[d] : 0u) + row[d];
+    }
+    __syncthreads();
+    const long wbase = (long)blockIdx.x * SPLIT_BLOCK + (long)w * (64 * SPLIT_ITEMS);
+    uint32_t key[SPLIT_ITEMS], val[SPLIT_ITEMS], rank[SPLIT_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SPLIT_ITEMS; ++i) {
+        const long idx = wbase + i * 64 + lane;
+        key[i] = idx < R ? tkeys[idx] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int i = 0; i < SPLIT_ITEMS; ++i) {
+        const long idx = wbase + i * 64 + lane;
+        val[i] = idx < R ? tvals[idx] : 0u;
+    }
+    const unsigned long long lt = lanemask_lt();
+    uint32_t* const mycnt = cnt + w * stride;
+#pragma unroll
+    for (int i = 0; i < SPLIT_ITEMS; ++i) {
+        const bool ok = key[i] < (uint32_t)ntiles;
+        const unsigned long long valid = __ballot(ok);
+        const unsigned long long m = match_digit<12>(key[i], valid);
+        const uint32_t prior = ok ? mycnt[key[i]] : 0u;
+        rank[i] = prior + (uint32_t)__popcll(m & lt);
+        if (ok && (m & lt) == 0ull) mycnt[key[i]] = prior + (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < stride; d += 256) {       // counts of the four waves -> pairs in the waves before each
+        const uint32_t c0 = cnt[d], c1 = cnt[stride + d], c2 = cnt[2 * stride + d];
+        cnt[d] = 0u;
+        cnt[stride + d] = c0;
+        cnt[2 * stride + d] = c0 + c1;
+        cnt[3 * stride + d] = c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SPLIT_ITEMS; ++i)
+        if (key[i] < (uint32_t)ntiles) out[rowoff[key[i]] + mycnt[key[i]] + rank[i]] = val[i];
+}
+
 // ---------------------------------------------------------------- stage 2 driver
 
 struct Stage2Layout {
-    size_t status, tmp_key, tmp_id, offs, rect_sorted, tkeysA, tkeysB, tvalsB, hist, bsum, tpartial, big, total;
+    size_t status, tmp_key, tmp_id, offs, rect_sorted, tkeysA, tkeysB, tvalsB, hist, bsum, tpartial, big, split, split_tot, total;
 };
 
 static inline int tile_bits_of(int ntiles)
@@ -1325,6 +1510,10 @@ static Stage2Layout stage2_layout(int V, long R, int ntiles)
     // partial digit histograms of the tile keys
     L.tpartial = take((size_t)HIST_BLOCKS * HIST_WORDS * 4);
     L.big = take(v * 8 + 16);       // rectangles of more than 64 tiles: {output position, id} (+ the list's counter, multi-launch path)
+    // tile split: the count table (one row per SPLIT_BLOCK pairs), then totals[stride] | base[stride]
+    const bool can_split = ntiles <= SPLIT_MAX_TILES;
+    L.split = take(can_split ? (size_t)cdiv((long)r, SPLIT_BLOCK) * split_stride(ntiles) * 4 : 0);
+    L.split_tot = take(can_split ? (size_t)split_stride(ntiles) * 8 : 0);
     L.total = o;
     return L;
 }
@@ -1445,7 +1634,9 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
         // 3. emission; the rectangles are gathered and the offsets scanned on the way
         prof_begin(VR_STAGE_EMIT, s);
         const int passes = radix_passes(bits);
-        uint32_t* va = (passes % 2 == 0) ? point_list : tvalsB;   // the last pass must land in point_list
+        static const bool split_env = [] { const char* e = getenv("VEGS_TILE_SPLIT"); return !(e && e[0] == '0'); }();   // (A/B switch)
+        const bool split = split_env && ntiles <= SPLIT_MAX_TILES;      // the tile sort as one scatter (k_split_*)
+        uint32_t* va = (split || passes % 2 != 0) ? tvalsB : point_list;   // the last pass (or the scatter) must land in point_list
         uint32_t* vb = (passes % 2 == 0) ? tvalsB : point_list;
         BigRects big_list;
         big_list.items = (uint2*)(base + L.big);
@@ -1461,6 +1652,24 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
         VR_KERNEL_CHECK("emit_scan", s, debug);
         prof_end(VR_STAGE_EMIT, s);
         // 4. stable sort by tile id
+        if (split) {
+            ProfScope ps(VR_STAGE_TILE_SORT, s);
+            const int nblk = (int)cdiv(R, SPLIT_BLOCK), stride = split_stride(ntiles);
+            uint32_t* const table = (uint32_t*)(base + L.split);
+            uint32_t* const totals = (uint32_t*)(base + L.split_tot);
+            uint32_t* const tbase = totals + stride;
+            hipLaunchKernelGGL(k_split_count, dim3(nblk), dim3(256), (size_t)stride * 4, s, (const uint32_t*)tkeysA, R, ntiles, stride,
+                               table, err);
+            hipLaunchKernelGGL(k_split_scan, dim3(stride / 16), dim3(256), 0, s, table, nblk, stride, totals);
+            if (debug_raise_guard == 1) VR_HIP(hipMemsetD32Async((hipDeviceptr_t)err, 1, 1, s));   // test hook: "a wait of THIS view timed out"
+            hipLaunchKernelGGL(k_split_base, dim3(1), dim3(1024), 0, s, (const uint32_t*)totals, ntiles, tbase, ranges,
+                               (const uint32_t*)err, guard_post, guard_seq);
+            hipLaunchKernelGGL(k_split_scatter, dim3(nblk), dim3(256), (size_t)stride * 20, s, (const uint32_t*)tkeysA,
+                               (const uint32_t*)va, R, ntiles, stride, (const uint32_t*)table, (const uint32_t*)tbase, point_list,
+                               (const uint32_t*)err);
+            VR_KERNEL_CHECK("tile split", s, debug);
+            return 0;
+        }
         ProfScope ps(VR_STAGE_TILE_SORT, s);
         const int hist_rows = (int)(cdiv(R, 4096) < HIST_BLOCKS ? cdiv(R, 4096) : HIST_BLOCKS);
         hipLaunchKernelGGL(k_digit_hist, dim3(hist_rows), dim3(HIST_THREADS), 0, s, (const uint32_t*)tkeysA, R, 0u,

@@ -669,6 +669,19 @@ def test_many_tiles_large_image(dev):
     _check_against_oracle(inputs, scenes.camera_c1(2048, 1200), [0, 0, 0], deg, 1.0, dev)
 
 
+@pytest.mark.parametrize("W,H", [(912, 912), (1024, 1024), (16, 16), (1376, 16)])
+def test_tile_sort_paths_around_the_split_limit(W, H, dev):
+    """The tile sort is one scatter over a (workgroup x tile) count table for frames of up to 3,264 tiles (binning.hip,
+    k_split_*) and two 6-bit radix passes above: 57 x 57 = 3,249 tiles (the table's row is 3,264 words: the scatter's 65,280
+    bytes of LDS, the most it ever takes), 64 x 64 = 4,096 tiles (the two-pass path with 12 key bits), one tile, one row of
+    tiles -- lists, ranges and images against the oracle."""
+    from vegs_amd import scenes
+    sc, deg = scenes.scene_random(P=6000, sh_degree=1, seed=W + H, extent=1.2, scale=0.05)
+    inputs = dict(means3D=sc["means3D"], shs=sc["shs"], colors_precomp=None, opacities=sc["opacities"],
+                  scales=sc["scales"], rotations=sc["rotations"], cov3D_precomp=None)
+    _check_against_oracle(inputs, scenes.camera_c1(W, H), [0.2, 0.1, 0.0], deg, 1.0, dev)
+
+
 @pytest.mark.parametrize("P,M,deg", [(3000, 16, 3), (1000, 16, 1), (777, 4, 1), (130, 9, 2), (64, 2, 0)])
 def test_split_sh_storage_equals_concatenated(P, M, deg, dev):
     """Extension of the op's `shs` argument: the pair (features_dc [P,1,3], features_rest [P,M-1,3]) as the

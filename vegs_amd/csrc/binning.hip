@@ -1336,19 +1336,14 @@ k_split_count(const uint32_t* __restrict__ tkeys, long R, int ntiles, int stride
 // (16 rows per thread and step instead of 8: the same 9 us.  k_split_base run by the LAST workgroup of this launch -- a
 // counter, device-scope totals -- instead of a launch of its own: 13.6 against 9.2 + 4.9 us; two launches it stays.)
 constexpr int SPLIT_SCAN_U = 8;
-#ifndef VR_SPLIT_W
-#define VR_SPLIT_W 16
-#endif
-constexpr int SPLIT_W = VR_SPLIT_W;               // tiles per strip
-constexpr int SPLIT_RL = 256 / SPLIT_W;           // row-lanes
 __global__ void __launch_bounds__(256)
 k_split_scan(uint32_t* __restrict__ table, int nblk, int stride, uint32_t* __restrict__ totals)
 {
-    __shared__ uint32_t part[SPLIT_RL][SPLIT_W + 1];
-    const int c = threadIdx.x % SPLIT_W, r = threadIdx.x / SPLIT_W;
-    const int col = blockIdx.x * SPLIT_W + c;
+    __shared__ uint32_t part[16][17];
+    const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + c;
     uint32_t carry = 0;
-    for (int row0 = 0; row0 < nblk; row0 += SPLIT_RL * SPLIT_SCAN_U) {
+    for (int row0 = 0; row0 < nblk; row0 += 16 * SPLIT_SCAN_U) {
         const int mine = row0 + r * SPLIT_SCAN_U;
         uint32_t v[SPLIT_SCAN_U], sum = 0;
 #pragma unroll
@@ -1360,7 +1355,7 @@ k_split_scan(uint32_t* __restrict__ table, int nblk, int stride, uint32_t* __res
         __syncthreads();
         uint32_t before = carry, all = 0;
 #pragma unroll
-        for (int q = 0; q < SPLIT_RL; ++q) {
+        for (int q = 0; q < 16; ++q) {
             const uint32_t t = part[q][c];
             if (q < r) before += t;
             all += t;
@@ -1425,55 +1420,19 @@ k_split_base(const uint32_t* __restrict__ totals, int ntiles, uint32_t* __restri
 __global__ void __launch_bounds__(256)
 k_split_scatter(const uint32_t* __restrict__ tkeys, const uint32_t* __restrict__ tvals, long R, int ntiles, int stride,
                 const uint32_t* __restrict__ table, const uint32_t* __restrict__ base, uint32_t* __restrict__ out,
-                const uint32_t* __restrict__ err, int2* __restrict__ ranges, uint32_t* __restrict__ post, uint32_t seq)
+                const uint32_t* __restrict__ err)
 {
     extern __shared__ uint32_t split_lds[];
     uint32_t* const cnt = split_lds;                    // [4][stride]: per wave, pairs of each tile so far -> pairs in the waves before
     uint32_t* const rowoff = split_lds + 4 * stride;    // [stride]: base[t] + pairs of t in the workgroups before this one
-    const uint32_t tripped = st_load(err);
-#ifdef VR_SPLIT_FUSED_BASE
-    if (blockIdx.x == 0 && threadIdx.x == 0 && post) {   // the view's guard word for the host (k_tile_ranges' other duty)
-        __hip_atomic_store(&post[1], tripped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&post[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-#endif
-    if (tripped != 0u) return;
+    if (st_load(err) != 0u) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t* const row = table + (size_t)blockIdx.x * stride;
-#ifdef VR_SPLIT_FUSED_BASE
-    {   // base[t] by every workgroup for itself: `base` holds the column TOTALS here (k_split_scan), scanned through LDS
-        __shared__ uint32_t wsum4[4];
-        const int per = stride / 256 + (stride % 256 ? 1 : 0);
-        const int t0 = min(stride, (int)threadIdx.x * per), t1 = min(stride, t0 + per);
-        uint32_t sum = 0;
-        for (int t = t0; t < t1; ++t) { const uint32_t v = t < ntiles ? base[t] : 0u; rowoff[t] = sum; sum += v; }
-        uint32_t incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) wsum4[w] = incl;
-        __syncthreads();
-        uint32_t run = incl - sum;
-        for (int q = 0; q < w; ++q) run += wsum4[q];
-        for (int t = t0; t < t1; ++t) {
-            const uint32_t b0 = rowoff[t] + run;
-            if (blockIdx.x == 0 && t < ntiles) {
-                const uint32_t tot = base[t];
-                if (tot) ranges[t] = make_int2((int)b0, (int)(b0 + tot));
-            }
-            rowoff[t] = b0 + row[t];
-        }
-        for (int d = threadIdx.x; d < 4 * stride; d += 256) cnt[d] = 0u;
-    }
-#else
     for (int d = threadIdx.x; d < stride; d += 256) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) cnt[q * stride + d] = 0u;
         rowoff[d] = (d < ntiles ? base[d] : 0u) + row[d];
     }
-#endif
     __syncthreads();
     const long wbase = (long)blockIdx.x * SPLIT_BLOCK + (long)w * (64 * SPLIT_ITEMS);
     uint32_t key[SPLIT_ITEMS], val[SPLIT_ITEMS], rank[SPLIT_ITEMS];
@@ -1701,19 +1660,13 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
             uint32_t* const tbase = totals + stride;
             hipLaunchKernelGGL(k_split_count, dim3(nblk), dim3(256), (size_t)stride * 4, s, (const uint32_t*)tkeysA, R, ntiles, stride,
                                table, err);
-            hipLaunchKernelGGL(k_split_scan, dim3(stride / SPLIT_W), dim3(256), 0, s, table, nblk, stride, totals);
+            hipLaunchKernelGGL(k_split_scan, dim3(stride / 16), dim3(256), 0, s, table, nblk, stride, totals);
             if (debug_raise_guard == 1) VR_HIP(hipMemsetD32Async((hipDeviceptr_t)err, 1, 1, s));   // test hook: "a wait of THIS view timed out"
-#ifdef VR_SPLIT_FUSED_BASE
-            hipLaunchKernelGGL(k_split_scatter, dim3(nblk), dim3(256), (size_t)stride * 20, s, (const uint32_t*)tkeysA,
-                               (const uint32_t*)va, R, ntiles, stride, (const uint32_t*)table, (const uint32_t*)totals, point_list,
-                               (const uint32_t*)err, ranges, guard_post, guard_seq);
-#else
             hipLaunchKernelGGL(k_split_base, dim3(1), dim3(1024), 0, s, (const uint32_t*)totals, ntiles, tbase, ranges,
                                (const uint32_t*)err, guard_post, guard_seq);
             hipLaunchKernelGGL(k_split_scatter, dim3(nblk), dim3(256), (size_t)stride * 20, s, (const uint32_t*)tkeysA,
                                (const uint32_t*)va, R, ntiles, stride, (const uint32_t*)table, (const uint32_t*)tbase, point_list,
-                               (const uint32_t*)err, ranges, guard_post, guard_seq);
-#endif
+                               (const uint32_t*)err);
             VR_KERNEL_CHECK("tile split", s, debug);
             return 0;
         }

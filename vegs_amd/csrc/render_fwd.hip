@@ -939,27 +939,15 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     const int lane = threadIdx.x;
     const int pixslot = w * 64 + lane;
     // ---- light tile: this workgroup (the one of segment 1) takes all of the tile's later segments, the others leave
-    __shared__ float run[LIGHT ? NPART : 1][64];          // running sums 0 .. 10, final T (11), last contributor (12, as bits)
     int nloop = 1;
-    bool light = false, pix_live = false;
+    bool light = false;
+    const uint32_t seg0 = c.seg - (uint32_t)c.sl;         // the tile's first segment
     if (LIGHT && first_fused) {
         const uint32_t needed_t = seg_needed[c.tile];
         light = needed_t >= 2u && needed_t <= LIGHT_MAX;
         if (light) {
             if (c.sl != 1) return;
             nloop = (int)needed_t - 1;
-            // k_seg_combine's first step: C = 0 + (first segment's sums), T = Tb x its product, its last contributor
-            const uint32_t seg0 = c.seg - 1u;
-            const float Tb0 = Tbuf[(size_t)seg0 * SEG + pixslot];
-            const float* src = part + (size_t)seg0 * (NPART * SEG) + pixslot;
-            pix_live = !(Tb0 < 0.0f);
-            float v0[NPART];
-#pragma unroll
-            for (int k = 0; k < NPART; ++k) v0[k] = pix_live ? src[k * SEG] : 0.0f;
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) run[k][lane] = 0.0f + v0[k];
-            run[11][lane] = pix_live ? Tb0 * v0[11] : 1.0f;
-            run[12][lane] = __uint_as_float(__float_as_uint(v0[12]) & 0x7FFFFFFFu);
         }
     }
     for (int it = 0; it < nloop; ++it) {
@@ -1075,42 +1063,64 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
         // last contributor: tile-relative list index + 1 of the last entry applied in this segment (0 = none)
         const uint32_t last = lastpos >= 0 ? (uint32_t)(c.sl * SEG + (int)rel_j[lastpos] + 1) : 0u;
         dst[12 * SEG] = __uint_as_float(last | (stopped ? 0x80000000u : 0u));
-        if (LIGHT && light && pix_live) {        // k_seg_combine's step for this segment (the pixel was alive at its start)
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) run[k][lane] += Cs[k];
-            run[11][lane] = Tb * p;
-            if (last) run[12][lane] = __uint_as_float(last);
-        }
-    } else {
-        pix_live = false;                        // finished before this segment: k_seg_combine stops adding there
     }
     if (it + 1 < nloop) __syncthreads();         // (the staging buffers are reused by the next segment)
     }
     if (LIGHT && light && c.inside) {
-        // ---- the tile's images for this region, as the three plane groups of k_seg_combine write them
-        const size_t N = (size_t)cam.H * cam.W, pix = c.pix;
-        float C[NCH];
+        // ---- the tile's images for this region: k_seg_combine's loop over the tile's needed segments -- the first one's sums
+        // (k_seg_alpha's launch) and the ones this lane has just stored --, plane by plane, with its operations in its order
+        __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): this lane's own stores above
+        const int needed = nloop + 1;
+        float Tbv[LIGHT_MAX];
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) C[k] = run[k][lane];
-        const float T = run[11][lane];
+        for (int j = 0; j < (int)LIGHT_MAX; ++j) Tbv[j] = j < needed ? Tbuf[(size_t)(seg0 + j) * SEG + pixslot] : -1.0f;
+        int jl = -1;                               // the pixel's last live segment (its sums stop at the first finished one)
+#pragma unroll
+        for (int j = 0; j < (int)LIGHT_MAX; ++j)
+            if (jl == j - 1 && !(Tbv[j] < 0.0f)) jl = j;
+        const float* const mine = part + (size_t)seg0 * (NPART * SEG) + pixslot;
+        auto plane_sum = [&](const int k) {
+            float v[LIGHT_MAX];
+#pragma unroll
+            for (int j = 0; j < (int)LIGHT_MAX; ++j) v[j] = j <= jl ? mine[(size_t)j * (NPART * SEG) + k * SEG] : 0.0f;
+            float C = 0.0f;
+#pragma unroll
+            for (int j = 0; j < (int)LIGHT_MAX; ++j)
+                if (j <= jl) C += v[j];
+            return C;
+        };
+        float T = 1.0f;
+        uint32_t lastc = 0;
+        if (jl >= 0) T = Tbv[jl] * mine[(size_t)jl * (NPART * SEG) + 11 * SEG];
+#pragma unroll
+        for (int j = 0; j < (int)LIGHT_MAX; ++j) {
+            if (j <= jl) {
+                const uint32_t l = __float_as_uint(mine[(size_t)j * (NPART * SEG) + 12 * SEG]) & 0x7FFFFFFFu;
+                if (l) lastc = l;
+            }
+        }
+        const size_t N = (size_t)cam.H * cam.W, pix = c.pix;
         o.final_T[pix] = T;
-        o.n_contrib[pix] = __float_as_uint(run[12][lane]);
-        o.color[pix] = fmaf(T, cam.bg[0], C[0]);
-        o.color[N + pix] = fmaf(T, cam.bg[1], C[1]);
-        o.color[2 * N + pix] = fmaf(T, cam.bg[2], C[2]);
+        o.n_contrib[pix] = lastc;
+        o.color[pix] = fmaf(T, cam.bg[0], plane_sum(0));
+        o.color[N + pix] = fmaf(T, cam.bg[1], plane_sum(1));
+        o.color[2 * N + pix] = fmaf(T, cam.bg[2], plane_sum(2));
         o.alpha[pix] = 1.0f - T;
-        float depth_out = C[3];
+        const float Cd = plane_sum(3);
+        float depth_out = Cd;
         if (cam.flags & FLAG_DEPTH_NORMALIZED) {
             const float A = 1.0f - T;
-            o.dsum[pix] = C[3];
-            depth_out = A > 0.0f ? C[3] / A : 0.0f;
+            o.dsum[pix] = Cd;
+            depth_out = A > 0.0f ? Cd / A : 0.0f;
         }
         o.depth[pix] = depth_out;
-        if (cam.flags & FLAG_FILL_EMPTY) C[4] += T;
+        float q0 = plane_sum(4);
+        if (cam.flags & FLAG_FILL_EMPTY) q0 += T;
+        o.quat[pix] = q0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o.quat[k * N + pix] = C[4 + k];
+        for (int k = 1; k < 4; ++k) o.quat[k * N + pix] = plane_sum(4 + k);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) o.scale[k * N + pix] = C[8 + k];
+        for (int k = 0; k < 3; ++k) o.scale[k * N + pix] = plane_sum(8 + k);
     }
 }
 

@@ -910,18 +910,12 @@ k_seg_merge(int ntiles, uint32_t* __restrict__ seg_off, uint32_t cap, const uint
 // ---- C: blend one segment from its boundary transmittance into segment-local sums.
 // part[seg][k][pix], k = 0..10 channel sums, 11 = local product p, 12 = local last-contributor | done<<31 (NPART, above)
 
-// LIGHT tiles (2 ... LIGHT_MAX needed segments: nine tiles in ten of a street view) are FINISHED here (round 5, `light`): the
-// workgroup of such a tile's segment 1 blends segments 1 ... needed-1 one after the other -- each into its own local sums, which
-// are stored for the backward as before -- and adds them to the first segment's sums in k_seg_combine's order, with its
-// operations: the images of the tile's region are written here and k_seg_combine skips the tile (it read 13 planes per segment
-// back for them).  The running sums live in LDS, not in registers (the kernel stays at 64 VGPRs).
-constexpr uint32_t LIGHT_MAX = 8u;
-template <bool FAST, bool LIGHT>
+template <bool FAST>
 __global__ void __launch_bounds__(64)
 k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off, uint32_t cap,
             const uint32_t* __restrict__ seg_needed, const uint32_t* __restrict__ point_list,
             const Splat* __restrict__ rec, const float* __restrict__ Tbuf, float* __restrict__ part,
-            const unsigned long long* __restrict__ segmask, int first_fused, FwdOut o)
+            const unsigned long long* __restrict__ segmask, int first_fused)
 {
     // ONE WAVE (8x8 region = "strip") PER WORKGROUP, like k_seg_bwd: the four strips of a segment see very different numbers
     // of relevant entries and live pixels; as independent 64-thread workgroups they are scheduled and retire
@@ -938,20 +932,6 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
     if (c.sl == 0 && first_fused) return;                // a tile's first segment was blended by k_seg_first
     const int lane = threadIdx.x;
     const int pixslot = w * 64 + lane;
-    // ---- light tile: this workgroup (the one of segment 1) takes all of the tile's later segments, the others leave
-    int nloop = 1;
-    bool light = false;
-    const uint32_t seg0 = c.seg - (uint32_t)c.sl;         // the tile's first segment
-    if (LIGHT && first_fused) {
-        const uint32_t needed_t = seg_needed[c.tile];
-        light = needed_t >= 2u && needed_t <= LIGHT_MAX;
-        if (light) {
-            if (c.sl != 1) return;
-            nloop = (int)needed_t - 1;
-        }
-    }
-    for (int it = 0; it < nloop; ++it) {
-    if (it > 0 && !seg_setup_at(cam, ranges, seg_off, c.seg + 1u, w, c)) break;
     // one batch of independent loads right after the segment descriptor (boundary transmittance, relevance masks,
     // all four 64-entry parts of the segment's list): one memory round trip instead of three dependent ones
     const float Tb = Tbuf[(size_t)c.seg * SEG + pixslot];
@@ -961,7 +941,7 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
 #pragma unroll
     for (int q = 0; q < 4; ++q) gid_q[q] = q * 64 + lane < c.count ? point_list[c.first + q * 64 + lane] : 0u;
     const bool done = Tb < 0.0f;          // pixel finished before this segment
-    if (__ballot(!done) == 0ull) break;   // nothing alive in this strip (nor, for a light tile, in its later segments)
+    if (__ballot(!done) == 0ull) return;  // nothing alive in this strip
     const unsigned long long mm[4] = {uniform64(mraw[0]), uniform64(mraw[1]), uniform64(mraw[2]), uniform64(mraw[3])};
     int nrel = 0;
     {
@@ -1064,64 +1044,6 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
         const uint32_t last = lastpos >= 0 ? (uint32_t)(c.sl * SEG + (int)rel_j[lastpos] + 1) : 0u;
         dst[12 * SEG] = __uint_as_float(last | (stopped ? 0x80000000u : 0u));
     }
-    if (it + 1 < nloop) __syncthreads();         // (the staging buffers are reused by the next segment)
-    }
-    if (LIGHT && light && c.inside) {
-        // ---- the tile's images for this region: k_seg_combine's loop over the tile's needed segments -- the first one's sums
-        // (k_seg_alpha's launch) and the ones this lane has just stored --, plane by plane, with its operations in its order
-        __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): this lane's own stores above
-        const int needed = nloop + 1;
-        float Tbv[LIGHT_MAX];
-#pragma unroll
-        for (int j = 0; j < (int)LIGHT_MAX; ++j) Tbv[j] = j < needed ? Tbuf[(size_t)(seg0 + j) * SEG + pixslot] : -1.0f;
-        int jl = -1;                               // the pixel's last live segment (its sums stop at the first finished one)
-#pragma unroll
-        for (int j = 0; j < (int)LIGHT_MAX; ++j)
-            if (jl == j - 1 && !(Tbv[j] < 0.0f)) jl = j;
-        const float* const mine = part + (size_t)seg0 * (NPART * SEG) + pixslot;
-        auto plane_sum = [&](const int k) {
-            float v[LIGHT_MAX];
-#pragma unroll
-            for (int j = 0; j < (int)LIGHT_MAX; ++j) v[j] = j <= jl ? mine[(size_t)j * (NPART * SEG) + k * SEG] : 0.0f;
-            float C = 0.0f;
-#pragma unroll
-            for (int j = 0; j < (int)LIGHT_MAX; ++j)
-                if (j <= jl) C += v[j];
-            return C;
-        };
-        float T = 1.0f;
-        uint32_t lastc = 0;
-        if (jl >= 0) T = Tbv[jl] * mine[(size_t)jl * (NPART * SEG) + 11 * SEG];
-#pragma unroll
-        for (int j = 0; j < (int)LIGHT_MAX; ++j) {
-            if (j <= jl) {
-                const uint32_t l = __float_as_uint(mine[(size_t)j * (NPART * SEG) + 12 * SEG]) & 0x7FFFFFFFu;
-                if (l) lastc = l;
-            }
-        }
-        const size_t N = (size_t)cam.H * cam.W, pix = c.pix;
-        o.final_T[pix] = T;
-        o.n_contrib[pix] = lastc;
-        o.color[pix] = fmaf(T, cam.bg[0], plane_sum(0));
-        o.color[N + pix] = fmaf(T, cam.bg[1], plane_sum(1));
-        o.color[2 * N + pix] = fmaf(T, cam.bg[2], plane_sum(2));
-        o.alpha[pix] = 1.0f - T;
-        const float Cd = plane_sum(3);
-        float depth_out = Cd;
-        if (cam.flags & FLAG_DEPTH_NORMALIZED) {
-            const float A = 1.0f - T;
-            o.dsum[pix] = Cd;
-            depth_out = A > 0.0f ? Cd / A : 0.0f;
-        }
-        o.depth[pix] = depth_out;
-        float q0 = plane_sum(4);
-        if (cam.flags & FLAG_FILL_EMPTY) q0 += T;
-        o.quat[pix] = q0;
-#pragma unroll
-        for (int k = 1; k < 4; ++k) o.quat[k * N + pix] = plane_sum(4 + k);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) o.scale[k * N + pix] = plane_sum(8 + k);
-    }
 }
 
 // ---- D: per tile, add the segment sums in order and write the images.
@@ -1141,7 +1063,7 @@ __device__ __forceinline__ void seg_combine_group(const Camera& cam, uint32_t ca
                                                   float* __restrict__ out_depth, float* __restrict__ out_quat,
                                                   float* __restrict__ out_scale, float* __restrict__ out_alpha,
                                                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                  float* __restrict__ dsum, int first_fused, int light_done)
+                                                  float* __restrict__ dsum, int first_fused)
 {
     // planes of `part` this group loads: [P0, P0 + NP) channel sums, then (WITH_P) the local product and (GROUP 0) the
     // last-contributor word
@@ -1169,7 +1091,6 @@ __device__ __forceinline__ void seg_combine_group(const Camera& cam, uint32_t ca
     const uint32_t s0 = seg_off[tile];
     if (first_fused && seg_off[tile + 1] - s0 == 1u) return;      // a tile with ONE segment was finished by seg_first_body
     const uint32_t needed = seg_needed[tile];
-    if (light_done && needed >= 2u && needed <= LIGHT_MAX) return;      // finished by k_seg_blend (`light`)
     float C[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) C[k] = 0.0f;
@@ -1236,17 +1157,17 @@ k_seg_combine(Camera cam, uint32_t cap, const uint32_t* __restrict__ seg_off, co
               const float* __restrict__ Tbuf, const float* __restrict__ part, float* __restrict__ out_color,
               float* __restrict__ out_depth, float* __restrict__ out_quat, float* __restrict__ out_scale,
               float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-              float* __restrict__ dsum, int first_fused, int light_done)
+              float* __restrict__ dsum, int first_fused)
 {
     if (blockIdx.y == 0)
         seg_combine_group<0>(cam, cap, seg_off, seg_needed, Tbuf, part, out_color, out_depth, out_quat, out_scale, out_alpha,
-                             final_T, n_contrib, dsum, first_fused, light_done);
+                             final_T, n_contrib, dsum, first_fused);
     else if (blockIdx.y == 1)
         seg_combine_group<1>(cam, cap, seg_off, seg_needed, Tbuf, part, out_color, out_depth, out_quat, out_scale, out_alpha,
-                             final_T, n_contrib, dsum, first_fused, light_done);
+                             final_T, n_contrib, dsum, first_fused);
     else
         seg_combine_group<2>(cam, cap, seg_off, seg_needed, Tbuf, part, out_color, out_depth, out_quat, out_scale, out_alpha,
-                             final_T, n_contrib, dsum, first_fused, light_done);
+                             final_T, n_contrib, dsum, first_fused);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1406,21 +1327,20 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     VR_KERNEL_CHECK("seg_alpha / seg_scan rounds", s, debug);
     hipLaunchKernelGGL(k_seg_merge, dim3(cdiv((long)nseg, 256), SEG_QUEUES + (chain ? 1 : 0)), dim3(256), 0, s, ntiles, seg_off,
                        (uint32_t)nseg, (const uint32_t*)seg_needed, chain ? 1 : 0);
-    static const bool light_env = [] { const char* e = getenv("VEGS_SEG_LIGHT"); return !(e && e[0] == '0'); }();   // (A/B switch)
-    const bool light = light_env && first_fused;       // tiles of 2 ... LIGHT_MAX needed segments are finished by k_seg_blend
     if (R > 0) {
-#define VR_BLEND(FST, LGT)                                                                                                \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_blend<FST, LGT>), dim3((unsigned)nseg * 4), dim3(64), 0, s, cam, ranges,  \
-                           (const uint32_t*)seg_off, (uint32_t)nseg, (const uint32_t*)seg_needed, point_list, rec,         \
-                           (const float*)Tbuf, part, (const unsigned long long*)segmask, first_fused, fwd_out)
-        if (fast) { if (light) VR_BLEND(true, true); else VR_BLEND(true, false); }
-        else { if (light) VR_BLEND(false, true); else VR_BLEND(false, false); }
-#undef VR_BLEND
+        if (fast)
+            hipLaunchKernelGGL(k_seg_blend<true>, dim3((unsigned)nseg * 4), dim3(64), 0, s, cam, ranges, (const uint32_t*)seg_off,
+                               (uint32_t)nseg, (const uint32_t*)seg_needed, point_list, rec, (const float*)Tbuf, part,
+                               (const unsigned long long*)segmask, first_fused);
+        else
+            hipLaunchKernelGGL(k_seg_blend<false>, dim3((unsigned)nseg * 4), dim3(64), 0, s, cam, ranges, (const uint32_t*)seg_off,
+                               (uint32_t)nseg, (const uint32_t*)seg_needed, point_list, rec, (const float*)Tbuf, part,
+                               (const unsigned long long*)segmask, first_fused);
         VR_KERNEL_CHECK("seg_blend", s, debug);
     }
     hipLaunchKernelGGL(k_seg_combine, dim3(2 * ntiles, 3), dim3(256), 0, s, cam, (uint32_t)nseg, (const uint32_t*)seg_off,
                        (const uint32_t*)seg_needed, (const float*)Tbuf, (const float*)part, out_color, out_depth,
-                       out_quat, out_scale, out_alpha, final_T, n_contrib, dsum, first_fused, (light && R > 0) ? 1 : 0);
+                       out_quat, out_scale, out_alpha, final_T, n_contrib, dsum, first_fused);
     VR_KERNEL_CHECK("seg_combine", s, debug);
     return 0;
 }

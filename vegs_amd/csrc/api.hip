@@ -57,7 +57,6 @@ struct MailRef { uint32_t* pinned; uint32_t* guard; int dev; };
 static std::mutex g_mail_mu;
 static std::vector<MailRef> g_mail_reg;
 static thread_local int g_raise_guard = 0;        // test hook: vr_debug_raise_guard (1 = raise the word, 2 = lose a workgroup, 3 = impatient walkers)
-static thread_local int g_pred_key_bits = 27;   // depth-key bits of this thread's last view (the speculative depth sort's plan)
 static thread_local int g_rebinned = 0;           // views re-binned under VR_FLAG_VERIFY_BINNING (vr_debug_rebinned)
 
 // the calling thread's mailbox for the current device, created on first use
@@ -409,7 +408,6 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
 
     uint32_t V = 0, R = 0, key_min = 0, n_huge = 0;
     int key_bits = 0;
-    int spec_bits = 0, spec_where = 0;      // the speculative depth sort of this call: the key bits it was queued for, its parity
     // R-sized buffers: requested up front when the caller supplied a capacity hint (see VrSaved)
     size_t Rcap = saved->binning_capacity > 0 ? (size_t)saved->binning_capacity : 0;
     void *binning = nullptr, *scr2 = nullptr, *scr3 = nullptr;
@@ -448,18 +446,6 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
                                   scr2 ? binning_stage2_status_bytes(P, (long)Rcap, (int)T) : 0, s, debug);
         prof_end(VR_STAGE_COMPACT, s);
         if (rc) return rc;
-        // the depth sort, queued for the digit plan of this thread's last view while the totals are on their way (binning.hip,
-        // onesweep_sort_speculative): needs the stage-2 scratch (a capacity hint) with its status words cleared by the apply kernel
-        static const bool spec_env = [] { const char* e = getenv("VEGS_SPEC_SORT"); return !(e && e[0] == '0'); }();   // (A/B switch)
-        if (spec_env && scr2 && status_zeroed && g_raise_guard == 0 && g_pred_key_bits > 0 &&
-            binning_single_launch_path(cam.flags, (long)P, (long)Rcap)) {
-            prof_begin(VR_STAGE_DEPTH_SORT, s);
-            rc = launch_depth_sort_speculative(P, (long)Rcap, (int)T, vis_key, vis_id, scan_scr, scr2, guard_word, totals_dev,
-                                               g_pred_key_bits, s, debug, &spec_where);
-            prof_end(VR_STAGE_DEPTH_SORT, s);
-            if (rc) return rc;
-            spec_bits = g_pred_key_bits;
-        }
         rc = wait_mailbox(g_pinned, seq, totals_dev, s);
         if (rc) return rc;
         V = g_pinned[0];
@@ -471,12 +457,6 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
             while (span) { ++key_bits; span >>= 1; }
         }
     }
-    // the speculative depth sort holds iff its launches found the plan they were queued for (same arithmetic on the device) and
-    // the buffers it used are the ones the rest of the binning gets
-    bool spec_ok = spec_bits > 0 && V > 0 && R <= Rcap && radix_sort_passes(key_bits) > 0 &&
-                   binning_digit(key_bits) == binning_digit(spec_bits) && radix_sort_passes(key_bits) == radix_sort_passes(spec_bits) &&
-                   binning_single_launch_path(cam.flags, (long)V, (long)R);
-    if (V > 0) g_pred_key_bits = key_bits;
     if (Rcap == 0 || R > Rcap) {   // no hint, or the hint was too small: size for the actual R
         Rcap = R;
         ranges_zeroed = status_zeroed = false;   // fresh buffers
@@ -493,8 +473,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
     g_raise_guard = 0;
     rc = launch_binning(cam, P, (int)V, (long)R, key_min, key_bits, vis_key, vis_id, rect, scan_scr, scr2, point_list,
                         ranges, ranges_zeroed, status_zeroed, guard_word,
-                        mail.pinned_dev + RING_AT + 2 * (mail.seq % RING_SLOTS), mail.seq, raise == 3 ? 0 : raise, n_huge, s, debug,
-                        P, (long)Rcap, spec_ok ? spec_where : -1);
+                        mail.pinned_dev + RING_AT + 2 * (mail.seq % RING_SLOTS), mail.seq, raise == 3 ? 0 : raise, n_huge, s, debug);
     if (rc) return rc;
     if (!lists && P > 0) {   // no binning kernel will post this forward's slot: the host does (nothing can have tripped)
         uint32_t* slot = g_pinned + RING_AT + 2 * (mail.seq % RING_SLOTS);
@@ -531,7 +510,7 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
             again.flags |= FLAG_SCAN_BINNING;
             rc = launch_binning(again, P, (int)V, (long)R, key_min, key_bits, vis_key, vis_id, rect, scan_scr, scr2, point_list,
                                 ranges, false, false, guard_word, mail.pinned_dev + RING_AT + 2 * (mail.seq % RING_SLOTS),
-                                mail.seq, 0, n_huge, s, debug, P, (long)Rcap);
+                                mail.seq, 0, n_huge, s, debug);
             if (rc) return rc;
             ++g_rebinned;
         }

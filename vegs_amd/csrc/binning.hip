@@ -506,7 +506,6 @@ static int radix_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, lo
     return 0;
 }
 int radix_sort_passes(int nbits) { return radix_passes(nbits); }
-int binning_digit(int nbits) { return radix_digit(nbits); }
 
 // generic entry for other translation units (knn.hip): sort (key,val) pairs on the low nbits of key - kmin
 size_t sort_pairs_scratch_bytes(long n)
@@ -694,20 +693,9 @@ k_digit_hist(const uint32_t* __restrict__ keys, long n, uint32_t kmin, int digit
 // Adds the G partial histograms up: workgroup (x, y) sums partials [32 y, 32 y + 32) for the 64 entries
 // [64 x, 64 x + 64) of the passes << digit totals and adds the result to `tot` (cleared with the status region):
 // G / 32 atomics per word instead of G.
-// `plan` (the speculative depth sort, onesweep_sort_speculative below): the launch was queued BEFORE the host knew the view's
-// totals {V, R, min key, max key} = plan[0..3]; it does its work only if they give the digit plan it was compiled into the
-// launch with (spec_digit, spec_passes), and nothing at all otherwise.
-__device__ __forceinline__ bool spec_plan_matches(const uint32_t* __restrict__ plan, int spec_digit, int spec_passes)
-{
-    if (plan[0] == 0u) return false;
-    const int key_bits = bits_of(plan[3] - plan[2]);
-    return radix_digit(key_bits) == spec_digit && radix_passes(key_bits) == spec_passes;
-}
 __global__ void __launch_bounds__(256)
-k_digit_sum(const uint32_t* __restrict__ partial, int G, int words, uint32_t* __restrict__ tot,
-            const uint32_t* __restrict__ plan, int spec_digit, int spec_passes)
+k_digit_sum(const uint32_t* __restrict__ partial, int G, int words, uint32_t* __restrict__ tot)
 {
-    if (plan && !spec_plan_matches(plan, spec_digit, spec_passes)) return;
     __shared__ uint32_t red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int d = blockIdx.x * 64 + lane;
@@ -730,21 +718,9 @@ template <int BITS>
 __global__ void __launch_bounds__(256)
 k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
            uint32_t* __restrict__ vals_out, long n, uint32_t kmin, int pass,
-           const uint32_t* __restrict__ totals, uint32_t* __restrict__ status, uint32_t* __restrict__ err, int lose_block0,
-           const uint32_t* __restrict__ plan, int spec_passes)
+           const uint32_t* __restrict__ totals, uint32_t* __restrict__ status, uint32_t* __restrict__ err, int lose_block0)
 {
     constexpr int SIZE = 1 << BITS;
-    long nblk_all = gridDim.x;
-    if (plan) {
-        // queued before the host knew V and the key span (k_digit_sum's comment): the grid covers P keys, `status` is the sort's
-        // first pass region; the view's own numbers come from device memory
-        if (!spec_plan_matches(plan, BITS, spec_passes)) return;
-        n = (long)plan[0];
-        kmin = plan[2];
-        nblk_all = (n + RADIX_BLOCK - 1) / RADIX_BLOCK;
-        if ((long)blockIdx.x >= nblk_all) return;
-        status += (size_t)pass * onesweep_pass_words(n, BITS);
-    }
     constexpr int BPT = (SIZE + 255) / 256;   // digits per thread in the per-digit phases
     __shared__ uint32_t cnt[4][SIZE];
     __shared__ uint32_t off[4][SIZE];
@@ -840,7 +816,7 @@ k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
     }
     // ---- elements with each digit in all earlier blocks: <= 15 posted sums from each of the three levels
     {
-        const long nblk = nblk_all, n2 = (nblk + FAN - 1) / FAN;
+        const long nblk = gridDim.x, n2 = (nblk + FAN - 1) / FAN;
         uint32_t* const level2 = status + nblk * SIZE;
         uint32_t* const level3 = level2 + n2 * SIZE;
         int d[BPT];
@@ -899,7 +875,7 @@ static int onesweep_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
     uint32_t* const totals = status;   // digit totals at the head of the status region
     status += HIST_WORDS;
     hipLaunchKernelGGL(k_digit_sum, dim3(cdiv((long)passes << digit, 64), cdiv(rows, 32)), dim3(256), 0, s, partial, rows,
-                       passes << digit, totals, (const uint32_t*)nullptr, 0, 0);
+                       passes << digit, totals);
     VR_KERNEL_CHECK("digit_sum", s, debug);
     uint32_t *ka = k0, *va = v0, *kb = k1, *vb = v1;
     for (int pass = 0; pass < passes; ++pass) {
@@ -907,7 +883,7 @@ static int onesweep_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
 #define VR_SWEEP(B)                                                                                           \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_onesweep<B>), dim3(nblk), dim3(256), 0, s, (const uint32_t*)ka,      \
                        (const uint32_t*)va, kb, vb, n, kmin, pass, (const uint32_t*)totals, st, err,        \
-                       (lose_block0 && pass == 0) ? 1 : 0, (const uint32_t*)nullptr, 0)
+                       (lose_block0 && pass == 0) ? 1 : 0)
         if (digit == 6) VR_SWEEP(6);
         else if (digit == 9) VR_SWEEP(9);
         else VR_SWEEP(8);
@@ -917,43 +893,6 @@ static int onesweep_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1,
         t = va; va = vb; vb = t;
         *res ^= 1;
     }
-    return 0;
-}
-
-// The same sort queued BEFORE the host has the view's totals (round 5): the forward's one host round trip -- V, R and the key
-// span come back while k_compact_apply runs, ~14 us, and the host needs ~20 to wake up and get its next launch to the GPU: a
-// 6 + 4 us hole in every view's queue (rocprofv3 --kernel-trace).  The depth sort's launches need nothing from the host but
-// its digit plan, and that is the plan of the camera's last view nearly always: they are queued behind k_compact_apply for
-// the PREDICTED plan, sized for P keys, and take V, the least key and the plan itself from device memory (`plan` = the
-// totals).  A launch whose prediction was wrong does nothing; the host, once it knows, sorts as before.  Returns the launches'
-// ping-pong parity in *res.
-static int onesweep_sort_speculative(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long n_max, int nbits,
-                                     const uint32_t* partial, int rows, uint32_t* status, uint32_t* err, const uint32_t* plan,
-                                     hipStream_t s, bool debug, int* res)
-{
-    const int digit = radix_digit(nbits);
-    const int passes = radix_passes(nbits);
-    const int nblk = cdiv(n_max, RADIX_BLOCK);
-    *res = 0;
-    if (passes == 0) return 0;
-    uint32_t* const totals = status;
-    status += HIST_WORDS;
-    hipLaunchKernelGGL(k_digit_sum, dim3(cdiv((long)passes << digit, 64), cdiv(rows, 32)), dim3(256), 0, s, partial, rows,
-                       passes << digit, totals, plan, digit, passes);
-    uint32_t *ka = k0, *va = v0, *kb = k1, *vb = v1;
-    for (int pass = 0; pass < passes; ++pass) {
-#define VR_SWEEP(B)                                                                                           \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_onesweep<B>), dim3(nblk), dim3(256), 0, s, (const uint32_t*)ka,      \
-                       (const uint32_t*)va, kb, vb, 0L, 0u, pass, (const uint32_t*)totals, status, err, 0, plan, passes)
-        if (digit == 6) VR_SWEEP(6);
-        else if (digit == 9) VR_SWEEP(9);
-        else VR_SWEEP(8);
-#undef VR_SWEEP
-        uint32_t* t = ka; ka = kb; kb = t;
-        t = va; va = vb; vb = t;
-        *res ^= 1;
-    }
-    VR_KERNEL_CHECK("speculative depth sort", s, debug);
     return 0;
 }
 
@@ -1648,43 +1587,20 @@ static int binning_multi_launch(const Camera& cam, int V, long R, uint32_t key_m
     return 0;
 }
 
-// The depth sort of launch_binning's single-launch path, queued before the host knows V / R / the key span (see
-// onesweep_sort_speculative): `scratch` laid out for (P, layR) as launch_binning will be told, its status words cleared by the
-// compaction (status_zeroed), pred_bits = the key bits the caller expects.  *where = parity of the result if the plan holds.
-int launch_depth_sort_speculative(int P, long layR, int ntiles, uint32_t* vis_key, uint32_t* vis_id, const void* stage1_scratch,
-                                  void* scratch, uint32_t* err, const uint32_t* totals_dev, int pred_bits, hipStream_t s,
-                                  bool debug, int* where)
-{
-    const Stage2Layout L = stage2_layout(P, layR, ntiles);
-    char* base = (char*)scratch;
-    const int rows = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
-    const uint32_t* dpartial = (const uint32_t*)((const char*)stage1_scratch + stage1_partial_offset((size_t)rows));
-    return onesweep_sort_speculative(vis_key, vis_id, (uint32_t*)(base + L.tmp_key), (uint32_t*)(base + L.tmp_id), P, pred_bits,
-                                     dpartial, rows, (uint32_t*)(base + L.status), err, totals_dev, s, debug, where);
-}
-
-bool binning_single_launch_path(uint32_t flags, long V, long R)
-{
-    return !((flags & FLAG_SCAN_BINNING) || V > ONESWEEP_MAX_N || R > ONESWEEP_MAX_N || V > EMIT_SCAN_MAX_V);
-}
-
-// layV / layR: what `scratch` was sized for (binning_stage2_scratch_bytes(layV, layR, tiles): the caller's P and capacity).
-// depth_sorted: -1, or the ping-pong parity of a speculative depth sort whose plan the caller has verified (V, key_min, key_bits).
 int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
                    uint32_t* vis_id, const uint4* rect, const void* stage1_scratch, void* scratch, uint32_t* point_list,
                    int2* ranges, bool ranges_zeroed, bool status_zeroed, uint32_t* err, uint32_t* guard_post,
-                   uint32_t guard_seq, int debug_raise_guard, uint32_t n_huge, hipStream_t s, bool debug, int layV, long layR,
-                   int depth_sorted)
+                   uint32_t guard_seq, int debug_raise_guard, uint32_t n_huge, hipStream_t s, bool debug)
 {
     // debug_raise_guard (tests): 1 = raise the guard word by hand after a VALID binning; 2 = lose workgroup 0 of the depth
     // sort's first pass, so that real waits run out and the lists that follow are built from a short prefix
     int ntiles = cam.gx * cam.gy;
     if (!ranges_zeroed) VR_HIP(hipMemsetAsync(ranges, 0, sizeof(int2) * (size_t)ntiles, s));
     if (V == 0 || R == 0) return 0;
-    Stage2Layout L = stage2_layout(layV, layR, ntiles);
+    Stage2Layout L = stage2_layout(V, R, ntiles);
     char* base = (char*)scratch;
     uint32_t* tile_keys = nullptr;
-    if (!binning_single_launch_path(cam.flags, V, R)) {
+    if ((cam.flags & FLAG_SCAN_BINNING) || (long)V > ONESWEEP_MAX_N || R > ONESWEEP_MAX_N || (long)V > EMIT_SCAN_MAX_V) {
         int rc = binning_multi_launch(cam, V, R, key_min, key_bits, vis_key, vis_id, rect, base, L, point_list,
                                       &tile_keys, n_huge, s, debug);
         if (rc) return rc;
@@ -1707,9 +1623,7 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
             (const uint32_t*)((const char*)stage1_scratch + stage1_partial_offset((size_t)rows));
         // 2. depth sort of the visible Gaussians on the bits of (key - kmin) that vary
         uint32_t* sorted_id = vis_id;
-        if (depth_sorted >= 0) {        // queued before the host's round trip (launch_depth_sort_speculative), plan verified
-            sorted_id = depth_sorted ? tmp_id : vis_id;
-        } else {
+        {
             ProfScope ps(VR_STAGE_DEPTH_SORT, s);
             int where = 0;
             int rc = onesweep_sort(vis_key, vis_id, tmp_key, tmp_id, V, key_min, key_bits, dpartial, rows, (uint32_t*)st,

@@ -77,15 +77,7 @@ int binning_tile_bits(int ntiles);
 int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
                    uint32_t* vis_id, const uint4* rect, const void* stage1_scratch, void* scratch, uint32_t* point_list,
                    int2* ranges, bool ranges_zeroed, bool status_zeroed, uint32_t* err, uint32_t* guard_post,
-                   uint32_t guard_seq, int debug_raise_guard, uint32_t n_huge, hipStream_t s, bool debug, int layV, long layR,
-                   int depth_sorted = -1);
-// the depth sort queued before the host has the view's totals (binning.hip): scratch laid out for (P, layR)
-int launch_depth_sort_speculative(int P, long layR, int ntiles, uint32_t* vis_key, uint32_t* vis_id, const void* stage1_scratch,
-                                  void* scratch, uint32_t* err, const uint32_t* totals_dev, int pred_bits, hipStream_t s,
-                                  bool debug, int* where);
-int radix_sort_passes(int nbits);                                    // passes the radix sorts take for `nbits` key bits
-int binning_digit(int nbits);                                        // digit width the radix sorts use for `nbits` key bits
-bool binning_single_launch_path(uint32_t flags, long V, long R);     // does launch_binning take the onesweep path for these sizes?
+                   uint32_t guard_seq, int debug_raise_guard, uint32_t n_huge, hipStream_t s, bool debug);
 
 // stable LSD radix sort of (key,val) u32 pairs on the low nbits of (key - kmin); ping-pongs between the two
 // pairs, *where = 0/1 tells which pair holds the result

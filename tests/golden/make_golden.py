@@ -201,18 +201,42 @@ CASES = {
     "case_flag_fill": dict(P=150, seed=24, scale=0.04, W=64, H=48, deg=0, bg=(0.2, 0.2, 0.2), mode="sh_sr", mod=1.0, flags=8),
     "case_flag_all": dict(P=260, seed=25, scale=0.05, W=64, H=48, deg=3, bg=(0.5, 0.4, 0.3), mode="sh_sr", mod=0.8, flags=15),
     "case_flag_dnorm_fill": dict(P=200, seed=26, scale=0.05, W=48, H=48, deg=1, bg=(0.0, 0.0, 0.0), mode="sh_sr", mod=1.2, flags=10),
+    # ---- round 6: cases that cross what the segmented kernels are built around (round-5 verdict: every case above has
+    # tile lists of at most 159 entries -- one 256-entry segment -- and rectangles of at most a few tiles)
+    # DEEP TILES: 6,000 translucent Gaussians on 24 tiles: lists of up to ~2,000 entries (8 segments), n_contrib up to
+    # ~1,300, ~3,900 pixels that STOP (T < 1e-4) in a later segment: segment carries, late stops, the backward's suffix sums
+    "case_deep_tiles": dict(P=6000, seed=41, scale=0.06, W=96, H=64, deg=2, bg=(0.1, 0.2, 0.3), mode="sh_sr", mod=1.0,
+                            opmean=-2.0, gout16=True),
+    # HUGE RECTANGLES: a 12 x 10-tile frame with splats whose rectangles cover more than 64 tiles (cell masks, the whole-wave /
+    # listed emission), some of 9 ... 64 tiles, among small ones
+    "case_huge_rect": dict(P=500, seed=42, scale=0.03, W=192, H=160, deg=1, bg=(0.0, 0.1, 0.0), mode="sh_sr", mod=1.0,
+                           giants=((0, 30.0), (1, 18.0), (2, 45.0), (3, 9.0), (4, 6.0), (5, 7.5), (6, 12.0), (7, 5.0)), gout16=True),
+    # the reference's frame (gaussian_renderer/__init__.py:109: torch.Size([3, 376, 1408])) with the KITTI-360 principal
+    # point offset: a street of discs rendered at 1408 x 376; the fixture keeps a CROP of the images (upstream gradients are
+    # zero outside it), so the file stays small while the tile grid (88 x 24), the projection and the lists are the frame's
+    "case_kitti_crop": dict(P=3000, seed=43, W=1408, H=376, deg=3, bg=(0.0, 0.0, 0.0), mode="sh_sr", mod=1.0,
+                            scene="street", length=40.0, cam="kitti", crop=(180, 276, 600, 792), gout16=True),
 }
 
 
 def build_case(c):
     from vegs_amd import scenes
-    sc, deg = scenes.scene_random(P=c["P"], sh_degree=c["deg"], seed=c["seed"], scale=c["scale"],
-                                  extent=c.get("extent", 0.5))
+    if c.get("scene") == "street":
+        sc, deg = scenes.scene_street(P=c["P"], length=c["length"], sh_degree=c["deg"], seed=c["seed"])
+    else:
+        sc, deg = scenes.scene_random(P=c["P"], sh_degree=c["deg"], seed=c["seed"], scale=c["scale"],
+                                      extent=c.get("extent", 0.5))
+    if c.get("opmean") is not None:      # translucent: many splats per pixel before it saturates
+        rng = np.random.default_rng(c["seed"] + 1000)
+        sc["opacities"] = (1 / (1 + np.exp(-rng.normal(c["opmean"], 1.0, sc["opacities"].shape)))).astype(np.float32)
+    for i, k in c.get("giants", ()):     # a few splats blown up: rectangles of tens to hundreds of tiles
+        sc["scales"][i] = (sc["scales"][i] * k).astype(np.float32)
+        sc["opacities"][i] = 0.35
     if c.get("opaque"):
         rng = np.random.default_rng(c["seed"] + 1000)
         sc["opacities"] = rng.uniform(0.5, 1.0, sc["opacities"].shape).astype(np.float32)
         sc["rotations"] = (sc["rotations"] * rng.uniform(0.8, 1.2, (c["P"], 1))).astype(np.float32)  # un-normalised q
-    cam = scenes.camera_c1(c["W"], c["H"])
+    cam = scenes.kitti_camera(2.0, 0.3, c["W"], c["H"]) if c.get("cam") == "kitti" else scenes.camera_c1(c["W"], c["H"])
     return sc, deg, cam
 
 
@@ -246,6 +270,14 @@ def part_b(only_new=False):
         rng = np.random.default_rng(c["seed"] + 7)
         names = ["color", "depth", "cov_quat", "cov_scale", "alpha"]
         gouts = [rng.normal(size=tuple(r.shape)).astype(np.float32) for r in res[:5]]
+        if c.get("gout16"):              # values a float16 holds: the stored arrays compress to half
+            gouts = [g.astype(np.float16).astype(np.float32) for g in gouts]
+        crop = c.get("crop")             # (y0, y1, x0, x1): upstream gradients vanish outside, only the crop is stored
+        if crop:
+            for g in gouts:
+                keep = g[:, crop[0]:crop[1], crop[2]:crop[3]].copy()
+                g[...] = 0.0
+                g[:, crop[0]:crop[1], crop[2]:crop[3]] = keep
         loss = sum((r * torch.tensor(g, dtype=torch.float64)).sum() for r, g in zip(res[:5], gouts))
         loss.backward()
         blob = {"meta": np.array([P, cam.image_width, cam.image_height, deg], np.int64),
@@ -257,9 +289,12 @@ def part_b(only_new=False):
             blob["in_" + k] = v
         for k, v in extra.items():
             blob[k] = v.detach().numpy().astype(np.float32)
+        if crop:
+            blob["crop"] = np.array(crop, np.int64)
         for n, r, g in zip(names, res[:5], gouts):
-            blob["out_" + n] = r.detach().numpy().astype(np.float32)
-            blob["gout_" + n] = g
+            o = r.detach().numpy().astype(np.float32)
+            blob["out_" + n] = o[:, crop[0]:crop[1], crop[2]:crop[3]] if crop else o
+            blob["gout_" + n] = g[:, crop[0]:crop[1], crop[2]:crop[3]] if crop else g
         blob["grad_means2D"] = m2d.grad.numpy().astype(np.float32)
         blob["grad_means3D"] = T["means3D"].grad.numpy().astype(np.float32)
         blob["grad_opacities"] = T["opacities"].grad.numpy().astype(np.float32)

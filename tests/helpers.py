@@ -16,6 +16,49 @@ FLAG_CASES = ["case_flag_scale", "case_flag_depthnorm", "case_flag_noalpha", "ca
               "case_flag_dnorm_fill"]
 
 
+# round 6: cases whose tile lists span several 256-entry segments (stops in later segments), whose rectangles exceed 64
+# tiles, and the reference's 1408 x 376 frame (a crop of its images): tests/golden/make_golden.py CASES
+DEEP_CASES = ["case_deep_tiles", "case_huge_rect", "case_kitti_crop"]
+FLAG_FULL_TILE_LISTS = 32768     # include/vegs_rast.h VR_FLAG_FULL_TILE_LISTS: the reference's lists (every tile of the rectangle)
+
+
+def assert_images_close(c, name, out, what=""):
+    """Forward images against a float64 golden: 1e-5 (x the channel's magnitude when that exceeds 1) -- except on the
+    KITTI-shaped street, whose 1e-5-thin discs seen edge-on amplify the fp32 rounding of the projection (conic
+    conditioning in the hundreds): there the bar is the north star's 1e-4 with at most 2 % of the pixels beyond 1e-5."""
+    street = name == "case_kitti_crop"
+    for n in OUT_NAMES:
+        scale = max(1.0, np.abs(c["out_" + n]).max())
+        d = np.abs(case_view(c, out[n]) - c["out_" + n])
+        assert d.max() < (1e-4 if street else 1e-5) * scale, (what, n, d.max())
+        if street:
+            assert (d > 1e-5 * scale).mean() < 0.02, (what, n, (d > 1e-5 * scale).mean())
+
+
+def case_gouts(c):
+    """Upstream gradients of the five images at full frame size (a cropped fixture holds them inside its crop only:
+    they are zero outside)."""
+    P, W, H, deg = (int(v) for v in c["meta"])
+    gouts = []
+    for n in OUT_NAMES:
+        g = c["gout_" + n]
+        if "crop" in c:
+            y0, y1, x0, x1 = (int(v) for v in c["crop"])
+            full = np.zeros((g.shape[0], H, W), np.float32)
+            full[:, y0:y1, x0:x1] = g
+            g = full
+        gouts.append(g)
+    return gouts
+
+
+def case_view(c, img):
+    """The part of a full-frame image the fixture stores."""
+    if "crop" not in c:
+        return img
+    y0, y1, x0, x1 = (int(v) for v in c["crop"])
+    return img[:, y0:y1, x0:x1]
+
+
 def case_flags(c):
     """VrFlags (include/vegs_rast.h) the golden case was rendered with (0 for the cases of round 1)."""
     return int(c["flags"]) if "flags" in c else 0

@@ -11,8 +11,9 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (FLAG_CASES, OUT_NAMES, assert_grad_close, case_flags, case_inputs, grad_mismatch, ill_conditioned, load_case,
-                     normal_guidance_loss, oracle_cam, oracle_cam_from_case, rel_err, summation_sensitivity)
+from helpers import (DEEP_CASES, FLAG_CASES, FLAG_FULL_TILE_LISTS, OUT_NAMES, assert_grad_close, assert_images_close, case_flags,
+                     case_gouts, case_inputs, grad_mismatch, ill_conditioned, load_case, normal_guidance_loss, oracle_cam,
+                     oracle_cam_from_case, rel_err, summation_sensitivity)
 
 pytestmark = pytest.mark.gpu
 
@@ -184,6 +185,37 @@ def test_golden_fixture(name, dev):
     for k in [k[5:] for k in c if k.startswith("grad_")]:
         assert_grad_close(k, grads[k], c["grad_" + k], rtol=1e-3)
     assert np.all(grads["means2D"][:, 2] == 0)
+
+
+@pytest.mark.parametrize("full_lists", [False, True])
+@pytest.mark.parametrize("name", DEEP_CASES)
+def test_deep_golden_fixture(name, full_lists, dev):
+    """HIP vs the float64 goldens that cross what the segmented kernels are built around (round 6; tests/golden/make_golden.py):
+    tile lists of up to 8 segments with thousands of pixels stopping behind the first one (segment carries Tb *= p, C += Cs,
+    late stops, the backward's suffix sums), rectangles of more than 64 tiles (cell masks, whole-wave emission), and the
+    reference's 1408 x 376 frame with its principal-point offset -- in both list modes.  These cases are rendered by
+    oracle/torch_ref.py (per-tile cumprod, autograd, float64), which knows nothing about segments: images within 1e-5 (the
+    street: the north star's 1e-4, helpers.assert_images_close), gradients per row within rtol 1e-3.  Then the same inputs
+    against the C oracle: radii, point list, ranges and images bit for bit."""
+    from oracle import oracle as orc
+    c = load_case(name)
+    P, W, H, deg = (int(v) for v in c["meta"])
+    flags = FLAG_FULL_TILE_LISTS if full_lists else 0
+    gouts = case_gouts(c)
+    out, grads, res = _run_hip(_settings(c, None, None, None, dev), case_inputs(c), dev, gouts, flags=flags)
+    assert np.array_equal(out["radii"], c["radii"])
+    assert_images_close(c, name, out, "hip vs float64")
+    for k in [k[5:] for k in c if k.startswith("grad_")]:
+        assert_grad_close(k, grads[k], c["grad_" + k], rtol=1e-3)
+    assert np.all(grads["means2D"][:, 2] == 0)
+    oc = orc.make_cam(H, W, c["tanfov"][0], c["tanfov"][1], c["bg"], float(c["scale_modifier"]), c["viewmatrix"],
+                      c["projmatrix"], c["campos"], deg, 16, flags=flags)
+    o_out, st = orc.forward(oc, **case_inputs(c))
+    pl, rg = _export_binning(res, H, W, dev)
+    assert res[0].grad_fn.num_rendered == st["R"]
+    assert np.array_equal(rg, st["ranges"]) and np.array_equal(pl, st["point_list"])
+    for n in OUT_NAMES:
+        assert np.array_equal(out[n], o_out[n]), (n, np.abs(out[n] - o_out[n]).max())
 
 
 @pytest.mark.parametrize("name", ["case_sh3", "case_precomp", "case_cull_deg1"] + FLAG_CASES)
@@ -559,6 +591,45 @@ def test_a_wait_that_really_times_out_is_recovered_or_reported(dev):
         p2["render"].sum().backward()
     assert T2["means3D"].grad is None
     p3, T3, l3 = run(False, DET)
+    assert torch.equal(p0["render"], p3["render"]) and torch.equal(T0["means3D"].grad, T3["means3D"].grad)
+
+
+def test_sorted_ids_that_are_not_a_permutation_fail_the_view(dev):
+    """The always-on PERMUTATION CHECK of the depth sort (binning.hip: perm_mix): the ids the compaction hands to the sort and
+    the ids the emission gets back are summed (plain and hashed) and compared by the last binning kernel.
+    vr_debug_raise_guard(4) overwrites ONE sorted id with its neighbour between the sort and the emission -- still a valid
+    index, nothing would fault, the lists would silently be wrong: the view must fail at its own backward (default) or be
+    binned again bit-exact (VR_FLAG_VERIFY_BINNING), and the next view is clean."""
+    from vegs_amd import _capi, harness, rasterizer, scenes
+    sc, deg = scenes.scene_street(P=60000, length=40.0, sh_degree=1, seed=19)
+    cam = scenes.kitti_camera(0.0, 0.0, 344, 94)
+    bg = torch.zeros(3, device=dev)
+
+    def run(trip, flags, backward=True):
+        T = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in sc.items()}
+        with rasterizer.flags(flags):
+            if trip:
+                _capi.check(_capi.load().vr_debug_raise_guard(4))
+            pkg = harness.render(cam, T, deg, bg)
+            if backward:
+                pkg["render"].sum().backward()
+        torch.cuda.synchronize()
+        return pkg, T
+    DET, VERIFY = rasterizer.FLAG_DETERMINISTIC, rasterizer.FLAG_VERIFY_BINNING
+    p0, T0 = run(False, DET)
+    p1, T1 = run(True, DET, backward=False)
+    with pytest.raises(Exception, match="not a permutation"):
+        p1["render"].sum().backward()
+    assert T1["means3D"].grad is None
+    assert float(p1["alpha"].abs().max()) == 0.0          # the failed view's tile ranges stayed empty: nothing was indexed
+    before = _capi.load().vr_debug_rebinned()
+    p2, T2 = run(True, DET | VERIFY)
+    assert _capi.load().vr_debug_rebinned() == before + 1
+    for k in ("render", "render_depth", "render_cov_quat", "render_cov_scale", "alpha"):
+        assert torch.equal(p0[k], p2[k]), k
+    for k in T0:
+        assert torch.equal(T0[k].grad, T2[k].grad), k
+    p3, T3 = run(False, DET)
     assert torch.equal(p0["render"], p3["render"]) and torch.equal(T0["means3D"].grad, T3["means3D"].grad)
 
 

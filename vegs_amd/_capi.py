@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libvegsrast.so")
+LIB_PATH = os.environ.get("VEGS_LIB") or os.path.join(_HERE, "_lib", "libvegsrast.so")   # (VEGS_LIB: reproducer builds, vegs_amd/build.py --variant)
 ABI_VERSION = 9
 
 # VrSettings.flags (include/vegs_rast.h, VrFlags)

@@ -37,7 +37,25 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+# Reproducer builds (profiles/experiments/README.md): the same sources with a -D switch, into their own library beside the
+# product one -- loaded only when VEGS_LIB names it (vegs_amd/_capi.py).  Never built by build() without --variant.
+VARIANTS = {"early": ["-DVR_EARLY_SH"]}
+
+
+def build_variant(name, force=False, verbose=False):
+    global OBJ_DIR, LIB
+    keep = (OBJ_DIR, LIB)
+    OBJ_DIR = os.path.join(OUT_DIR, "obj_" + name)
+    LIB = os.path.join(OUT_DIR, "libvegsrast_%s.so" % name)
+    FLAGS.extend(VARIANTS[name])
+    try:
+        return build(force, verbose, harness=False)
+    finally:
+        del FLAGS[-len(VARIANTS[name]):]
+        OBJ_DIR, LIB = keep
+
+
+def build(force=False, verbose=False, harness=True):
     os.makedirs(OBJ_DIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
@@ -63,7 +81,8 @@ def build(force=False, verbose=False):
     objs = [os.path.join(OBJ_DIR, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _newer(LIB, objs):
         run([_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", LIB])
-    build_c_harness(force or bool(jobs))
+    if harness:
+        build_c_harness(force or bool(jobs))
     return LIB
 
 
@@ -87,4 +106,7 @@ def build_c_harness(force=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:
+        print(build_variant(sys.argv[sys.argv.index("--variant") + 1], force="--force" in sys.argv, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

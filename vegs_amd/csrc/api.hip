@@ -2,6 +2,7 @@
 // layout, and the kernel sequence of forward / backward / mark_visible.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -31,7 +32,8 @@ static thread_local VrCounters g_counters = {0, 0, 0, 0, 0};
 // host-pinned, coherent mailbox that the totals kernel writes (V, R, min key, max key, guard word; then a sequence
 // number the host polls) and the device-side guard word: one per (host thread, device)
 constexpr int MAX_DEVICES = 64;
-// pinned words: [0..4] totals of the forward in flight, [8] its sequence number; from word RING_AT a ring of RING_SLOTS
+// pinned words: [0..11] six 64-bit {value, sequence number} pairs: the totals of the forward in flight (V, R, min key, max
+// key, 0, large rectangles), each stamped with that forward's sequence number; from word RING_AT a ring of RING_SLOTS
 // {seq, guard} pairs: slot seq % RING_SLOTS is filled by the LAST binning kernel of forward `seq` with the guard word as
 // it stands after all of that view's waiting passes (k_tile_ranges).  vr_backward / the export calls find the slot
 // through VrSaved.ticket = (mailbox id + 1) << 32 | seq -- PyTorch runs the op's backward on its autograd thread, so
@@ -56,7 +58,7 @@ static thread_local Mailbox g_mail[MAX_DEVICES] = {};
 struct MailRef { uint32_t* pinned; uint32_t* guard; int dev; };
 static std::mutex g_mail_mu;
 static std::vector<MailRef> g_mail_reg;
-static thread_local int g_raise_guard = 0;        // test hook: vr_debug_raise_guard (1 = raise the word, 2 = lose a workgroup, 3 = impatient walkers)
+static thread_local int g_raise_guard = 0;        // test hook: vr_debug_raise_guard (1 = raise the word, 2 = lose a workgroup, 3 = impatient walkers, 4 = break the sorted ids)
 static thread_local int g_rebinned = 0;           // views re-binned under VR_FLAG_VERIFY_BINNING (vr_debug_rebinned)
 
 // the calling thread's mailbox for the current device, created on first use
@@ -131,8 +133,9 @@ static int check_ticket(uint64_t ticket, hipStream_t s, bool wait = true, bool* 
     }
     if (__atomic_load_n(&slot[1], __ATOMIC_RELAXED) == 0u) return VR_OK;
     __atomic_store_n(&slot[1], GUARD_REPORTED, __ATOMIC_RELAXED);   // (the device word is the forward's own: nothing to clear)
-    set_error("a look-back wait in this view's binning timed out: its lists, images and gradients are invalid "
-              "(re-render the view; VR_FLAG_SCAN_BINNING avoids inter-workgroup waits)");
+    set_error("this view's binning failed (a look-back wait timed out, or the depth sort's output was not a permutation of "
+              "the visible ids): its lists, images and gradients are invalid (re-render the view; VR_FLAG_SCAN_BINNING "
+              "avoids inter-workgroup waits)");
     return VR_ERR_HIP;
 }
 
@@ -161,11 +164,23 @@ static int report_earlier(Mailbox& mail)
 // Waits until the totals kernel has published this call's sequence number in the mailbox.  Polls host memory (the
 // kernel's system-scope release store); every ~50 us of polling it also asks the stream for errors, and after 20 ms it
 // falls back to a blocking stream synchronisation and a plain copy of the device-side totals.
-static int wait_mailbox(uint32_t* pinned, uint32_t seq, const uint32_t* totals_dev, hipStream_t s)
+// The six totals of forward `seq`, once all six mailbox words carry that sequence number (each word is one 8-byte store of
+// the kernel: value and stamp cannot be torn apart, and no assumption is made about the order the stores arrive in).
+static bool read_mailbox(const uint32_t* pinned, uint32_t seq, uint32_t out[6])
+{
+    const unsigned long long* m64 = reinterpret_cast<const unsigned long long*>(pinned);
+    for (int k = 0; k < 6; ++k) {
+        const unsigned long long w = __atomic_load_n(&m64[k], __ATOMIC_ACQUIRE);
+        if ((uint32_t)(w >> 32) != seq) return false;
+        out[k] = (uint32_t)w;
+    }
+    return true;
+}
+static int wait_mailbox(const uint32_t* pinned, uint32_t seq, const uint32_t* totals_dev, hipStream_t s, uint32_t out[6])
 {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 1;; ++spins) {
-        if (__atomic_load_n(&pinned[8], __ATOMIC_ACQUIRE) == seq) return 0;
+        if (read_mailbox(pinned, seq, out)) return 0;
         __builtin_ia32_pause();
         if ((spins & 4095u) == 0u) {
             const hipError_t q = hipStreamQuery(s);
@@ -173,8 +188,8 @@ static int wait_mailbox(uint32_t* pinned, uint32_t seq, const uint32_t* totals_d
             const auto dt = std::chrono::steady_clock::now() - t0;
             if (q == hipSuccess || dt > std::chrono::milliseconds(20)) {
                 VR_HIP(hipStreamSynchronize(s));
-                if (__atomic_load_n(&pinned[8], __ATOMIC_ACQUIRE) == seq) return 0;
-                VR_HIP(hipMemcpy(pinned, totals_dev, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                if (read_mailbox(pinned, seq, out)) return 0;
+                VR_HIP(hipMemcpy(out, totals_dev, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
                 return 0;
             }
         }
@@ -446,14 +461,16 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
                                   scr2 ? binning_stage2_status_bytes(P, (long)Rcap, (int)T) : 0, s, debug);
         prof_end(VR_STAGE_COMPACT, s);
         if (rc) return rc;
-        rc = wait_mailbox(g_pinned, seq, totals_dev, s);
+        uint32_t tot[6];
+        rc = wait_mailbox(g_pinned, seq, totals_dev, s, tot);
         if (rc) return rc;
-        V = g_pinned[0];
-        R = g_pinned[1];
-        n_huge = g_pinned[5];
+        V = tot[0];
+        R = tot[1];
+        n_huge = tot[5];
+        if (V > (uint32_t)P) return fail(VR_ERR_HIP, "the compaction reports %u visible Gaussians of %d", V, P);
         if (V > 0) {
-            key_min = g_pinned[2];
-            uint32_t span = g_pinned[3] - g_pinned[2];
+            key_min = tot[2];
+            uint32_t span = tot[3] - tot[2];
             while (span) { ++key_bits; span >>= 1; }
         }
     }
@@ -524,6 +541,16 @@ int vr_forward(const VrSettings* st, const VrInputs* in, const VrOutputs* out, V
                            (float*)((char*)image + IL.dsum), saved->needed_hint, s, debug, raise == 3 ? 0 : -1);
     prof_end(VR_STAGE_RENDER_FWD, s);
     if (rc) return rc;
+    // VEGS_DEBUG_BINNING=n: every n-th forward ends with a post-mortem of its depth sort (binning.hip: debug_verify_binning)
+    static const int dbg_every = [] { const char* e = getenv("VEGS_DEBUG_BINNING"); return e ? atoi(e) : 0; }();
+    if (dbg_every > 0 && lists && !(cam.flags & FLAG_SCAN_BINNING)) {
+        static std::atomic<unsigned> dbg_n{0};
+        if (++dbg_n % (unsigned)dbg_every == 0u) {
+            const int nbad = debug_verify_binning(P, (int)V, (long)R, key_min, key_bits, vis_key, vis_id, depth_key, tile_count,
+                                                  scan_scr, scr2, totals_dev, nullptr, guard_word, (int)T, s);
+            if (nbad != 0) return fail(VR_ERR_HIP, "VEGS_DEBUG_BINNING: forward %u failed its depth-sort post-mortem (%d findings, stderr)", dbg_n.load(), nbad);
+        }
+    }
 
     saved->geom = geom;
     saved->binning = binning;
@@ -636,8 +663,11 @@ static int backward_first(const Camera& cam, const VrSettings* st, const VrInput
                               gin->dL_dcolors_sh, s, debug);
         if (rc) return rc;
     }
-    // the second look at the guard (see above).  A tripped view's ranges are empty: what was queued computed zeros.
-    if (guard_pending) return check_ticket(saved->ticket, s, false, nullptr);
+    // The second look at the guard (see above), now with this call's kernels queued.  If the forward's last binning kernel
+    // STILL has not run, the host waits for it here (round 6, advisor finding): it lies in front of everything this call
+    // queued, so the GPU has work for the whole wait, and "a failed view fails its OWN backward" holds without exception --
+    // the gradients of a tripped view (zeros: its ranges are empty) never reach an optimizer step unnoticed.
+    if (guard_pending) return check_ticket(saved->ticket, s, true, nullptr);
     return VR_OK;
 }
 
@@ -931,7 +961,7 @@ int vr_debug_set_guard(uint32_t value, void* stream)
 int vr_debug_raise_guard(int on)
 {
     g_err[0] = 0;
-    g_raise_guard = (on == 2 || on == 3) ? on : (on != 0 ? 1 : 0);
+    g_raise_guard = (on >= 2 && on <= 4) ? on : (on != 0 ? 1 : 0);
     return VR_OK;
 }
 

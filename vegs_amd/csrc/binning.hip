@@ -14,7 +14,10 @@
 // R-sized traffic is 2 passes of 8-byte pairs instead of upstream's 6 passes of 12-byte pairs.
 // Ranking inside a pass uses wave64 ballots (match-by-digit), no per-element atomics.
 #include "../../include/vegs_rast.h"
+#include <stdio.h>
 #include <stdlib.h>
+
+#include <vector>
 
 #include "vr_host.h"
 
@@ -240,13 +243,16 @@ k_scan_totals(const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ bs
         if (err_clear) __hip_atomic_store(err_clear, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         totals[4] = 0u;
         totals[5] = t2;      // Gaussians whose rectangle has more than 64 tiles (who emits them: emit_big_inline)
-        // The host's copy: written straight into its pinned, coherent mailbox, sequence number last (release at system
-        // scope); the host polls that word.  No copy command and no event on the stream: the apply kernel follows
-        // this one without the ~10 us the two used to put between them.
+        // The host's copy: written straight into its pinned, coherent mailbox as six 64-bit {value, sequence number} words --
+        // every word says by itself which forward it belongs to, so the host's view of the six does not depend on the order
+        // in which the stores arrive (round 6; before: six values and then the sequence number, with a release in between).
+        // No copy command and no event on the stream: the apply kernel follows this one without the ~10 us the two used
+        // to put between them.
         if (host_mail) {
+            unsigned long long* const m64 = reinterpret_cast<unsigned long long*>(host_mail);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) __hip_atomic_store(&host_mail[k], totals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&host_mail[8], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int k = 0; k < 6; ++k)
+                __hip_atomic_store(&m64[k], ((unsigned long long)seq << 32) | totals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -268,12 +274,32 @@ static int run_scan(Src src, Sink sink, long n, uint32_t* bsum, hipStream_t s, b
 
 // block sums of the compaction scan (4 words per block), then one partial digit histogram of the depth keys per block
 // stage-1 scratch: five per-block values of the compaction's reduce pass (count, list entries, min key, max key, large
-// rectangles), then the per-block digit histograms of the depth keys
+// rectangles), then the per-block digit histograms of the depth keys, then the per-block id checksums (below)
 static inline size_t stage1_partial_offset(size_t nb) { return align_up(5 * nb * sizeof(uint32_t), 256); }
+static inline size_t stage1_chk_offset(size_t nb) { return stage1_partial_offset(nb) + align_up(nb * HIST_WORDS * sizeof(uint32_t), 256); }
 size_t binning_stage1_scratch_bytes(int P)
 {
     size_t nb = (size_t)cdiv(P > 0 ? P : 1, SCAN_BLOCK);
-    return stage1_partial_offset(nb) + align_up(nb * HIST_WORDS * sizeof(uint32_t), 256);
+    return stage1_chk_offset(nb) + align_up(nb * sizeof(uint2), 256);
+}
+
+// PERMUTATION CHECK of the depth sort (always on, round 6).  The sort's passes move (key, id) pairs to positions computed
+// from sums that OTHER workgroups posted; should any of that ever go wrong -- a stale status word, a lost workgroup, a
+// hardware hiccup -- the value buffer stops being a permutation of the visible ids (slots written twice, others holding
+// whatever was there before) and everything downstream would index with it.  So the ids are summed on the way in (the
+// compaction: one pair of sums per workgroup, no atomics) and on the way out (the emission), both as a plain sum and as the
+// sum of a hash, and the last binning kernel compares the two: a mismatch fails the view like a timed-out wait (guard word,
+// empty tile ranges).  Two multisets of V ids with equal sums and equal hashed sums that are NOT equal would need a
+// coincidence of 2^-64.
+__device__ __forceinline__ uint32_t perm_mix(uint32_t id) { return (id ^ (id >> 11)) * 0x9E3779B1u + 0x7F4A7C15u; }
+// block-wide sums of two values per thread (256 threads) -> thread 0 stores them
+__device__ __forceinline__ void block_store_pair(uint32_t a, uint32_t b, uint2* dst, uint32_t* lds8)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+    if ((threadIdx.x & 63) == 0) { lds8[threadIdx.x >> 6] = a; lds8[4 + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) *dst = make_uint2(lds8[0] + lds8[1] + lds8[2] + lds8[3], lds8[4] + lds8[5] + lds8[6] + lds8[7]);
 }
 
 // Two halves: the totals {V, R, min key, max key} reach the host (host_mail, see k_scan_totals) while the apply kernel
@@ -596,7 +622,10 @@ __device__ __forceinline__ void sum_posted(const uint32_t* st, long first, int c
 #pragma unroll
             for (int i = 0; i < FAN - 1; ++i) { all &= v[k][i]; s[k] += v[k][i] & ST_VALUE; }
         }
-        if (all || clk.expired(polls)) {
+        // (a guard word that is already up -- another workgroup's wait ran out, or it found the view broken -- ends this
+        // wait too: the view is lost, its workgroups must not sit out their own two seconds one after the other)
+        const bool lost = (polls & (SPIN_CHECK - 1)) == SPIN_CHECK - 1 && st_load(err) != 0u;
+        if (all || lost || clk.expired(polls)) {
             if (!all) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int k = 0; k < NB; ++k) acc[k] += s[k];
@@ -733,13 +762,16 @@ k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
     // values that are not a permutation of the input any more -- slots written twice, others holding stale or uninitialised
     // memory.  This pass would rank keys whose digit counts no longer add up to the totals it scatters by: destinations
     // beyond the buffers.  The view is lost either way (k_tile_ranges leaves it empty and reports it): nothing is touched.
-    const uint32_t tripped = st_load(err);
+    // The decision is the WORKGROUP's (one load, through LDS): were it every thread's own, a guard word going up while the
+    // workgroup starts could send some of its waves home and leave the others ranking against half-initialised counters.
+    __shared__ uint32_t s_tripped;
+    if (threadIdx.x == 0) s_tripped = st_load(err);
     for (int d = threadIdx.x; d < SIZE; d += 256) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) cnt[k][d] = 0;
     }
-    if (tripped) return;
     __syncthreads();
+    if (s_tripped) return;
     const long wbase = b * RADIX_BLOCK + (long)w * (64 * RADIX_ITEMS);
     uint32_t key[RADIX_ITEMS], val[RADIX_ITEMS], rank[RADIX_ITEMS];
     const unsigned long long lt = lanemask_lt();
@@ -854,8 +886,11 @@ k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
         const uint32_t d = digit_of<BITS>(k, kmin, shift);
         const uint32_t dst = gl[d] + ((uint32_t)j - loc[d]);
         const uint32_t v = sval[j];
-        keys_out[dst] = k;
-        vals_out[dst] = v;
+        // (sums that do not add up -- a wait that gave up in THIS launch -- must not become a store beyond the buffers)
+        if (dst < (uint32_t)n) {
+            keys_out[dst] = k;
+            vals_out[dst] = v;
+        }
     }
 }
 
@@ -905,9 +940,11 @@ __global__ void __launch_bounds__(256)
 k_compact_apply(const uint4* __restrict__ rect, const uint32_t* __restrict__ depth_key, long n,
                 const uint32_t* __restrict__ bsum, const uint32_t* __restrict__ totals, int tile_bits,
                 uint32_t* __restrict__ vis_key, uint32_t* __restrict__ vis_id, uint32_t* __restrict__ partial,
-                uint32_t* __restrict__ zero_a, long zero_na, uint4* __restrict__ status, long status_bytes)
+                uint32_t* __restrict__ zero_a, long zero_na, uint4* __restrict__ status, long status_bytes,
+                uint2* __restrict__ chk_in)
 {
     __shared__ uint32_t lds4[4];
+    __shared__ uint32_t chk_lds[8];
     __shared__ uint32_t h[HIST_WORDS];
     const uint32_t V = totals[0], R = totals[1], kmin = totals[2];
     const int key_bits = V ? bits_of(totals[3] - kmin) : 0;
@@ -949,21 +986,23 @@ k_compact_apply(const uint4* __restrict__ rect, const uint32_t* __restrict__ dep
         if (lane == 0) rowcnt[k][w] = (uint32_t)__popcll(m);
     }
     __syncthreads();
-    uint32_t run = prefix;
+    uint32_t run = prefix, c1 = 0u, c2 = 0u;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) {
             if (ww == w && v[k]) {
                 const uint32_t ex = run + before[k];
+                const uint32_t id = (uint32_t)(base + (long)k * 256);
                 vis_key[ex] = key[k];
-                vis_id[ex] = (uint32_t)(base + (long)k * 256);
+                vis_id[ex] = id;
+                c1 += id; c2 += perm_mix(id);
             }
             run += rowcnt[k][ww];
         }
         hist_key(h, key[k] - kmin, v[k] != 0u, digit, passes, lane);
     }
-    __syncthreads();
+    block_store_pair(c1, c2, chk_in + blockIdx.x, chk_lds);     // (its barrier also completes h)
     for (int d = threadIdx.x; d < words; d += 256) partial[(size_t)blockIdx.x * words + d] = h[d];
 }
 
@@ -974,9 +1013,10 @@ int launch_compact_apply(int P, const uint4* rect, const uint32_t* depth_key, vo
     int nb = cdiv(P > 0 ? P : 1, SCAN_BLOCK);
     uint32_t* bsum = (uint32_t*)scratch;
     uint32_t* partial = (uint32_t*)((char*)scratch + stage1_partial_offset((size_t)nb));
+    uint2* chk_in = (uint2*)((char*)scratch + stage1_chk_offset((size_t)nb));
     hipLaunchKernelGGL(k_compact_apply, dim3(nb), dim3(256), 0, s, rect, depth_key, (long)P, (const uint32_t*)bsum,
                        totals_dev, tile_bits, vis_key, vis_id, partial, zero_a, zero_na, (uint4*)status,
-                       (long)status_bytes);
+                       (long)status_bytes, chk_in);
     VR_KERNEL_CHECK("compact_apply", s, debug);
     return 0;
 }
@@ -1182,7 +1222,8 @@ __device__ __forceinline__ unsigned long long sum_posted_wave(const unsigned lon
 #pragma unroll
         for (int j = 0; j < PER; ++j) both &= v[j];
         const bool all = __ballot((both & SE_POSTED) == 0ull) == 0ull;
-        if (all || clk.expired(polls)) {
+        const bool lost = (polls & (SPIN_CHECK - 1)) == SPIN_CHECK - 1 && st_load(err) != 0u;     // (see sum_posted)
+        if (all || lost || clk.expired(polls)) {
             if (!all && lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned long long s = 0ull;
 #pragma unroll
@@ -1201,27 +1242,35 @@ __device__ __forceinline__ unsigned long long sum_posted_wave(const unsigned lon
 // k of the workgroup lies behind batch k - 1.
 template <int ITEMS>
 __global__ void __launch_bounds__(256)
-k_emit_scan(int V, int P, int gx, const uint32_t* __restrict__ sorted_id, const uint4* __restrict__ rect,
+k_emit_scan(int V, int P, long R, int gx, const uint32_t* __restrict__ sorted_id, const uint4* __restrict__ rect,
             unsigned long long* __restrict__ status, uint32_t* __restrict__ err, uint32_t* __restrict__ tkeys,
-            uint32_t* __restrict__ tvals, BigRects big_list)
+            uint32_t* __restrict__ tvals, BigRects big_list, uint2* __restrict__ chk_out)
 {
     __shared__ uint32_t lds4[4];
+    __shared__ uint32_t chk_lds[8];
     __shared__ unsigned long long s_before;
     const int lane = threadIdx.x & 63;
     uint32_t cnt[ITEMS], id[ITEMS];
     uint4 rc[ITEMS];
-    // (a wait of this view's depth sort ran out: `sorted_id` may hold anything -- it is not used as an index; see k_onesweep)
-    if (st_load(err) != 0u) return;
+    // A wait of this view's depth sort ran out: `sorted_id` may hold anything.  The workgroup does NOT leave (threads deciding
+    // one by one could leave half a workgroup behind its barriers): it takes part in everything with empty rectangles.
+    const bool dead = st_load(err) != 0u;
+    uint32_t c1 = 0u, c2 = 0u;
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
         const int r = (blockIdx.x * ITEMS + k) * 256 + threadIdx.x;
         cnt[k] = 0; id[k] = 0;
-        if (r < V) id[k] = sorted_id[r];
+        if (r < V && !dead) { id[k] = sorted_id[r]; c1 += id[k]; c2 += perm_mix(id[k]); }
     }
+    // (the ids as they came out of the sort, whatever they are: the compaction's sums must come back -- PERMUTATION CHECK)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { c1 += __shfl_xor(c1, d, 64); c2 += __shfl_xor(c2, d, 64); }
+    if (lane == 0) { chk_lds[threadIdx.x >> 6] = c1; chk_lds[4 + (threadIdx.x >> 6)] = c2; }
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
         const int r = (blockIdx.x * ITEMS + k) * 256 + threadIdx.x;
         rc[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (dead) continue;
         // the packed rectangle + tile mask is gathered by id HERE (1.65 M random 16-byte reads): this kernel is bound by
         // the latency of its waits, not by bandwidth, and hides them; in the last depth-sort pass they cost 22 us
         // An id beyond the model cannot come out of a sound depth sort: it is not used as an index (the gather would
@@ -1256,9 +1305,55 @@ k_emit_scan(int V, int P, int gx, const uint32_t* __restrict__ sorted_id, const 
         if (lane == 0) s_before = within + upper;
     }
     __syncthreads();
+    if (threadIdx.x == 0)
+        chk_out[blockIdx.x] = make_uint2(chk_lds[0] + chk_lds[1] + chk_lds[2] + chk_lds[3], chk_lds[4] + chk_lds[5] + chk_lds[6] + chk_lds[7]);
 #pragma unroll
-    for (int k = 0; k < ITEMS; ++k)
-        emit_rects(rc[k], cnt[k], (uint32_t)s_before + ex[k], id[k], gx, lane, tkeys, tvals, big_list);
+    for (int k = 0; k < ITEMS; ++k) {
+        // Entries that would land beyond the R the lists were sized for: the ids are not the compaction's (repeated ones
+        // repeat their rectangles) or a posted sum was wrong.  Nothing is written there; the view fails.
+        const unsigned long long first = s_before + ex[k];
+        if (cnt[k] != 0u && first + cnt[k] > (unsigned long long)R) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cnt[k] = 0u;
+        }
+        emit_rects(rc[k], cnt[k], (uint32_t)first, id[k], gx, lane, tkeys, tvals, big_list);
+    }
+}
+
+// The PERMUTATION CHECK's verdict (see perm_mix): sums of the compaction's per-workgroup pairs against the emission's.  One
+// workgroup; on a mismatch the guard word goes up.  Returns (to every thread) whether the view is failed.
+__device__ __forceinline__ bool perm_check_failed(const uint2* __restrict__ chk_in, int n_in, const uint2* __restrict__ chk_out,
+                                                  int n_out, uint32_t* err, uint32_t* lds /* [2 * waves + 1] */)
+{
+    uint32_t a1 = 0u, a2 = 0u;
+    for (int j = threadIdx.x; j < n_in; j += blockDim.x) { const uint2 c = chk_in[j]; a1 += c.x; a2 += c.y; }
+    for (int j = threadIdx.x; j < n_out; j += blockDim.x) { const uint2 c = chk_out[j]; a1 -= c.x; a2 -= c.y; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { a1 += __shfl_xor(a1, d, 64); a2 += __shfl_xor(a2, d, 64); }
+    const int nw = (int)blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) { lds[threadIdx.x >> 6] = a1; lds[nw + (threadIdx.x >> 6)] = a2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t1 = 0u, t2 = 0u;
+        for (int q = 0; q < nw; ++q) { t1 += lds[q]; t2 += lds[nw + q]; }
+        const uint32_t bad = (t1 | t2) != 0u ? 1u : 0u;
+        if (bad) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds[2 * nw] = bad;
+    }
+    __syncthreads();
+    return lds[2 * nw] != 0u;
+}
+// ... as a launch of its own in front of k_tile_ranges (frames of more than SPLIT_MAX_TILES tiles; k_split_base does it itself)
+__global__ void __launch_bounds__(1024)
+k_perm_check(const uint2* __restrict__ chk_in, int n_in, const uint2* __restrict__ chk_out, int n_out, uint32_t* __restrict__ err)
+{
+    __shared__ uint32_t lds[33];
+    (void)perm_check_failed(chk_in, n_in, chk_out, n_out, err, lds);
+}
+// test hook (vr_debug_raise_guard(4)): the sorted ids stop being a permutation -- one of them is written over its neighbour
+__global__ void k_debug_break_permutation(uint32_t* sorted_id, int V)
+{
+    if (V > 1) sorted_id[V / 2] = sorted_id[V / 2 - 1];
 }
 
 // Also (thread 0 of the launch): the look-back guard word as it stands after ALL waiting passes of this view, posted
@@ -1311,9 +1406,11 @@ k_split_count(const uint32_t* __restrict__ tkeys, long R, int ntiles, int stride
 {
     extern __shared__ uint32_t split_lds[];
     uint32_t* const h = split_lds;                 // [stride]
-    if (st_load(err) != 0u) return;                // (a wait of this view's depth sort / emission ran out: the keys may be anything)
+    __shared__ uint32_t s_tripped;                 // (a wait of this view's depth sort / emission ran out: the keys may be anything;
+    if (threadIdx.x == 0) s_tripped = st_load(err);   //  the workgroup decides as one, see k_onesweep)
     for (int d = threadIdx.x; d < stride; d += 256) h[d] = 0u;
     __syncthreads();
+    if (s_tripped) return;
     const long base = (long)blockIdx.x * SPLIT_BLOCK;
     uint32_t k[SPLIT_ITEMS];
 #pragma unroll
@@ -1376,11 +1473,15 @@ k_split_scan(uint32_t* __restrict__ table, int nblk, int stride, uint32_t* __res
 // forward's sequence number into the host's pinned ring slot (what k_tile_ranges does on the two-pass path).
 __global__ void __launch_bounds__(1024)
 k_split_base(const uint32_t* __restrict__ totals, int ntiles, uint32_t* __restrict__ base, int2* __restrict__ ranges,
-             const uint32_t* __restrict__ err, uint32_t* __restrict__ post, uint32_t seq)
+             uint32_t* __restrict__ err, uint32_t* __restrict__ post, uint32_t seq, const uint2* __restrict__ chk_in, int n_in,
+             const uint2* __restrict__ chk_out, int n_out)
 {
     __shared__ uint32_t wsum[16];
-    uint32_t tripped = 0u;
-    if (err) tripped = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ uint32_t chk_lds[33];
+    // the depth sort's output was a permutation of the compaction's ids?  (raises the guard word itself if not)
+    const bool broken = chk_in && perm_check_failed(chk_in, n_in, chk_out, n_out, err, chk_lds);
+    uint32_t tripped = broken ? 1u : 0u;
+    if (err && !broken) tripped = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 0 && post) {
         __hip_atomic_store(&post[1], tripped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&post[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1425,7 +1526,8 @@ k_split_scatter(const uint32_t* __restrict__ tkeys, const uint32_t* __restrict__
     extern __shared__ uint32_t split_lds[];
     uint32_t* const cnt = split_lds;                    // [4][stride]: per wave, pairs of each tile so far -> pairs in the waves before
     uint32_t* const rowoff = split_lds + 4 * stride;    // [stride]: base[t] + pairs of t in the workgroups before this one
-    if (st_load(err) != 0u) return;
+    __shared__ uint32_t s_tripped;
+    if (threadIdx.x == 0) s_tripped = st_load(err);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t* const row = table + (size_t)blockIdx.x * stride;
     for (int d = threadIdx.x; d < stride; d += 256) {
@@ -1434,6 +1536,7 @@ k_split_scatter(const uint32_t* __restrict__ tkeys, const uint32_t* __restrict__
         rowoff[d] = (d < ntiles ? base[d] : 0u) + row[d];
     }
     __syncthreads();
+    if (s_tripped) return;
     const long wbase = (long)blockIdx.x * SPLIT_BLOCK + (long)w * (64 * SPLIT_ITEMS);
     uint32_t key[SPLIT_ITEMS], val[SPLIT_ITEMS], rank[SPLIT_ITEMS];
 #pragma unroll
@@ -1469,13 +1572,16 @@ k_split_scatter(const uint32_t* __restrict__ tkeys, const uint32_t* __restrict__
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < SPLIT_ITEMS; ++i)
-        if (key[i] < (uint32_t)ntiles) out[rowoff[key[i]] + mycnt[key[i]] + rank[i]] = val[i];
+        if (key[i] < (uint32_t)ntiles) {
+            const uint32_t dst = rowoff[key[i]] + mycnt[key[i]] + rank[i];
+            if (dst < (uint32_t)R) out[dst] = val[i];
+        }
 }
 
 // ---------------------------------------------------------------- stage 2 driver
 
 struct Stage2Layout {
-    size_t status, tmp_key, tmp_id, offs, rect_sorted, tkeysA, tkeysB, tvalsB, hist, bsum, tpartial, big, split, split_tot, total;
+    size_t status, tmp_key, tmp_id, offs, rect_sorted, tkeysA, tkeysB, tvalsB, hist, bsum, tpartial, big, split, split_tot, chk, total;
 };
 
 static inline int tile_bits_of(int ntiles)
@@ -1514,6 +1620,7 @@ static Stage2Layout stage2_layout(int V, long R, int ntiles)
     const bool can_split = ntiles <= SPLIT_MAX_TILES;
     L.split = take(can_split ? (size_t)cdiv((long)r, SPLIT_BLOCK) * split_stride(ntiles) * 4 : 0);
     L.split_tot = take(can_split ? (size_t)split_stride(ntiles) * 8 : 0);
+    L.chk = take((size_t)cdiv((long)v, 256) * sizeof(uint2));      // the emission's id checksums, one pair per workgroup
     L.total = o;
     return L;
 }
@@ -1587,6 +1694,175 @@ static int binning_multi_launch(const Camera& cam, int V, long R, uint32_t key_m
     return 0;
 }
 
+// ---------------------------------------------------------------- post-mortem of one view's depth sort (VEGS_DEBUG_BINNING)
+//
+// A debugging aid, not part of the product path: api.hip calls it at the END of vr_forward (after the render stage has
+// been queued, so the forward's own launch sequence runs as always) when the environment asks for it.  It synchronises the
+// stream, copies the binning's intermediate state to the host and checks every invariant the depth sort rests on; the
+// first violated one is reported with enough context to tell a lost workgroup from a stale status word from wrong digit
+// totals.  Returns 0 when everything holds.  (What survives until the end of the forward: the compaction's inputs, the
+// output of the LAST pass and -- the ping-pong partner -- the output of the pass before it, the status words of all passes.)
+int debug_verify_binning(int P, int V, long R, uint32_t key_min, int key_bits, const uint32_t* vis_key, const uint32_t* vis_id,
+                         const uint32_t* depth_key, const uint32_t* tile_count, const void* stage1_scratch, const void* scratch,
+                         const uint32_t* totals_dev, const uint32_t* pinned, const uint32_t* err, int ntiles, hipStream_t s)
+{
+    VR_HIP(hipStreamSynchronize(s));
+    int bad = 0;
+    auto say = [&](const char* fmt, auto... a) { fprintf(stderr, "[vegs debug binning] "); fprintf(stderr, fmt, a...); fputc('\n', stderr); ++bad; };
+    uint32_t tot[6] = {0, 0, 0, 0, 0, 0}, errw = 0;
+    VR_HIP(hipMemcpy(tot, totals_dev, sizeof tot, hipMemcpyDeviceToHost));
+    if (err) VR_HIP(hipMemcpy(&errw, err, 4, hipMemcpyDeviceToHost));
+    if (errw) say("guard word = %u", errw);
+    if (tot[0] != (uint32_t)V || tot[1] != (uint32_t)R) say("host V,R = %d,%ld but device totals = %u,%u", V, R, tot[0], tot[1]);
+    if (V > 0 && tot[2] != key_min) say("host key_min = 0x%x, device 0x%x", key_min, tot[2]);
+    if (V > 0 && bits_of(tot[3] - tot[2]) != key_bits) say("host key_bits = %d, device span says %d", key_bits, bits_of(tot[3] - tot[2]));
+    if (pinned && (pinned[0] != tot[0] || pinned[1] != tot[1] || (V > 0 && (pinned[2] != tot[2] || pinned[3] != tot[3]))))
+        say("mailbox {%u,%u,0x%x,0x%x} != device totals {%u,%u,0x%x,0x%x}", pinned[0], pinned[1], pinned[2], pinned[3], tot[0],
+            tot[1], tot[2], tot[3]);
+    if (V <= 0 || R <= 0 || (long)V > ONESWEEP_MAX_N || R > ONESWEEP_MAX_N) return bad;
+    std::vector<uint32_t> dk(P), tc(P);
+    VR_HIP(hipMemcpy(dk.data(), depth_key, (size_t)P * 4, hipMemcpyDeviceToHost));
+    VR_HIP(hipMemcpy(tc.data(), tile_count, (size_t)P * 4, hipMemcpyDeviceToHost));
+    long nvis = 0, nent = 0, mism = 0;
+    for (int i = 0; i < P; ++i) {
+        const bool a = dk[i] != DEPTH_KEY_NONE, b = tc[i] != 0u;
+        nvis += a; nent += tc[i] & TILE_COUNT_MASK; mism += a != b;
+    }
+    if (nvis != V || nent != R || mism) say("preprocess arrays: %ld keys (V = %d), %ld entries (R = %ld), %ld rows where key and count disagree", nvis, V, nent, R, mism);
+    const Stage2Layout L = stage2_layout(V, R, ntiles);
+    const char* base = (const char*)scratch;
+    const int digit = radix_digit(key_bits), passes = radix_passes(key_bits), SIZE = 1 << digit;
+    const int nblk = cdiv(V, RADIX_BLOCK);
+    std::vector<uint32_t> kA(V), iA(V), kB(V), iB(V);
+    VR_HIP(hipMemcpy(kA.data(), vis_key, (size_t)V * 4, hipMemcpyDeviceToHost));
+    VR_HIP(hipMemcpy(iA.data(), vis_id, (size_t)V * 4, hipMemcpyDeviceToHost));
+    VR_HIP(hipMemcpy(kB.data(), base + L.tmp_key, (size_t)V * 4, hipMemcpyDeviceToHost));
+    VR_HIP(hipMemcpy(iB.data(), base + L.tmp_id, (size_t)V * 4, hipMemcpyDeviceToHost));
+    // output of pass q (0-based) lies in B when q is even, in A when odd; q = -1 is the compaction (A)
+    auto check_pairs = [&](const std::vector<uint32_t>& K, const std::vector<uint32_t>& I, int done, const char* what) {
+        std::vector<uint8_t> seen(P, 0);
+        long oob = 0, keymis = 0, dup = 0, order = 0, first_bad = -1;
+        const int sb = done * digit;
+        const uint32_t mask = sb >= 32 ? 0xFFFFFFFFu : ((1u << sb) - 1u);
+        for (long j = 0; j < V; ++j) {
+            const uint32_t id = I[j];
+            bool b = false;
+            if (id >= (uint32_t)P) { ++oob; b = true; }
+            else {
+                if (dk[id] != K[j] || dk[id] == DEPTH_KEY_NONE) { ++keymis; b = true; }
+                if (seen[id]) { ++dup; b = true; }
+                seen[id] = 1;
+            }
+            if (j > 0) {
+                const uint32_t a0 = (K[j - 1] - key_min) & mask, a1 = (K[j] - key_min) & mask;
+                if (a0 > a1 || (a0 == a1 && I[j - 1] >= id)) { ++order; b = true; }
+            }
+            if (b && first_bad < 0) first_bad = j;
+        }
+        if (oob || keymis || dup || order) {
+            say("%s (sorted on %d bits): %ld ids beyond P, %ld pairs whose key is not the id's depth key, %ld duplicate ids, %ld order violations; first at %ld (block %ld)",
+                what, sb, oob, keymis, dup, order, first_bad, first_bad / RADIX_BLOCK);
+            // which destination blocks hold the bad pairs
+            std::vector<long> per(nblk, 0);
+            for (long j = 0; j < V; ++j) {
+                const uint32_t id = I[j];
+                if (id >= (uint32_t)P || dk[id] != K[j]) ++per[j / RADIX_BLOCK];
+            }
+            int shown = 0;
+            for (int b = 0; b < nblk && shown < 12; ++b)
+                if (per[b]) { fprintf(stderr, "[vegs debug binning]    destination block %d: %ld bad pairs\n", b, per[b]); ++shown; }
+            for (long j = first_bad; j < first_bad + 4 && j < V; ++j)
+                fprintf(stderr, "[vegs debug binning]    [%ld] key 0x%08x id 0x%08x\n", j, K[j], I[j]);
+        }
+        return oob + keymis + dup + order;
+    };
+    const std::vector<uint32_t>& kLast = (passes & 1) ? kB : kA, & iLast = (passes & 1) ? iB : iA;
+    const std::vector<uint32_t>& kPrev = (passes & 1) ? kA : kB, & iPrev = (passes & 1) ? iA : iB;
+    if (passes >= 1) check_pairs(kPrev, iPrev, passes - 1, passes == 1 ? "compaction output" : "output of the pass before the last");
+    check_pairs(kLast, iLast, passes, "output of the last pass");
+    if (passes == 0) return bad;
+    // status region: digit totals, then per pass level 1 | 2 | 3
+    const StatusPlan sp = status_plan(V, R, key_bits, tile_bits_of(ntiles));
+    std::vector<uint32_t> st(sp.depth / 4);
+    VR_HIP(hipMemcpy(st.data(), base + L.status, sp.depth, hipMemcpyDeviceToHost));
+    // digit totals against the keys themselves
+    {
+        std::vector<uint32_t> h((size_t)passes << digit, 0u);
+        for (int i = 0; i < P; ++i)
+            if (dk[i] != DEPTH_KEY_NONE)
+                for (int p = 0; p < passes; ++p) ++h[((size_t)p << digit) + (((dk[i] - key_min) >> (p * digit)) & (SIZE - 1))];
+        long wrong = 0, firstw = -1;
+        for (size_t d = 0; d < h.size(); ++d)
+            if (h[d] != st[d]) { ++wrong; if (firstw < 0) firstw = (long)d; }
+        if (wrong) say("digit totals: %ld of %zu words differ from the keys' histogram (first: word %ld holds %u, should be %u)", wrong,
+                       h.size(), firstw, st[firstw], h[firstw]);
+    }
+    const size_t per_pass = onesweep_pass_words(V, digit);
+    const long n2 = (nblk + FAN - 1) / FAN, n3 = (n2 + FAN - 1) / FAN;
+    for (int p = 0; p < passes; ++p) {
+        const uint32_t* l1 = st.data() + HIST_WORDS + (size_t)p * per_pass;
+        const uint32_t* l2 = l1 + (size_t)nblk * SIZE;
+        const uint32_t* l3 = l2 + (size_t)n2 * SIZE;
+        long unposted = 0, sum_bad = 0, l2_bad = 0, l3_bad = 0;
+        for (int d = 0; d < SIZE; ++d) {
+            uint64_t sum = 0;
+            for (int b = 0; b < nblk; ++b) {
+                const uint32_t w = l1[(size_t)b * SIZE + d];
+                if (!(w & ST_POSTED)) ++unposted;
+                sum += w & ST_VALUE;
+            }
+            if (sum != st[((size_t)p << digit) + d]) ++sum_bad;
+            for (long g = 0; g < n2; ++g) {
+                if ((g + 1) * FAN > nblk) continue;     // incomplete group: never posted
+                uint64_t s2 = 0;
+                for (int b = (int)g * FAN; b < (int)(g + 1) * FAN; ++b) s2 += l1[(size_t)b * SIZE + d] & ST_VALUE;
+                const uint32_t w = l2[(size_t)g * SIZE + d];
+                if (!(w & ST_POSTED) || (w & ST_VALUE) != s2) ++l2_bad;
+            }
+            for (long g = 0; g < n3; ++g) {
+                if ((g + 1) * FAN * FAN > nblk) continue;
+                uint64_t s3 = 0;
+                for (int b = (int)g * FAN * FAN; b < (int)(g + 1) * FAN * FAN; ++b) s3 += l1[(size_t)b * SIZE + d] & ST_VALUE;
+                const uint32_t w = l3[(size_t)g * SIZE + d];
+                if (!(w & ST_POSTED) || (w & ST_VALUE) != s3) ++l3_bad;
+            }
+        }
+        if (unposted || sum_bad || l2_bad || l3_bad)
+            say("pass %d status: %ld level-1 words not posted, %ld digits whose posted counts do not add up to the total, %ld / %ld bad level-2 / level-3 words",
+                p, unposted, sum_bad, l2_bad, l3_bad);
+    }
+    // the last pass once more on the host, from its intact input: where SHOULD every pair have gone?
+    {
+        const int p = passes - 1, shift = p * digit;
+        std::vector<uint32_t> start(SIZE, 0u);
+        uint32_t run = 0;
+        for (int d = 0; d < SIZE; ++d) { start[d] = run; run += st[((size_t)p << digit) + d]; }
+        std::vector<uint32_t> next(start);
+        long moved_wrong = 0, firstm = -1;
+        for (long j = 0; j < V; ++j) {
+            const uint32_t d = ((kPrev[j] - key_min) >> shift) & (SIZE - 1);
+            const uint32_t dst = next[d]++;
+            if (dst >= (uint32_t)V || kLast[dst] != kPrev[j] || iLast[dst] != iPrev[j]) { ++moved_wrong; if (firstm < 0) firstm = j; }
+        }
+        if (moved_wrong)
+            say("last pass replayed on the host: %ld of %d pairs are not where the pass should have put them (first: source %ld, source block %ld)",
+                moved_wrong, V, firstm, firstm / RADIX_BLOCK);
+        if (moved_wrong) {
+            std::vector<long> per(nblk, 0);
+            std::vector<uint32_t> nx(start);
+            for (long j = 0; j < V; ++j) {
+                const uint32_t d = ((kPrev[j] - key_min) >> shift) & (SIZE - 1);
+                const uint32_t dst = nx[d]++;
+                if (dst >= (uint32_t)V || kLast[dst] != kPrev[j] || iLast[dst] != iPrev[j]) ++per[j / RADIX_BLOCK];
+            }
+            int shown = 0;
+            for (int b = 0; b < nblk && shown < 16; ++b)
+                if (per[b]) { fprintf(stderr, "[vegs debug binning]    source block %d: %ld pairs misplaced\n", b, per[b]); ++shown; }
+        }
+    }
+    return bad;
+}
+
 int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, int key_bits, uint32_t* vis_key,
                    uint32_t* vis_id, const uint4* rect, const void* stage1_scratch, void* scratch, uint32_t* point_list,
                    int2* ranges, bool ranges_zeroed, bool status_zeroed, uint32_t* err, uint32_t* guard_post,
@@ -1645,8 +1921,11 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
         // (one batch of 256 Gaussians per workgroup: with 2 / 4 batches -- half / a quarter of the posted sums and look-backs,
         // the gathers of all batches in flight together -- the stage went 66 -> 81 / 93 us: the serial emission of a
         // workgroup's batches outweighs what the shorter look-back saves; round 5, profiles/experiments/README.md)
-        hipLaunchKernelGGL(k_emit_scan<1>, dim3(cdiv(V, 256)), dim3(256), 0, s, V, P, cam.gx, (const uint32_t*)sorted_id,
-                           rect, (unsigned long long*)(st + sp.depth), err, tkeysA, va, big_list);
+        uint2* const chk_out = (uint2*)(base + L.chk);
+        const uint2* const chk_in = (const uint2*)((const char*)stage1_scratch + stage1_chk_offset((size_t)rows));
+        if (debug_raise_guard == 4) hipLaunchKernelGGL(k_debug_break_permutation, dim3(1), dim3(1), 0, s, sorted_id, V);
+        hipLaunchKernelGGL(k_emit_scan<1>, dim3(cdiv(V, 256)), dim3(256), 0, s, V, P, R, cam.gx, (const uint32_t*)sorted_id,
+                           rect, (unsigned long long*)(st + sp.depth), err, tkeysA, va, big_list, chk_out);
         if (!big_list.inline_big)
             hipLaunchKernelGGL(k_emit_big, dim3(EMIT_BIG_GRID), dim3(64), 0, s, big_list, rect, cam.gx, tkeysA, va);
         VR_KERNEL_CHECK("emit_scan", s, debug);
@@ -1663,7 +1942,7 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
             hipLaunchKernelGGL(k_split_scan, dim3(stride / 16), dim3(256), 0, s, table, nblk, stride, totals);
             if (debug_raise_guard == 1) VR_HIP(hipMemsetD32Async((hipDeviceptr_t)err, 1, 1, s));   // test hook: "a wait of THIS view timed out"
             hipLaunchKernelGGL(k_split_base, dim3(1), dim3(1024), 0, s, (const uint32_t*)totals, ntiles, tbase, ranges,
-                               (const uint32_t*)err, guard_post, guard_seq);
+                               err, guard_post, guard_seq, chk_in, rows, (const uint2*)chk_out, cdiv(V, 256));
             hipLaunchKernelGGL(k_split_scatter, dim3(nblk), dim3(256), (size_t)stride * 20, s, (const uint32_t*)tkeysA,
                                (const uint32_t*)va, R, ntiles, stride, (const uint32_t*)table, (const uint32_t*)tbase, point_list,
                                (const uint32_t*)err);
@@ -1671,6 +1950,7 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
             return 0;
         }
         ProfScope ps(VR_STAGE_TILE_SORT, s);
+        hipLaunchKernelGGL(k_perm_check, dim3(1), dim3(1024), 0, s, chk_in, rows, (const uint2*)chk_out, cdiv(V, 256), err);
         const int hist_rows = (int)(cdiv(R, 4096) < HIST_BLOCKS ? cdiv(R, 4096) : HIST_BLOCKS);
         hipLaunchKernelGGL(k_digit_hist, dim3(hist_rows), dim3(HIST_THREADS), 0, s, (const uint32_t*)tkeysA, R, 0u,
                            radix_digit(bits), passes, tpartial);

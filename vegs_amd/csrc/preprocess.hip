@@ -85,6 +85,28 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
         pz3 = means3D[3 * (size_t)i + 2];
         xform43(cam.view, px3, py3, pz3, t0, t1, t2);
     }
+#ifdef VR_EARLY_SH
+    // REPRODUCER BUILD ONLY (python -m vegs_amd.build --variant early; profiles/experiments/README.md, round 5/6): the SH rows
+    // of every Gaussian in front of the near plane requested a round trip earlier.  Same results, different timing and
+    // register pressure: the build whose bench runs ended in a memory fault in k_emit_scan.
+    float4 eA[6], eB[6];
+    unsigned long long front_rows = 0ull;
+    if (HALF == 1 && shs) {
+        front_rows = __ballot(in_range && t2 > NEAR_Z);
+        if (front_rows != 0ull) {
+            const size_t wf = (size_t)(blockIdx.x * blockDim.x + w * 64);
+            const float4* s4 = reinterpret_cast<const float4*>(shs + wf * 48);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int v = lane + 64 * j, r = v / 6, c = v - r * 6;
+                if ((front_rows >> r) & 1ull) {
+                    eA[j] = nt_load4(&s4[r * 12 + c]);
+                    eB[j] = nt_load4(&s4[r * 12 + 6 + c]);
+                }
+            }
+        }
+    }
+#endif
     if (in_range) {
         if (t2 > NEAR_Z) {
             float h0, h1, h2;
@@ -233,6 +255,9 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
                     const int v = lane + 64 * j, r = v / 6, c = v - r * 6;
                     ok[j] = (vis_rows >> r) & 1ull;
                     at[j] = r * (SH_HALF_STRIDE / 4) + c;
+#ifdef VR_EARLY_SH
+                    if (HALF == 1) { tA[j] = eA[j]; tB[j] = eB[j]; continue; }
+#endif
                     if (ok[j]) {
                         tA[j] = nt_load4(&src4[r * 12 + c]);
                         tB[j] = nt_load4(&src4[r * 12 + 6 + c]);

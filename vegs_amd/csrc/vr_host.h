@@ -79,6 +79,11 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
                    int2* ranges, bool ranges_zeroed, bool status_zeroed, uint32_t* err, uint32_t* guard_post,
                    uint32_t guard_seq, int debug_raise_guard, uint32_t n_huge, hipStream_t s, bool debug);
 
+// VEGS_DEBUG_BINNING: post-mortem of one view's depth sort at the end of vr_forward (synchronises; a debugging aid)
+int debug_verify_binning(int P, int V, long R, uint32_t key_min, int key_bits, const uint32_t* vis_key, const uint32_t* vis_id,
+                         const uint32_t* depth_key, const uint32_t* tile_count, const void* stage1_scratch, const void* scratch,
+                         const uint32_t* totals_dev, const uint32_t* pinned, const uint32_t* err, int ntiles, hipStream_t s);
+
 // stable LSD radix sort of (key,val) u32 pairs on the low nbits of (key - kmin); ping-pongs between the two
 // pairs, *where = 0/1 tells which pair holds the result
 size_t sort_pairs_scratch_bytes(long n);

@@ -66,6 +66,25 @@ def profile_figures(kern, sources):
     return d.get(kern), (d.get("_valu_insts") or {}).get(kern), d.get("_collected")
 
 
+def whole_view_traffic():
+    """HBM bytes of one whole view (forward + backward) from the committed PMC profile: the sum over the view's kernels of
+    counter bytes per launch x launches per view (profiles/make_traffic.py: `_whole_view`) -- or None when ANY kernel source
+    has changed since the counters were collected."""
+    import hashlib
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        return None
+    for f, want in (d.get("_sources") or {}).items():
+        try:
+            h = hashlib.sha256(open(os.path.join(ROOT, "vegs_amd", "csrc", f), "rb").read()).hexdigest()[:16]
+        except OSError:
+            h = None
+        if h != want:
+            return None
+    return (d.get("_whole_view") or {}).get("bytes")
+
+
 def build_workload(args):
     if args.workload == "c3":
         P, length, seed = args.gaussians or 2_000_000, 250.0, 2
@@ -156,7 +175,7 @@ def prepare(sc, deg, cams, device, rng, count=True, cam_ts=None):
 
 
 def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="train", exchange_on=True, streams=1,
-              direct=None):
+              direct=None, keep_grads=False):
     """One step = `vps` views forward + backward on this rank, then (N > 1) the gradient exchange.
     exchange "dense": all-reduce of the 59-float/Gaussian gradients.  "factored": the op returns the 3-float factor of
     the SH gradient, the ranks all-gather the factors (12 B) and all-reduce the other 11 floats (44 B), and every rank
@@ -169,7 +188,12 @@ def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="trai
     T, cams, cam_ts, gouts, params, deg, bg = (wl[k] for k in ("T", "cams", "cam_ts", "gouts", "params", "deg", "bg"))
     n_views = len(cams)
     fact_x = world > 1 and exchange in ("factored", "direct") and vps == 1
-    factored = factored or fact_x
+    # several views per rank and step at N > 1 (round 6): what iteration.Trainer does -- every view's SH gradient stays its
+    # 3-float factor, the other 11 floats are ACCUMULATED IN PLACE over the rank's views, and the step ends with ONE all-gather
+    # of the k factors per rank + ONE all-reduce of the 11 floats, instead of an all-reduce of 59 dense floats (DESIGN section 8:
+    # the configuration priced at ~78 % efficiency).  (`direct` has no multi-view gather: RCCL carries it.)
+    fact_multi = world > 1 and exchange in ("factored", "direct") and vps > 1
+    factored = factored or fact_x or fact_multi
     others = [T[k] for k in ("means3D", "opacities", "scales", "rotations")]
     from vegs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     m2d = torch.zeros_like(T["means3D"], requires_grad=True) if mode == "noglue" else None
@@ -213,7 +237,7 @@ def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="trai
             return
         sink = torch.zeros_like(T["means3D"], requires_grad=True) if factored else None
         if factored and not fact_x and vps > 1:
-            sinks.append((sink, cam_ts[v]["campos"]))
+            sinks.append((sink, cam_ts[v]["campos"]))        # (fact_multi included: its factors are gathered at the step's end)
         pkg = harness.render(cams[v], T, deg, bg, cam_t=cam_ts[v], sh_color_grad=sink)
         if fact_x:          # overlapped exchange: the factors start travelling between the backward's two halves
             with xch.armed(cam_ts[v]["campos"]):
@@ -226,17 +250,32 @@ def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="trai
     def step(i):
         done = []
         sinks.clear()
-        for k in range(vps):
-            v = vdist.view_for_rank(i * vps + k, rank, world, n_views)
-            vs.run(one_view, v)
-            done.append(v)
-        vs.join()
+        from vegs_amd import rasterizer as _rast
+        old_acc = _rast.accumulate_grads(True) if fact_multi else None
+        try:
+            for k in range(vps):
+                v = vdist.view_for_rank(i * vps + k, rank, world, n_views)
+                vs.run(one_view, v)
+                done.append(v)
+            vs.join()
+        finally:
+            if fact_multi:
+                _rast.accumulate_grads(old_acc)
         if mode == "forward":
             return done
         if fact_x:
             from vegs_amd import optim
             F, Cc = xch.finish(others)
             T["shs"].grad = optim.sh_grad_from_factors(T["means3D"].detach(), Cc, F, deg, T["shs"].shape[1], 1.0 / world)
+        elif fact_multi:
+            from vegs_amd import optim
+            F = torch.stack([s_.grad for s_, _ in sinks])
+            Cc = torch.stack([c.reshape(3) for _, c in sinks]).to(F.device, torch.float32)
+            if exchange_on:
+                F, Cc = vdist.all_gather_views(F, Cc, world)          # [world * vps, P, 3], [world * vps, 3]
+                vdist.allreduce_grads(others, world)
+            T["shs"].grad = optim.sh_grad_from_factors(T["means3D"].detach(), Cc, F, deg, T["shs"].shape[1], 1.0 / world)
+            sinks.clear()
         elif world > 1 and exchange_on:
             vdist.allreduce_grads(params, world)
         if sinks:
@@ -246,8 +285,9 @@ def make_step(wl, rank, world, vps, factored=False, exchange="dense", mode="trai
             F = torch.stack([s_.grad for s_, _ in sinks])
             Cc = torch.stack([c.reshape(3) for _, c in sinks]).to(F.device, torch.float32)
             T["shs"].grad = optim.sh_grad_from_factors(T["means3D"].detach(), Cc, F, deg, T["shs"].shape[1], 1.0)
-        for p in params:
-            p.grad = None
+        if not keep_grads:          # (keep_grads: tests compare the step's final gradients across exchange schemes)
+            for p in params:
+                p.grad = None
         return done
     return step
 
@@ -661,13 +701,18 @@ def main():
         # what the exchange costs: the same K steps once more WITHOUT any collective (every rank; outside the headline's
         # timed regions).  exposed = ms per step with - without: the part of the exchange that compute does not hide.
         fact = args.exchange in ("factored", "direct") and vps == 1
+        fact_m = args.exchange in ("factored", "direct") and vps > 1
         step0 = make_step(wl, rank, world, vps, factored=fact, exchange=args.exchange, exchange_on=False, direct=direct_x)
         dt0, _, _ = timed_median(step0, args.steps, world, 1, first=args.warmup)
-        scheme = args.exchange if fact else "dense"
+        scheme = args.exchange if fact else ("factored" if fact_m else "dense")
         exchange = {"scheme": scheme + (" (all-gather of the SH factors started between the backward's two halves, "
                                         "all-reduce of the other 11 floats after it; one wait)" if fact else "")
+                              + (f" ({vps} views per rank: their SH factors gathered and the in-place accumulated 11 floats "
+                                 "all-reduced once, at the step's end)" if fact_m else "")
                               + (" -- peer-to-peer over hipIpc windows, no RCCL" if scheme == "direct" else ""),
-                    "exchange_bytes_per_rank": vdist.exchange_bytes_per_rank(P, world, "factored" if fact else "dense"),
+                    "exchange_bytes_per_rank": vdist.exchange_bytes_per_rank(P, world, "factored" if (fact or fact_m) else "dense")
+                                               + ((vps - 1) * (world - 1) * 12 * P if fact_m else 0),
+                    "expected": vdist.exchange_model(P, world, "dense" if scheme == "dense" else "factored", vps),
                     "ms_per_step_without_exchange": round(dt0 / args.steps * 1e3, 4),
                     "exchange_exposed_ms": round((elapsed - dt0) / args.steps * 1e3, 4),
                     "communicator": ranks_seen}
@@ -775,6 +820,8 @@ def main():
                                                               if args.exchange == "direct" and vps == 1 else
                                                               " + RCCL all-gather of SH factors (3 f32) + all-reduce (11 f32) per Gaussian"
                                                               if args.exchange == "factored" and vps == 1 else
+                                                              f" + RCCL all-gather of {vps} SH factors per rank (3 f32 each) + all-reduce (11 f32, accumulated in place over the rank's views) per Gaussian"
+                                                              if args.exchange in ("factored", "direct") and vps > 1 else
                                                               " + RCCL grad all-reduce (59 f32/Gaussian)"),
                    "mean_counters": {k: round(v, 1) for k, v in mean.items()}},
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -788,6 +835,8 @@ def main():
                      "stage_ms": stage_ms,
                      "stages": stage_frac,
                      "whole_view_alg_bytes": round(b_alg),
+                     # (counter bytes of every kernel of one view, committed profile; null while any kernel source is newer)
+                     "whole_view_traffic": whole_view_traffic(),
                      "whole_view_frac": round(b_alg / t_view / 1e9 / HBM_PEAK_GBS, 5),
                      "whole_view_frac_on_reference_lists": round(b_alg_ref / t_view / 1e9 / HBM_PEAK_GBS, 5)},
     }

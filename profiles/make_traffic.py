@@ -35,6 +35,32 @@ def per_kernel(d, counter, scale=1.0, extra=None):
     return {name: int(tot / max(n, 1)) for name, (tot, n) in sorted(acc.items())}
 
 
+# kernels of one view's forward / backward (everything vr_forward / vr_backward launches on the headline path; the counting and
+# export kernels of bench.py's bookkeeping are not part of a view)
+FWD = ["k_preprocess", "k_scan_reduce", "k_scan_totals", "k_compact_apply", "k_digit_sum", "k_onesweep", "k_emit_scan", "k_emit_big",
+       "k_split_count", "k_split_scan", "k_split_base", "k_split_scatter", "k_perm_check", "k_digit_hist", "k_tile_ranges",
+       "k_seg_table", "k_seg_alpha", "k_seg_scan", "k_seg_merge", "k_seg_blend", "k_seg_combine"]
+BWD = ["k_seg_u", "k_seg_suffix", "k_seg_bwd", "k_preprocess_bwd", "k_sh_factor"]
+
+
+def whole_view(d, per_launch):
+    """HBM bytes of ONE view: sum over its kernels of bytes per launch x launches per view (a kernel's dispatches over the
+    dispatches of its half's anchor kernel: k_preprocess runs once per forward, k_preprocess_bwd once per backward)."""
+    disp = {}
+    for k, v in d.items():
+        if "vr::" in k:
+            name = k.split("vr::")[1].split("<")[0].split("(")[0]
+            disp[name] = disp.get(name, 0) + v["dispatches"]
+    rows, total = {}, 0.0
+    for names, anchor in ((FWD, "k_preprocess"), (BWD, "k_preprocess_bwd")):
+        for n in names:
+            if n in per_launch and disp.get(anchor):
+                per_view = disp[n] / disp[anchor]
+                rows[n] = {"launches_per_view": round(per_view, 3), "bytes_per_view": int(per_launch[n] * per_view)}
+                total += per_launch[n] * per_view
+    return {"bytes": int(total), "kernels": rows}
+
+
 if __name__ == "__main__":
     d = json.load(open(sys.argv[1]))
     try:
@@ -47,7 +73,9 @@ if __name__ == "__main__":
                     "weighted by dispatches",
            "_collected": {"date": datetime.date.today().isoformat(), "commit": commit or os.environ.get("VEGS_COMMIT", "")},
            "_sources": source_hashes()}
-    out.update(per_kernel(d, "FETCH_SIZE", 2048.0, lambda v: v.get("WRITE_SIZE", 0.0) * 1024))
+    per_launch = per_kernel(d, "FETCH_SIZE", 2048.0, lambda v: v.get("WRITE_SIZE", 0.0) * 1024)
+    out.update(per_launch)
+    out["_whole_view"] = whole_view(d, per_launch)
     if len(sys.argv) > 2:
         sq = json.load(open(sys.argv[2]))
         out["_valu_insts"] = per_kernel(sq, "SQ_INSTS_VALU")

@@ -190,3 +190,76 @@ def test_all_gather_views_and_flat_bucket_gloo(tmp_path):
             continue
         want = (R[0]["local"][k] + R[1]["local"][k]) * 0.5
         assert torch.equal(R[0]["grads"][k], R[1]["grads"][k]) and torch.allclose(R[0]["grads"][k], want, rtol=0, atol=1e-7)
+
+
+def _worker_multiview(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from oracle import torch_ref
+    from vegs_amd import dist as vdist
+    vdist.init_from_env(backend="gloo")
+    P, k, deg = 500, 2, 3
+    g = torch.Generator().manual_seed(1)                       # the model: the same on every rank
+    means = torch.randn(P, 3, generator=g, dtype=torch.float64)
+    sh = torch.randn(P, 16, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    g = torch.Generator().manual_seed(50 + rank)               # this rank's k views
+    campos = (torch.randn(k, 3, generator=g) * 3).double()      # (fp32 values: the gather carries camera centres as fp32)
+    factors = torch.randn(k, P, 3, generator=g, dtype=torch.float64)
+    others = [torch.zeros(s, dtype=torch.float64, requires_grad=True) for s in [(P, 3), (P, 1), (P, 3), (P, 4)]]
+    per_view = [[torch.randn(p.shape, generator=g, dtype=torch.float64) for p in others] for _ in range(k)]
+
+    def dense_sh(c, f):      # dL/dsh of one view = basis(dir(c, mean)) x factor (oracle/torch_ref.sh_to_rgb is linear in sh)
+        d = means - c[None]
+        d = d / d.norm(dim=1, keepdim=True)
+        return torch.autograd.grad(torch_ref.sh_to_rgb(deg, sh, d), sh, grad_outputs=f)[0]
+    # dense scheme: autograd's sum over the local views, then the mean over the ranks of all 59 floats
+    sh_dense = sum(dense_sh(campos[v], factors[v]) for v in range(k))
+    dparams = [torch.zeros_like(sh_dense, requires_grad=True)] + [torch.zeros_like(p, requires_grad=True) for p in others]
+    dparams[0].grad = sh_dense.clone()
+    for j, p in enumerate(dparams[1:]):
+        p.grad = sum(per_view[v][j] for v in range(k))
+    vdist.allreduce_grads(dparams, world, flat_bucket_bytes=1 << 40)
+    # factored scheme with several views per rank (bench.py make_step: fact_multi; iteration.Trainer.step_views): the factors
+    # stay factors, the 11 other floats are accumulated locally (in place) and reduced once
+    for j, p in enumerate(others):
+        p.grad = per_view[0][j].clone()
+        for v in range(1, k):
+            p.grad.add_(per_view[v][j])
+    F, Cc = vdist.all_gather_views(factors, campos, world)
+    vdist.allreduce_grads(others, world, flat_bucket_bytes=1 << 40)
+    sh_fact = sum(dense_sh(Cc[v].double(), F[v]) for v in range(world * k)) / world
+    torch.save(dict(sh_dense=dparams[0].grad, sh_fact=sh_fact, others_dense=[p.grad for p in dparams[1:]],
+                    others_fact=[p.grad for p in others], F=F, C=Cc, model=vdist.exchange_model(2_000_000, world, "factored", k)),
+               os.path.join(outdir, f"m{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_multi_view_factored_exchange_equals_dense_gloo(tmp_path):
+    """Several views per rank and step at N > 1 (bench.py --views-per-step k, round 6): all-gather of the k factors per rank +
+    all-reduce of the locally accumulated 11 floats  ==  all-reduce of the 59 dense floats of autograd's per-rank sums.  The
+    SH rebuild is done here with the float64 restatement's basis (the HIP kernel's is pinned against it on the GPU)."""
+    world = 2
+    mp.spawn(_worker_multiview, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    R = [torch.load(tmp_path / f"m{r}.pt") for r in range(world)]
+    for r in range(world):
+        assert R[r]["F"].shape == (4, 500, 3) and R[r]["C"].shape == (4, 3)
+        assert torch.allclose(R[r]["sh_fact"], R[r]["sh_dense"], rtol=0, atol=1e-12)
+        for a, b in zip(R[r]["others_fact"], R[r]["others_dense"]):
+            assert torch.allclose(a, b, rtol=0, atol=1e-12)
+    assert torch.equal(R[0]["sh_fact"], R[1]["sh_fact"])
+
+
+def test_exchange_model_matches_design_section_8():
+    """vegs_amd.dist.exchange_model: the PREDICTION bench.py prints beside the measured exchange time."""
+    from vegs_amd import dist as vdist
+    assert vdist.exchange_model(2_000_000, 1, "factored") is None
+    m = vdist.exchange_model(2_000_000, 8, "factored")
+    assert m["links_per_gpu"] == 7 and m["all_reduce"]["bytes"] == 88_000_000 and m["all_gather"]["block_bytes"] == 24_000_000
+    assert m["all_reduce"]["bytes_per_link_direct"] == 22_000_000                 # 2 x 11 MB per link (DESIGN: "2 x 72 us")
+    assert abs(m["all_reduce"]["ms_direct"] - 0.1438) < 1e-3 and abs(m["all_gather"]["ms_direct"] - 0.1569) < 1e-3
+    assert abs(m["all_reduce"]["ms_ring"] - 2 * 7 / 8 * 88e6 / 300e9 * 1e3) < 1e-3
+    d = vdist.exchange_model(2_000_000, 8, "dense")
+    assert d["all_gather"] is None and d["all_reduce"]["bytes"] == 472_000_000 and abs(d["all_reduce"]["ms_ring"] - 2.7533) < 1e-3
+    m2 = vdist.exchange_model(2_000_000, 8, "factored", views_per_rank=2)
+    assert m2["all_gather"]["block_bytes"] == 48_000_000 and m2["all_reduce"] == m["all_reduce"]

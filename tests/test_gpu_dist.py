@@ -188,6 +188,59 @@ def test_two_ranks_equal_mean_of_two_views(tmp_path):
     assert (R[0]["den"] == 2).sum() > 1000                                         # the stereo views overlap
 
 
+MULTI_VIEW_WORKER = r"""
+import os, sys, types, numpy as np, torch
+sys.path.insert(0, %(root)r)
+import bench
+from vegs_amd import dist as vdist
+rank, world, local = vdist.init_from_env()
+assert world == 2 and torch.distributed.get_backend() == "gloo"
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+args = types.SimpleNamespace(workload="c2", gaussians=120000, width=688, height=188, disc_scale=1.0)
+sc, deg, cams, P = bench.build_workload(args)
+wl = bench.prepare(sc, deg, cams, dev, np.random.default_rng(1234))
+out = {}
+for scheme in ("dense", "factored"):
+    for p in wl["params"]:
+        p.grad = None
+    step = bench.make_step(wl, rank, world, 2, exchange=scheme, keep_grads=True)        # TWO views per rank and step
+    views = step(3)
+    assert len(views) == 2
+    torch.cuda.synchronize()
+    for k, p in zip(("means3D", "shs", "opacities", "scales", "rotations"), wl["params"]):
+        out[scheme + "_" + k] = p.grad.cpu().numpy()
+np.savez(os.path.join(%(out)r, "mv%%d.npz" %% rank), **out)
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+print("RANK_OK", rank)
+"""
+
+
+def test_bench_multi_view_factored_exchange_equals_the_dense_one(tmp_path):
+    """bench.py --gpus 2 --views-per-step 2 (round-5 verdict item 7a): with the factored exchange every view's SH gradient
+    stays its 3-float factor, the other 11 floats accumulate IN PLACE over the rank's two views, and the step ends with one
+    all-gather of 2 x 2 factors and one all-reduce of 11 floats -- the step's final gradients must be the dense scheme's
+    (all-reduce of 59 floats of autograd's sums), on both ranks, per row."""
+    from helpers import assert_grad_close
+    env = dict(os.environ, VEGS_DIST_BACKEND="gloo")
+    script = MULTI_VIEW_WORKER % dict(root=ROOT, out=str(tmp_path))
+    sp = tmp_path / "worker_mv.py"
+    sp.write_text(script)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(sp)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and r.stdout.count("RANK_OK") == 2, r.stdout[-3000:] + r.stderr[-3000:]
+    R = [np.load(tmp_path / f"mv{q}.npz") for q in range(2)]
+    for k in ("means3D", "shs", "opacities", "scales", "rotations"):
+        for q in range(2):
+            assert np.abs(R[q]["dense_" + k]).max() > 0
+            assert_grad_close(f"rank {q} {k}", R[q]["factored_" + k], R[q]["dense_" + k], rtol=2e-5, floor=2e-7,
+                              outliers=0.0, near=0.0)
+        # every rank ends the step with the same tensors (fp32 atomics inside a view differ from run to run: not bit-equal)
+        assert_grad_close(f"ranks agree {k}", R[0]["factored_" + k], R[1]["factored_" + k], rtol=2e-5, floor=2e-7, outliers=0.0, near=0.0)
+
+
 def test_bench_two_ranks_gloo_transport(tmp_path):
     """bench.py --gpus 2 under torch.distributed.run (the driver's launch line), both ranks on the one GPU of this
     box with the gloo transport: the N > 1 code path of the benchmark runs end to end and reports n_gpus 2."""

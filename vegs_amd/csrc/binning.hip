@@ -1434,9 +1434,18 @@ k_split_count(const uint32_t* __restrict__ tkeys, long R, int ntiles, int stride
 // counter, device-scope totals -- instead of a launch of its own: 13.6 against 9.2 + 4.9 us; two launches it stays.)
 constexpr int SPLIT_SCAN_U = 8;
 __global__ void __launch_bounds__(256)
-k_split_scan(uint32_t* __restrict__ table, int nblk, int stride, uint32_t* __restrict__ totals)
+k_split_scan(uint32_t* __restrict__ table, int nblk, int stride, uint32_t* __restrict__ totals, const uint2* __restrict__ chk_in,
+             int n_in, const uint2* __restrict__ chk_out, int n_out, uint32_t* __restrict__ err)
 {
     __shared__ uint32_t part[16][17];
+    // One workgroup more than there are strips: the depth sort's PERMUTATION CHECK rides along (its ~8 k loads under the
+    // strips' column walks; as a step of k_split_base, a single workgroup on the critical path, it cost 3.5 us).  It raises the
+    // guard word, which k_split_base -- the next launch -- posts and k_split_scatter obeys.
+    if ((int)blockIdx.x == stride / 16) {
+        __shared__ uint32_t chk_lds[9];
+        if (chk_in) (void)perm_check_failed(chk_in, n_in, chk_out, n_out, err, chk_lds);
+        return;
+    }
     const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
     const int col = blockIdx.x * 16 + c;
     uint32_t carry = 0;
@@ -1473,15 +1482,12 @@ k_split_scan(uint32_t* __restrict__ table, int nblk, int stride, uint32_t* __res
 // forward's sequence number into the host's pinned ring slot (what k_tile_ranges does on the two-pass path).
 __global__ void __launch_bounds__(1024)
 k_split_base(const uint32_t* __restrict__ totals, int ntiles, uint32_t* __restrict__ base, int2* __restrict__ ranges,
-             uint32_t* __restrict__ err, uint32_t* __restrict__ post, uint32_t seq, const uint2* __restrict__ chk_in, int n_in,
-             const uint2* __restrict__ chk_out, int n_out)
+             const uint32_t* __restrict__ err, uint32_t* __restrict__ post, uint32_t seq)
 {
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t chk_lds[33];
-    // the depth sort's output was a permutation of the compaction's ids?  (raises the guard word itself if not)
-    const bool broken = chk_in && perm_check_failed(chk_in, n_in, chk_out, n_out, err, chk_lds);
-    uint32_t tripped = broken ? 1u : 0u;
-    if (err && !broken) tripped = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the guard word as it stands after the waits of the depth sort and the emission AND the permutation check of k_split_scan)
+    uint32_t tripped = 0u;
+    if (err) tripped = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 0 && post) {
         __hip_atomic_store(&post[1], tripped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&post[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1939,10 +1945,11 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
             uint32_t* const tbase = totals + stride;
             hipLaunchKernelGGL(k_split_count, dim3(nblk), dim3(256), (size_t)stride * 4, s, (const uint32_t*)tkeysA, R, ntiles, stride,
                                table, err);
-            hipLaunchKernelGGL(k_split_scan, dim3(stride / 16), dim3(256), 0, s, table, nblk, stride, totals);
+            hipLaunchKernelGGL(k_split_scan, dim3(stride / 16 + 1), dim3(256), 0, s, table, nblk, stride, totals, chk_in, rows,
+                               (const uint2*)chk_out, cdiv(V, 256), err);
             if (debug_raise_guard == 1) VR_HIP(hipMemsetD32Async((hipDeviceptr_t)err, 1, 1, s));   // test hook: "a wait of THIS view timed out"
             hipLaunchKernelGGL(k_split_base, dim3(1), dim3(1024), 0, s, (const uint32_t*)totals, ntiles, tbase, ranges,
-                               err, guard_post, guard_seq, chk_in, rows, (const uint2*)chk_out, cdiv(V, 256));
+                               (const uint32_t*)err, guard_post, guard_seq);
             hipLaunchKernelGGL(k_split_scatter, dim3(nblk), dim3(256), (size_t)stride * 20, s, (const uint32_t*)tkeysA,
                                (const uint32_t*)va, R, ntiles, stride, (const uint32_t*)table, (const uint32_t*)tbase, point_list,
                                (const uint32_t*)err);

@@ -349,3 +349,42 @@ def exchange_bytes_per_rank(P, world, scheme, rows=None):
         return int(ar(236 * P))
     rows = P if rows is None else rows
     return int((world - 1) * 12 * P + ar(44 * rows))
+
+
+# xGMI on an 8 x MI355X node (MI355X_MICROARCH.md): every GPU has a private link to each of its 7 peers, ~153 GB/s per
+# direction and link; RCCL's rings on 8 fully connected GPUs reach ~300 GB/s of bus bandwidth.
+XGMI_LINK_GBS = 153.0
+RCCL_RING_BUS_GBS = 300.0
+
+
+def exchange_model(P, world, scheme, views_per_rank=1, link_gbs=XGMI_LINK_GBS, ring_bus_gbs=RCCL_RING_BUS_GBS):
+    """What one step's gradient exchange is EXPECTED to move and cost on an xGMI node -- the prediction a first real
+    multi-GPU run is read against (bench.py emits it beside the measured `exchange_exposed_ms`; no link has been measured by
+    this build).  Per Gaussian: dense = all-reduce of 59 floats; factored = all-gather of 3 floats per local view +
+    all-reduce of 11 floats.  Two transports per collective: RCCL's ring (bus bandwidth) and a direct one-hop algorithm that
+    drives every link at once (what vegs_amd/xgmi.py does; RCCL may or may not).  Returns a dict of bytes and milliseconds."""
+    if world <= 1:
+        return None
+    links = min(world - 1, 7)
+    k = max(1, int(views_per_rank))
+    ar_bytes = (236 if scheme == "dense" else 44) * P              # the all-reduced block
+    ag_block = 0 if scheme == "dense" else 12 * P * k              # this rank's all-gathered block
+    ring = lambda nbytes: 2.0 * (world - 1) / world * nbytes / (ring_bus_gbs * 1e9) * 1e3
+    # direct two-shot all-reduce: every rank pushes (N-1)/N of the block over its N-1 links, and the reduced shards come back
+    ar_link = 2.0 * ar_bytes / world
+    ag_link = float(ag_block)                                        # one copy of the block to every peer, one per link
+    return {
+        "scheme": scheme, "views_per_rank": k, "links_per_gpu": links, "link_GBs_per_direction": link_gbs,
+        "rccl_ring_bus_GBs_assumed": ring_bus_gbs,
+        "all_reduce": {"bytes": int(ar_bytes), "sent_per_rank_ring": int(2.0 * (world - 1) / world * ar_bytes),
+                       "bytes_per_link_direct": int(ar_link), "ms_ring": round(ring(ar_bytes), 4),
+                       "ms_direct": round(ar_link / (link_gbs * 1e9) * 1e3, 4)},
+        "all_gather": None if scheme == "dense" else {
+            "block_bytes": int(ag_block), "received_per_rank": int((world - 1) * ag_block), "bytes_per_link_direct": int(ag_link),
+            "ms_ring": round((world - 1) / world * world * ag_block / (ring_bus_gbs * 1e9) * 1e3, 4),
+            "ms_direct": round(ag_link / (link_gbs * 1e9) * 1e3, 4)},
+        "note": "predictions, not measurements: ms_ring = RCCL ring at the assumed bus bandwidth, ms_direct = one hop over all links "
+                "at once; with the overlapped scheme the all-gather starts ~0.14 ms before the backward ends (under "
+                "k_preprocess_bwd) and the all-reduce follows it, so exchange_exposed_ms should land between "
+                "ms_direct(all_reduce) and ms_ring(all_reduce) + what the all-gather's tail adds",
+    }

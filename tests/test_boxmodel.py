@@ -1,4 +1,4 @@
-"""CPU: vegs_amd.boxmodel.BoxModel's op-by-op composition (fused=False) against outputs of the reference's OWN class
+"""CPU: the op-by-op BoxModel statement (oracle/boxmodel_oracle.py: BoxModelOpByOp) against outputs of the reference's OWN class
 (model/boxmodel.py, run by tests/golden/make_golden.py part_e -> ref_boxmodel.npz): adjustbox2world(), its gradients, and
 three rounds of train.py:270-274 (optimizer.step, zero_grad, regularize).  The HIP kernels are compared with both in
 tests/test_gpu_boxmodel.py."""
@@ -12,7 +12,10 @@ REF = np.load(os.path.join(HERE, "golden", "ref_boxmodel.npz"))
 
 
 def _model(i, fused=False, device="cpu"):
-    from vegs_amd.boxmodel import BoxModel
+    if fused:
+        from vegs_amd.boxmodel import BoxModel
+    else:
+        from oracle.boxmodel_oracle import BoxModelOpByOp as BoxModel
     bm = BoxModel(torch.tensor(REF["box2world"][i]), lr=float(REF["lr"]), lambda_reg=float(REF["lambda_reg"]), device=device,
                   fused=fused)
     with torch.no_grad():

@@ -1,4 +1,5 @@
-"""CPU: the C-ABI library loads and exports every symbol include/vegs_rast.h declares, and the
+"""CPU: the C-ABI library loads and exports every symbol include/*.h declares (the stable headers and
+include/vegs_rast_debug.h, the experimental / test-only part), and the
 product path fails loudly (no fallback) when asked to run without a GPU."""
 import ctypes
 import os
@@ -48,7 +49,7 @@ def test_flag_values_agree_between_header_binding_and_kernels():
     csrc/vr_device.h (what the kernels test; tied to the header by a static_assert in api.hip) -- and a renumbering in one of
     them would silently flip e.g. the default tile-list semantics.  The header's values are parsed and compared with both."""
     from vegs_amd import _capi
-    hdr = open(os.path.join(ROOT, "include", "vegs_rast.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "vegs_rast.h")).read() + open(os.path.join(ROOT, "include", "vegs_rast_debug.h")).read()
     header = {m.group(1): 1 << int(m.group(2)) for m in re.finditer(r"\bVR_(FLAG_[A-Z_]+)\s*=\s*1u\s*<<\s*(\d+)", hdr)}
     assert len(header) >= 12 and len(set(header.values())) == len(header)          # distinct bits
     dev = open(os.path.join(ROOT, "vegs_amd", "csrc", "vr_device.h")).read()

@@ -22,7 +22,8 @@ def test_needed_hint_cache_is_opt_in(monkeypatch):
 
 def test_flag_constants_match_the_header():
     from vegs_amd import _capi
-    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "vegs_rast.h")).read()
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    hdr = open(os.path.join(inc, "vegs_rast.h")).read() + open(os.path.join(inc, "vegs_rast_debug.h")).read()
     for name, value in (("VR_FLAG_DETERMINISTIC", _capi.FLAG_DETERMINISTIC), ("VR_FLAG_SCAN_BINNING", _capi.FLAG_SCAN_BINNING),
                         ("VR_FLAG_ROUNDS_OFF", _capi.FLAG_ROUNDS_OFF), ("VR_FLAG_ROUNDS_ON", _capi.FLAG_ROUNDS_ON)):
         shift = value.bit_length() - 1

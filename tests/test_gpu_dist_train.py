@@ -144,7 +144,9 @@ def test_fused_box_step_equals_the_reference_composition():
     bg = torch.zeros(3, device=dev)
     out = []
     for fused in (False, True):
-        tr = iteration.Trainer(sc, dev, n_boxes=3, fused=fused, box_points=1500, optimise_boxes=True)
+        from oracle.boxmodel_oracle import BoxModelOpByOp       # (the op-by-op pose class is the checker's: not in the product package)
+        tr = iteration.Trainer(sc, dev, n_boxes=3, fused=fused, box_points=1500, optimise_boxes=True,
+                               box_model_cls=None if fused else BoxModelOpByOp)
         first = None
         for it in range(3):
             cam = cams[it % 3]

@@ -14,63 +14,46 @@ written against the reference's class reads the same; what differs is how MANY i
     regularize_all(box_models)    regularize() of every model: one launch for the regularizer's gradients, one
                                   multi-tensor Adam launch (vegs_amd.optim.step_many), zero_grad
 
-(vegs_amd/csrc/instances.hip: k_box_fwd / k_box_bwd / k_box_reg, C ABI include/vegs_instances.h.)  fused=False keeps the
-reference's op-by-op ATen composition -- device-agnostic, what the CPU tests pin against the reference's own class
-(tests/golden/ref_boxmodel.npz) and what the GPU tests compare the kernels with.
+(vegs_amd/csrc/instances.hip: k_box_fwd / k_box_bwd / k_box_reg, C ABI include/vegs_instances.h.)  There is no CPU path: the
+op-by-op ATen statement of the same class -- what the CPU tests pin against the reference's own class
+(tests/golden/ref_boxmodel.npz) and what the GPU tests compare the kernels with -- is test infrastructure and lives in
+oracle/boxmodel_oracle.py (BoxModelOpByOp).  adjust_all / regularize_all accept such objects beside BoxModels (any object
+with adjustbox2world() / regularize() and `fused == False` is simply called), so that a comparison run can mix them in.
 """
 import torch
 
-from . import _capi, harness
+from . import _capi
 
 
 class BoxModel:
+    fused = True
+
     def __init__(self, box2world, lr=0.005, lambda_reg=0.001, device=None, fused=True):
         """box2world: the annotated pose, 4x4 (obj_box2world, model/boxmodel.py:16-21: [R | T] of the annotation).
         lr / lambda_reg: arguments/__init__.py:116-117 (boxmodel_lr, boxmodel_lambda_reg)."""
+        if not fused:
+            raise ValueError("vegs_amd.boxmodel.BoxModel is the HIP path; the op-by-op composition is test infrastructure: "
+                             "oracle.boxmodel_oracle.BoxModelOpByOp")
+        from . import optim
         device = torch.device(device) if device is not None else torch.as_tensor(box2world).device
-        self.fused = bool(fused)
         self.lr, self.lambda_reg = lr, lambda_reg
         self.delta_r = torch.tensor([1., 0., 0., 0.], device=device, requires_grad=True)
         self.delta_s = torch.tensor([1., 1., 1.], device=device, requires_grad=True)
         self.delta_t = torch.tensor([0., 0., 0.], device=device, requires_grad=True)
-        if self.fused:
-            from . import optim
-            self.optimizer = optim.Adam([self.delta_r, self.delta_s, self.delta_t], lr=lr)
-        else:
-            self.optimizer = torch.optim.Adam([self.delta_r, self.delta_s, self.delta_t], lr=lr)
+        self.optimizer = optim.Adam([self.delta_r, self.delta_s, self.delta_t], lr=lr)
         self.box2world = torch.as_tensor(box2world, dtype=torch.float32).to(device).contiguous()
 
-    # ---- the reference's composition, op by op (model/boxmodel.py:23-42)
-    @property
-    def d_box2world(self):
-        dev = self.delta_r.device
-        d = torch.eye(4, device=dev)
-        d_s = torch.eye(3, device=dev)
-        d_s[0, 0], d_s[1, 1], d_s[2, 2] = self.delta_s[0], self.delta_s[1], self.delta_s[2]
-        d = d.clone()
-        d[:3, :3] = torch.matmul(d_s, harness.quaternion_to_matrix(self.delta_r))
-        d[:3, 3] = self.delta_t
-        return d
-
     def adjustbox2world(self):
-        if self.fused:
-            return adjust_all([self])[0]
-        return torch.matmul(self.box2world, self.d_box2world)
+        return adjust_all([self])[0]
 
     def regularize(self, iteration=None):
-        if self.fused:
-            return regularize_all([self])
-        ident = torch.tensor([1., 0., 0., 0.], device=self.delta_r.device)
-        loss = torch.norm(self.delta_r - ident) + torch.norm(self.delta_s - 1) + torch.norm(self.delta_t)
-        loss = self.lambda_reg * loss
-        loss.backward()
-        self.optimizer.step()
-        self.optimizer.zero_grad()
+        return regularize_all([self])
 
     def get_deltas(self):
         with torch.no_grad():
-            return [torch.norm(self.delta_r.detach().cpu() - torch.tensor([1., 0., 0., 0.])).item(),
-                    torch.norm(self.delta_s.detach().cpu() - 1.).item(), torch.norm(self.delta_t.detach().cpu()).item()]
+            r, s, t = (x.detach().cpu() for x in (self.delta_r, self.delta_s, self.delta_t))
+            return [torch.linalg.vector_norm(r - torch.tensor([1., 0., 0., 0.])).item(),
+                    torch.linalg.vector_norm(s - 1.0).item(), torch.linalg.vector_norm(t).item()]
 
 
 def _table(box_models):
@@ -124,7 +107,7 @@ def adjust_all(box_models, nan_guard=True):
     deltas.  nan_guard: apply train.py:199-205 inside the backward."""
     if not box_models:
         raise ValueError("no box models")
-    if not all(b.fused for b in box_models):
+    if not all(getattr(b, "fused", False) for b in box_models):       # op-by-op checker objects in the list: called one by one
         return torch.stack([b.adjustbox2world() for b in box_models])
     flat = []
     for b in box_models:
@@ -138,7 +121,7 @@ def regularize_all(box_models):
     |delta_s - 1| + |delta_t|), backward, optimizer.step(), zero_grad -- as two launches for all models."""
     if not box_models:
         return
-    if not all(b.fused for b in box_models):
+    if not all(getattr(b, "fused", False) for b in box_models):
         for b in box_models:
             with torch.enable_grad():
                 b.regularize()

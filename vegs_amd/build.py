@@ -17,6 +17,7 @@ OBJ_DIR = os.path.join(OUT_DIR, "obj")
 LIB = os.path.join(OUT_DIR, "libvegsrast.so")
 SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "render_fwd.hip", "render_bwd.hip", "preprocess_bwd.hip", "knn.hip", "losses.hip", "optim.hip", "instances.hip", "densify.hip", "xgmi.hip"]
 HEADERS = ["vr_device.h", "vr_host.h", "vr_segment.h", os.path.join("..", "..", "include", "vegs_rast.h"),
+           os.path.join("..", "..", "include", "vegs_rast_debug.h"),
            os.path.join("..", "..", "include", "vegs_loss.h"), os.path.join("..", "..", "include", "vegs_optim.h"),
            os.path.join("..", "..", "include", "vegs_instances.h"), os.path.join("..", "..", "include", "vegs_xgmi.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC",

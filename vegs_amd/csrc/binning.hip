@@ -13,7 +13,7 @@
 //   5. tile ranges from key boundaries.
 // R-sized traffic is 2 passes of 8-byte pairs instead of upstream's 6 passes of 12-byte pairs.
 // Ranking inside a pass uses wave64 ballots (match-by-digit), no per-element atomics.
-#include "../../include/vegs_rast.h"
+#include "../../include/vegs_rast_debug.h"
 #include <stdio.h>
 #include <stdlib.h>
 

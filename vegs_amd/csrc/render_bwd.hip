@@ -24,7 +24,7 @@
 // Lanes hold a chunk back-to-front (lane l <-> entry 63-l) so both are PREFIX scans over lanes.
 // Per-splat gradients stay in registers until the chunk is finished, are transposed through LDS and leave as one
 // coalesced set of global atomics per (region, splat) -- ~250x fewer atomics than one per fragment.
-#include "../../include/vegs_rast.h"
+#include "../../include/vegs_rast_debug.h"
 #include "vr_host.h"
 #include "vr_segment.h"
 

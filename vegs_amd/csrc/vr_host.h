@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/vegs_rast_debug.h"   // (the stable header + the experimental / test-only entries the library also exports)
 #include "vr_device.h"
 
 namespace vr {

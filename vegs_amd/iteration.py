@@ -172,10 +172,18 @@ class InstanceModel:
         return self.p["xyz"].shape[0]
 
 
-def make_instance_models(n, device, fused, points=8196, seed=5, spacing=12.0, lrs=None, box_lr=0.005, lambda_reg=0.001):
+def make_instance_models(n, device, fused, points=8196, seed=5, spacing=12.0, lrs=None, box_lr=0.005, lambda_reg=0.001,
+                         box_model_cls=None):
     """n dynamic objects: (InstanceModel, BoxModel) pairs -- the Gaussians of make_boxes as raw parameters with optimizers,
-    the pose as the reference's BoxModel (annotated box2world + the learnable deltas)."""
+    the pose as the reference's BoxModel (annotated box2world + the learnable deltas).  box_model_cls: the pose class
+    (default vegs_amd.boxmodel.BoxModel, the HIP path; the op-by-op ATen variant of an iteration -- a comparison aid -- passes
+    the checker's class, oracle.boxmodel_oracle.BoxModelOpByOp, which the product package does not import)."""
     from . import boxmodel
+    if box_model_cls is None:
+        if not fused:
+            raise ValueError("the op-by-op iteration needs box_model_cls=oracle.boxmodel_oracle.BoxModelOpByOp "
+                             "(test infrastructure; vegs_amd.boxmodel.BoxModel is the HIP path)")
+        box_model_cls = boxmodel.BoxModel
     models, boxes = [], []
     brng = np.random.default_rng(seed)
     for i in range(n):
@@ -185,7 +193,7 @@ def make_instance_models(n, device, fused, points=8196, seed=5, spacing=12.0, lr
         B[:3, :3] = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32) * 1.5
         B[:3, 3] = [10.0 + spacing * i, brng.uniform(-3, 3), -0.8]
         models.append(InstanceModel(b, device, fused, lrs))
-        boxes.append(boxmodel.BoxModel(torch.tensor(B), lr=box_lr, lambda_reg=lambda_reg, device=device, fused=fused))
+        boxes.append(box_model_cls(torch.tensor(B), lr=box_lr, lambda_reg=lambda_reg, device=device, fused=fused))
     return models, boxes
 
 
@@ -204,7 +212,8 @@ class Trainer:
     N ranks x 1 view == 1 process x N views: tests/test_gpu_dist_train.py."""
 
     def __init__(self, sc, device, n_boxes=0, fused=True, box_points=8196, factored_sh=False, lrs=None,
-                 optimise_boxes=False, world=1, rank=0, group=None, exchange="factored", schedule=None, seed=0):
+                 optimise_boxes=False, world=1, rank=0, group=None, exchange="factored", schedule=None, seed=0,
+                 box_model_cls=None):
         """factored_sh (fused variant): the op returns the 3-float factor of the SH gradient and Adam consumes it directly
         (optim.adam_step_sh_factored) -- the static model's dense [P,16,3] gradient is never written.  With box instances
         in frame the factor covers the concatenated op inputs: the static model's rows feed Adam, the instances' few
@@ -230,7 +239,8 @@ class Trainer:
         self.optimise_boxes = bool(optimise_boxes and n_boxes)
         self.instances, self.box_models, self.boxes = [], [], []
         if self.optimise_boxes:
-            self.instances, self.box_models = make_instance_models(n_boxes, device, fused, box_points, lrs=lrs)
+            self.instances, self.box_models = make_instance_models(n_boxes, device, fused, box_points, lrs=lrs,
+                                                                   box_model_cls=box_model_cls)
         elif n_boxes:
             self.boxes = make_boxes(n_boxes, device, box_points)
         self.opt = (optim.Adam if fused else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)

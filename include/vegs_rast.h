@@ -215,10 +215,14 @@ typedef struct VrSaved {
                                  vr_export_needed / vr_debug_export_binning called with this VrSaved return VR_ERR_HIP
                                  for exactly this view (0 = nothing to check).  Pass it on unchanged.
                                  ABI v9: every forward in flight has its OWN device guard word (views on different
-                                 streams cannot fail each other), and vr_backward never blocks the host on the slot:
-                                 not posted yet = it queues its kernels (a tripped view's tile ranges are empty: they
-                                 compute zeros), asks once more, and leaves a still-missing answer to the thread's
-                                 next vr_forward, which reports "an earlier view's binning timed out". */
+                                 streams cannot fail each other).  vr_backward asks for the slot without blocking; not
+                                 posted yet = it queues its kernels (a failed view's tile ranges are empty: they compute
+                                 zeros) and then WAITS for the slot before it returns (round 6: the forward's last binning
+                                 kernel lies in front of everything the call queued, so healthy runs lose nothing, and a
+                                 failed view always fails its OWN backward).  A view's binning fails when a bounded wait
+                                 runs out or when the depth sort's output is not a permutation of the visible ids (an
+                                 always-on checksum comparison); a view that never gets a backward is reported by the
+                                 thread's next vr_forward. */
 } VrSaved;
 
 /* Incoming gradients, one per differentiable output (NULL = zero). */

@@ -1433,17 +1433,26 @@ k_split_count(const uint32_t* __restrict__ tkeys, long R, int ntiles, int stride
 // (16 rows per thread and step instead of 8: the same 9 us.  k_split_base run by the LAST workgroup of this launch -- a
 // counter, device-scope totals -- instead of a launch of its own: 13.6 against 9.2 + 4.9 us; two launches it stays.)
 constexpr int SPLIT_SCAN_U = 8;
+constexpr int PERM_BLOCKS = 8;      // extra workgroups of k_split_scan that add up the permutation check's checksums
 __global__ void __launch_bounds__(256)
 k_split_scan(uint32_t* __restrict__ table, int nblk, int stride, uint32_t* __restrict__ totals, const uint2* __restrict__ chk_in,
-             int n_in, const uint2* __restrict__ chk_out, int n_out, uint32_t* __restrict__ err)
+             int n_in, const uint2* __restrict__ chk_out, int n_out, uint2* __restrict__ perm_part)
 {
     __shared__ uint32_t part[16][17];
-    // One workgroup more than there are strips: the depth sort's PERMUTATION CHECK rides along (its ~8 k loads under the
-    // strips' column walks; as a step of k_split_base, a single workgroup on the critical path, it cost 3.5 us).  It raises the
-    // guard word, which k_split_base -- the next launch -- posts and k_split_scatter obeys.
-    if ((int)blockIdx.x == stride / 16) {
-        __shared__ uint32_t chk_lds[9];
-        if (chk_in) (void)perm_check_failed(chk_in, n_in, chk_out, n_out, err, chk_lds);
+    // PERM_BLOCKS workgroups more than there are strips: the depth sort's PERMUTATION CHECK rides along -- each of them adds up
+    // an eighth of the two checksum arrays (in - out) under the strips' column walks and leaves its pair in perm_part[];
+    // k_split_base, the next launch, adds the eight pairs and raises the guard word if they do not cancel.  (As a step of
+    // k_split_base alone -- one workgroup on the critical path, ~8 k loads -- the check cost 3.5 us; as ONE extra workgroup
+    // here 2.8 us: the launch waited for it.)
+    if ((int)blockIdx.x >= stride / 16) {
+        __shared__ uint32_t chk_lds[8];
+        const int part = (int)blockIdx.x - stride / 16;
+        uint32_t a1 = 0u, a2 = 0u;
+        if (chk_in) {
+            for (int j = part * 256 + threadIdx.x; j < n_in; j += PERM_BLOCKS * 256) { const uint2 c = chk_in[j]; a1 += c.x; a2 += c.y; }
+            for (int j = part * 256 + threadIdx.x; j < n_out; j += PERM_BLOCKS * 256) { const uint2 c = chk_out[j]; a1 -= c.x; a2 -= c.y; }
+        }
+        block_store_pair(a1, a2, perm_part + part, chk_lds);
         return;
     }
     const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
@@ -1482,12 +1491,22 @@ k_split_scan(uint32_t* __restrict__ table, int nblk, int stride, uint32_t* __res
 // forward's sequence number into the host's pinned ring slot (what k_tile_ranges does on the two-pass path).
 __global__ void __launch_bounds__(1024)
 k_split_base(const uint32_t* __restrict__ totals, int ntiles, uint32_t* __restrict__ base, int2* __restrict__ ranges,
-             const uint32_t* __restrict__ err, uint32_t* __restrict__ post, uint32_t seq)
+             uint32_t* __restrict__ err, uint32_t* __restrict__ post, uint32_t seq, const uint2* __restrict__ perm_part)
 {
     __shared__ uint32_t wsum[16];
-    // (the guard word as it stands after the waits of the depth sort and the emission AND the permutation check of k_split_scan)
+    // the guard word as it stands after the waits of the depth sort and the emission -- and the verdict of the PERMUTATION
+    // CHECK: the eight partial (in - out) checksum pairs of k_split_scan must cancel (every thread adds them up: 8 cached loads)
     uint32_t tripped = 0u;
     if (err) tripped = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (perm_part) {
+        uint32_t t1 = 0u, t2 = 0u;
+#pragma unroll
+        for (int q = 0; q < PERM_BLOCKS; ++q) { const uint2 c = perm_part[q]; t1 += c.x; t2 += c.y; }
+        if ((t1 | t2) != 0u) {
+            tripped = 1u;
+            if (threadIdx.x == 0 && err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (k_split_scatter obeys it)
+        }
+    }
     if (threadIdx.x == 0 && post) {
         __hip_atomic_store(&post[1], tripped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&post[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1626,7 +1645,7 @@ static Stage2Layout stage2_layout(int V, long R, int ntiles)
     const bool can_split = ntiles <= SPLIT_MAX_TILES;
     L.split = take(can_split ? (size_t)cdiv((long)r, SPLIT_BLOCK) * split_stride(ntiles) * 4 : 0);
     L.split_tot = take(can_split ? (size_t)split_stride(ntiles) * 8 : 0);
-    L.chk = take((size_t)cdiv((long)v, 256) * sizeof(uint2));      // the emission's id checksums, one pair per workgroup
+    L.chk = take(((size_t)cdiv((long)v, 256) + 8) * sizeof(uint2));      // the emission's id checksums, one pair per workgroup (+ the check's 8 partial pairs)
     L.total = o;
     return L;
 }
@@ -1945,11 +1964,12 @@ int launch_binning(const Camera& cam, int P, int V, long R, uint32_t key_min, in
             uint32_t* const tbase = totals + stride;
             hipLaunchKernelGGL(k_split_count, dim3(nblk), dim3(256), (size_t)stride * 4, s, (const uint32_t*)tkeysA, R, ntiles, stride,
                                table, err);
-            hipLaunchKernelGGL(k_split_scan, dim3(stride / 16 + 1), dim3(256), 0, s, table, nblk, stride, totals, chk_in, rows,
-                               (const uint2*)chk_out, cdiv(V, 256), err);
+            uint2* const perm_part = chk_out + cdiv(V, 256);
+            hipLaunchKernelGGL(k_split_scan, dim3(stride / 16 + PERM_BLOCKS), dim3(256), 0, s, table, nblk, stride, totals, chk_in, rows,
+                               (const uint2*)chk_out, cdiv(V, 256), perm_part);
             if (debug_raise_guard == 1) VR_HIP(hipMemsetD32Async((hipDeviceptr_t)err, 1, 1, s));   // test hook: "a wait of THIS view timed out"
             hipLaunchKernelGGL(k_split_base, dim3(1), dim3(1024), 0, s, (const uint32_t*)totals, ntiles, tbase, ranges,
-                               (const uint32_t*)err, guard_post, guard_seq);
+                               err, guard_post, guard_seq, (const uint2*)perm_part);
             hipLaunchKernelGGL(k_split_scatter, dim3(nblk), dim3(256), (size_t)stride * 20, s, (const uint32_t*)tkeysA,
                                (const uint32_t*)va, R, ntiles, stride, (const uint32_t*)table, (const uint32_t*)tbase, point_list,
                                (const uint32_t*)err);

@@ -71,8 +71,10 @@ typedef struct VrXgmiSegment {
  * FAILURE CONTRACT (ABI v9).  Every device-side wait for a peer is bounded (10 s of wall clock by default;
  * vr_xgmi_set_wait_bound).  A wait that runs out raises the window's error word -- in the window and in a pinned host
  * mirror -- instead of hanging the queue, and the error is STICKY:
- *   * the reduce kernel whose wait ran out adds nothing, writes nothing into any rank's result[] and posts no epoch, so
- *     the peers waiting for its shard run into their own bound: every rank of the job learns, within two bounds;
+ *   * a reduce kernel whose wait ran out posts no epoch, so the peers waiting for its shard run into their own bound: every
+ *     rank of the job learns, within two bounds.  Its workgroups decide one by one: those whose wait ran out add and write
+ *     nothing, one whose poll succeeded just before may already have written its part -- result[] of a failed exchange may
+ *     be PARTIAL (see the last paragraph);
  *   * vr_xgmi_allreduce / _allgather_begin / _allgather_wait read the host mirror FIRST (one host load, no
  *     synchronisation) and return VR_ERR_HIP once it is set: the call after the failed exchange fails, on every rank;
  *     vr_xgmi_failed() is the same test as a predicate, vr_xgmi_check() synchronises `stream` first.

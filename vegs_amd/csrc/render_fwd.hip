@@ -1286,7 +1286,11 @@ int launch_render_fwd(const Camera& cam, long R, const int2* ranges, const uint3
     // chain mode (the segment table's comment): a forward without rounds whose table comes from k_seg_table; its arrays
     // (flags [cap] | dead and launch order [2 x tiles, padded]) live in the lists of the rounds
     const bool chain = chain_env && !rounds && first_fused && one_table && ntiles <= SEGTAB_MAX_TILES && R / SEG >= ntiles + 256;
-    if (one_table && ntiles <= SEGTAB_MAX_TILES && nseg > 0) {
+    // A HINTED forward takes the two-kernel table (round 6, advisor finding): k_seg_offsets -- ONE workgroup -- reads the
+    // caller's hint array once and leaves the limits in this call's own buffer; in k_seg_table every workgroup would read the
+    // array itself, and another stream rendering the same camera (its forward ends by REWRITING the array) could make them
+    // disagree on list positions and counts.  (Hints are an opt-in of no_grad forwards; the second launch costs ~4 us there.)
+    if (one_table && !needed_hint && ntiles <= SEGTAB_MAX_TILES && nseg > 0) {
         hipLaunchKernelGGL(k_seg_table, dim3(cdiv((long)nseg, 256)), dim3(256), 0, s, ranges, ntiles, seg_off,
                            (const uint32_t*)needed_hint, seg_needed, (uint32_t)nseg, auto_rounds ? first : 0x3FFFFFFFu, first_fused,
                            chain ? 1 : 0);

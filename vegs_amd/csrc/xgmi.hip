@@ -89,9 +89,12 @@ __device__ __forceinline__ bool wait_all(const unsigned long long* words, int wo
                 __builtin_amdgcn_s_sleep(8);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system scope: what the peers wrote before posting is visible from here on
     }
     __syncthreads();
+    // ONE acquire fence per thread, BEHIND the barrier (round 6, advisor finding: it used to sit inside the branch of the
+    // polling threads, the others relying on the barrier alone): system scope -- what the peers wrote before posting is
+    // visible to every thread of the workgroup from here on
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     return __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull;
 }
 
@@ -146,8 +149,10 @@ __global__ void __launch_bounds__(XG_THREADS) k_xg_push(XgArgs a)
 __global__ void __launch_bounds__(XG_THREADS) k_xg_reduce(XgArgs a)
 {
     unsigned long long* mine = flags_of(a.peer[a.rank]);
-    // a push that never arrived (or an earlier failure on this window): recv[] is not the peers' data -- nothing is summed,
-    // nothing is written into anybody's result[], no epoch is posted
+    // a push that never arrived (or an earlier failure on this window): recv[] is not the peers' data -- this workgroup sums
+    // nothing, writes nothing and the kernel posts no epoch.  (The decision is the WORKGROUP's: one whose poll succeeded just
+    // before another's ran out may already have written its part of the shard -- result[] of a failed exchange is PARTIAL,
+    // never to be consumed; every exchange call tests the window's sticky error word, vegs_xgmi.h.)
     if (wait_all(mine + XG_FLAG_A, a.world, a.epoch, mine + XG_ERR, a.err_host, a.wait_ticks)) return;
     const float* recv = a.peer[a.rank] + a.recv_offset;
     for (int t = 0; t < a.nseg; ++t) {

@@ -89,6 +89,41 @@ def test_headline_loop_under_the_depth_sorts_post_mortem():
     assert r.returncode == 0 and "clean" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
+_BLIND_CHECK = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from vegs_amd import _capi, harness, scenes
+_capi.load()
+dev = torch.device("cuda:0")
+sc, deg = scenes.scene_street(P=60000, length=40.0, sh_degree=1, seed=19)
+cam = scenes.kitti_camera(0.0, 0.0, 344, 94)
+T = {k: torch.tensor(v, device=dev) for k, v in sc.items()}
+with torch.no_grad():
+    harness.render(cam, T, deg, torch.zeros(3, device=dev))          # a sound view passes the post-mortem
+    _capi.check(_capi.load().vr_debug_raise_guard(4))                # the next forward's sorted ids get one duplicate
+    try:
+        harness.render(cam, T, deg, torch.zeros(3, device=dev))
+    except Exception as e:
+        print("CAUGHT", str(e)[:200])
+        sys.exit(0)
+print("NOT CAUGHT")
+sys.exit(1)
+"""
+
+
+def test_the_post_mortem_is_not_blind():
+    """The instrument of the test above, shown an injected fault: vr_debug_raise_guard(4) overwrites one sorted id with its
+    neighbour behind the depth sort; under VEGS_DEBUG_BINNING=1 that forward must FAIL with the post-mortem's finding (a
+    duplicate id / a pair whose key is not its id's depth key), after a sound forward of the same view passed."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _BLIND_CHECK % root], capture_output=True, text=True,
+                       env=dict(os.environ, VEGS_DEBUG_BINNING="1"), timeout=600)
+    assert r.returncode == 0 and "CAUGHT" in r.stdout and "post-mortem" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "duplicate ids" in r.stderr and "output of the last pass" in r.stderr, r.stderr[-3000:]
+
+
 def test_two_views_in_flight_do_not_disturb_each_other(dev):  # noqa: F811
     """Two streams, two different views, no synchronisation between the forwards: each view's lists and image equal its
     quiet run's (separate guard words and status regions per forward in flight, ABI v9)."""

@@ -242,9 +242,9 @@ k_preprocess(Camera cam, int P, const float* __restrict__ means3D, const float* 
                 // Both halves of the wave's rows are requested at once (12 loads per lane in flight, rows of culled Gaussians
                 // left out); the second half waits in registers while the first is evaluated.  (Requesting them a round trip
                 // EARLIER -- for every Gaussian in front of the near plane, before the covariance and the tile test -- measured
-                // slower, 0.152 against 0.148 ms, AND three bench runs of four with that build ended in a memory fault in
-                // k_emit_scan (garbage ids out of the depth sort; never with this one, same sources otherwise).  The cause was
-                // not found; the variant is gone: profiles/experiments/README.md.)
+                // slower, 0.152 against 0.148 ms.  That build's bench runs once ended in a memory fault in k_emit_scan on one box
+                // (garbage ids out of the depth sort); it is kept as the reproducer build -DVR_EARLY_SH above and has not
+                // faulted since, with or without the depth sort's post-mortem: profiles/experiments/README.md, round 6.)
                 const float* rows = HALF == 1 ? shs + wave_first * 48 : shs_tail + (wave_first - (size_t)tail_start) * 48;
                 const float4* src4 = reinterpret_cast<const float4*>(rows);
                 float4 tA[6], tB[6];

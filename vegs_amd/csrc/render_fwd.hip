@@ -354,8 +354,12 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
     // reads are issued before any of them is used; the entries are still applied strictly in list order.
     // (render forward 0.360 -> 0.340 ms.  Not in seg_first_body -- 5 KB more of LDS would cost it a workgroup per CU, and the
     // near splats of a first segment reach most quadrants anyway -- nor in k_seg_blend, where per-chunk lists bought nothing.)
-    uint8_t* const ql = reinterpret_cast<uint8_t*>(qspace) + w * 1024;     // 4 lists of up to 256 entry indices
-    uint8_t* const rel = reinterpret_cast<uint8_t*>(qspace) + 4096 + w * 256; // the strip's relevant entries, compacted
+    // List stride 260 bytes, not 256 (round 6): the four quadrants read their lists' dword t / 4 in ONE ds_read_b32, and lists
+    // 256 bytes apart put the four addresses on one bank (a 4-way conflict per four entries: part of the kernel's
+    // SQ_LDS_BANK_CONFLICT count, profiles/experiments/README.md); 65 dwords apart they fall on four consecutive banks.
+    constexpr int QL_STRIDE = 260;
+    uint8_t* const ql = reinterpret_cast<uint8_t*>(qspace) + w * (4 * QL_STRIDE);     // 4 lists of up to 256 entry indices
+    uint8_t* const rel = reinterpret_cast<uint8_t*>(qspace) + 4 * (4 * QL_STRIDE) + w * 256; // the strip's relevant entries, compacted
     int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
     {
         const unsigned long long lt = (1ull << lane) - 1ull;
@@ -384,7 +388,7 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
                 const bool r = have && (odd || rect_relevant_facing(A, inv_A, B, Cc, inv_C, lim, xl, xh, yl, yh));
                 const unsigned long long bm = __ballot(r);
                 int& n = q == 0 ? n0 : (q == 1 ? n1 : (q == 2 ? n2 : n3));
-                if (r) ql[q * 256 + n + __popcll(bm & lt)] = (uint8_t)j;
+                if (r) ql[q * QL_STRIDE + n + __popcll(bm & lt)] = (uint8_t)j;
                 n += __popcll(bm);
             }
         }
@@ -393,7 +397,7 @@ __device__ __forceinline__ float seg_alpha_body(const SegCtx& c, const uint32_t*
         const int myq = ((lane >> 5) & 1) * 2 + ((lane >> 2) & 1);
         const int n_mine = myq == 0 ? n0 : (myq == 1 ? n1 : (myq == 2 ? n2 : n3));
         const int trips = max(max(n0, n1), max(n2, n3));
-        const uint8_t* const myl = ql + myq * 256;
+        const uint8_t* const myl = ql + myq * QL_STRIDE;
         auto apply = [&](const float4 a, const float4 b, const bool act) {
             float dx, dy;
             const float power = splat_power2(a.x, a.y, a.z, a.w, b.x, pxf, pyf, dx, dy);
@@ -700,7 +704,7 @@ k_seg_alpha(Camera cam, const int2* __restrict__ ranges, uint32_t* __restrict__ 
     __shared__ float4 lds[ROUND == 0 ? 4 : 2][SEG];
     __shared__ float2 lds_s[ROUND == 0 ? SEG : 1];
     __shared__ unsigned long long masks[16];
-    __shared__ uint32_t qextra[ROUND == 0 ? 1 : 1280];                  // (quarter-wave lists: round 0 borrows the fused path's planes)
+    __shared__ uint32_t qextra[ROUND == 0 ? 1 : 1296];                  // (quarter-wave lists: round 0 borrows the fused path's planes)
     void* const qspace = ROUND == 0 ? (void*)&lds[ROUND == 0 ? 2 : 0][0] : (void*)qextra;
     // the round's work list: round 0 one workgroup per entry (the grid is sized for it: AUTO_FIRST segments per tile
     // without a hint); the catch-up rounds a fixed grid striding over a list whose length only the device knows

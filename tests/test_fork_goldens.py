@@ -17,7 +17,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, OUT_NAMES, assert_grad_close, case_inputs, oracle_cam_from_case
+from helpers import GOLDEN, OUT_NAMES, assert_grad_close, case_gouts, case_inputs, oracle_cam_from_case
 
 FORK_DIR = os.path.join(GOLDEN, "fork")
 FWD_ATOL = 1e-4            # BASELINE.json north_star: "outputs within 1e-4 abs"
@@ -77,7 +77,8 @@ def _oracle_run(c, flags, three):
     cam.flags = ctypes.c_uint(flags & 0xF).value
     out, st = orc.forward(cam, **case_inputs(c))
     which = ("color", "cov_quat", "cov_scale") if three else OUT_NAMES
-    g = [c["gout_" + n] if n in which else None for n in OUT_NAMES]
+    full = dict(zip(OUT_NAMES, case_gouts(c)))          # (a cropped fixture's upstream gradients, padded to the frame)
+    g = [full[n] if n in which else None for n in OUT_NAMES]
     return out, orc.backward(cam, st, *g)
 
 
@@ -235,7 +236,8 @@ def test_hip_matches_the_fork():
     dev = torch.device("cuda:0")
     flags = check_oracle_against_fork(cases)[0]
     for name, c, f in cases:
-        g = [c["gout_" + n] if n in ("color", "cov_quat", "cov_scale") else None for n in OUT_NAMES]
+        full = dict(zip(OUT_NAMES, case_gouts(c)))
+        g = [full[n] if n in ("color", "cov_quat", "cov_scale") else None for n in OUT_NAMES]
         out, grads, _ = _run_hip(_settings(c, None, None, None, dev), case_inputs(c), dev, g, flags=flags)
         assert np.array_equal(out["radii"], f["radii"])
         notes = []

@@ -69,7 +69,13 @@ def run_case(path, device):
             result["radii"] = radii.detach().cpu().numpy().astype(np.int32)
         tensors, grads = [], []
         for n in which:
-            g = torch.tensor(z["gout_" + n], dtype=torch.float32, device=dev).reshape(outs[n].shape)
+            g_np = z["gout_" + n]
+            if "crop" in z.files:      # a case that stores a CROP of its images: the upstream gradients are zero outside it
+                y0, y1, x0, x1 = (int(v) for v in z["crop"])
+                full = np.zeros((g_np.shape[0], H, W), np.float32)
+                full[:, y0:y1, x0:x1] = g_np
+                g_np = full
+            g = torch.tensor(g_np, dtype=torch.float32, device=dev).reshape(outs[n].shape)
             if outs[n].requires_grad:
                 tensors.append(outs[n])
                 grads.append(g)

@@ -768,7 +768,7 @@ def main():
                      "frac_of_measured_issue_peak": round(valu_insts / (ms_k * 1e-3) / 1e9 / VALU_MEASURED_GINST, 4),
                      "note": "instructions, not issue slots: a packed fp32 instruction takes two slots and a transcendental "
                              "~3.5 (profiles/tools/ubench/pk_rate.hip); with ~40 % of this kernel's instructions packed and four "
-                             "reciprocals per trip its stream is ~230 us of pure issue (DESIGN section 14)"},
+                             "reciprocals per trip its stream is ~230 us of pure issue (HISTORY.md section 14)"},
                  "l2_atomics": None if flushes is None else {
                      "kernel": kern, "flushes_per_view": round(flushes), "atomics_per_view": round(17 * flushes),
                      "achieved_gatomics_per_s": round(17 * flushes / (ms_k * 1e-3) / 1e9, 2) if ms_k > 0 else None,

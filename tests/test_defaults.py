@@ -5,7 +5,7 @@ import os
 
 def test_needed_hint_cache_is_opt_in(monkeypatch):
     """The per-camera needed-segment hints pay only while the model stands still between two visits of a camera; a
-    training loop revisits a camera once per epoch, where they cost time: off unless asked for,
+    training loop revisits a camera once per epoch, where they cost time (HISTORY.md section 12): off unless asked for,
     and then for forwards that will not be differentiated (evaluation) only."""
     from vegs_amd import rasterizer
     monkeypatch.delenv("VEGS_RAST_HINTS", raising=False)

@@ -1022,7 +1022,7 @@ def test_non_finite_inputs_do_not_crash_or_poison_the_frame(dev):
 
 def test_needed_hints_are_offered_to_no_grad_forwards_only(dev):
     """needed_hints(True): the per-camera cache serves forwards that will not be differentiated (evaluation of fixed
-    cameras); a training forward never gets a hint -- hints one epoch old cost time."""
+    cameras); a training forward never gets a hint -- hints one epoch old cost time (HISTORY.md section 12)."""
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     from vegs_amd import rasterizer, scenes
     sc, deg = scenes.scene_street(P=30000, length=40.0, sh_degree=1, seed=3)

@@ -135,7 +135,7 @@ _LAST_R = {}
 # a camera has to come back before anything is spent on it.
 # An EVALUATION-ONLY feature, OFF by default: a hint pays only while the model stands still between two visits of a
 # camera (re-rendering fixed views of a trained model under torch.no_grad(): -3 % of the forward); in training a camera
-# comes back once per epoch, and hints one epoch old COST 1.5 ... 4 % (BENCH_r03) -- so a forward
+# comes back once per epoch, and hints one epoch old COST 1.5 ... 4 % (HISTORY.md section 12, BENCH_r03) -- so a forward
 # that will be differentiated never gets one: needed_hints(True) / VEGS_RAST_HINTS=1 turn the cache on for forwards under
 # no_grad only.  ("always" -- tests: the hinted kernels' catch-up rounds under a backward -- lifts that restriction.)
 _NEEDED = {}

@@ -148,8 +148,10 @@ k_seg_u(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict_
     if (c.sl * SEG < nc) {   // the pixel applied entries of this segment (otherwise `part` is not defined for it)
         const float* src = part + (size_t)c.seg * (NPART_B * SEG) + threadIdx.x;
 #pragma unroll
-        for (int k = 0; k < NCH; ++k)
+        for (int k = 0; k < NCH; ++k) {
+            if (k == 3 && dL_ddepth == nullptr) continue;      // (no gradient on the depth image: fma(x, 0, U) = U, the plane is not read)
             if (k < nu) U = fmaf(src[k * SEG], pg.g[k], U);
+        }
     }
     Ubuf[(size_t)c.seg * SEG + threadIdx.x] = U;
 }
@@ -199,7 +201,11 @@ k_seg_suffix(int ntiles, uint32_t cap, const uint32_t* __restrict__ seg_off, con
 template <bool EXACT>
 __device__ __forceinline__ float bwd_rcp(float x) { return EXACT ? 1.0f / x : __builtin_amdgcn_rcpf(x); }
 
-template <bool NO_EXTRA, bool DET, bool FAST>
+// NO_DEPTH (round 6): no upstream gradient on the depth image (dL_ddepth == NULL: VEGS' losses reach colour, cov_quat and
+// cov_scale only, train.py:152-168) -- its channel's terms, fma(depth_s, 0, u) in the <attr, g> chain and fma(w, 0, acc) in the
+// accumulators, are the identity for every finite depth and are left out: bit-identical sums, two packed instructions fewer
+// per trip.
+template <bool NO_EXTRA, bool DET, bool FAST, bool NO_DEPTH = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restrict__ seg_off, uint32_t cap,
           const uint32_t* __restrict__ seg_needed, const uint32_t* __restrict__ point_list,
@@ -393,7 +399,7 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
 #pragma unroll
                     for (int k = 2; k + 1 < NCH; k += 2) {
                         u0 = f2_fma(f2_splat(at[k]), g[k], u0);
-                        u1 = f2_fma(f2_splat(at[k + 1]), g[k + 1], u1);
+                        if (!(NO_DEPTH && k + 1 == 3)) u1 = f2_fma(f2_splat(at[k + 1]), g[k + 1], u1);
                     }
                     u = f2_fma(f2_splat(at[NCH - 1]), g[NCH - 1], u0) + u1;
                 } else {
@@ -430,7 +436,8 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                     acc[2] = f2_fma(ady, dy, acc[2]);
                     acc[3] = f2_fma(G, dLda, acc[3]);
 #pragma unroll
-                    for (int k = 0; k < NCH; ++k) acc[4 + k] = f2_fma(wgt, g[k], acc[4 + k]);
+                    for (int k = 0; k < NCH; ++k)
+                        if (!(NO_DEPTH && k == 3)) acc[4 + k] = f2_fma(wgt, g[k], acc[4 + k]);
                     acc[15] = f2_fma(a, f2_fma(f2_splat(cA), dx, f2_splat(cB) * dy), acc[15]);
                     acc[16] = f2_fma(a, f2_fma(f2_splat(cC), dy, f2_splat(cB) * dx), acc[16]);
                 }
@@ -543,10 +550,13 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
     hipLaunchKernelGGL(k_seg_suffix, dim3(2 * ntiles), dim3(256), 0, s, ntiles, (uint32_t)nseg, seg_off, seg_needed, Ubuf);
     VR_KERNEL_CHECK("seg_suffix", s, debug);
     prof_begin(VR_STAGE_K_SEG_BWD, s);
-#define VR_BWD2(NOX, DETM, FST)                                                                                        \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_bwd<NOX, DETM, FST>), dim3(nseg * 4), dim3(64), 0, s, cam, ranges, seg_off, \
+#define VR_BWD3(NOX, DETM, FST, NODEP)                                                                                 \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_bwd<NOX, DETM, FST, NODEP>), dim3(nseg * 4), dim3(64), 0, s, cam, ranges, seg_off, \
                        (uint32_t)nseg, seg_needed, point_list, rec, Tbuf, (const float*)Ubuf, final_T, n_contrib, dL_dcolor, dL_ddepth, \
                        dL_dquat, dL_dscale, dL_dalpha, gacc, gmean2D, segmask, dsum, gpart)
+    // (NO_DEPTH: the production instantiations only -- not the all-channels-off colour-only one, which never sees channel 3, nor
+    // the deterministic test mode)
+#define VR_BWD2(NOX, DETM, FST) do { if (!(NOX) && !(DETM) && dL_ddepth == nullptr) VR_BWD3(NOX, DETM, FST, true); else VR_BWD3(NOX, DETM, FST, false); } while (0)
 #define VR_BWD(NOX, DETM) do { if (cam.flags & FLAG_FAST_EXP) VR_BWD2(NOX, DETM, true); else VR_BWD2(NOX, DETM, false); } while (0)
     {
         const bool nox = (cam.flags & FLAG_EXTRA_NO_ALPHA_GRAD) != 0u;
@@ -555,6 +565,7 @@ int launch_render_bwd(const Camera& cam, long R, const int2* ranges, const uint3
     }
 #undef VR_BWD
 #undef VR_BWD2
+#undef VR_BWD3
     prof_end(VR_STAGE_K_SEG_BWD, s);
     VR_KERNEL_CHECK("seg_bwd", s, debug);
     if (gpart) {

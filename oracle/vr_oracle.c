@@ -620,6 +620,10 @@ void or_render_bwd(const OrCam* cam, int P, const int* ranges, const uint32_t* p
                         g_attr[(size_t)NCH * id + k] += (double)(w * g[k]);
                     }
                     float dL_dalpha_s = T * u - (behind + Tf * bgdot) / oma;
+                    /* magnitude of the OPERANDS of that difference (g_abs below): what an fp32 evaluation of the term rounds
+                     * against -- for a near-opaque splat (1 / (1 - alpha) up to 100) in front of others the two operands are
+                     * each far larger than their difference */
+                    const float dLda_mag = fabsf(T * u) + fabsf(behind + Tf * bgdot) / oma;
                     behind = fmaf(w, u, behind);
                     /* alpha = min(0.99, op*G): gradient passes straight through as upstream does */
                     float dL_dG = op * dL_dalpha_s;
@@ -639,9 +643,13 @@ void or_render_bwd(const OrCam* cam, int P, const int* ranges, const uint32_t* p
 #pragma omp atomic
                     g_opacity[id] += (double)(G * dL_dalpha_s);
                     if (g_abs) {
-                        const float t[6] = {dL_dG * dG_ddx * (0.5f * (float)W), dL_dG * dG_ddy * (0.5f * (float)H),
-                                            -0.5f * gdx * dx * dL_dG, -gdx * dy * dL_dG, -0.5f * gdy * dy * dL_dG,
-                                            G * dL_dalpha_s};
+                        /* every term is (a coefficient) x dL/dalpha: its scale is |coefficient| x the magnitude of dL/dalpha's
+                         * OPERANDS (round 6; until then |term| itself, which hides the cancellation inside dL/dalpha: fuzz seeds
+                         * 11136, 17962 -- rows measured "well conditioned" that no fp32 evaluation can hold) */
+                        const float mG = op * dLda_mag;
+                        const float t[6] = {mG * dG_ddx * (0.5f * (float)W), mG * dG_ddy * (0.5f * (float)H),
+                                            -0.5f * gdx * dx * mG, -gdx * dy * mG, -0.5f * gdy * dy * mG,
+                                            G * dLda_mag};
                         for (int k = 0; k < 6; ++k) {
 #pragma omp atomic
                             g_abs[17 * (size_t)id + k] += (double)fabsf(t[k]);

@@ -151,7 +151,7 @@ def _check_against_oracle(inputs, cam, bg, deg, mod, dev, seed=0, grad_rtol=GRAD
                 # (means2D too -- round 6, fuzz seed 9345: 1500 splats as large as the scene on a 296 x 13 frame with upstream
                 # gradients on depth and alpha only; two screen-space gradients whose terms cancel were off by 2.3 / 1.3
                 # allowances, the same value in every run and with every build back to round 5: fp32 summation, not atomics)
-                sens = summation_sensitivity(oc, st, og, names=("means3D", "means2D", "scales", "rotations", "opacities"), rtol=grad_rtol, floor=1e-6)
+                sens = summation_sensitivity(oc, st, og, names=("means3D", "means2D", "scales", "rotations", "opacities", "cov3D_precomp"), rtol=grad_rtol, floor=1e-6)
             if k in sens:
                 moved = sens[k]
                 factor = 4.0 if (flags | hip_flags) & 256 else 8.0

@@ -64,6 +64,17 @@ __device__ __forceinline__ void wave_prefix_add_x2(float& a, float& b)
                  : "+v"(a), "+v"(b));
 }
 
+// the scan result of the lane BELOW (lane 0: zero) -- an inclusive prefix turned into the exclusive one without a subtraction
+__device__ __forceinline__ void wave_shift_up_x2(float a, float b, float& xa, float& xb)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_mov_b32_dpp %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_mov_b32_dpp %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 0"
+                 : "=&v"(xa), "=&v"(xb)
+                 : "v"(a), "v"(b));
+}
+
 // per-pixel upstream gradients of the 11 blended channels
 struct PixGrad {
     float g[NCH];
@@ -409,7 +420,14 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                 float sa = wu.x, sb = wu.y;
                 wave_prefix_add_x2(sa, sb);                               // sum over entries >= mine
                 const f2 psum = {sa, sb};
-                const f2 behind = Sc + (psum - wu);
+                // "behind" = the carry + the EXCLUSIVE prefix, taken from the lane below (round 6).  It used to be psum - wu: for a
+                // near-opaque splat in front of faint ones (opacity 1: alpha clamped at 0.99) that subtraction leaves the small
+                // sum behind it with the absolute rounding error of the large one, and dL/dalpha then divides by 1 - alpha = 0.01
+                // -- fuzz seed 11136: an opacity gradient off by 4.7 % where the checker's sequential sum and the float64
+                // restatement agree to 1e-4.  Same two issue slots as the subtraction.
+                float ea, eb;
+                wave_shift_up_x2(sa, sb, ea, eb);
+                const f2 behind = Sc + (f2){ea, eb};
                 // carries for the next (nearer) chunk: values at the chunk's first entry = lane 63
                 if (lane == 63) {
                     const f2 Sn = Sc + psum;

@@ -214,3 +214,110 @@ void chunk_stats(int H, int W, const int* ranges, const uint32_t* point_list, co
     }
     for (int k = 0; k < 13; ++k) out[k] = o[k];
 }
+
+/* tail statistics (round 6): scheme 0's LAST chunk of a unit holds n = nrel - 64*floor((nrel-1)/64) entries; when n <= 16 the
+ * wave could hold the chunk once per 16-lane row and let every row walk another pixel pair (8 trips of 4 pairs), when n <= 32
+ * once per half (16 trips of 2 pairs).  out[0..2] cheap/reject/accepted trips of ALL chunks now; out[3..5] the same with tails
+ * <= 16 row-packed; out[6..8] with tails <= 16 row-packed and tails <= 32 half-packed; out[9] chunks, out[10] tails <= 16,
+ * out[11] tails 17..32, out[12] tails 33..48, out[13] tails 49..64 (incl. full last chunks), out[14] units,
+ * out[15] accepted trips now that belong to tails <= 16, out[16] to tails 17..32 */
+void tail_stats(int H, int W, const int* ranges, const uint32_t* point_list, const float* xy, const float* conic_op,
+                const uint32_t* n_contrib, double* out)
+{
+    int gx = (W + 15) / 16, gy = (H + 15) / 16;
+    double o[23] = {0};
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gx * gy; ++tile) {
+        int tx = tile % gx, ty = tile / gx;
+        int s = ranges[2 * tile], e = ranges[2 * tile + 1];
+        double lo[23] = {0};
+        int maxnc = 0;
+        for (int ly = 0; ly < 16; ++ly) for (int lx = 0; lx < 16; ++lx) {
+            int px = tx * 16 + lx, py = ty * 16 + ly;
+            if (px < W && py < H && (int)n_contrib[(size_t)py * W + px] > maxnc) maxnc = n_contrib[(size_t)py * W + px];
+        }
+        static __thread unsigned long long hit[256];
+        static __thread int relj[256];
+        for (int sb = s; sb < e && sb - s < maxnc; sb += 256) {
+            int se = sb + 256 < e ? sb + 256 : e;
+            for (int reg = 0; reg < 4; ++reg) {
+                int nrel = 0, nc[64], wmax = 0;
+                for (int l = 0; l < 64; ++l) {
+                    int px = tx * 16 + (reg % 2) * 8 + (l % 8), py = ty * 16 + (reg / 2) * 8 + (l / 8);
+                    nc[l] = (px < W && py < H) ? (int)n_contrib[(size_t)py * W + px] : 0;
+                    if (nc[l] > wmax) wmax = nc[l];
+                }
+                for (int j = sb; j < se; ++j) {
+                    int id = point_list[j];
+                    unsigned long long h = 0; int any = 0;
+                    for (int l = 0; l < 64; ++l) {
+                        int px = tx * 16 + (reg % 2) * 8 + (l % 8), py = ty * 16 + (reg / 2) * 8 + (l / 8);
+                        if (px >= W || py >= H) continue;
+                        float dx = xy[2 * id] - (float)px, dy = xy[2 * id + 1] - (float)py;
+                        const float* con = conic_op + 4 * id;
+                        float q = fmaf(con[2] * dy, dy, (con[0] * dx) * dx);
+                        float power = fmaf(-0.5f, q, -((con[1] * dx) * dy));
+                        if (power > 0.0f) continue;
+                        float alpha = fminf(0.99f, con[3] * vr_exp(power));
+                        if (alpha < 1.0f / 255.0f) continue;
+                        any = 1;
+                        if (j - s < nc[l]) h |= 1ull << l;
+                    }
+                    if (any) { hit[nrel] = h; relj[nrel] = j - s; nrel++; }
+                }
+                if (!nrel) continue;
+                lo[14] += 1;
+                /* entries behind EVERY pixel's last contributor dropped before chunking (relj >= wmax), then modes 2's packing */
+                int ncut = 0;
+                while (ncut < nrel && relj[ncut] < wmax) ++ncut;
+                lo[20] += nrel; lo[21] += ncut;
+                for (int c0 = 0; c0 < ncut; c0 += 64) {
+                    int c1 = c0 + 64 < ncut ? c0 + 64 : ncut;
+                    int n = c1 - c0, tail = c1 == ncut;
+                    int chunk_lo = relj[c0];
+                    lo[22] += 1;
+                    unsigned long long all = 0;
+                    for (int r = c0; r < c1; ++r) all |= hit[r];
+                    int per = tail && n <= 16 ? 4 : tail && n <= 32 ? 2 : 1;
+                    for (int g = 0; g < 32 / per; ++g) {
+                        unsigned long long pm = 0;
+                        for (int k = 0; k < per; ++k) pm |= 3ull << (2 * (g * per + k));
+                        int mnc = 0;
+                        for (int l = 0; l < 64; ++l) if ((pm >> l) & 1ull) if (nc[l] > mnc) mnc = nc[l];
+                        int cls = mnc <= chunk_lo ? 0 : !(all & pm) ? 1 : 2;
+                        lo[17 + cls] += 1;
+                    }
+                }
+                for (int c0 = 0; c0 < nrel; c0 += 64) {
+                    int c1 = c0 + 64 < nrel ? c0 + 64 : nrel;
+                    int n = c1 - c0, tail = c1 == nrel;
+                    int chunk_lo = relj[c0];
+                    lo[9] += 1;
+                    if (tail) lo[10 + (n - 1) / 16] += 1;
+                    if (!(chunk_lo < wmax)) continue;
+                    unsigned long long all = 0;
+                    for (int r = c0; r < c1; ++r) all |= hit[r];
+                    /* trips of this chunk under a grouping of `per` pairs per trip: pairs g*per .. g*per+per-1 */
+                    for (int mode = 0; mode < 3; ++mode) {
+                        int per = 1;
+                        if (tail && n <= 16 && mode >= 1) per = 4;
+                        else if (tail && n <= 32 && mode >= 2) per = 2;
+                        for (int g = 0; g < 32 / per; ++g) {
+                            unsigned long long pm = 0;
+                            for (int k = 0; k < per; ++k) pm |= 3ull << (2 * (g * per + k));
+                            int mnc = 0;
+                            for (int l = 0; l < 64; ++l) if ((pm >> l) & 1ull) if (nc[l] > mnc) mnc = nc[l];
+                            int cls = mnc <= chunk_lo ? 0 : !(all & pm) ? 1 : 2;
+                            lo[3 * mode + cls] += 1;
+                            if (mode == 0 && cls == 2 && tail && n <= 16) lo[15] += 1;
+                            if (mode == 0 && cls == 2 && tail && n > 16 && n <= 32) lo[16] += 1;
+                        }
+                    }
+                }
+            }
+        }
+#pragma omp critical
+        { for (int k = 0; k < 23; ++k) o[k] += lo[k]; }
+    }
+    for (int k = 0; k < 23; ++k) out[k] = o[k];
+}

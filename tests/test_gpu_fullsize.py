@@ -305,8 +305,8 @@ def _oracle_parity(name, sc_inputs, deg, cam, dev, hip_runs=1, flags=0):
         bad = assert_grad_close(f"{name} det {k}", h_grads[k], og[k], rtol=2e-4, floor=2e-7, outliers=1e-5 if plain else 1e-4,
                                 near=1e-5 if plain else 1e-3, cap=3.0, explain=explain, ill=ill)
         # EVERY offender is explained: its error is within 8x of what the summation-rounding model moves the oracle's
-        # own result by (plus the allowance) -- the model takes the largest of three 1-sigma draws, the actual rounding
-        # may sit at 3 sigma
+        # own result by (plus the allowance) -- the model takes the largest of sixteen 1-sigma draws (helpers.py), the actual
+        # rounding may sit at 3 sigma
         _, ratio = grad_mismatch(h_grads[k], og[k], 2e-4, 2e-7)
         unexplained = bad[ratio[bad] > 1.0 + EXPLAIN_FACTOR * moved[k][bad]]
         # how many rows needed an explanation at all, and the largest multiple of its measured movement any of them used

@@ -31,6 +31,12 @@
 namespace vr {
 
 constexpr int NACC = 17;  // conic(3) opacity(1) attr(11) mean2D(2)
+#ifndef VR_BWD_CUT
+#define VR_BWD_CUT 1             // (0: A/B build that keeps the entries behind every pixel's last contributor, --variant nocut)
+#endif
+#ifndef VR_BWD_PACK_TAILS
+#define VR_BWD_PACK_TAILS 1      // (0: the A/B build without row-packed tail chunks, python -m vegs_amd.build --variant nopack)
+#endif
 
 // wave64 inclusive prefix scans in DPP: row_shr 1,2,4,8 inside each 16-lane row, then row_bcast 15 / 31.
 // VOP2-DPP semantics do the masking for free: a lane whose DPP source is out of range (or whose row is
@@ -73,6 +79,69 @@ __device__ __forceinline__ void wave_shift_up_x2(float a, float b, float& xa, fl
                  "s_nop 0"
                  : "=&v"(xa), "=&v"(xb)
                  : "v"(a), "v"(b));
+}
+
+// ---- the same scans restricted to GROUPS of 64 / ROWS lanes (ROWS = 2: the wave's halves, ROWS = 4: its 16-lane DPP rows), for
+// the row-packed tail chunks of k_seg_bwd (below): the full scan minus its last one / two steps
+template <int ROWS>
+__device__ __forceinline__ void group_prefix_mul_x2(float& a, float& b)
+{
+    if (ROWS == 1) { wave_prefix_mul_x2(a, b); return; }
+    if (ROWS == 2)
+        asm volatile("s_nop 1\n\t"
+                     VR_DPP2("v_mul_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")
+                     VR_DPP2("v_mul_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
+                     VR_DPP2("v_mul_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf")
+                     VR_DPP2("v_mul_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
+                     VR_DPP2("v_mul_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+                     "s_nop 0"
+                     : "+v"(a), "+v"(b));
+    else
+        asm volatile("s_nop 1\n\t"
+                     VR_DPP2("v_mul_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")
+                     VR_DPP2("v_mul_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
+                     VR_DPP2("v_mul_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf")
+                     VR_DPP2("v_mul_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
+                     "s_nop 0"
+                     : "+v"(a), "+v"(b));
+}
+template <int ROWS>
+__device__ __forceinline__ void group_prefix_add_x2(float& a, float& b)
+{
+    if (ROWS == 1) { wave_prefix_add_x2(a, b); return; }
+    if (ROWS == 2)
+        asm volatile("s_nop 1\n\t"
+                     VR_DPP2("v_add_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")
+                     VR_DPP2("v_add_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
+                     VR_DPP2("v_add_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf")
+                     VR_DPP2("v_add_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
+                     VR_DPP2("v_add_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+                     "s_nop 0"
+                     : "+v"(a), "+v"(b));
+    else
+        asm volatile("s_nop 1\n\t"
+                     VR_DPP2("v_add_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")
+                     VR_DPP2("v_add_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
+                     VR_DPP2("v_add_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf")
+                     VR_DPP2("v_add_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
+                     "s_nop 0"
+                     : "+v"(a), "+v"(b));
+}
+// the scan result of the lane below INSIDE the group (the group's first lane: zero)
+template <int ROWS>
+__device__ __forceinline__ void group_shift_up_x2(float a, float b, float& xa, float& xb, int lane)
+{
+    if (ROWS == 4) {
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b32_dpp %0, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                     "v_mov_b32_dpp %1, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                     "s_nop 0"
+                     : "=&v"(xa), "=&v"(xb)
+                     : "v"(a), "v"(b));
+        return;
+    }
+    wave_shift_up_x2(a, b, xa, xb);
+    if (ROWS == 2 && lane == 32) { xa = 0.0f; xb = 0.0f; }
 }
 
 // per-pixel upstream gradients of the 11 blended channels
@@ -212,6 +281,141 @@ k_seg_suffix(int ntiles, uint32_t cap, const uint32_t* __restrict__ seg_off, con
 template <bool EXACT>
 __device__ __forceinline__ float bwd_rcp(float x) { return EXACT ? 1.0f / x : __builtin_amdgcn_rcpf(x); }
 
+// The pixel loop of one chunk.  ROWS = 1: the wave holds 64 entries and walks the region's 32 pixel pairs one per trip.
+// ROWS = 4 / 2 (round 6, the ROW-PACKED TAIL): a region's relevant entries are cut into chunks of 64 from the front, so the last
+// chunk holds 1 ... 64 of them -- and a chunk of <= 16 (<= 32) entries used to cost the same 32 trips with three quarters
+// (half) of the lanes empty.  Such a chunk is now held once per 16-lane DPP row (once per half), and every row (half) walks
+// ANOTHER pixel pair of the trip: 8 (16) trips, the scans stop at the row (half) boundary, the pixel state arrives as one LDS
+// broadcast per group instead of per wave, and the groups' partial sums are added at the flush.  On the headline view 29 % of
+// the chunks are such tails (profiles/tools/pairstats.py: tail_stats): accepted trips 820 k -> 725 k.
+template <int ROWS, bool NO_EXTRA, bool DET, bool FAST, bool NO_DEPTH>
+__device__ __forceinline__ void bwd_chunk_trips(const int lane, const int e, const int chunk_lo, const int v_nc, const float sx,
+                                                const float sy, const float kA, const float kB, const float kC, const float thr2,
+                                                const float op, const float cA, const float cB, const float cC,
+                                                const float (&at)[NCH], f2 (&acc)[NACC], float4 (*pix)[32], const int2* ncp)
+{
+    constexpr int SPAN = 64 / ROWS;
+    constexpr bool no_extra = NO_EXTRA;
+    const int grp = ROWS == 1 ? 0 : lane / SPAN;
+    for (int t = 0; t < 32 / ROWS; ++t) {
+        int pp, nc0, nc1;
+        if (ROWS == 1) {
+            pp = t;
+            nc0 = __builtin_amdgcn_readlane(v_nc, 2 * t);
+            nc1 = __builtin_amdgcn_readlane(v_nc, 2 * t + 1);
+            if (max(nc0, nc1) <= chunk_lo) continue;  // neither pixel has a contributor in this chunk (wave-uniform)
+        } else {        // every group its own pair: the pixels' last contributors come from LDS, per lane
+            pp = t * ROWS + grp;
+            const int2 n = ncp[pp];
+            nc0 = n.x;
+            nc1 = n.y;
+            if (__builtin_amdgcn_ballot_w64(max(nc0, nc1) > chunk_lo) == 0ull) continue;
+        }
+        const float4 r0 = pix[0][pp];
+        const f2 pxf = {r0.x, r0.y}, pyf = {r0.z, r0.w};
+        f2 dx, dy;
+        const f2 power = splat_power2_x2(sx, sy, kA, kB, kC, pxf, pyf, dx, dy);    // in units of log2 e, as the forward
+        // thr2 <= power <= 0 as ONE comparison: the median of (power, thr2, 0) is power itself.  (A splat too faint
+        // to reach 1/255 anywhere has thr2 > 0 and passes this at power == 0 exactly; the alpha test below drops it.)
+        const bool pre0 = (e < nc0) & (__builtin_amdgcn_fmed3f(power.x, thr2, 0.0f) == power.x);
+        const bool pre1 = (e < nc1) & (__builtin_amdgcn_fmed3f(power.y, thr2, 0.0f) == power.y);
+        if (__builtin_amdgcn_ballot_w64(pre0 | pre1) == 0ull) continue;  // no splat of the chunk reaches the pair: carries unchanged
+        // The forward's own 2^x (bit for bit: same operations), not the hardware's: WHICH fragments contributed is
+        // the forward's decision (alpha >= 1/255), and v_exp_f32 agrees with it only to ~2 ulp -- rare to matter,
+        // but a faint splat has ALL its fragments at the threshold, and one fragment of twenty classified the other
+        // way moved its gradient by 4.5 % (the C-harness test caught it).  Evaluated for both pixels in packed
+        // arithmetic; +14 us per view over two v_exp_f32 -- and so did the two cheaper-looking alternatives (a band
+        // test around the threshold with the exact function inline or out of line in the rare branch).
+        f2 G;
+        if (FAST) {      // VR_FLAG_FAST_EXP: the instruction the forward of this view used
+            G.x = __builtin_amdgcn_exp2f(power.x);
+            G.y = __builtin_amdgcn_exp2f(power.y);
+        } else {
+            const f2 n = {rintf(power.x), rintf(power.y)};
+            const f2 f = power - n;
+            f2 p = f2_splat(EXP2_C5);
+            p = f2_fma(p, f, f2_splat(EXP2_C4));
+            p = f2_fma(p, f, f2_splat(EXP2_C3));
+            p = f2_fma(p, f, f2_splat(EXP2_C2));
+            p = f2_fma(p, f, f2_splat(EXP2_C1));
+            p = f2_fma(p, f, f2_splat(1.0f));
+            G.x = ldexpf(p.x, (int)n.x);
+            G.y = ldexpf(p.y, (int)n.y);
+        }
+        const f2 alpha = {fminf(ALPHA_MAX, op * G.x), fminf(ALPHA_MAX, op * G.y)};
+        const bool contrib0 = pre0 && !(alpha.x < ALPHA_MIN), contrib1 = pre1 && !(alpha.y < ALPHA_MIN);
+        const f2 a_eff = {contrib0 ? alpha.x : 0.0f, contrib1 ? alpha.y : 0.0f};
+        G.x = contrib0 ? G.x : 0.0f;              // (exp of a positive exponent may be inf: keep it out of 0*inf)
+        G.y = contrib1 ? G.y : 0.0f;
+        const float4 r1 = pix[1][pp], r2 = pix[2][pp], r3 = pix[3][pp], r4 = pix[4][pp],
+                     r5 = pix[5][pp], r6 = pix[6][pp], r7 = pix[7][pp];
+        const f2 bgterm = {r1.x, r1.y}, Tc = {r7.x, r7.y}, Sc = {r7.z, r7.w};
+        const f2 g[NCH] = {{r1.z, r1.w}, {r2.x, r2.y}, {r2.z, r2.w}, {r3.x, r3.y}, {r3.z, r3.w}, {r4.x, r4.y},
+                           {r4.z, r4.w}, {r5.x, r5.y}, {r5.z, r5.w}, {r6.x, r6.y}, {r6.z, r6.w}};
+        const f2 om = f2_splat(1.0f) - a_eff;
+        float pa = om.x, pb = om.y;
+        group_prefix_mul_x2<ROWS>(pa, pb);                               // prod over entries >= mine
+        const f2 Tl = Tc * (f2){bwd_rcp<DET>(pa), bwd_rcp<DET>(pb)};   // T in front of my splat
+        const f2 wgt = a_eff * Tl;
+        // <attr, g> in two independent chains (a dependent v_pk_fma_f32 costs an extra wait state)
+        f2 u0 = f2_splat(at[0]) * g[0], u1 = f2_splat(at[1]) * g[1];
+        f2 u;
+        if (!no_extra) {
+#pragma unroll
+            for (int k = 2; k + 1 < NCH; k += 2) {
+                u0 = f2_fma(f2_splat(at[k]), g[k], u0);
+                if (!(NO_DEPTH && k + 1 == 3)) u1 = f2_fma(f2_splat(at[k + 1]), g[k + 1], u1);
+            }
+            u = f2_fma(f2_splat(at[NCH - 1]), g[NCH - 1], u0) + u1;
+        } else {
+            u = f2_fma(f2_splat(at[2]), g[2], u0) + u1;     // colour channels only (wave-uniform branch)
+        }
+        const f2 wu = wgt * u;
+        float sa = wu.x, sb = wu.y;
+        group_prefix_add_x2<ROWS>(sa, sb);                               // sum over entries >= mine
+        const f2 psum = {sa, sb};
+        // "behind" = the carry + the EXCLUSIVE prefix, taken from the lane below (round 6).  It used to be psum - wu: for a
+        // near-opaque splat in front of faint ones (opacity 1: alpha clamped at 0.99) that subtraction leaves the small
+        // sum behind it with the absolute rounding error of the large one, and dL/dalpha then divides by 1 - alpha = 0.01
+        // -- fuzz seed 11136: an opacity gradient off by 4.7 % where the checker's sequential sum and the float64
+        // restatement agree to 1e-4.  Same two issue slots as the subtraction.
+        float ea, eb;
+        group_shift_up_x2<ROWS>(sa, sb, ea, eb, lane);
+        const f2 behind = Sc + (f2){ea, eb};
+        // carries for the next (nearer) chunk: values at the chunk's first entry = the group's last lane
+        if ((lane & (SPAN - 1)) == SPAN - 1) {
+            const f2 Sn = Sc + psum;
+            pix[7][pp] = make_float4(Tl.x, Tl.y, Sn.x, Sn.y);
+        }
+        if (contrib0 || contrib1) {
+            // Per-fragment work kept to what depends on the pixel.  With a = dL/dG * G (zero for a lane that does
+            // not contribute: G and alpha are masked above, everything below is finite):
+            //   conic:   dA += -1/2 a dx^2   dB += -a dx dy   dC += -1/2 a dy^2
+            //   mean2D:  dx += -a (A dx + B dy)   dy += -a (C dy + B dx)
+            // the factors -1/2 and -1 belong to the SPLAT, i.e. to the lane: sum(a dx dx), sum(a dx dy),
+            // sum(a dy dy), sum(a (A dx + B dy)), sum(a (C dy + B dx)) are accumulated here (12 packed operations
+            // instead of 20) and the signs applied once per entry at the flush.  (The conic cannot be pulled out of
+            // the mean2D sums as well: A sum(a dx) + B sum(a dy) cancels AFTER the sums were rounded, and for edge-on
+            // discs that lost two digits -- the C-harness test caught rows off by 2 %.)
+            const f2 inv_om = {bwd_rcp<DET>(om.x), bwd_rcp<DET>(om.y)};
+            // (finite also for a lane that does not contribute: its alpha is 0, so 1 - alpha = 1, and the prefix
+            // product of at most 64 factors >= 0.01 it divides by cannot reach zero before Tc itself has)
+            const f2 dLda = f2_fma(Tl, u, -(behind + bgterm) * inv_om);
+            const f2 a = (f2_splat(op) * dLda) * G;
+            const f2 adx = a * dx, ady = a * dy;
+            acc[0] = f2_fma(adx, dx, acc[0]);
+            acc[1] = f2_fma(adx, dy, acc[1]);
+            acc[2] = f2_fma(ady, dy, acc[2]);
+            acc[3] = f2_fma(G, dLda, acc[3]);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+                if (!(NO_DEPTH && k == 3)) acc[4 + k] = f2_fma(wgt, g[k], acc[4 + k]);
+            acc[15] = f2_fma(a, f2_fma(f2_splat(cA), dx, f2_splat(cB) * dy), acc[15]);
+            acc[16] = f2_fma(a, f2_fma(f2_splat(cC), dy, f2_splat(cB) * dx), acc[16]);
+        }
+    }
+}
+
 // NO_DEPTH (round 6): no upstream gradient on the depth image (dL_ddepth == NULL: VEGS' losses reach colour, cov_quat and
 // cov_scale only, train.py:152-168) -- its channel's terms, fma(depth_s, 0, u) in the <attr, g> chain and fma(w, 0, acc) in the
 // accumulators, are the identity for every finite depth and are left out: bit-identical sums, two packed instructions fewer
@@ -231,6 +435,7 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     __shared__ uint32_t rel_gid[SEG];             // the strip's relevant entries, ascending: Gaussian id ...
     __shared__ unsigned short rel_j[SEG];         // ... and entry index inside the segment
     __shared__ float4 pix[8][32];                 // per PIXEL PAIR [slot][pair]: coords, bg term, 11 upstream grads, carries
+    __shared__ int2 ncp[32];                      // per pixel pair: the two pixels' n_contrib (row-packed tail chunks read it per lane)
     SegCtx c;
     const int w = (int)(blockIdx.x & 3u);
     const int ntiles = cam.gx * cam.gy;
@@ -260,8 +465,24 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     const float Tnext = c.flag == 2u ? Tbuf[(size_t)(c.seg + 1) * SEG + pixslot] : -1.0f;
     float v_Scar = Ubuf[(size_t)c.seg * SEG + pixslot];
 
-    // ---- the entries relevant to this strip, compacted in list order
-    const unsigned long long m0 = uniform64(mraw0), m1 = uniform64(mraw1), m2 = uniform64(mraw2), m3 = uniform64(mraw3);
+    // the region's farthest last contributor: list entries at or behind it reach no pixel of this wave in the backward
+    int mx = v_nc;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
+    const int wave_maxc = mx;
+
+    // ---- the entries relevant to this strip, compacted in list order.  The forward's masks say "alpha >= 1/255 at some pixel
+    // of the region"; a pixel that has stopped takes nothing from the entries behind its last contributor, so the entries
+    // behind EVERY pixel's last contributor are dropped here (round 6: 15 % of the held entries of the headline view, the
+    // regions' last needed segments; they used to be gathered, held and skipped chunk by chunk)
+    unsigned long long m0 = uniform64(mraw0), m1 = uniform64(mraw1), m2 = uniform64(mraw2), m3 = uniform64(mraw3);
+    if (VR_BWD_CUT) {
+        const int cut = wave_maxc - c.sl * SEG;        // entries [0, cut) of the segment can still matter
+        m0 = cut >= 64 ? m0 : cut <= 0 ? 0ull : m0 & ((1ull << cut) - 1ull);
+        m1 = cut >= 128 ? m1 : cut <= 64 ? 0ull : m1 & ((1ull << (cut - 64)) - 1ull);
+        m2 = cut >= 192 ? m2 : cut <= 128 ? 0ull : m2 & ((1ull << (cut - 128)) - 1ull);
+        m3 = cut >= 256 ? m3 : cut <= 192 ? 0ull : m3 & ((1ull << (cut - 192)) - 1ull);
+    }
     const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
     const int nrel = n0 + n1 + n2 + n3;
     if (nrel == 0) return;
@@ -308,23 +529,23 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
         float other[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) other[k] = __shfl_xor(mine[k], 1, 64);
+        const int nc_other = __shfl_xor(v_nc, 1, 64);
         if ((lane & 1) == 0) {
 #pragma unroll
             for (int sl = 0; sl < 8; ++sl)
                 pix[sl][lane >> 1] = make_float4(mine[2 * sl], other[2 * sl], mine[2 * sl + 1], other[2 * sl + 1]);
+            ncp[lane >> 1] = make_int2(v_nc, nc_other);
         }
     }
     __syncthreads();
 
-    int mx = v_nc;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
-    const int wave_maxc = mx;
     const int nchunks = (nrel + 63) >> 6;
 
     for (int ch = nchunks - 1; ch >= 0; --ch) {
-        // ---- lane l owns the strip's relevant entry number ch*64 + (63-l): back-to-front over lanes
-        const int r = ch * 64 + (63 - lane);
+        // ---- lane l owns the strip's relevant entry number ch*64 + (63-l): back-to-front over lanes.  The LAST chunk (the first
+        // one walked) may hold few entries: <= 16 of them are held once per 16-lane row, <= 32 once per half (bwd_chunk_trips)
+        const int span = !VR_BWD_PACK_TAILS ? 64 : (nrel - ch * 64 <= 16 ? 16 : nrel - ch * 64 <= 32 ? 32 : 64);      // (wave-uniform)
+        const int r = ch * 64 + (span - 1 - (lane & (span - 1)));
         const bool has = r < nrel;
         const int ej = has ? (int)rel_j[r] : 0;        // entry index inside the segment
         // tile-relative list index; a lane without an entry sits behind every pixel's last contributor, so the
@@ -354,112 +575,11 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
         const int chunk_lo = seg_lo + (int)rel_j[ch * 64];
 
         if (chunk_lo < wave_maxc) {
-            for (int pp = 0; pp < 32; ++pp) {
-                const int nc0 = __builtin_amdgcn_readlane(v_nc, 2 * pp), nc1 = __builtin_amdgcn_readlane(v_nc, 2 * pp + 1);
-                if (max(nc0, nc1) <= chunk_lo) continue;  // neither pixel has a contributor in this chunk (wave-uniform)
-                const float4 r0 = pix[0][pp];
-                const f2 pxf = {r0.x, r0.y}, pyf = {r0.z, r0.w};
-                f2 dx, dy;
-                const f2 power = splat_power2_x2(sx, sy, kA, kB, kC, pxf, pyf, dx, dy);    // in units of log2 e, as the forward
-                // thr2 <= power <= 0 as ONE comparison: the median of (power, thr2, 0) is power itself.  (A splat too faint
-                // to reach 1/255 anywhere has thr2 > 0 and passes this at power == 0 exactly; the alpha test below drops it.)
-                const bool pre0 = (e < nc0) & (__builtin_amdgcn_fmed3f(power.x, thr2, 0.0f) == power.x);
-                const bool pre1 = (e < nc1) & (__builtin_amdgcn_fmed3f(power.y, thr2, 0.0f) == power.y);
-                if (__builtin_amdgcn_ballot_w64(pre0 | pre1) == 0ull) continue;  // no splat of the chunk reaches the pair: carries unchanged
-                // The forward's own 2^x (bit for bit: same operations), not the hardware's: WHICH fragments contributed is
-                // the forward's decision (alpha >= 1/255), and v_exp_f32 agrees with it only to ~2 ulp -- rare to matter,
-                // but a faint splat has ALL its fragments at the threshold, and one fragment of twenty classified the other
-                // way moved its gradient by 4.5 % (the C-harness test caught it).  Evaluated for both pixels in packed
-                // arithmetic; +14 us per view over two v_exp_f32 -- and so did the two cheaper-looking alternatives (a band
-                // test around the threshold with the exact function inline or out of line in the rare branch).
-                f2 G;
-                if (FAST) {      // VR_FLAG_FAST_EXP: the instruction the forward of this view used
-                    G.x = __builtin_amdgcn_exp2f(power.x);
-                    G.y = __builtin_amdgcn_exp2f(power.y);
-                } else {
-                    const f2 n = {rintf(power.x), rintf(power.y)};
-                    const f2 f = power - n;
-                    f2 p = f2_splat(EXP2_C5);
-                    p = f2_fma(p, f, f2_splat(EXP2_C4));
-                    p = f2_fma(p, f, f2_splat(EXP2_C3));
-                    p = f2_fma(p, f, f2_splat(EXP2_C2));
-                    p = f2_fma(p, f, f2_splat(EXP2_C1));
-                    p = f2_fma(p, f, f2_splat(1.0f));
-                    G.x = ldexpf(p.x, (int)n.x);
-                    G.y = ldexpf(p.y, (int)n.y);
-                }
-                const f2 alpha = {fminf(ALPHA_MAX, op * G.x), fminf(ALPHA_MAX, op * G.y)};
-                const bool contrib0 = pre0 && !(alpha.x < ALPHA_MIN), contrib1 = pre1 && !(alpha.y < ALPHA_MIN);
-                const f2 a_eff = {contrib0 ? alpha.x : 0.0f, contrib1 ? alpha.y : 0.0f};
-                G.x = contrib0 ? G.x : 0.0f;              // (exp of a positive exponent may be inf: keep it out of 0*inf)
-                G.y = contrib1 ? G.y : 0.0f;
-                const float4 r1 = pix[1][pp], r2 = pix[2][pp], r3 = pix[3][pp], r4 = pix[4][pp],
-                             r5 = pix[5][pp], r6 = pix[6][pp], r7 = pix[7][pp];
-                const f2 bgterm = {r1.x, r1.y}, Tc = {r7.x, r7.y}, Sc = {r7.z, r7.w};
-                const f2 g[NCH] = {{r1.z, r1.w}, {r2.x, r2.y}, {r2.z, r2.w}, {r3.x, r3.y}, {r3.z, r3.w}, {r4.x, r4.y},
-                                   {r4.z, r4.w}, {r5.x, r5.y}, {r5.z, r5.w}, {r6.x, r6.y}, {r6.z, r6.w}};
-                const f2 om = f2_splat(1.0f) - a_eff;
-                float pa = om.x, pb = om.y;
-                wave_prefix_mul_x2(pa, pb);                               // prod over entries >= mine
-                const f2 Tl = Tc * (f2){bwd_rcp<DET>(pa), bwd_rcp<DET>(pb)};   // T in front of my splat
-                const f2 wgt = a_eff * Tl;
-                // <attr, g> in two independent chains (a dependent v_pk_fma_f32 costs an extra wait state)
-                f2 u0 = f2_splat(at[0]) * g[0], u1 = f2_splat(at[1]) * g[1];
-                f2 u;
-                if (!no_extra) {
-#pragma unroll
-                    for (int k = 2; k + 1 < NCH; k += 2) {
-                        u0 = f2_fma(f2_splat(at[k]), g[k], u0);
-                        if (!(NO_DEPTH && k + 1 == 3)) u1 = f2_fma(f2_splat(at[k + 1]), g[k + 1], u1);
-                    }
-                    u = f2_fma(f2_splat(at[NCH - 1]), g[NCH - 1], u0) + u1;
-                } else {
-                    u = f2_fma(f2_splat(at[2]), g[2], u0) + u1;     // colour channels only (wave-uniform branch)
-                }
-                const f2 wu = wgt * u;
-                float sa = wu.x, sb = wu.y;
-                wave_prefix_add_x2(sa, sb);                               // sum over entries >= mine
-                const f2 psum = {sa, sb};
-                // "behind" = the carry + the EXCLUSIVE prefix, taken from the lane below (round 6).  It used to be psum - wu: for a
-                // near-opaque splat in front of faint ones (opacity 1: alpha clamped at 0.99) that subtraction leaves the small
-                // sum behind it with the absolute rounding error of the large one, and dL/dalpha then divides by 1 - alpha = 0.01
-                // -- fuzz seed 11136: an opacity gradient off by 4.7 % where the checker's sequential sum and the float64
-                // restatement agree to 1e-4.  Same two issue slots as the subtraction.
-                float ea, eb;
-                wave_shift_up_x2(sa, sb, ea, eb);
-                const f2 behind = Sc + (f2){ea, eb};
-                // carries for the next (nearer) chunk: values at the chunk's first entry = lane 63
-                if (lane == 63) {
-                    const f2 Sn = Sc + psum;
-                    pix[7][pp] = make_float4(Tl.x, Tl.y, Sn.x, Sn.y);
-                }
-                if (contrib0 || contrib1) {
-                    // Per-fragment work kept to what depends on the pixel.  With a = dL/dG * G (zero for a lane that does
-                    // not contribute: G and alpha are masked above, everything below is finite):
-                    //   conic:   dA += -1/2 a dx^2   dB += -a dx dy   dC += -1/2 a dy^2
-                    //   mean2D:  dx += -a (A dx + B dy)   dy += -a (C dy + B dx)
-                    // the factors -1/2 and -1 belong to the SPLAT, i.e. to the lane: sum(a dx dx), sum(a dx dy),
-                    // sum(a dy dy), sum(a (A dx + B dy)), sum(a (C dy + B dx)) are accumulated here (12 packed operations
-                    // instead of 20) and the signs applied once per entry at the flush.  (The conic cannot be pulled out of
-                    // the mean2D sums as well: A sum(a dx) + B sum(a dy) cancels AFTER the sums were rounded, and for edge-on
-                    // discs that lost two digits -- the C-harness test caught rows off by 2 %.)
-                    const f2 inv_om = {bwd_rcp<DET>(om.x), bwd_rcp<DET>(om.y)};
-                    // (finite also for a lane that does not contribute: its alpha is 0, so 1 - alpha = 1, and the prefix
-                    // product of at most 64 factors >= 0.01 it divides by cannot reach zero before Tc itself has)
-                    const f2 dLda = f2_fma(Tl, u, -(behind + bgterm) * inv_om);
-                    const f2 a = (f2_splat(op) * dLda) * G;
-                    const f2 adx = a * dx, ady = a * dy;
-                    acc[0] = f2_fma(adx, dx, acc[0]);
-                    acc[1] = f2_fma(adx, dy, acc[1]);
-                    acc[2] = f2_fma(ady, dy, acc[2]);
-                    acc[3] = f2_fma(G, dLda, acc[3]);
-#pragma unroll
-                    for (int k = 0; k < NCH; ++k)
-                        if (!(NO_DEPTH && k == 3)) acc[4 + k] = f2_fma(wgt, g[k], acc[4 + k]);
-                    acc[15] = f2_fma(a, f2_fma(f2_splat(cA), dx, f2_splat(cB) * dy), acc[15]);
-                    acc[16] = f2_fma(a, f2_fma(f2_splat(cC), dy, f2_splat(cB) * dx), acc[16]);
-                }
-            }
+#define VR_TRIPS(R) bwd_chunk_trips<R, NO_EXTRA, DET, FAST, NO_DEPTH>(lane, e, chunk_lo, v_nc, sx, sy, kA, kB, kC, thr2, op, cA, cB, cC, at, acc, pix, ncp)
+            if (span == 16) VR_TRIPS(4);
+            else if (span == 32) VR_TRIPS(2);
+            else VR_TRIPS(1);
+#undef VR_TRIPS
             // ---- per-entry sums of the chunk -> LDS (entry-major) -> one coalesced set of global atomics per entry
             if (has) {
                 float o[NACC];
@@ -475,11 +595,12 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                 for (int k = 0; k < NACC; ++k) stage[lane * NACC + k] = o[k];
             }
             __syncthreads();
-            for (int v = lane; v < 64 * NACC; v += 64) {
+            for (int v = lane; v < span * NACC; v += 64) {
                 const int l = v / NACC, k = v - l * NACC;
-                const int rr = ch * 64 + (63 - l);
+                const int rr = ch * 64 + (span - 1 - l);
                 if (rr >= nrel) continue;
-                const float sum = stage[v];
+                float sum = stage[v];
+                for (int gq = span; gq < 64; gq += span) sum += stage[v + gq * NACC];      // (row-packed chunk: the groups' partial sums)
                 if (sum == 0.0f) continue;
                 const float val = k < 15 ? sum : sum * (k == 15 ? 0.5f * (float)cam.W : 0.5f * (float)cam.H);
                 if (DET) {   // deterministic mode: this (list entry, region)'s own slot, summed later in list order

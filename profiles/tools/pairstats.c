@@ -225,12 +225,12 @@ void tail_stats(int H, int W, const int* ranges, const uint32_t* point_list, con
                 const uint32_t* n_contrib, double* out)
 {
     int gx = (W + 15) / 16, gy = (H + 15) / 16;
-    double o[23] = {0};
+    double o[27] = {0};
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gx * gy; ++tile) {
         int tx = tile % gx, ty = tile / gx;
         int s = ranges[2 * tile], e = ranges[2 * tile + 1];
-        double lo[23] = {0};
+        double lo[27] = {0};
         int maxnc = 0;
         for (int ly = 0; ly < 16; ++ly) for (int lx = 0; lx < 16; ++lx) {
             int px = tx * 16 + lx, py = ty * 16 + ly;
@@ -287,6 +287,34 @@ void tail_stats(int H, int W, const int* ranges, const uint32_t* point_list, con
                         int cls = mnc <= chunk_lo ? 0 : !(all & pm) ? 1 : 2;
                         lo[17 + cls] += 1;
                     }
+                    /* ... and a tail of 33 .. 48 entries as a half-packed chunk of 32 + a row-packed rest (out[23..25], out[26] chunks) */
+                    if (tail && n > 32 && n <= 48) {
+                        for (int part = 0; part < 2; ++part) {
+                            int p0 = part == 0 ? c0 : c0 + 32, p1 = part == 0 ? c0 + 32 : c1;
+                            int plo = relj[p0], pper = part == 0 ? 2 : 4;
+                            unsigned long long pall = 0;
+                            for (int r = p0; r < p1; ++r) pall |= hit[r];
+                            lo[26] += 1;
+                            for (int g = 0; g < 32 / pper; ++g) {
+                                unsigned long long pm = 0;
+                                for (int k = 0; k < pper; ++k) pm |= 3ull << (2 * (g * pper + k));
+                                int mnc = 0;
+                                for (int l = 0; l < 64; ++l) if ((pm >> l) & 1ull) if (nc[l] > mnc) mnc = nc[l];
+                                int cls = mnc <= plo ? 0 : !(pall & pm) ? 1 : 2;
+                                lo[23 + cls] += 1;
+                            }
+                        }
+                    } else {
+                        lo[26] += 1;
+                        for (int g = 0; g < 32 / per; ++g) {
+                            unsigned long long pm = 0;
+                            for (int k = 0; k < per; ++k) pm |= 3ull << (2 * (g * per + k));
+                            int mnc = 0;
+                            for (int l = 0; l < 64; ++l) if ((pm >> l) & 1ull) if (nc[l] > mnc) mnc = nc[l];
+                            int cls = mnc <= chunk_lo ? 0 : !(all & pm) ? 1 : 2;
+                            lo[23 + cls] += 1;
+                        }
+                    }
                 }
                 for (int c0 = 0; c0 < nrel; c0 += 64) {
                     int c1 = c0 + 64 < nrel ? c0 + 64 : nrel;
@@ -317,7 +345,7 @@ void tail_stats(int H, int W, const int* ranges, const uint32_t* point_list, con
             }
         }
 #pragma omp critical
-        { for (int k = 0; k < 23; ++k) o[k] += lo[k]; }
+        { for (int k = 0; k < 27; ++k) o[k] += lo[k]; }
     }
-    for (int k = 0; k < 23; ++k) out[k] = o[k];
+    for (int k = 0; k < 27; ++k) out[k] = o[k];
 }

@@ -42,7 +42,7 @@ for sname, k in (("64 entries x 2 pixels (now)", 0), ("32 entries x 4 pixels (pa
     print(f"k_seg_bwd {sname}: chunks {ch[9 + k]:.0f} trips cheap {cheap:.0f} reject {rej:.0f} accepted {acc:.0f}  cost(4/25/116) {(4 * cheap + 25 * rej + 116 * acc) / 1e6:.1f} M")
 print("units", ch[12])
 
-ts = np.zeros(23)
+ts = np.zeros(27)
 L.tail_stats(376, 1376, p(st["ranges"]), p(st["point_list"]), p(st["xy"]), p(st["conic_op"]), p(st["n_contrib"]), p(ts))
 print(f"tails: units {ts[14]:.0f} chunks {ts[9]:.0f}; last chunk <=16: {ts[10]:.0f}, 17..32: {ts[11]:.0f}, 33..48: {ts[12]:.0f}, 49..64: {ts[13]:.0f}")
 for name, k in (("now", 0), ("tails <= 16 row-packed (8 trips x 4 pairs)", 1), ("... and tails <= 32 half-packed (16 trips x 2 pairs)", 2)):
@@ -51,3 +51,5 @@ for name, k in (("now", 0), ("tails <= 16 row-packed (8 trips x 4 pairs)", 1), (
 print(f"accepted trips now inside tails <= 16: {ts[15]:.0f}, inside tails 17..32: {ts[16]:.0f}")
 cheap, rej, acc = ts[17:20]
 print(f"k_seg_bwd ... and entries behind every pixel's last contributor dropped before chunking: held entries {ts[20]:.0f} -> {ts[21]:.0f}, chunks {ts[9]:.0f} -> {ts[22]:.0f}, trips cheap {cheap:.0f} reject {rej:.0f} accepted {acc:.0f}  cost(4/25/116) {(4 * cheap + 25 * rej + 116 * acc) / 1e6:.1f} M")
+cheap, rej, acc = ts[23:26]
+print(f"k_seg_bwd ... and tails of 33 .. 48 entries as 32 half-packed + a row-packed rest: chunks {ts[26]:.0f}, trips cheap {cheap:.0f} reject {rej:.0f} accepted {acc:.0f}  cost(4/25/116) {(4 * cheap + 25 * rej + 116 * acc) / 1e6:.1f} M")

@@ -167,20 +167,30 @@ def assert_grad_close(name, got, want, rtol=1e-3, floor=1e-6, outliers=1e-4, nea
     return bad
 
 
-def summation_sensitivity(cam, st, og, names=("means3D", "scales", "rotations"), rtol=2e-4, floor=2e-7, eps=2e-6, seeds=16):
+def summation_sensitivity(cam, st, og, names=("means3D", "scales", "rotations"), rtol=2e-4, floor=2e-7, eps=2e-6, seeds=3, rows=None):
     """MEASURED conditioning of the dense gradients with respect to fp32 summation: the per-Gaussian sums the oracle's
     preprocess backward starts from (its double sums, og["_per_gaussian"], from orc.backward(abs_sums=True)) are
     perturbed by eps * (sum of the ABSOLUTE per-fragment terms) * N(0,1) -- eps = 2e-6 is what an fp32 sum of a few
     hundred to a few thousand rounded terms carries (sqrt(n) * 6e-8 per addition plus ~3e-7 per term from v_exp_f32 /
     v_rcp_f32) -- and the oracle's own fp32 chain re-run.  Returns {name: per-row movement in units of the comparison's
     allowance (rtol, floor)}: a row that moves by m cannot be held closer than ~m allowances by ANY fp32 implementation.
-    The movement is the largest over `seeds` random directions in the space of the 17 sums.  Round 6: 16 draws instead of 3 --
-    an edge-on disc amplifies ONE direction of that space (headline view 5, row 1357233, conic conditioning 114: 8.9 allowances
-    over three draws, 35.2 over sixteen), three draws sample it poorly, and a build that adds the same terms in another order
-    (k_seg_bwd's row-packed tail chunks) landed on that direction with 35.4."""
+    The movement is the largest over `seeds` random directions in the space of the 17 sums.
+    rows (round 6): measure these rows only (the chain is per Gaussian; returns arrays of len(rows)) -- cheap enough for many
+    draws.  An edge-on disc amplifies ONE direction of that space and three draws sample it poorly (headline view 5, row
+    1357233, conic conditioning 114: 8.9 allowances over three draws, 35.2 over sixteen; a build that adds the same terms in
+    another order -- k_seg_bwd's row-packed tail chunks -- landed on that direction with 35.4): the full-size tests
+    re-measure their offenders with 64 draws."""
     from oracle import oracle as orc
     pg = og["_per_gaussian"]
     assert pg.get("abs") is not None, "run orc.backward(..., abs_sums=True)"
+    tmax = {k: max(np.abs(np.asarray(og[k], np.float64)).max(), 1e-30) for k in names if og.get(k) is not None}
+    if rows is not None:
+        rows = np.asarray(rows, np.int64)
+        cut = lambda a: None if a is None else np.ascontiguousarray(np.asarray(a)[rows])
+        st = dict(st, inputs={k: cut(v) for k, v in st["inputs"].items()}, radii=cut(st["radii"]), cov3D=cut(st["cov3D"]),
+                  clamped=cut(st["clamped"]))
+        pg = {k: cut(v) for k, v in pg.items()}
+        og = {k: (cut(og[k]) if og.get(k) is not None else None) for k in names}
     moved = {}
     for seed in range(seeds):
         g = orc.preprocess_backward(cam, st, pg["mean2D"], pg["conic"], pg["opacity"], pg["attr"],
@@ -190,7 +200,7 @@ def summation_sensitivity(cam, st, og, names=("means3D", "scales", "rotations"),
                 continue
             w = np.asarray(og[k], np.float64).reshape(og[k].shape[0], -1)
             d = np.abs(np.asarray(g[k], np.float64).reshape(w.shape) - w).max(axis=1)
-            allow = rtol * np.abs(w).max(axis=1) + floor * max(np.abs(w).max(), 1e-30)
+            allow = rtol * np.abs(w).max(axis=1) + floor * tmax[k]
             moved[k] = np.maximum(moved.get(k, 0.0), d / allow)
     return moved
 

@@ -305,12 +305,15 @@ def _oracle_parity(name, sc_inputs, deg, cam, dev, hip_runs=1, flags=0):
         bad = assert_grad_close(f"{name} det {k}", h_grads[k], og[k], rtol=2e-4, floor=2e-7, outliers=1e-5 if plain else 1e-4,
                                 near=1e-5 if plain else 1e-3, cap=3.0, explain=explain, ill=ill)
         # EVERY offender is explained: its error is within 8x of what the summation-rounding model moves the oracle's
-        # own result by (plus the allowance) -- the model takes the largest of sixteen 1-sigma draws (helpers.py), the actual
+        # own result by (plus the allowance) -- the model takes the largest of three 1-sigma draws (64 for the offenders), the actual
         # rounding may sit at 3 sigma
         _, ratio = grad_mismatch(h_grads[k], og[k], 2e-4, 2e-7)
-        unexplained = bad[ratio[bad] > 1.0 + EXPLAIN_FACTOR * moved[k][bad]]
+        # (the offenders' movement re-measured over 64 directions: three draws undersample the one direction an edge-on disc
+        # amplifies -- helpers.summation_sensitivity)
+        mv = np.maximum(moved[k][bad], summation_sensitivity(oc, st, og, names=(k,), rows=bad, seeds=64)[k]) if len(bad) else moved[k][bad]
+        unexplained = bad[ratio[bad] > 1.0 + EXPLAIN_FACTOR * mv]
         # how many rows needed an explanation at all, and the largest multiple of its measured movement any of them used
-        used = float(((ratio[bad] - 1.0) / np.maximum(moved[k][bad], 1e-9)).max()) if len(bad) else 0.0
+        used = float(((ratio[bad] - 1.0) / np.maximum(mv, 1e-9)).max()) if len(bad) else 0.0
         print(f"[{name}] {k}: {len(bad)} of {len(ratio)} rows outside rtol 2e-4 needed an explanation "
               f"(largest: {used:.2f} x its measured summation sensitivity; allowed {EXPLAIN_FACTOR})")
         assert len(unexplained) == 0, (name, k, "rows outside 2e-4 beyond what fp32 summation explains",

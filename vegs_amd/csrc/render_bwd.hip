@@ -31,9 +31,6 @@
 namespace vr {
 
 constexpr int NACC = 17;  // conic(3) opacity(1) attr(11) mean2D(2)
-#ifndef VR_BWD_CUT
-#define VR_BWD_CUT 1             // (0: A/B build that keeps the entries behind every pixel's last contributor, --variant nocut)
-#endif
 #ifndef VR_BWD_PACK_TAILS
 #define VR_BWD_PACK_TAILS 1      // (0: the A/B build without row-packed tail chunks, python -m vegs_amd.build --variant nopack)
 #endif
@@ -465,24 +462,8 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     const float Tnext = c.flag == 2u ? Tbuf[(size_t)(c.seg + 1) * SEG + pixslot] : -1.0f;
     float v_Scar = Ubuf[(size_t)c.seg * SEG + pixslot];
 
-    // the region's farthest last contributor: list entries at or behind it reach no pixel of this wave in the backward
-    int mx = v_nc;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
-    const int wave_maxc = mx;
-
-    // ---- the entries relevant to this strip, compacted in list order.  The forward's masks say "alpha >= 1/255 at some pixel
-    // of the region"; a pixel that has stopped takes nothing from the entries behind its last contributor, so the entries
-    // behind EVERY pixel's last contributor are dropped here (round 6: 15 % of the held entries of the headline view, the
-    // regions' last needed segments; they used to be gathered, held and skipped chunk by chunk)
-    unsigned long long m0 = uniform64(mraw0), m1 = uniform64(mraw1), m2 = uniform64(mraw2), m3 = uniform64(mraw3);
-    if (VR_BWD_CUT) {
-        const int cut = wave_maxc - c.sl * SEG;        // entries [0, cut) of the segment can still matter
-        m0 = cut >= 64 ? m0 : cut <= 0 ? 0ull : m0 & ((1ull << cut) - 1ull);
-        m1 = cut >= 128 ? m1 : cut <= 64 ? 0ull : m1 & ((1ull << (cut - 64)) - 1ull);
-        m2 = cut >= 192 ? m2 : cut <= 128 ? 0ull : m2 & ((1ull << (cut - 128)) - 1ull);
-        m3 = cut >= 256 ? m3 : cut <= 192 ? 0ull : m3 & ((1ull << (cut - 192)) - 1ull);
-    }
+    // ---- the entries relevant to this strip, compacted in list order
+    const unsigned long long m0 = uniform64(mraw0), m1 = uniform64(mraw1), m2 = uniform64(mraw2), m3 = uniform64(mraw3);
     const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
     const int nrel = n0 + n1 + n2 + n3;
     if (nrel == 0) return;
@@ -539,6 +520,10 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     }
     __syncthreads();
 
+    int mx = v_nc;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
+    const int wave_maxc = mx;
     const int nchunks = (nrel + 63) >> 6;
 
     for (int ch = nchunks - 1; ch >= 0; --ch) {

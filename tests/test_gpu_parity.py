@@ -360,6 +360,25 @@ def test_c1_random_10k(dev):
     _check_against_oracle(inputs, scenes.camera_c1(256, 256), [0, 0, 0], deg, 1.0, dev)
 
 
+@pytest.mark.parametrize("det", [0, 256], ids=["atomic", "deterministic"])
+@pytest.mark.parametrize("N", [1, 9, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 72, 80, 81, 96, 97, 128, 129, 150, 200])
+def test_backward_chunk_tails(N, det, dev):
+    """k_seg_bwd cuts a region's relevant entries into chunks of 64 and holds a LAST chunk of <= 16 / <= 32 entries once per
+    16-lane row / per half-wave (round 6: row-packed tails): N translucent splats piled onto one 8 x 8
+    region (no pixel stops), N around every boundary of that scheme -- a tail alone, a tail behind one and two full chunks,
+    chunks of exactly 16 / 32 / 64 -- with the gradients of all of them against the oracle, atomic and deterministic."""
+    from vegs_amd import scenes
+    rng = np.random.default_rng(1000 + N)
+    sc, deg = scenes.scene_random(P=N, sh_degree=1, seed=N, extent=0.02, scale=0.05)
+    sc["opacities"] = (1 / (1 + np.exp(-rng.normal(-2.5, 0.5, (N, 1))))).astype(np.float32)
+    inputs = dict(means3D=sc["means3D"], shs=sc["shs"], colors_precomp=None, opacities=sc["opacities"],
+                  scales=sc["scales"], rotations=sc["rotations"], cov3D_precomp=None)
+    h_out, h_grads, o_out, st = _check_against_oracle(inputs, scenes.camera_c1(40, 40), [0.1, 0.2, 0.3], deg, 1.0, dev, seed=N,
+                                                      hip_flags=det)
+    assert float(h_out["alpha"].max()) < 0.9999 or N > 64        # translucent: every entry reaches the pixels behind it
+    assert int(st["n_contrib"].max()) >= min(N, 8)
+
+
 @pytest.mark.parametrize("W,H", [(1376, 376), (200, 120)])
 def test_street_small_ragged_image(W, H, dev):
     """KITTI-360-shaped street (VEGS discs), SH degree 3; 376 and 120/200 are not multiples of 16."""

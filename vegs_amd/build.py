@@ -40,7 +40,8 @@ def _newer(target, deps):
 
 # Reproducer builds (profiles/experiments/README.md): the same sources with a -D switch, into their own library beside the
 # product one -- loaded only when VEGS_LIB names it (vegs_amd/_capi.py).  Never built by build() without --variant.
-VARIANTS = {"early": ["-DVR_EARLY_SH"], "nopack": ["-DVR_BWD_PACK_TAILS=0"]}
+VARIANTS = {"early": ["-DVR_EARLY_SH"], "nopack": ["-DVR_BWD_PACK_TAILS=0", "-DVR_BWD_PREFETCH=0"],
+            "nopref": ["-DVR_BWD_PREFETCH=0"]}
 
 
 def build_variant(name, force=False, verbose=False):

@@ -31,6 +31,9 @@
 namespace vr {
 
 constexpr int NACC = 17;  // conic(3) opacity(1) attr(11) mean2D(2)
+#ifndef VR_BWD_PREFETCH
+#define VR_BWD_PREFETCH 1        // (0: A/B build that gathers a chunk's records when it starts, --variant nopref)
+#endif
 #ifndef VR_BWD_PACK_TAILS
 #define VR_BWD_PACK_TAILS 1      // (0: the A/B build without row-packed tail chunks, python -m vegs_amd.build --variant nopack)
 #endif
@@ -526,6 +529,28 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
     const int wave_maxc = mx;
     const int nchunks = (nrel + 63) >> 6;
 
+    // The chunk's records are gathered one chunk AHEAD (round 6): the next (nearer) chunk is always a full one (lane l <-> entry
+    // 63 - l), its 80-byte records are requested right after this chunk's sums are staged and travel under the flush.
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = make_float4(0.f, 0.f, 1.0f, 0.f), q2 = q0, q3 = q0, q4 = q0;     // (an empty lane: thr = 1)
+    auto gather = [&](const int r_, const bool has_) {
+        asm volatile("" ::: "memory");        // (not hoisted above the pixel loop: twenty more live registers there spill)
+        if (has_) {
+            const float4* src = reinterpret_cast<const float4*>(rec + rel_gid[r_]);
+            q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; q4 = src[4];
+        }
+    };
+    // (the last chunk walked redefines the registers too -- with anything: a value carried around the loop would have to
+    // survive the pixel loop, twenty registers the kernel does not have)
+    auto next_records = [&](const int ch_) {
+        if (ch_ > 0) gather((ch_ - 1) * 64 + (63 - lane), true);
+        else q0 = q1 = q2 = q3 = q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if (VR_BWD_PREFETCH) {
+        const int nch0 = (nrel + 63) >> 6, n_last = nrel - (nch0 - 1) * 64;
+        const int span0 = !VR_BWD_PACK_TAILS ? 64 : (n_last <= 16 ? 16 : n_last <= 32 ? 32 : 64);
+        const int r0 = (nch0 - 1) * 64 + (span0 - 1 - (lane & (span0 - 1)));
+        gather(r0, r0 < nrel);
+    }
     for (int ch = nchunks - 1; ch >= 0; --ch) {
         // ---- lane l owns the strip's relevant entry number ch*64 + (63-l): back-to-front over lanes.  The LAST chunk (the first
         // one walked) may hold few entries: <= 16 of them are held once per 16-lane row, <= 32 once per half (bwd_chunk_trips)
@@ -540,9 +565,8 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
         float at[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) at[k] = 0.0f;
+        if (!VR_BWD_PREFETCH) gather(r, has);
         if (has) {
-            const float4* src = reinterpret_cast<const float4*>(rec + rel_gid[r]);
-            const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4];
             sx = q0.x; sy = q0.y; cA = q0.z; cB = q0.w; cC = q1.x; op = q1.y; thr = q1.z;
             at[0] = q2.x; at[1] = q2.y; at[2] = q2.z; at[3] = q1.w;
             at[4] = q2.w; at[5] = q3.x; at[6] = q3.y; at[7] = q3.z;
@@ -579,6 +603,7 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
 #pragma unroll
                 for (int k = 0; k < NACC; ++k) stage[lane * NACC + k] = o[k];
             }
+            if (VR_BWD_PREFETCH) next_records(ch);
             __syncthreads();
             for (int v = lane; v < span * NACC; v += 64) {
                 const int l = v / NACC, k = v - l * NACC;
@@ -597,6 +622,8 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
                 else atomicAdd(&gmean2D[(size_t)gid * 3 + (k - 15)], val);
             }
             __syncthreads();
+        } else if (VR_BWD_PREFETCH) {
+            next_records(ch);
         }
     }
 }

@@ -592,7 +592,7 @@ def main():
                          "the other 11 floats; dense = RCCL all-reduce of all 59 floats per Gaussian; direct = the factored "
                          "scheme over hand-written peer-to-peer kernels: every rank pushes 1/N shards into all peers' hipIpc "
                          "windows at once, vegs_amd/csrc/xgmi.hip)")
-    ap.add_argument("--probe-timeout", type=float, default=300.0,
+    ap.add_argument("--probe-timeout", type=float, default=120.0,
                     help="N > 1, --exchange auto: wall-clock limit in seconds for the child processes that set up, verify and "
                          "time the direct exchange; what is left of them is killed")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported "

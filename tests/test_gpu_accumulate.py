@@ -61,7 +61,18 @@ def test_accumulated_in_place_equals_autograd_accumulation_bit_for_bit(dev, stre
         pkg = harness.render(cams[v], T, deg, bg, cam_t=cam_ts[v])
         torch.autograd.backward([pkg["render"], pkg["render_cov_quat"], pkg["render_cov_scale"]], gouts[v])
         return pkg["viewspace_points"].grad
-    want, m_want = _batch(T, one, 6, dev, False, streams)
+    # The reference: autograd's own accumulation of the six views on ONE stream.  (Round 6: it used to run on `streams` streams
+    # as well, and one run of the whole suite in ~60 failed there.  profiles/tools/r06/accum_diag.py: every view's gradient is
+    # bit-reproducible, one-stream sums are, the IN-PLACE sums on two streams are and equal them -- this module orders
+    # consecutive accumulations with an event --, but two runs of AUTOGRAD's accumulation on two streams now and then differ
+    # from each other by an fp32 rounding in a fifth of the rows: PyTorch fixes no order between the AccumulateGrad steps of
+    # views whose backwards ran on different streams.  Not a wrong sum, and not this library's order to vouch for.)
+    want, m_want = _batch(T, one, 6, dev, False, 1)
+    if streams > 1:      # ... the two-stream autograd sums agree with them to the order of the additions
+        want2, _ = _batch(T, one, 6, dev, False, streams)
+        for k in want:
+            d = float((want[k] - want2[k]).abs().max())
+            assert d <= 4e-7 * float(want[k].abs().max()), ("autograd accumulation on %d streams" % streams, k, d)
     ptrs = {}
 
     def one_spy(v):
@@ -70,7 +81,11 @@ def test_accumulated_in_place_equals_autograd_accumulation_bit_for_bit(dev, stre
         return out
     got, m_got = _batch(T, one_spy, 6, dev, True, streams)
     for k in want:
-        assert torch.equal(want[k], got[k]), (k, float((want[k] - got[k]).abs().max()))
+        if not torch.equal(want[k], got[k]):
+            again, _ = _batch(T, one_spy, 6, dev, True, streams)          # (diagnosis: is the in-place path itself reproducible?)
+            rows = (want[k] != got[k]).reshape(want[k].shape[0], -1).any(dim=1)
+            raise AssertionError((k, "max abs diff", float((want[k] - got[k]).abs().max()), "rows", int(rows.sum()),
+                                  "in-place run reproducible", bool(torch.equal(again[k], got[k]))))
         assert float(got[k].abs().max()) > 0
     for a, b in zip(m_want, m_got):                    # the per-view screen-space gradient is returned as always
         assert torch.equal(a, b) and float(a[:, 2].abs().max()) == 0.0

@@ -5,7 +5,11 @@ the time is spent in short, latency-bound launches (the five radix passes, the p
 the 256 CUs idle.  Two independent views on two streams fill each other's idle stretches: on the headline scene
 forward-only rendering goes from 0.73 to 0.58 ms per view, a batch of 8 training views from 1.56 to 1.36 ms per
 view (profiles/tools/streams_probe.py).  Nothing inside a view changes -- its kernels run in the same order on ONE
-stream -- so every image is bit-identical to the one-stream result.
+stream -- so every image, and every view's own gradient, is bit-identical to the one-stream result.  What is NOT fixed
+is the order in which autograd adds the gradients of views whose backwards ran on different streams into a shared leaf's
+`.grad`: the sums of two runs can differ by an fp32 rounding (profiles/tools/r06/accum_diag.py).  With
+`rasterizer.accumulate_grads(True)` the library adds in place and orders consecutive accumulations itself: bit-equal to
+autograd's accumulation on one stream (tests/test_gpu_accumulate.py).
 
 Who has independent views: the reference's evaluation and video loops (train.py:338-508, render_video.py:162,202:
 one render() per camera under no_grad, nothing carried from frame to frame) and this build's view batches (several

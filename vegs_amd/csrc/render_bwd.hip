@@ -288,6 +288,8 @@ __device__ __forceinline__ float bwd_rcp(float x) { return EXACT ? 1.0f / x : __
 // ANOTHER pixel pair of the trip: 8 (16) trips, the scans stop at the row (half) boundary, the pixel state arrives as one LDS
 // broadcast per group instead of per wave, and the groups' partial sums are added at the flush.  On the headline view 29 % of
 // the chunks are such tails (profiles/tools/pairstats.py: tail_stats): accepted trips 820 k -> 725 k.
+typedef float f4n __attribute__((ext_vector_type(4)));          // (a native vector: loads through an LDS-qualified pointer)
+typedef __attribute__((address_space(3))) f4n lds_f4;
 template <int ROWS, bool NO_EXTRA, bool DET, bool FAST, bool NO_DEPTH>
 __device__ __forceinline__ void bwd_chunk_trips(const int lane, const int e, const int chunk_lo, const int v_nc, const float sx,
                                                 const float sy, const float kA, const float kB, const float kC, const float thr2,
@@ -311,7 +313,12 @@ __device__ __forceinline__ void bwd_chunk_trips(const int lane, const int e, con
             nc1 = n.y;
             if (__builtin_amdgcn_ballot_w64(max(nc0, nc1) > chunk_lo) == 0ull) continue;
         }
-        const float4 r0 = pix[0][pp];
+        // the pair's LDS row address in ONE vector register for all nine accesses of the trip (the compiler re-materialised it
+        // from a scalar three times per trip)
+        uint32_t paddr = (uint32_t)(uintptr_t)(lds_f4*)&pix[0][pp];
+        asm volatile("" : "+v"(paddr));
+        lds_f4* const prow = (lds_f4*)(uintptr_t)paddr;        // prow[32 * slot] = pix[slot][pp]
+        const f4n r0 = prow[0];
         const f2 pxf = {r0.x, r0.y}, pyf = {r0.z, r0.w};
         f2 dx, dy;
         const f2 power = splat_power2_x2(sx, sy, kA, kB, kC, pxf, pyf, dx, dy);    // in units of log2 e, as the forward
@@ -347,12 +354,22 @@ __device__ __forceinline__ void bwd_chunk_trips(const int lane, const int e, con
         const f2 a_eff = {contrib0 ? alpha.x : 0.0f, contrib1 ? alpha.y : 0.0f};
         G.x = contrib0 ? G.x : 0.0f;              // (exp of a positive exponent may be inf: keep it out of 0*inf)
         G.y = contrib1 ? G.y : 0.0f;
-        const float4 r1 = pix[1][pp], r2 = pix[2][pp], r3 = pix[3][pp], r4 = pix[4][pp],
-                     r5 = pix[5][pp], r6 = pix[6][pp], r7 = pix[7][pp];
+        const f4n r1 = prow[32], r2 = prow[64], r3 = prow[96], r4 = prow[128],
+                  r5 = prow[160], r6 = prow[192], r7 = prow[224];
         const f2 bgterm = {r1.x, r1.y}, Tc = {r7.x, r7.y}, Sc = {r7.z, r7.w};
         const f2 g[NCH] = {{r1.z, r1.w}, {r2.x, r2.y}, {r2.z, r2.w}, {r3.x, r3.y}, {r3.z, r3.w}, {r4.x, r4.y},
                            {r4.z, r4.w}, {r5.x, r5.y}, {r5.z, r5.w}, {r6.x, r6.y}, {r6.z, r6.w}};
         const f2 om = f2_splat(1.0f) - a_eff;
+        // 1 / (1 - alpha) for dL/dalpha below, taken HERE: the scan then runs in place on `om`'s registers (two moves per trip
+        // fewer; a trip that reaches this point almost always has a contributing lane)
+        // (finite also for a lane that does not contribute: its alpha is 0, so 1 - alpha = 1, and the prefix
+        // product of at most 64 factors >= 0.01 it divides by cannot reach zero before Tc itself has)
+        f2 inv_om = {bwd_rcp<DET>(om.x), bwd_rcp<DET>(om.y)};
+        {   // (pinned in front of the scan: sunk into the block that uses it, the reciprocals keep `om` alive across the scan)
+            float ia = inv_om.x, ib = inv_om.y;
+            asm volatile("" : "+v"(ia), "+v"(ib));
+            inv_om.x = ia; inv_om.y = ib;
+        }
         float pa = om.x, pb = om.y;
         group_prefix_mul_x2<ROWS>(pa, pb);                               // prod over entries >= mine
         const f2 Tl = Tc * (f2){bwd_rcp<DET>(pa), bwd_rcp<DET>(pb)};   // T in front of my splat
@@ -385,7 +402,7 @@ __device__ __forceinline__ void bwd_chunk_trips(const int lane, const int e, con
         // carries for the next (nearer) chunk: values at the chunk's first entry = the group's last lane
         if ((lane & (SPAN - 1)) == SPAN - 1) {
             const f2 Sn = Sc + psum;
-            pix[7][pp] = make_float4(Tl.x, Tl.y, Sn.x, Sn.y);
+            prow[224] = (f4n){Tl.x, Tl.y, Sn.x, Sn.y};
         }
         if (contrib0 || contrib1) {
             // Per-fragment work kept to what depends on the pixel.  With a = dL/dG * G (zero for a lane that does
@@ -397,9 +414,6 @@ __device__ __forceinline__ void bwd_chunk_trips(const int lane, const int e, con
             // instead of 20) and the signs applied once per entry at the flush.  (The conic cannot be pulled out of
             // the mean2D sums as well: A sum(a dx) + B sum(a dy) cancels AFTER the sums were rounded, and for edge-on
             // discs that lost two digits -- the C-harness test caught rows off by 2 %.)
-            const f2 inv_om = {bwd_rcp<DET>(om.x), bwd_rcp<DET>(om.y)};
-            // (finite also for a lane that does not contribute: its alpha is 0, so 1 - alpha = 1, and the prefix
-            // product of at most 64 factors >= 0.01 it divides by cannot reach zero before Tc itself has)
             const f2 dLda = f2_fma(Tl, u, -(behind + bgterm) * inv_om);
             const f2 a = (f2_splat(op) * dLda) * G;
             const f2 adx = a * dx, ady = a * dy;
@@ -581,7 +595,7 @@ k_seg_bwd(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restric
         for (int k = 0; k < NACC; ++k) acc[k] = f2_splat(0.0f);
         // nearest list index held by this chunk (its first relevant entry): pixels whose last
         // contributor lies in front of it have nothing to do here
-        const int chunk_lo = seg_lo + (int)rel_j[ch * 64];
+        const int chunk_lo = __builtin_amdgcn_readfirstlane(seg_lo + (int)rel_j[ch * 64]);       // (wave-uniform: a scalar compare per trip)
 
         if (chunk_lo < wave_maxc) {
 #define VR_TRIPS(R) bwd_chunk_trips<R, NO_EXTRA, DET, FAST, NO_DEPTH>(lane, e, chunk_lo, v_nc, sx, sy, kA, kB, kC, thr2, op, cA, cB, cC, at, acc, pix, ncp)

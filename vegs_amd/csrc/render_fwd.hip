@@ -498,7 +498,9 @@ __device__ __forceinline__ void seg_first_body(const Camera& cam, const int tile
         const bool apply = valid && !stop;
         gx = stop ? GATED : gx;
         pstop = stop ? pn : pstop;
-        if (__builtin_amdgcn_ballot_w64(apply) == 0ull) return;
+        // (no "nobody applies it" exit here any more -- round 6: the ballot of `valid && !stop` is lowered through a vector
+        // register, v_cndmask + v_cmp + a branch on EVERY entry that reaches this point, to skip a block that the rare entry
+        // nobody applies walks with wgt = 0: exact no-ops)
         const float wgt = apply ? alpha * (Tb * p) : 0.0f;
         const float4 cc = lds[2][i];
         const float4 d = lds[3][i];
@@ -1005,7 +1007,7 @@ k_seg_blend(Camera cam, const int2* __restrict__ ranges, const uint32_t* __restr
             const bool stop = valid && (Tb * pn < T_EPS);
             const bool apply = valid && !stop;
             gx = stop ? GATED : gx;
-            if (__builtin_amdgcn_ballot_w64(apply) == 0ull) return;
+            // (no "nobody applies it" exit: seg_first_body's comment)
             const float wgt = apply ? alpha * (Tb * p) : 0.0f;
             const float4 cc = lds[2][i];  // r g b qw
             const float4 d = lds[3][i];   // qx qy qz s0

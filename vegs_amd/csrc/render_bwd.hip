@@ -24,8 +24,6 @@
 // Lanes hold a chunk back-to-front (lane l <-> entry 63-l) so both are PREFIX scans over lanes.
 // Per-splat gradients stay in registers until the chunk is finished, are transposed through LDS and leave as one
 // coalesced set of global atomics per (region, splat) -- ~250x fewer atomics than one per fragment.
-// (3) A region's LAST chunk of <= 16 / <= 32 entries is held once per DPP row / half-wave, every group walking another pixel
-// pair (bwd_chunk_trips); the next chunk's records are requested while the current one's sums are flushed.
 #include "../../include/vegs_rast_debug.h"
 #include "vr_host.h"
 #include "vr_segment.h"
